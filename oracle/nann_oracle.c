@@ -1,0 +1,653 @@
+/*
+ * nann_oracle.c -- CPU restatement of the NANN retrieval hot path.
+ * TEST INFRASTRUCTURE ONLY (see nann_oracle.h for the rules and the parity
+ * status of each function).  Plain C11, no dependencies beyond libc/libm/
+ * pthreads.  Citations are relative to /root/reference/;
+ * UO/ = tensorflow/tensorflow/core/user_ops/.
+ *
+ * Canonical floating-point orders (shared with the HIP kernels):
+ *
+ *  L2 scorer, d = 8*L, L a power of two:
+ *      p[l] = 0; for k in 0..7: t = q[8l+k] - x[8l+k]; p[l] = fmaf(t,t,p[l])
+ *      for s = 1,2,4,..,L/2: p[l] = p[l] + p[l^s]      (xor butterfly)
+ *      score = 0.0f - p[0]
+ *  MLP scorer (x=[q;e], W1 [2d,H1], W2 [H1,H2], w3 [H2]):
+ *      u[j]  = b1[j];  for k in 0..d-1:      u[j]  = fmaf(q[k], W1[k][j], u[j])
+ *      a1[j] = u[j];   for k in ORDER_E(d):  a1[j] = fmaf(e[k], W1[d+k][j], a1[j])
+ *      h1[j] = prelu(a1[j], alpha1[j])
+ *      a2[m] = b2[m];  for k in ORDER_H(H1): a2[m] = fmaf(h1[k], W2[k][m], a2[m])
+ *      h2[m] = prelu(a2[m], alpha2[m])
+ *      p_s   = 0;      for m in ORDER_O(H2, s): p_s = fmaf(h2[m], w3[m], p_s)   s=0,1
+ *      score = p_0 + p_1
+ *    ORDER_E(d)  = 0, d/2, 1, d/2+1, ..., d/2-1, d-1
+ *    ORDER_H(H)  = for t in 0..H/32-1, r in 0..15: k0 = 32t + (r&3) + 8(r>>2); k0, k0+4
+ *    ORDER_O(H,s)= for t in 0..H/32-1, r in 0..15:      32t + (r&3) + 8(r>>2) + 4s
+ *    (these are the k orders in which v_mfma_f32_32x32x2_f32 consumes its
+ *     operands when the layer-1 accumulators feed layer 2 in place)
+ *    prelu(x,a)  = (x > 0 ? x : 0) + a * (x < 0 ? x : 0)     (model_util.py:9-11)
+ */
+#define _GNU_SOURCE
+#include "nann_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#ifdef __F16C__
+#include <immintrin.h>
+#endif
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* ragged validation: GroupGather_kernel.cc:9-16, bitmap_ops.cc:12-19        */
+int oracle_validate_ragged(int64_t n_values, const int64_t* row_splits,
+                           int64_t n_splits) {
+  if (n_splits == 0) return 1;
+  if (row_splits[0] != 0) return 2;
+  if (row_splits[n_splits - 1] != n_values) return 3;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* GroupGather, unique=false: GroupGather_kernel.cc:136-170                  */
+int oracle_group_gather_i32(const int32_t* pv, int64_t n_pv, const int64_t* prs,
+                            int64_t n_prs, const int64_t* iv, int64_t n_iv,
+                            const int64_t* irs, int64_t n_irs, int32_t* out_values,
+                            int64_t out_cap, int64_t* out_rs, int64_t* n_out,
+                            int64_t* n_out_splits, int* ragged_code) {
+  int code = oracle_validate_ragged(n_pv, prs, n_prs);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_PARAMS; /* :62-64 */
+  code = oracle_validate_ragged(n_iv, irs, n_irs);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_INDICES; /* :65-67 */
+
+  if (n_prs == 1 || n_irs == 1) { /* void inputs -> ([], [0])  :69-77 */
+    out_rs[0] = 0;
+    *n_out = 0;
+    *n_out_splits = 1;
+    return ORACLE_OK;
+  }
+  const int64_t num_groups = n_irs - 1;
+  const int64_t n_rows = n_prs - 1;
+  out_rs[0] = 0;
+  *n_out_splits = n_irs;
+  /* count pass :137-145 */
+  int64_t sum = 0;
+  for (int64_t i = 0; i < num_groups; ++i) {
+    for (int64_t j = irs[i]; j < irs[i + 1]; ++j) {
+      const int64_t idx = iv[j];
+      if (idx < 0 || idx >= n_rows) return ORACLE_ERR_INDEX_OUT_OF_RANGE; /* UB in the reference */
+      sum += prs[idx + 1] - prs[idx];
+    }
+    out_rs[i + 1] = sum;
+  }
+  *n_out = sum;
+  if (!out_values) return ORACLE_OK;
+  if (out_cap < sum) return ORACLE_ERR_BAD_ARGUMENT;
+  /* fill pass :152-168 */
+  for (int64_t i = 0; i < num_groups; ++i) {
+    int64_t w = out_rs[i];
+    for (int64_t j = irs[i]; j < irs[i + 1]; ++j) {
+      const int64_t g = iv[j];
+      for (int64_t k = prs[g]; k < prs[g + 1]; ++k) out_values[w++] = pv[k];
+    }
+  }
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* BitmapRefDifference: bitmap_ops.cc:175-257 (hot loop :224-232)            */
+int oracle_bitmap_ref_difference_i32(const int32_t* values, int64_t n_values,
+                                     const int64_t* row_splits, int64_t n_splits,
+                                     int32_t* bitmap, int64_t n_words,
+                                     int32_t* out_values, int64_t* out_rs,
+                                     int64_t* n_out, int64_t* n_out_splits,
+                                     int* ragged_code) {
+  const int code = oracle_validate_ragged(n_values, row_splits, n_splits);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_INPUT; /* :182-184 */
+  if (n_splits == 1) { /* void input :187-196, bitmap forwarded untouched */
+    out_rs[0] = 0;
+    *n_out = 0;
+    *n_out_splits = 1;
+    return ORACLE_OK;
+  }
+  const int64_t num_groups = n_splits - 1;
+  /* bounds pre-check (the reference has none: Appendix C) so that an error
+   * leaves the bitmap untouched */
+  for (int64_t j = 0; j < n_values; ++j) {
+    const int64_t v = values[j];
+    if (v < 0 || (v >> 5) >= n_words) return ORACLE_ERR_INDEX_OUT_OF_RANGE;
+  }
+  uint32_t* bm = (uint32_t*)bitmap;
+  int64_t w = 0;
+  out_rs[0] = 0;
+  for (int64_t i = 0; i < num_groups; ++i) { /* ONE bitmap for all groups */
+    for (int64_t j = row_splits[i]; j < row_splits[i + 1]; ++j) {
+      const int32_t node = values[j];
+      const int32_t flag_index = node >> 5;
+      const uint32_t bit = 1u << (node & 31);
+      if (!(bm[flag_index] & bit)) {
+        out_values[w++] = node;
+        bm[flag_index] |= bit;
+      }
+    }
+    out_rs[i + 1] = w;
+  }
+  *n_out = w;
+  *n_out_splits = n_splits;
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* GatherV2, axis 0: gather_functor.h:38-116 (memcpy per row :96-103)        */
+int oracle_gather_rows(const void* params, int64_t n_rows, int64_t row_bytes,
+                       const int32_t* idx, int64_t n_idx, void* out, int64_t* bad_i) {
+  const char* p = (const char*)params;
+  char* o = (char*)out;
+  for (int64_t i = 0; i < n_idx; ++i) {
+    const int64_t r = idx[i];
+    if (r < 0 || r >= n_rows) { /* FastBoundsCheck, gather_functor.h:85-89 */
+      if (bad_i) *bad_i = i;
+      return ORACLE_ERR_INDEX_OUT_OF_RANGE;
+    }
+    memcpy(o + i * row_bytes, p + r * row_bytes, (size_t)row_bytes);
+  }
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* TopKV2: topk_op.cc:104-205.  stable_comp (:134-142): a before b iff
+ * v[a] > v[b] or (v[a] == v[b] and a < b).                                  */
+static inline int topk_better(const float* v, int32_t a, int32_t b) {
+  if (v[b] < v[a]) return 1;
+  if (v[b] > v[a]) return 0;
+  return a < b;
+}
+
+static int topk_qsort_cmp(const void* pa, const void* pb, void* ctx) {
+  const float* v = (const float*)ctx;
+  const int32_t a = *(const int32_t*)pa, b = *(const int32_t*)pb;
+  if (a == b) return 0;
+  return topk_better(v, a, b) ? -1 : 1;
+}
+
+int oracle_topk_f32(const float* values, int64_t n, int32_t k, float* out_values,
+                    int32_t* out_indices) {
+  if (k < 0) return ORACLE_ERR_BAD_ARGUMENT;
+  if (n < k) return ORACLE_ERR_TOPK_K_GT_N; /* :67-71 */
+  if (k == 0) return ORACLE_OK;
+  /* bounded heap whose root is the WORST kept element (gtl::TopN, :176-193) */
+  int32_t* heap = out_indices;
+  int32_t size = 0;
+  for (int32_t c = 0; c < (int32_t)n; ++c) {
+    if (size < k) {
+      int32_t i = size++;
+      heap[i] = c;
+      while (i > 0) { /* sift up: parent must be worse-or-equal than child */
+        const int32_t p = (i - 1) >> 1;
+        if (topk_better(values, heap[p], heap[i])) {
+          const int32_t t = heap[p]; heap[p] = heap[i]; heap[i] = t;
+          i = p;
+        } else break;
+      }
+    } else if (topk_better(values, c, heap[0])) {
+      heap[0] = c;
+      int32_t i = 0;
+      for (;;) {
+        const int32_t l = 2 * i + 1, r = l + 1;
+        int32_t w = i; /* w = worst among i, l, r */
+        if (l < size && topk_better(values, heap[w], heap[l])) w = l;
+        if (r < size && topk_better(values, heap[w], heap[r])) w = r;
+        if (w == i) break;
+        const int32_t t = heap[w]; heap[w] = heap[i]; heap[i] = t;
+        i = w;
+      }
+    }
+  }
+  qsort_r(heap, (size_t)k, sizeof(int32_t), topk_qsort_cmp, (void*)values);
+  for (int32_t i = 0; i < k; ++i) out_values[i] = values[out_indices[i]];
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* exact scalar conversions                                                  */
+float oracle_half_to_float(uint16_t h) {
+#ifdef __F16C__
+  return _cvtsh_ss(h); /* exact, same value as the bit-level path below */
+#endif
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const uint32_t exp = (h >> 10) & 0x1f;
+  uint32_t man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else { /* subnormal: normalise */
+      int e = -1;
+      do { man <<= 1; ++e; } while (!(man & 0x400u));
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7f800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+float oracle_bf16_to_float(uint16_t h) {
+  const uint32_t bits = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+uint16_t oracle_float_to_half(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t man = x & 0x7fffffu;
+  if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    const int shift = 14 - exp; /* 14..24 */
+    uint32_t hm = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hm & 1))) ++hm;
+    return (uint16_t)(sign | hm);
+  }
+  uint32_t hm = man >> 13;
+  const uint32_t rem = man & 0x1fffu;
+  uint32_t out = sign | ((uint32_t)exp << 10) | hm;
+  if (rem > 0x1000u || (rem == 0x1000u && (hm & 1))) ++out; /* carries into exp correctly */
+  return (uint16_t)out;
+}
+
+static inline float load_elem(const void* row, int dtype, int k) {
+  switch (dtype) {
+    case ORACLE_EMB_F16: return oracle_half_to_float(((const uint16_t*)row)[k]);
+    case ORACLE_EMB_BF16: return oracle_bf16_to_float(((const uint16_t*)row)[k]);
+    default: return ((const float*)row)[k];
+  }
+}
+
+static inline int64_t elem_bytes(int dtype) { return dtype == ORACLE_EMB_F32 ? 4 : 2; }
+
+void oracle_user_seq_mean(const uint16_t* seq, int seq_len, int d, float* q) {
+  int count = 0;
+  for (int r = 0; r < seq_len; ++r) {
+    int nz = 0;
+    for (int k = 0; k < d; ++k) nz |= (seq[(int64_t)r * d + k] & 0x7fffu) != 0;
+    count += nz;
+  }
+  for (int k = 0; k < d; ++k) {
+    float s = 0.0f;
+    for (int r = 0; r < seq_len; ++r) s = s + oracle_half_to_float(seq[(int64_t)r * d + k]);
+    q[k] = count ? s / (float)count : 0.0f;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* scorers                                                                   */
+static inline float prelu(float x, float a) {
+  const float pos = x > 0.0f ? x : 0.0f;
+  const float neg = x < 0.0f ? x : 0.0f;
+  return pos + a * neg;
+}
+
+static int is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static float score_l2_row(const float* q, const void* row, int dtype, int d) {
+  float p[64], t2[64];
+  const int L = d / 8;
+  for (int l = 0; l < L; ++l) {
+    float acc = 0.0f;
+    for (int k = 0; k < 8; ++k) {
+      const float t = q[8 * l + k] - load_elem(row, dtype, 8 * l + k);
+      acc = fmaf(t, t, acc);
+    }
+    p[l] = acc;
+  }
+  for (int s = 1; s < L; s <<= 1) {
+    for (int l = 0; l < L; ++l) t2[l] = p[l] + p[l ^ s];
+    memcpy(p, t2, sizeof(float) * (size_t)L);
+  }
+  return 0.0f - p[0];
+}
+
+/* per-query part of the MLP: u[j] = b1[j] + sum_k q[k] W1[k][j] */
+static void mlp_query_part(const oracle_scorer_t* sc, const float* q, float* u) {
+  for (int j = 0; j < sc->h1; ++j) {
+    float acc = sc->b1[j];
+    for (int k = 0; k < sc->d; ++k) acc = fmaf(q[k], sc->w1[(int64_t)k * sc->h1 + j], acc);
+    u[j] = acc;
+  }
+}
+
+static float score_mlp_row(const oracle_scorer_t* sc, const float* u, const void* row,
+                           float* h1, float* h2) {
+  const int d = sc->d, H1 = sc->h1, H2 = sc->h2;
+  float e[512];
+  for (int k = 0; k < d; ++k) e[k] = load_elem(row, sc->emb_dtype, k);
+  for (int j = 0; j < H1; ++j) {
+    float acc = u[j];
+    for (int kk = 0; kk < d / 2; ++kk) { /* ORDER_E */
+      acc = fmaf(e[kk], sc->w1[(int64_t)(d + kk) * H1 + j], acc);
+      acc = fmaf(e[d / 2 + kk], sc->w1[(int64_t)(d + d / 2 + kk) * H1 + j], acc);
+    }
+    h1[j] = prelu(acc, sc->alpha1[j]);
+  }
+  for (int m = 0; m < H2; ++m) {
+    float acc = sc->b2[m];
+    for (int t = 0; t < H1 / 32; ++t)
+      for (int r = 0; r < 16; ++r) { /* ORDER_H */
+        const int k0 = 32 * t + (r & 3) + 8 * (r >> 2);
+        acc = fmaf(h1[k0], sc->w2[(int64_t)k0 * H2 + m], acc);
+        acc = fmaf(h1[k0 + 4], sc->w2[(int64_t)(k0 + 4) * H2 + m], acc);
+      }
+    h2[m] = prelu(acc, sc->alpha2[m]);
+  }
+  float p[2];
+  for (int s = 0; s < 2; ++s) {
+    float acc = 0.0f;
+    for (int t = 0; t < H2 / 32; ++t)
+      for (int r = 0; r < 16; ++r) { /* ORDER_O */
+        const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * s;
+        acc = fmaf(h2[m], sc->w3[m], acc);
+      }
+    p[s] = acc;
+  }
+  return p[0] + p[1];
+}
+
+static int scorer_ok(const oracle_scorer_t* sc) {
+  if (sc->d <= 0 || sc->d % 8 || sc->d > 512 || !is_pow2(sc->d / 8)) return 0;
+  if (sc->kind == ORACLE_SCORER_MLP) {
+    if (sc->h1 <= 0 || sc->h1 % 32 || sc->h2 <= 0 || sc->h2 % 32) return 0;
+    if (sc->h1 > 1024 || sc->h2 > 1024 || sc->d % 2) return 0;
+  }
+  return 1;
+}
+
+int oracle_score_rows(const oracle_scorer_t* sc, const float* q, const void* rows,
+                      int64_t n, float* out) {
+  if (!scorer_ok(sc)) return ORACLE_ERR_BAD_ARGUMENT;
+  if (n <= 0) return ORACLE_ERR_EMPTY_SCORE_BATCH; /* blaze_xla_predictor.cc:259-263 */
+  const int64_t rb = (int64_t)sc->d * elem_bytes(sc->emb_dtype);
+  if (sc->kind == ORACLE_SCORER_L2) {
+    for (int64_t i = 0; i < n; ++i)
+      out[i] = score_l2_row(q, (const char*)rows + i * rb, sc->emb_dtype, sc->d);
+    return ORACLE_OK;
+  }
+  float u[1024], h1[1024], h2[1024];
+  mlp_query_part(sc, q, u);
+  for (int64_t i = 0; i < n; ++i)
+    out[i] = score_mlp_row(sc, u, (const char*)rows + i * rb, h1, h2);
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* the traversal schedule: build_opt_graph.py:109-149     */
+typedef struct {
+  int32_t* ids; float* scores; int64_t cap;
+} buf_t;
+
+static int ensure(buf_t* b, int64_t n) {
+  if (n <= b->cap) return 1;
+  int64_t c = b->cap ? b->cap : 1024;
+  while (c < n) c *= 2;
+  int32_t* ni = (int32_t*)realloc(b->ids, (size_t)c * sizeof(int32_t));
+  if (!ni) return 0;
+  b->ids = ni;
+  float* ns = (float*)realloc(b->scores, (size_t)c * sizeof(float));
+  if (!ns) return 0;
+  b->scores = ns;
+  b->cap = c;
+  return 1;
+}
+
+/* forward(): GatherV2 + BlazeXlaOp + Squeeze, build_opt_graph.py:91-107 */
+static int forward(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                   const int32_t* ids, int64_t n, float* scores, char** tmp,
+                   int64_t* tmp_cap) {
+  if (n <= 0) return ORACLE_ERR_EMPTY_SCORE_BATCH;
+  const int64_t rb = (int64_t)ix->d * elem_bytes(ix->emb_dtype);
+  if (n * rb > *tmp_cap) {
+    char* t = (char*)realloc(*tmp, (size_t)(n * rb));
+    if (!t) return ORACLE_ERR_BAD_ARGUMENT;
+    *tmp = t;
+    *tmp_cap = n * rb;
+  }
+  int rc = oracle_gather_rows(ix->item_embs, ix->n_items, rb, ids, n, *tmp, NULL);
+  if (rc) return rc;
+  rc = oracle_score_rows(sc, q, *tmp, n, scores);
+  if (rc) return rc;
+  /* tf.squeeze of a [1,1] logits tensor yields a scalar: TopKV2 (:63-65) and
+   * ConcatV2 then reject it */
+  if (n == 1) return ORACLE_ERR_TOPK_SCALAR_INPUT;
+  return ORACLE_OK;
+}
+
+/* top_k(): TopKV2 + Gather(ids, indices), build_opt_graph.py:52-66 */
+static int topk_ids(const int32_t* ids, const float* scores, int64_t n, int32_t k,
+                    int32_t* out_ids, float* out_scores, int32_t* tmp_idx) {
+  const int rc = oracle_topk_f32(scores, n, k, out_scores, tmp_idx);
+  if (rc) return rc;
+  for (int32_t i = 0; i < k; ++i) out_ids[i] = ids[tmp_idx[i]];
+  return ORACLE_OK;
+}
+
+int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                  const int32_t t[6], int64_t* out_item_ids, float* out_scores,
+                  int32_t* out_index, oracle_counters_t* ctr) {
+  if (!ix || !sc || !scorer_ok(sc) || sc->d != ix->d || sc->emb_dtype != ix->emb_dtype)
+    return ORACLE_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < 6; ++i)
+    if (t[i] < 0) return ORACLE_ERR_BAD_ARGUMENT;
+  oracle_counters_t c;
+  memset(&c, 0, sizeof c);
+  int rc = ORACLE_OK;
+  const int64_t n_words = (ix->n_items + 31) / 32; /* build_opt_graph.py:114 */
+  int32_t* bm = (int32_t*)malloc((size_t)(n_words > 0 ? n_words : 1) * 4);
+  buf_t cand = {0, 0, 0}, pool = {0, 0, 0}, beam = {0, 0, 0};
+  char* tmp = NULL;
+  int64_t tmp_cap = 0;
+  int32_t* tmp_idx = NULL;
+  int32_t* raw = NULL;
+  int64_t raw_cap = 0;
+  int64_t rs2[2], ors[2], n_out, n_os;
+
+#define FAIL(code) do { rc = (code); goto done; } while (0)
+#define CHECK(expr) do { rc = (expr); if (rc) goto done; } while (0)
+
+  /* ---- level 2 (entry layer): lines :111-112 ---- */
+  const int64_t E = ix->n_enter;
+  if (!ensure(&cand, E + 1) || !bm) FAIL(ORACLE_ERR_BAD_ARGUMENT);
+  c.scored[0] = E;
+  CHECK(forward(ix, sc, q, ix->enter_points, E, cand.scores, &tmp, &tmp_cap));
+  {
+    int64_t maxk = E;
+    for (int i = 0; i < 6; ++i) if (t[i] > maxk) maxk = t[i];
+    const int64_t poolcap = (int64_t)t[1] + t[2] + t[3] + t[4] + 1;
+    if (poolcap > maxk) maxk = poolcap;
+    tmp_idx = (int32_t*)malloc((size_t)(maxk + 1) * 4);
+    if (!tmp_idx || !ensure(&beam, maxk + 1) || !ensure(&pool, poolcap))
+      FAIL(ORACLE_ERR_BAD_ARGUMENT);
+  }
+  /* R, sR = topk(EP, s, t0) */
+  CHECK(topk_ids(ix->enter_points, cand.scores, E, t[0], beam.ids, beam.scores, tmp_idx));
+  int64_t nR = t[0];
+
+  /* ---- level 1: lines :114-127 ---- */
+  {
+    /* C = ragged_gather(NB1, R)  :116 */
+    int64_t irs[2] = {0, nR};
+    int64_t* iv = (int64_t*)malloc((size_t)(nR ? nR : 1) * 8);
+    if (!iv) FAIL(ORACLE_ERR_BAD_ARGUMENT);
+    for (int64_t i = 0; i < nR; ++i) iv[i] = beam.ids[i];
+    rc = oracle_group_gather_i32(ix->nb_values[1], ix->nb_nnz[1], ix->nb_row_splits[1],
+                                 ix->n_items + 1, iv, nR, irs, 2, NULL, 0, ors, &n_out,
+                                 &n_os, NULL);
+    if (!rc) {
+      if (n_out > raw_cap) {
+        free(raw);
+        raw = (int32_t*)malloc((size_t)(n_out ? n_out : 1) * 4);
+        raw_cap = n_out;
+      }
+      rc = oracle_group_gather_i32(ix->nb_values[1], ix->nb_nnz[1], ix->nb_row_splits[1],
+                                   ix->n_items + 1, iv, nR, irs, 2, raw, raw_cap, ors,
+                                   &n_out, &n_os, NULL);
+    }
+    free(iv);
+    if (rc) goto done;
+    const int64_t nG = n_out;
+    c.frontier[1] = nR;
+    c.gathered[1] = nG;
+    /* flags = zeros  :115-118 */
+    memset(bm, 0, (size_t)n_words * 4);
+    /* R = diff(R, bm)  :119-120 -- marks the entry winners */
+    if (!ensure(&cand, nR + nG + 1)) FAIL(ORACLE_ERR_BAD_ARGUMENT);
+    rs2[0] = 0; rs2[1] = nR;
+    CHECK(oracle_bitmap_ref_difference_i32(beam.ids, nR, rs2, 2, bm, n_words, cand.ids, ors,
+                                           &n_out, &n_os, NULL));
+    if (n_out != nR) FAIL(ORACLE_ERR_BAD_ARGUMENT); /* duplicate enter points: the
+        reference graph would concat ids and scores of different lengths */
+    memcpy(cand.scores, beam.scores, (size_t)nR * 4);
+    /* C = diff(C, bm)  :121-122 */
+    rs2[1] = nG;
+    CHECK(oracle_bitmap_ref_difference_i32(raw, nG, rs2, 2, bm, n_words, cand.ids + nR, ors,
+                                           &n_out, &n_os, NULL));
+    const int64_t nC = n_out;
+    c.scored[1] = nC;
+    /* sC = forward(C)  :124 */
+    CHECK(forward(ix, sc, q, cand.ids + nR, nC, cand.scores + nR, &tmp, &tmp_cap));
+    /* P, sP = topk(R || C, sR || sC, t1)  :125-127 */
+    CHECK(topk_ids(cand.ids, cand.scores, nR + nC, t[1], pool.ids, pool.scores, tmp_idx));
+  }
+  int64_t nP = t[1];
+
+  /* ---- level 0: lines :129-141 ---- */
+  memset(bm, 0, (size_t)n_words * 4); /* re-Assign zeros :131 */
+  rs2[0] = 0; rs2[1] = nP;
+  CHECK(oracle_bitmap_ref_difference_i32(pool.ids, nP, rs2, 2, bm, n_words, beam.ids, ors,
+                                         &n_out, &n_os, NULL)); /* :132-133 */
+  int64_t nB = n_out;
+  for (int i = 0; i < 3; ++i) {
+    int64_t irs[2] = {0, nB};
+    int64_t* iv = (int64_t*)malloc((size_t)(nB ? nB : 1) * 8);
+    if (!iv) FAIL(ORACLE_ERR_BAD_ARGUMENT);
+    for (int64_t j = 0; j < nB; ++j) iv[j] = beam.ids[j];
+    rc = oracle_group_gather_i32(ix->nb_values[0], ix->nb_nnz[0], ix->nb_row_splits[0],
+                                 ix->n_items + 1, iv, nB, irs, 2, NULL, 0, ors, &n_out,
+                                 &n_os, NULL);
+    if (!rc) {
+      if (n_out > raw_cap) {
+        free(raw);
+        raw = (int32_t*)malloc((size_t)(n_out ? n_out : 1) * 4);
+        raw_cap = n_out;
+      }
+      rc = oracle_group_gather_i32(ix->nb_values[0], ix->nb_nnz[0], ix->nb_row_splits[0],
+                                   ix->n_items + 1, iv, nB, irs, 2, raw, raw_cap, ors,
+                                   &n_out, &n_os, NULL); /* :136 */
+    }
+    free(iv);
+    if (rc) goto done;
+    const int64_t nG = n_out;
+    c.frontier[2 + i] = nB;
+    c.gathered[2 + i] = nG;
+    if (!ensure(&cand, nG + 1)) FAIL(ORACLE_ERR_BAD_ARGUMENT);
+    rs2[1] = nG;
+    CHECK(oracle_bitmap_ref_difference_i32(raw, nG, rs2, 2, bm, n_words, cand.ids, ors,
+                                           &n_out, &n_os, NULL)); /* :137 */
+    const int64_t nC = n_out;
+    c.scored[2 + i] = nC;
+    CHECK(forward(ix, sc, q, cand.ids, nC, cand.scores, &tmp, &tmp_cap)); /* :138 */
+    /* B, sB = topk(C, sC, t[2+i]) -- beam = best NEW nodes only  :139 */
+    CHECK(topk_ids(cand.ids, cand.scores, nC, t[2 + i], beam.ids, beam.scores, tmp_idx));
+    nB = t[2 + i];
+    memcpy(pool.ids + nP, beam.ids, (size_t)nB * 4);       /* :140 */
+    memcpy(pool.scores + nP, beam.scores, (size_t)nB * 4); /* :141 */
+    nP += nB;
+  }
+  /* ---- final: lines :143-149 ---- */
+  CHECK(oracle_topk_f32(pool.scores, nP, t[5], out_scores, tmp_idx));
+  for (int32_t i = 0; i < t[5]; ++i) {
+    const int32_t ii = pool.ids[tmp_idx[i]];
+    if (out_index) out_index[i] = ii;
+    out_item_ids[i] = ix->item_ids[ii]; /* Gather(item_ids, P) :144 */
+  }
+done:
+  if (ctr) *ctr = c;
+  free(bm); free(cand.ids); free(cand.scores); free(pool.ids); free(pool.scores);
+  free(beam.ids); free(beam.scores); free(tmp); free(tmp_idx); free(raw);
+  return rc;
+#undef FAIL
+#undef CHECK
+}
+
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const oracle_index_t* ix; const oracle_scorer_t* sc; const float* q;
+  int64_t nq; const int32_t* t; int64_t* ids; float* scores; int32_t* index;
+  oracle_counters_t* ctr; int32_t* status; int64_t next; pthread_mutex_t mu;
+} batch_t;
+
+static void* batch_worker(void* arg) {
+  batch_t* b = (batch_t*)arg;
+  const int32_t k = b->t[5];
+  for (;;) {
+    pthread_mutex_lock(&b->mu);
+    const int64_t i = b->next++;
+    pthread_mutex_unlock(&b->mu);
+    if (i >= b->nq) break;
+    b->status[i] = oracle_search(b->ix, b->sc, b->q + i * b->ix->d, b->t, b->ids + i * k,
+                                 b->scores + i * k, b->index ? b->index + i * k : NULL,
+                                 b->ctr ? b->ctr + i : NULL);
+  }
+  return NULL;
+}
+
+int oracle_search_batch(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                        int64_t nq, const int32_t t[6], int64_t* ids, float* scores,
+                        int32_t* index, oracle_counters_t* ctr, int32_t* status,
+                        int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  batch_t b = {ix, sc, q, nq, t, ids, scores, index, ctr, status, 0, PTHREAD_MUTEX_INITIALIZER};
+  pthread_t th[256];
+  int started = 0;
+  for (int i = 1; i < n_threads; ++i)
+    if (pthread_create(&th[started], NULL, batch_worker, &b) == 0) ++started;
+  batch_worker(&b);
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  return ORACLE_OK;
+}
+
+int oracle_brute_force(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                       int32_t k, int32_t* out_index, float* out_scores) {
+  if (!scorer_ok(sc)) return ORACLE_ERR_BAD_ARGUMENT;
+  float* s = (float*)malloc((size_t)(ix->n_items ? ix->n_items : 1) * 4);
+  if (!s) return ORACLE_ERR_BAD_ARGUMENT;
+  int rc = oracle_score_rows(sc, q, ix->item_embs, ix->n_items, s);
+  if (!rc) rc = oracle_topk_f32(s, ix->n_items, k, out_scores, out_index);
+  free(s);
+  return rc;
+}
+
+int oracle_merge_topk(const float* scores, const int64_t* ids, int n_shards, int32_t k_in,
+                      int32_t k_out, float* out_scores, int64_t* out_ids) {
+  const int64_t n = (int64_t)n_shards * k_in;
+  int32_t* idx = (int32_t*)malloc((size_t)(k_out ? k_out : 1) * 4);
+  if (!idx) return ORACLE_ERR_BAD_ARGUMENT;
+  const int rc = oracle_topk_f32(scores, n, k_out, out_scores, idx);
+  if (!rc)
+    for (int32_t i = 0; i < k_out; ++i) out_ids[i] = ids[idx[i]];
+  free(idx);
+  return rc;
+}

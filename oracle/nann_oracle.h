@@ -1,0 +1,185 @@
+/*
+ * nann_oracle.h -- CPU restatement of the NANN HNSW-with-model-scoring retrieval
+ * hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  It is the checker, never the product: nothing under
+ * nann_amd/ imports, links or calls it, and the product path fails loudly
+ * when the HIP extension is missing.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - oracle_group_gather / oracle_bitmap_ref_difference: PINNED against the
+ *     reference's own test inputs (group_gather_test.py:18-26,
+ *     bitmap_ref_difference.py:16-29) with the outputs the reference kernels
+ *     produced for them, committed in tests/golden/.
+ *   - oracle_topk / oracle_gather_rows / oracle_search: restated from
+ *     topk_op.cc:104-205, gather_functor.h:38-116 and
+ *     build_opt_graph.py:69-149.  The reference holds no expected outputs
+ *     for these (its tests are print-only) -> "parity unpinned" beyond the
+ *     algorithm text; the total order (value desc, index asc) fully
+ *     determines TopKV2's result.
+ *   - scorers: the BASELINE scorers (L2, 3-layer MLP) behind the BlazeXlaOp
+ *     contract (rows scored independently, f32 logits); the reference's own
+ *     trained model has no checkpoint in the tree -> unpinned by construction.
+ *
+ * All file:line citations are relative to /root/reference/.
+ * UO/ = tensorflow/tensorflow/core/user_ops/.
+ */
+#ifndef NANN_ORACLE_H_
+#define NANN_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (shared numbering with include/nann_hip.h) */
+enum {
+  ORACLE_OK = 0,
+  ORACLE_ERR_INVALID_RAGGED_PARAMS = 1,  /* GroupGather_kernel.cc:62-64  */
+  ORACLE_ERR_INVALID_RAGGED_INDICES = 2, /* GroupGather_kernel.cc:65-67  */
+  ORACLE_ERR_INVALID_RAGGED_INPUT = 3,   /* bitmap_ops.cc:182-184        */
+  ORACLE_ERR_TOPK_K_GT_N = 4,            /* topk_op.cc:67-71             */
+  ORACLE_ERR_INDEX_OUT_OF_RANGE = 5,     /* gather_op.cc:173 (and the bounds
+                                            checks the reference omits)  */
+  ORACLE_ERR_EMPTY_SCORE_BATCH = 6,      /* blaze_xla_predictor.cc:259-263 */
+  ORACLE_ERR_BAD_ARGUMENT = 7,
+  ORACLE_ERR_TOPK_SCALAR_INPUT = 8       /* topk_op.cc:63-65 after Squeeze of
+                                            a single candidate            */
+};
+
+enum { ORACLE_EMB_F16 = 0, ORACLE_EMB_BF16 = 1, ORACLE_EMB_F32 = 2 };
+enum { ORACLE_SCORER_L2 = 0, ORACLE_SCORER_MLP = 1 };
+
+/* ragged validation, GroupGather_kernel.cc:9-16 / bitmap_ops.cc:12-19:
+ * returns 0 or the reference's code 1/2/3. */
+int oracle_validate_ragged(int64_t n_values, const int64_t* row_splits,
+                           int64_t n_splits);
+
+/* GroupGather<int32>, unique=false path (GroupGather_kernel.cc:55-173).
+ * out_values may be NULL to query *n_out only.  out_row_splits has
+ * n_indices_splits entries (or 1 entry on the void-input path).
+ * *n_out_splits receives the number of row_splits written. */
+int oracle_group_gather_i32(const int32_t* params_values, int64_t n_params_values,
+                            const int64_t* params_row_splits, int64_t n_params_splits,
+                            const int64_t* indices_values, int64_t n_indices_values,
+                            const int64_t* indices_row_splits, int64_t n_indices_splits,
+                            int32_t* out_values, int64_t out_cap,
+                            int64_t* out_row_splits, int64_t* n_out,
+                            int64_t* n_out_splits, int* ragged_code);
+
+/* BitmapRefDifference<int32> (bitmap_ops.cc:175-257).  bitmap is mutated in
+ * place (Ref semantics).  n_bitmap_words is used for the bounds check the
+ * reference omits (Appendix C) -> ORACLE_ERR_INDEX_OUT_OF_RANGE. */
+int oracle_bitmap_ref_difference_i32(const int32_t* values, int64_t n_values,
+                                     const int64_t* row_splits, int64_t n_splits,
+                                     int32_t* bitmap, int64_t n_bitmap_words,
+                                     int32_t* out_values, int64_t* out_row_splits,
+                                     int64_t* n_out, int64_t* n_out_splits,
+                                     int* ragged_code);
+
+/* GatherV2 axis 0 (gather_functor.h:38-116): out[i,:] = params[idx[i],:].
+ * row_bytes = slice bytes.  bad index -> ORACLE_ERR_INDEX_OUT_OF_RANGE and
+ * *bad_i = first bad position (gather_op.cc:170-175). */
+int oracle_gather_rows(const void* params, int64_t n_rows, int64_t row_bytes,
+                       const int32_t* idx, int64_t n_idx, void* out,
+                       int64_t* bad_i);
+
+/* TopKV2 sorted=true (topk_op.cc:104-205): values descending, ties broken by
+ * lower input index.  n < k -> ORACLE_ERR_TOPK_K_GT_N. */
+int oracle_topk_f32(const float* values, int64_t n, int32_t k,
+                    float* out_values, int32_t* out_indices);
+
+/* exact conversions used by every scorer */
+float oracle_half_to_float(uint16_t h);
+float oracle_bf16_to_float(uint16_t h);
+uint16_t oracle_float_to_half(float f); /* round-to-nearest-even */
+
+/* user sequence -> query vector (mean of non-pad rows, f32).
+ * seq: f16[seq_len, d]; a row is "pad" iff all its elements are zero.
+ * q[k] = (sum_r seq[r][k], r ascending, plain f32 adds) / count. */
+void oracle_user_seq_mean(const uint16_t* seq_f16, int seq_len, int d, float* q);
+
+typedef struct {
+  int kind;          /* ORACLE_SCORER_* */
+  int d;             /* embedding dim */
+  int emb_dtype;     /* ORACLE_EMB_* of item rows */
+  /* MLP only: x=[q;e] in R^{2d} -> H1 -> PReLU -> H2 -> PReLU -> 1 (no bias)
+   * (model.py:218-219 last layer bias-free; model_util.py:9-11
+   * PReLU = max(0,x)+alpha*min(0,x), per-channel alpha) */
+  int h1, h2;
+  const float* w1;     /* [2d, h1] row-major */
+  const float* b1;     /* [h1] */
+  const float* alpha1; /* [h1] */
+  const float* w2;     /* [h1, h2] row-major */
+  const float* b2;     /* [h2] */
+  const float* alpha2; /* [h2] */
+  const float* w3;     /* [h2] */
+} oracle_scorer_t;
+
+/* Score n item rows (already gathered, contiguous [n, d] in emb_dtype)
+ * against one query vector q f32[d]: the BlazeXlaOp contract
+ * (blaze_xla_predictor.cc:360-459: pad -> rows scored independently ->
+ * slice; f32 logits).  n == 0 -> ORACLE_ERR_EMPTY_SCORE_BATCH.
+ * Canonical summation orders are documented in nann_oracle.c and DESIGN.md;
+ * the HIP kernels use the same orders so L2 scores are bit-identical. */
+int oracle_score_rows(const oracle_scorer_t* sc, const float* q,
+                      const void* rows, int64_t n, float* out_scores);
+
+typedef struct {
+  int64_t n_items;
+  int d;
+  int emb_dtype;
+  const void* item_embs;      /* [n_items, d] */
+  const int64_t* item_ids;    /* [n_items] */
+  /* level 0 and level 1 adjacency in the reference's on-disk layout
+   * (build_hnsw_index.py:49-66): values int32, row_splits int64[n_items+1] */
+  const int32_t* nb_values[2];
+  const int64_t* nb_row_splits[2];
+  int64_t nb_nnz[2];
+  const int32_t* enter_points; /* [n_enter] ascending internal indices */
+  int64_t n_enter;
+} oracle_index_t;
+
+#define ORACLE_NUM_ROUNDS 5 /* entry, level-1, level-0 x3 */
+typedef struct {
+  int64_t frontier[ORACLE_NUM_ROUNDS]; /* F_r: rows walked          */
+  int64_t gathered[ORACLE_NUM_ROUNDS]; /* G_r: neighbours gathered  */
+  int64_t scored[ORACLE_NUM_ROUNDS];   /* S_r: unique rows scored   */
+} oracle_counters_t;
+
+/* The traversal schedule of build_opt_graph.py:109-149
+ * for one query.  out_* have level_topn[5] entries.  out_index = internal
+ * indices before the item_ids gather (not a reference output; for tests). */
+int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc,
+                  const float* q, const int32_t level_topn[6],
+                  int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                  oracle_counters_t* ctr);
+
+/* n_queries independent searches, one query per thread (mirrors the
+ * reference's sessions x threads concurrency, gen_benchmark_conf.py:22-30).
+ * status[i] per query.  Returns ORACLE_OK if the batch ran. */
+int oracle_search_batch(const oracle_index_t* ix, const oracle_scorer_t* sc,
+                        const float* q /*[n_queries,d]*/, int64_t n_queries,
+                        const int32_t level_topn[6], int64_t* out_item_ids,
+                        float* out_scores, int32_t* out_index,
+                        oracle_counters_t* ctr /*[n_queries] or NULL*/,
+                        int32_t* status, int n_threads);
+
+/* brute force: score all items, TopKV2 top-k (recall ground truth; mirrors
+ * test_all, main.py:194-237). */
+int oracle_brute_force(const oracle_index_t* ix, const oracle_scorer_t* sc,
+                       const float* q, int32_t k, int32_t* out_index,
+                       float* out_scores);
+
+/* merge per-shard top-k lists: concat in shard order then TopKV2 semantics
+ * (SURVEY.md 8e).  scores/ids: [n_shards, k_in]. */
+int oracle_merge_topk(const float* scores, const int64_t* ids, int n_shards,
+                      int32_t k_in, int32_t k_out, float* out_scores,
+                      int64_t* out_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANN_ORACLE_H_ */
