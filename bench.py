@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- retrieval QPS of the fused HNSW-with-model-scoring traversal on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic UserBehavior-shaped
+queries: comm_seq -> query vectors -> layered traversal (neighbour gather, visited-bitmap
+dedup, embedding gather + L2 scoring, top-k) -> top-200 item ids.  Inputs are resident
+in HBM when the timed region starts.
+
+Workload (BASELINE.json configs[1]): 1M items x 128-d f16, M=32, ef_search=128
+(level_topn = [128]*5 + [200]), L2 scoring, on each GPU.  With N > 1 ranks the corpus
+is N shards of 1M items (configs[3] shape: item-id sharding); every rank searches every
+query on its shard, per-shard top-200 lists are all-gathered over RCCL and merged.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the traversal kernel's ALGORITHMIC
+bytes (BASELINE.md section 4 formula over the kernel's own per-round counters, which the
+parity tests pin to the oracle's) against 8 TB/s HBM; `cpu_baseline` is the oracle
+(oracle/nann_oracle.c, a port of the reference's CPU op loops) timed on this box's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--items", type=int, default=1_000_000, help="items per GPU")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--topk", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=4096, help="queries per step")
+    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "knn"])
+    ap.add_argument("--noise", type=float, default=1.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--merge", default="device", choices=["device", "host"])
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from nann_amd import ops, retrieval, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    topn = [args.ef] * 5 + [args.topk]
+    t0 = time.time()
+    g = synth.make_index(args.items, args.dim, ef=args.ef, mode=args.graph, noise=args.noise,
+                         device=str(dev), shard=rank)
+    index = retrieval.Index.from_dict(g, device=dev)
+    scorer = ops.Scorer("l2", args.dim)
+    seq_host = synth.make_queries_from_centres(args.dim, args.batch, noise=args.noise)
+    comm_seq = torch.as_tensor(seq_host).to(dev)
+    setup_s = time.time() - t0
+
+    sharded = shard.ShardedSearch(index, scorer, topn, world, merge=args.merge) if world > 1 else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i=None):
+        q = ops.user_seq_mean(comm_seq)
+        if i is not None:
+            ev[i][0].record()
+        r = retrieval.search(index, scorer, q, topn, want_counters=True)
+        if i is not None:
+            ev[i][1].record()
+        if sharded is not None:
+            return sharded.merge(r), r
+        return (r.item_ids, r.scores), r
+
+    for _ in range(args.warmup):
+        out, r = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        out, r = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the traversal kernel (rank-local launch, HIP events on its stream)
+    from oracle import oracle as O  # checker / baseline only
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    status = r.status.cpu().numpy()
+    counters = r.counters.cpu().numpy().astype(np.int64)
+    n_valid = int((status == 0).sum())
+    bytes_per_launch = float(O.algorithmic_bytes(counters, args.dim, 2, len(g["enter_points"]),
+                                                 args.topk).sum())
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel_ms": round(kern_ms, 4),
+                "algorithmic_bytes_per_query": round(bytes_per_launch / args.batch, 1),
+                "rows_scored_per_query": round(float(counters[:, 2, :].sum(1).mean()), 1)}
+
+    # ---- whole-job throughput: every rank searched every query on its 1M-item shard
+    qps = args.batch * args.steps / elapsed
+    value = qps * world
+    result = {
+        "metric": "retrieval QPS @ recall@200 parity, 1M items/128-d",
+        "value": round(value, 1), "unit": "queries/s x 1M-item shards searched",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 rows / f32 L2",
+        "data": "synthetic",
+        "config": {"workload": f"{args.items} items/GPU x {args.dim}-d f16, M=32 {args.graph} graph, "
+                               f"ef_search={args.ef}, top-{args.topk}, L2 scoring (BASELINE configs[1]"
+                               + (", sharded as configs[3]" if world > 1 else "") + ")",
+                   "level_topn": topn, "batch": args.batch, "items_total": args.items * world,
+                   "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
+                   "merge": args.merge if world > 1 else None},
+        "qps_end_to_end": round(qps, 1), "valid_queries": n_valid, "setup_s": round(setup_s, 1),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1:
+        oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+        osc = O.Scorer("l2", args.dim, O.EMB_F16)
+        qh = ops.user_seq_mean(comm_seq).cpu().numpy()
+        cores = os.cpu_count() or 1
+        if not args.no_cpu_baseline:
+            # bounded sample: grow the chunk until the time budget is used
+            n_done, t_cpu, chunk = 0, 0.0, min(args.batch, 4 * cores)
+            first = None
+            while t_cpu < args.cpu_seconds and n_done < 50 * args.batch:
+                sel = np.arange(n_done, n_done + chunk) % args.batch
+                t1 = time.perf_counter()
+                res = O.search_batch(oix, osc, qh[sel], topn, n_threads=cores)
+                t_cpu += time.perf_counter() - t1
+                if first is None:
+                    first = (sel, res)
+                n_done += chunk
+                chunk = min(args.batch, chunk * 2)
+            result["cpu_baseline"] = {"value": round(n_done / t_cpu, 1), "unit": "queries/s", "cores": cores,
+                                      "kind": "port",
+                                      "sample": f"{n_done} queries of the same batch, one query per thread, "
+                                                f"{t_cpu:.1f} s"}
+            # parity on the first CPU chunk: identical ids/scores => identical recall
+            sel, (st, ids, scores, idx, ctr) = first
+            gi = out[0].cpu().numpy()[sel]
+            gs = out[1].cpu().numpy()[sel]
+            ok = st == 0
+            result["parity"] = {"queries_checked": int(len(sel)),
+                                "status_equal": bool((status[sel] == st).all()),
+                                "ids_equal": bool((gi[ok] == ids[ok]).all()),
+                                "scores_bitwise_equal": bool((gs[ok].view(np.uint32) == scores[ok].view(np.uint32)).all())}
+        # recall@k of the traversal vs brute force under the same scorer (test_all, main.py:194-237)
+        hits, nrec = 0, 0
+        gidx = r.index.cpu().numpy()
+        for b in range(min(16, args.batch)):
+            if status[b]:
+                continue
+            rc, bi, _ = O.brute_force(oix, osc, qh[b], args.topk)
+            hits += len(set(bi.tolist()) & set(gidx[b].tolist()))
+            nrec += args.topk
+        result["recall_at_k_vs_bruteforce"] = round(hits / max(nrec, 1), 4)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+/*
+ * nann_hip.h -- C ABI of libnann_hip.so: the MI355X (gfx950) implementation of
+ * NANN's HNSW-with-model-scoring retrieval hot path.
+ *
+ * Every entry point replaces one piece of the reference's TensorFlow custom-op
+ * path (citations relative to /root/reference/,
+ * UO/ = tensorflow/tensorflow/core/user_ops/).  extern "C", POD arguments,
+ * int status returns, no exceptions/STL/torch types across the boundary.
+ * The op-kernel shims in nann_amd/tf_ops/ (REGISTER_OP / REGISTER_KERNEL_BUILDER
+ * with the reference's op names) and the Python mirror in nann_amd/ops.py are
+ * thin callers of this file.  INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Memory convention: unless a parameter is marked [host], data pointers are
+ * DEVICE pointers (HBM) valid on the library's current HIP device, and the
+ * call is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ * default stream).  Calls that return a data-dependent count synchronise the
+ * stream before returning (exactly where the reference must know the size to
+ * allocate_output: GroupGather_kernel.cc:147-148, bitmap_ops.cc:245).
+ * All entry points are thread-safe and re-entrant on shared immutable handles.
+ */
+#ifndef NANN_HIP_H_
+#define NANN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NANN_ABI_VERSION 1
+
+/* status codes; 1..8 share the oracle's numbering (oracle/nann_oracle.h) and
+ * map to the TF errors the reference raises at the cited lines */
+enum nann_status {
+  NANN_OK = 0,
+  NANN_ERR_INVALID_RAGGED_PARAMS = 1,  /* InvalidArgument, GroupGather_kernel.cc:62-64 */
+  NANN_ERR_INVALID_RAGGED_INDICES = 2, /* InvalidArgument, GroupGather_kernel.cc:65-67 */
+  NANN_ERR_INVALID_RAGGED_INPUT = 3,   /* InvalidArgument, bitmap_ops.cc:182-184 */
+  NANN_ERR_TOPK_K_GT_N = 4,            /* InvalidArgument, topk_op.cc:67-71 */
+  NANN_ERR_INDEX_OUT_OF_RANGE = 5,     /* InvalidArgument, gather_op.cc:170-175; also the
+                                          bounds checks the reference omits (UB there) */
+  NANN_ERR_EMPTY_SCORE_BATCH = 6,      /* blaze_xla_predictor.cc:259-263 */
+  NANN_ERR_BAD_ARGUMENT = 7,
+  NANN_ERR_TOPK_SCALAR_INPUT = 8,      /* topk_op.cc:63-65 after Squeeze of one candidate */
+  NANN_ERR_HIP = 100,                  /* a HIP runtime call failed (nann_last_error) */
+  NANN_ERR_NO_DEVICE = 101,
+  NANN_ERR_UNSUPPORTED = 102,
+  NANN_ERR_CAPACITY = 103,             /* caller-provided output too small; count returned */
+  NANN_ERR_IO = 104,                   /* HugeConst: file/npy header problems */
+  NANN_ERR_DTYPE_MISMATCH = 105,       /* HugeConst: huge_const_op.cc:117-147 */
+  NANN_ERR_SHAPE_MISMATCH = 106        /* HugeConst: huge_const_op.cc:111-115 */
+};
+
+enum nann_dtype { NANN_F16 = 0, NANN_BF16 = 1, NANN_F32 = 2, NANN_I32 = 3, NANN_I64 = 4,
+                  NANN_F64 = 5 };
+enum nann_scorer_kind { NANN_SCORER_L2 = 0, NANN_SCORER_MLP = 1 };
+
+typedef void* nann_stream_t; /* hipStream_t */
+
+int nann_abi_version(void);
+/* [host] NUL-terminated description of the calling thread's last failure */
+const char* nann_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU; never fails) */
+int nann_device_count(void);
+
+/* ---- device memory plumbing for hosts without torch (the TF shims) -------- */
+int nann_malloc(void** dev_ptr, int64_t nbytes);
+int nann_free(void* dev_ptr);
+/* kind: 0 host->device, 1 device->host, 2 device->device; async on stream */
+int nann_memcpy(void* dst, const void* src, int64_t nbytes, int kind, nann_stream_t stream);
+int nann_stream_synchronize(nann_stream_t stream);
+
+/* ---- a6: HugeConst (UO/huge_const_op/huge_const_op.cc:58-226) --------------
+ * Loads a .npy (format 1.0/2.0, C order) into HBM once; the GPU kernel of the
+ * reference op does the same one-time H2D copy (:187-218).  expect_dtype /
+ * expect_shape mirror the op's dtype/shape attrs and are validated against
+ * the header (:108-147).  path [host]; expect_shape [host]. */
+int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
+                         int expect_rank, void** dev_ptr, int64_t* nbytes);
+
+/* ---- a1: GroupGather<int32>, unique=false (UO/beam_search_op/
+ *          GroupGather_kernel.cc:55-173) -------------------------------------
+ * Step 1 (count): validates both ragged inputs (codes 1/2/3 in *ragged_code
+ * [host]), writes ret_row_splits (device, n_indices_splits entries, or [0] on
+ * the void-input path), returns the number of values in *n_ret [host] and the
+ * number of row_splits written in *n_ret_splits [host].
+ * Step 2 (fill): writes ret_values (device, n_ret entries).  scratch_offsets
+ * (device, int64[n_indices_values + 1]) carries the per-row output offsets
+ * from step 1 to step 2. */
+int nann_group_gather_count(const int64_t* params_row_splits, int64_t n_params_splits,
+                            int64_t n_params_values, const int64_t* indices_values,
+                            int64_t n_indices_values, const int64_t* indices_row_splits,
+                            int64_t n_indices_splits, int64_t* ret_row_splits,
+                            int64_t* scratch_offsets, int64_t* n_ret, int64_t* n_ret_splits,
+                            int32_t* ragged_code, nann_stream_t stream);
+int nann_group_gather_fill(const int32_t* params_values, const int64_t* params_row_splits,
+                           const int64_t* indices_values, int64_t n_indices_values,
+                           const int64_t* scratch_offsets, int32_t* ret_values,
+                           nann_stream_t stream);
+
+/* ---- a2: BitmapRefDifference<int32> (UO/bitmap_op/bitmap_ops.cc:175-257) ---
+ * Serial-scan semantics: first occurrence of every id whose bit is clear is
+ * kept, in input order, and its bit is set; ONE bitmap shared by all groups.
+ * idx_flag (device, int32[n_flag_words]) is mutated in place (Ref input).
+ * c_values (device) must hold n_values entries; c_row_splits n_splits entries.
+ * *n_out / *n_out_splits [host].  ids outside [0, 32*n_flag_words) ->
+ * NANN_ERR_INDEX_OUT_OF_RANGE with the bitmap untouched (UB in the reference). */
+int nann_bitmap_ref_difference(const int32_t* idx_next_values, int64_t n_values,
+                               const int64_t* idx_next_row_splits, int64_t n_splits,
+                               int32_t* idx_flag, int64_t n_flag_words, int32_t* c_values,
+                               int64_t* c_row_splits, int64_t* n_out, int64_t* n_out_splits,
+                               int32_t* ragged_code, nann_stream_t stream);
+
+/* ---- a3: GatherV2 axis 0 (core/kernels/gather_functor.h:38-116) ------------
+ * out[i,:] = params[indices[i],:]; row_bytes must be a multiple of 4.
+ * A bad index returns NANN_ERR_INDEX_OUT_OF_RANGE and its position in *bad_i
+ * [host] (gather_op.cc:170-175). */
+int nann_gather_rows(const void* params, int64_t n_rows, int64_t row_bytes,
+                     const int32_t* indices, int64_t n_indices, void* out, int64_t* bad_i,
+                     nann_stream_t stream);
+
+/* ---- a5: TopKV2 sorted=true (core/kernels/topk_op.cc:40-205) ---------------
+ * values f32[n_rows, n_cols] -> out_values f32[n_rows,k], out_indices
+ * i32[n_rows,k]; descending, ties -> lower index.  n_cols < k ->
+ * NANN_ERR_TOPK_K_GT_N (checked on the host, nothing launched). */
+int nann_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k,
+              float* out_values, int32_t* out_indices, nann_stream_t stream);
+
+/* ---- a4: the scorer behind the BlazeXlaOp contract (UO/blaze_op/
+ *          blaze_xla_kernel.cc:24-33, blaze_xla_predictor.cc:360-459) --------
+ * A scorer holds what the frozen scoring GraphDef holds in the reference.
+ * L2: s = -||q - x||^2.  MLP: x=[q;e] -> h1 -> PReLU -> h2 -> PReLU -> 1
+ * (weights f32; [host] pointers, copied to HBM at creation). */
+typedef struct nann_scorer nann_scorer;
+typedef struct {
+  int32_t kind;      /* nann_scorer_kind */
+  int32_t d;         /* embedding dim: 64, 128, 256 or 512 */
+  int32_t emb_dtype; /* NANN_F16 / NANN_BF16 / NANN_F32 of item rows */
+  int32_t h1, h2;    /* MLP only; multiples of 32 */
+  const float* w1;     /* [2d, h1] row-major */
+  const float* b1;     /* [h1] */
+  const float* alpha1; /* [h1] PReLU slope (model_util.py:9-11) */
+  const float* w2;     /* [h1, h2] */
+  const float* b2;     /* [h2] */
+  const float* alpha2; /* [h2] */
+  const float* w3;     /* [h2]; last layer has no bias (model.py:218-219) */
+} nann_scorer_desc;
+int nann_scorer_create(const nann_scorer_desc* desc /*[host]*/, nann_scorer** out);
+void nann_scorer_destroy(nann_scorer* s);
+
+/* comm_seq f16[n_queries, seq_len, d] -> q f32[n_queries, d]: mean over
+ * non-pad (not all-zero) rows; the user side of forward()
+ * (build_opt_graph.py:76-79, 91-107). */
+int nann_user_seq_mean(const void* comm_seq_f16, int64_t n_queries, int32_t seq_len, int32_t d,
+                       float* q, nann_stream_t stream);
+
+/* Score n rows against ONE query vector q f32[d] (rows are scored
+ * independently, f32 logits -- the contract PadToStatic/SliceToDynamic rely
+ * on).  indices == NULL: rows = item_emb[n, d] as BlazeXlaOp receives them
+ * (already gathered).  indices != NULL: fused GatherV2 + score over
+ * table[n_table_rows, d] (out-of-range -> NANN_ERR_INDEX_OUT_OF_RANGE,
+ * *bad_i [host]).  n == 0 -> NANN_ERR_EMPTY_SCORE_BATCH. */
+int nann_score(const nann_scorer* scorer, const float* q, const void* table,
+               int64_t n_table_rows, const int32_t* indices, int64_t n, float* out_scores,
+               int64_t* bad_i, nann_stream_t stream);
+
+/* ---- a6 + a7: resident index and the fused traversal -----------------------
+ * The index is what the serving graph's HugeConst nodes hold
+ * (build_opt_graph.py:83-90, 70): item_embs [N,d], item_ids i64[N], per level
+ * CSR (values i32, row_splits i64[N+1]) for levels 0 and 1, enter_points
+ * i32[E] (ascending, unique). */
+typedef struct nann_index nann_index;
+typedef struct {
+  int64_t n_items;
+  int32_t d;
+  int32_t emb_dtype;
+  const void* item_embs;
+  const int64_t* item_ids;
+  const int32_t* nb_values[2];
+  const int64_t* nb_row_splits[2];
+  int64_t nb_nnz[2];
+  const int32_t* enter_points;
+  int64_t n_enter;
+  int32_t on_device; /* 0: [host] pointers, copied to HBM once (HugeConst's one-time
+                        H2D); 1: device pointers, borrowed for the handle's lifetime */
+} nann_index_desc;
+int nann_index_create(const nann_index_desc* desc /*[host]*/, nann_index** out);
+void nann_index_destroy(nann_index* ix);
+/* [host] out: n_items, d, n_enter, max row length at level 0 / 1, bitmap words */
+int nann_index_info(const nann_index* ix, int64_t out[6]);
+
+#define NANN_NUM_ROUNDS 5
+/* Workspace bytes nann_search needs for (index, level_topn, n_queries). */
+int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6] /*[host]*/,
+                                int64_t n_queries, int64_t* nbytes);
+
+/* The whole schedule of build_model() (NANN_impls/nann/delivery/
+ * build_opt_graph.py:109-149) for n_queries independent
+ * queries, one persistent workgroup per query slot, visited bitmap in LDS.
+ *   q            f32[n_queries, d]      (nann_user_seq_mean of comm_seq)
+ *   level_topn   [host] i32[6]          (the `level_topn` feed)
+ *   workspace    device, nann_search_workspace_bytes(...) bytes
+ *   out_item_ids i64[n_queries, level_topn[5]]   ('top_k' fetch)
+ *   out_scores   f32[n_queries, level_topn[5]]   (not a reference output;
+ *                                                 for the 1e-5 check) or NULL
+ *   out_index    i32[n_queries, level_topn[5]]   internal indices or NULL
+ *   status       i32[n_queries]: per-query nann_status -- a query the
+ *                reference would fail (k > n, empty score batch, ...) gets
+ *                its code here and zeroed outputs
+ *   counters     i32[n_queries, 3, NANN_NUM_ROUNDS] (F_r, G_r, S_r per round:
+ *                rows walked, neighbours gathered, rows scored) or NULL
+ * Asynchronous on `stream`. */
+int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
+                int64_t n_queries, const int32_t level_topn[6], void* workspace,
+                int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
+                int32_t* out_index, int32_t* status, int32_t* counters, nann_stream_t stream);
+
+/* ---- 8(e): merge of per-shard top-k lists ----------------------------------
+ * scores f32[n_queries, n_shards, k_in], ids i64[n_queries, n_shards, k_in]
+ * (shard-major as all-gathered); concat in shard order, then TopKV2 order
+ * (score desc, ties -> lower shard then lower local rank).
+ * nann_merge_topk: device pointers; nann_merge_topk_host: [host] pointers. */
+int nann_merge_topk(const float* scores, const int64_t* ids, int64_t n_queries, int32_t n_shards,
+                    int32_t k_in, int32_t k_out, float* out_scores, int64_t* out_ids,
+                    nann_stream_t stream);
+int nann_merge_topk_host(const float* scores, const int64_t* ids, int64_t n_queries,
+                         int32_t n_shards, int32_t k_in, int32_t k_out, float* out_scores,
+                         int64_t* out_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANN_HIP_H_ */

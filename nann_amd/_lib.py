@@ -1,0 +1,79 @@
+"""ctypes view of libnann_hip.so (the C ABI in include/nann_hip.h).
+
+There is no fallback: if the HIP extension is missing this module raises, and
+every op in nann_amd goes through it.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+OK = 0
+STATUS_NAMES = {
+    0: "OK", 1: "INVALID_RAGGED_PARAMS", 2: "INVALID_RAGGED_INDICES", 3: "INVALID_RAGGED_INPUT",
+    4: "TOPK_K_GT_N", 5: "INDEX_OUT_OF_RANGE", 6: "EMPTY_SCORE_BATCH", 7: "BAD_ARGUMENT",
+    8: "TOPK_SCALAR_INPUT", 100: "HIP", 101: "NO_DEVICE", 102: "UNSUPPORTED", 103: "CAPACITY",
+    104: "IO", 105: "DTYPE_MISMATCH", 106: "SHAPE_MISMATCH",
+}
+F16, BF16, F32, I32, I64, F64 = 0, 1, 2, 3, 4, 5
+SCORER_L2, SCORER_MLP = 0, 1
+NUM_ROUNDS = 5
+
+# every symbol include/nann_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "nann_abi_version", "nann_last_error", "nann_device_count", "nann_malloc", "nann_free",
+    "nann_memcpy", "nann_stream_synchronize", "nann_huge_const_load", "nann_group_gather_count",
+    "nann_group_gather_fill", "nann_bitmap_ref_difference", "nann_gather_rows", "nann_topk",
+    "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
+    "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
+    "nann_search", "nann_merge_topk", "nann_merge_topk_host",
+]
+
+
+class ScorerDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("emb_dtype", C.c_int32),
+                ("h1", C.c_int32), ("h2", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("alpha1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("alpha2", C.c_void_p),
+                ("w3", C.c_void_p)]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("n_items", C.c_int64), ("d", C.c_int32), ("emb_dtype", C.c_int32),
+                ("item_embs", C.c_void_p), ("item_ids", C.c_void_p),
+                ("nb_values", C.c_void_p * 2), ("nb_row_splits", C.c_void_p * 2),
+                ("nb_nnz", C.c_int64 * 2),
+                ("enter_points", C.c_void_p), ("n_enter", C.c_int64),
+                ("on_device", C.c_int32)]
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Load (building first if the sources are newer) the HIP extension."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            try:
+                _build.build()
+            except Exception as e:  # no hipcc and no prebuilt library: fail loudly
+                raise ImportError(
+                    f"nann_amd: HIP extension {path} is missing and could not be built ({e}); "
+                    "there is no CPU fallback") from e
+        L = C.CDLL(path)
+        L.nann_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            getattr(L, name)  # AttributeError if the ABI is incomplete
+        L.nann_scorer_destroy.restype = None
+        L.nann_index_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def last_error():
+    return lib().nann_last_error().decode("utf-8", "replace")

@@ -1,0 +1,1132 @@
+// nann_hip.hip -- kernels + C ABI of libnann_hip.so (gfx950 only).
+// The ABI is documented in include/nann_hip.h; the workgroup building blocks
+// in nann_device.h.  Reference citations are relative to /root/reference/.
+#include "../../include/nann_hip.h"
+#include "nann_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace nann;
+
+// ===========================================================================
+// host-side helpers
+// ===========================================================================
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return fail(NANN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)
+
+struct DeviceInfo {
+  bool ok = false;
+  int cus = 0;
+  size_t lds_max = 0;
+};
+
+// per-device facts, queried once
+int device_info(DeviceInfo* out) {
+  static std::mutex mu;
+  static DeviceInfo cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(NANN_ERR_NO_DEVICE, "no HIP device");
+  if (dev < 0 || dev >= 64) return fail(NANN_ERR_NO_DEVICE, "device ordinal out of range");
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cache[dev].ok) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    cache[dev].cus = p.multiProcessorCount;
+    cache[dev].lds_max = p.maxSharedMemoryPerMultiProcessor ? p.maxSharedMemoryPerMultiProcessor
+                                                            : p.sharedMemPerBlock;
+    if (cache[dev].lds_max < p.sharedMemPerBlock) cache[dev].lds_max = p.sharedMemPerBlock;
+    cache[dev].ok = true;
+  }
+  *out = cache[dev];
+  return NANN_OK;
+}
+
+// small result block shared between a kernel and the host for calls that
+// return data-dependent counts (they synchronise anyway)
+struct OpResult {
+  long long n_out;
+  long long n_out_splits;
+  long long bad_i;
+  int code;  // ragged validation code 1/2/3
+  int err;   // nann_status
+};
+
+struct ResultBuf {
+  OpResult* dev = nullptr;
+  OpResult* host = nullptr;
+  int device = -1;
+};
+
+int get_result_buf(ResultBuf** out) {
+  thread_local ResultBuf rb;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (!rb.dev || rb.device != dev) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rb.dev), sizeof(OpResult)));
+    if (!rb.host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&rb.host), sizeof(OpResult)));
+    rb.device = dev;
+  }
+  *out = &rb;
+  return NANN_OK;
+}
+
+int fetch_result(ResultBuf* rb, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(rb->host, rb->dev, sizeof(OpResult), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return NANN_OK;
+}
+
+inline hipStream_t as_stream(nann_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+// ===========================================================================
+// kernels: per-op drop-ins
+// ===========================================================================
+
+// ragged validation (GroupGather_kernel.cc:9-16, bitmap_ops.cc:12-19)
+__device__ __forceinline__ int validate_ragged(long long n_values, const int64_t* rs, long long n_splits) {
+  if (n_splits == 0) return 1;
+  if (rs[0] != 0) return 2;
+  if (rs[n_splits - 1] != n_values) return 3;
+  return 0;
+}
+
+// GroupGather count pass (:137-145) for all groups at once: per frontier row j
+// the output offset (exclusive scan of row lengths), then ret_row_splits.
+__global__ __launch_bounds__(kNT) void k_group_gather_count(
+    const int64_t* params_row_splits, long long n_params_splits, long long n_params_values,
+    const int64_t* indices_values, long long n_iv, const int64_t* indices_row_splits,
+    long long n_irs, int64_t* ret_row_splits, int64_t* offsets, OpResult* res) {
+  __shared__ long long s_wave[kNW];
+  __shared__ long long s_running;
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  if (tid == 0) {
+    res->n_out = 0; res->n_out_splits = 0; res->bad_i = -1; res->code = 0; res->err = 0;
+    s_running = 0; s_bad = 0;
+  }
+  __syncthreads();
+  int code = validate_ragged(n_params_values, params_row_splits, n_params_splits);
+  if (code) {
+    if (tid == 0) { res->code = code; res->err = NANN_ERR_INVALID_RAGGED_PARAMS; }
+    return;
+  }
+  // indices ragged: its values are indices_values
+  code = validate_ragged(n_iv, indices_row_splits, n_irs);
+  if (code) {
+    if (tid == 0) { res->code = code; res->err = NANN_ERR_INVALID_RAGGED_INDICES; }
+    return;
+  }
+  if (n_params_splits == 1 || n_irs == 1) {  // void inputs -> ([], [0])  :69-77
+    if (tid == 0) { ret_row_splits[0] = 0; res->n_out = 0; res->n_out_splits = 1; }
+    return;
+  }
+  const long long n_rows = n_params_splits - 1;
+  for (long long j0 = 0; j0 < n_iv; j0 += kNT) {
+    const long long j = j0 + tid;
+    long long len = 0;
+    if (j < n_iv) {
+      const long long idx = indices_values[j];
+      if (idx < 0 || idx >= n_rows) s_bad = 1;
+      else len = params_row_splits[idx + 1] - params_row_splits[idx];
+    }
+    long long inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    long long wb = 0, tot = 0;
+    for (int w = 0; w < kNW; ++w) { const long long t = s_wave[w]; if (w < wave) wb += t; tot += t; }
+    const long long run = s_running;
+    if (j < n_iv) offsets[j] = run + wb + inc - len;
+    __syncthreads();
+    if (tid == 0) s_running = run + tot;
+    __syncthreads();
+  }
+  if (s_bad) {
+    if (tid == 0) res->err = NANN_ERR_INDEX_OUT_OF_RANGE;
+    return;
+  }
+  if (tid == 0) offsets[n_iv] = s_running;
+  __syncthreads();
+  for (long long i = tid; i < n_irs; i += kNT) ret_row_splits[i] = offsets[indices_row_splits[i]];
+  if (tid == 0) { res->n_out = s_running; res->n_out_splits = n_irs; }
+}
+
+// GroupGather fill pass (:152-168): one wavefront per gathered row.
+__global__ __launch_bounds__(256) void k_group_gather_fill(const int32_t* __restrict__ params_values,
+                                                           const int64_t* __restrict__ params_row_splits,
+                                                           const int64_t* __restrict__ indices_values,
+                                                           long long n_iv,
+                                                           const int64_t* __restrict__ offsets,
+                                                           int32_t* __restrict__ ret_values) {
+  const int lane = lane_id();
+  const long long wave_global = (long long)blockIdx.x * (blockDim.x >> 6) + wave_id();
+  const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long j = wave_global; j < n_iv; j += n_waves) {
+    const long long g = indices_values[j];
+    const long long s = params_row_splits[g], e = params_row_splits[g + 1], o = offsets[j];
+    for (long long c = lane; c < e - s; c += 64) ret_values[o + c] = params_values[s + c];
+  }
+}
+
+// BitmapRefDifference (bitmap_ops.cc:175-257): one workgroup; the bitmap is
+// staged into LDS when it fits, walked by one wavefront, and written back.
+template <bool kLds>
+__global__ __launch_bounds__(kNT) void k_bitmap_ref_difference(
+    const int32_t* values, long long n_values, const int64_t* row_splits, long long n_splits,
+    uint32_t* flags, long long n_words, int32_t* c_values, int64_t* c_row_splits, OpResult* res) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int& s_bad = *reinterpret_cast<int*>(smem);  // first 16 bytes: flags; bitmap follows
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    res->n_out = 0; res->n_out_splits = 0; res->bad_i = -1; res->code = 0; res->err = 0;
+    s_bad = 0;
+  }
+  __syncthreads();
+  const int code = validate_ragged(n_values, row_splits, n_splits);
+  if (code) {
+    if (tid == 0) { res->code = code; res->err = NANN_ERR_INVALID_RAGGED_INPUT; }
+    return;
+  }
+  if (n_splits == 1) {  // void input :187-196; bitmap forwarded untouched
+    if (tid == 0) { c_row_splits[0] = 0; res->n_out = 0; res->n_out_splits = 1; }
+    return;
+  }
+  // bounds pre-check so that an error leaves the bitmap untouched
+  const unsigned long long limit = (unsigned long long)n_words * 32ull;
+  for (long long j = tid; j < n_values; j += kNT) {
+    const int32_t v = values[j];
+    if (v < 0 || (unsigned long long)v >= limit) s_bad = 1;
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) res->err = NANN_ERR_INDEX_OUT_OF_RANGE;
+    return;
+  }
+  uint32_t* bm = kLds ? reinterpret_cast<uint32_t*>(smem + 16) : flags;
+  if (kLds) {
+    for (long long w = tid; w < n_words; w += kNT) bm[w] = flags[w];
+  }
+  __syncthreads();
+  if (wave_id() == 0) {
+    int err = 0;
+    long long base = 0;
+    const long long groups = n_splits - 1;
+    const uint32_t n_items = limit < 0x7fffffffull ? (uint32_t)limit : 0x7fffffffu;
+    if (lane_id() == 0) c_row_splits[0] = 0;
+    for (long long g = 0; g < groups; ++g) {  // ONE bitmap for all groups
+      const long long s = row_splits[g], e = row_splits[g + 1];
+      const int kept = wave_walk<kLds>(values + s, (int)(e - s), bm, n_items, c_values + base, &err);
+      base += kept;
+      if (lane_id() == 0) c_row_splits[g + 1] = base;
+    }
+    if (lane_id() == 0) { res->n_out = base; res->n_out_splits = n_splits; }
+  }
+  __syncthreads();
+  if (kLds) {
+    for (long long w = tid; w < n_words; w += kNT) flags[w] = bm[w];
+  }
+}
+
+// GatherV2 axis 0 (gather_functor.h:96-103): word-wise coalesced row copy.
+template <typename W>
+__global__ __launch_bounds__(256) void k_gather_rows(const W* __restrict__ params, long long n_rows,
+                                                     long long row_words,
+                                                     const int32_t* __restrict__ indices,
+                                                     long long n_idx, W* __restrict__ out,
+                                                     OpResult* res) {
+  const long long total = n_idx * row_words;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total;
+       w += (long long)gridDim.x * blockDim.x) {
+    const long long i = w / row_words, c = w - i * row_words;
+    const long long r = indices[i];
+    if (r < 0 || r >= n_rows) {  // FastBoundsCheck, gather_functor.h:85-89
+      atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
+      continue;
+    }
+    out[w] = params[r * row_words + c];
+  }
+}
+
+__global__ void k_init_result(OpResult* res) {
+  res->n_out = 0; res->n_out_splits = 0; res->bad_i = 0x7fffffffffffffffll; res->code = 0; res->err = 0;
+}
+
+// TopKV2 (topk_op.cc:104-205): one workgroup per row.
+__global__ __launch_bounds__(kNT) void k_topk(const float* values, long long n_cols, int k,
+                                              float* out_values, int32_t* out_indices) {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[kPhaseScratch];
+  const long long row = blockIdx.x;
+  wg_topk(nullptr, values + row * n_cols, (int)n_cols, k, out_indices + row * k, nullptr,
+          out_values + row * k, nullptr, nullptr, scratch);
+}
+
+// merge of per-shard top-k lists: TopKV2 over the shard-major
+// concatenation, ids carried along.
+__global__ __launch_bounds__(kNT) void k_merge_topk(const float* scores, const int64_t* ids,
+                                                    int n_in, int k_out, float* out_scores,
+                                                    int64_t* out_ids) {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[kPhaseScratch];
+  const long long qi = blockIdx.x;
+  wg_topk(nullptr, scores + qi * n_in, n_in, k_out, nullptr, nullptr, out_scores + qi * k_out,
+          ids + qi * n_in, out_ids + qi * k_out, scratch);
+}
+
+// comm_seq f16[B, L, d] -> q f32[B, d]; one workgroup per query, one thread per
+// dimension.  Same order as oracle_user_seq_mean.
+__global__ void k_user_seq_mean(const uint16_t* seq, int seq_len, int d, float* q) {
+  __shared__ int s_count;
+  const long long b = blockIdx.x;
+  const uint16_t* s = seq + b * seq_len * d;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  for (int r = threadIdx.x; r < seq_len; r += blockDim.x) {
+    int nz = 0;
+    for (int k = 0; k < d; ++k) nz |= (s[(long long)r * d + k] & 0x7fffu) != 0;
+    if (nz) atomicAdd(&s_count, 1);
+  }
+  __syncthreads();
+  const int count = s_count;
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
+    float acc = 0.0f;
+    for (int r = 0; r < seq_len; ++r) acc = acc + half_bits_to_float(s[(long long)r * d + k]);
+    q[b * d + k] = count ? acc / (float)count : 0.0f;
+  }
+}
+
+// stand-alone scorer (the BlazeXlaOp contract): rows scored independently.
+template <int LPR, int DT>
+__global__ __launch_bounds__(256) void k_score_l2(const void* table, long long n_table_rows, int d,
+                                                  const int32_t* indices, long long n,
+                                                  const float* qv, float* scores, OpResult* res) {
+  constexpr int GPW = 64 / LPR;
+  const int lane = lane_id();
+  const int sub = lane % LPR, grp = lane / LPR;
+  float q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
+  const long long wave_global = (long long)blockIdx.x * (blockDim.x >> 6) + wave_id();
+  const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long i0 = wave_global * GPW; i0 < n; i0 += n_waves * GPW) {
+    const long long i = i0 + grp;
+    long long row = -1;
+    if (i < n) {
+      row = indices ? (long long)indices[i] : i;
+      if (row < 0 || row >= n_table_rows) {
+        if (sub == 0) atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
+        row = -1;
+      }
+    }
+    float x[8];
+    if (row >= 0) {
+      const RowChunk<DT> ch = load_chunk<DT>(table, (size_t)row, d, sub);
+      chunk_to_float<DT>(ch, x);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = 0.0f;
+    }
+    const float s = l2_finish<LPR>(q, x);
+    if (sub == 0 && i < n) scores[i] = s;
+  }
+}
+
+// ===========================================================================
+// the fused traversal (build_opt_graph.py:109-149)
+// ===========================================================================
+struct SearchArgs {
+  const void* emb;
+  const int64_t* item_ids;
+  const int32_t* nbv[2];
+  const int64_t* nbrs[2];
+  const int32_t* enter;
+  int n_enter;
+  uint32_t n_items;
+  int d;
+  const float* q;
+  int n_queries;
+  int t[6];
+  unsigned char* ws;
+  unsigned long long slot_bytes;
+  uint32_t bm_words;  // padded to a multiple of 4
+  int max_cand, max_raw, pool_cap;
+  int64_t* out_ids;
+  float* out_scores;
+  int32_t* out_index;
+  int32_t* status;
+  int32_t* counters;
+};
+
+struct SlotView {
+  int32_t* cand_ids;
+  float* cand_scores;
+  int32_t* raw;
+  int32_t* beam_ids;
+  float* beam_scores;
+  int32_t* pool_ids;
+  float* pool_scores;
+  uint32_t* gbitmap;
+};
+
+__host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_raw, int pool_cap,
+                                                          uint32_t gbm_words, unsigned long long off[8]) {
+  unsigned long long o = 0;
+  auto put = [&](int i, unsigned long long bytes) { off[i] = o; o += (bytes + 255ull) & ~255ull; };
+  put(0, 4ull * max_cand);  // cand_ids
+  put(1, 4ull * max_cand);  // cand_scores
+  put(2, 4ull * max_raw);   // raw
+  put(3, 4ull * kMaxK);     // beam_ids
+  put(4, 4ull * kMaxK);     // beam_scores
+  put(5, 4ull * pool_cap);  // pool_ids
+  put(6, 4ull * pool_cap);  // pool_scores
+  put(7, 4ull * gbm_words); // bitmap in HBM (large shards only)
+  return o;
+}
+
+template <int LPR, int DT, bool LDSBM>
+__device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
+                          unsigned char* scratch, float* qv, int* misc, int32_t* ctr) {
+  const int tid = threadIdx.x;
+  const int wave = wave_id(), lane = lane_id();
+  const int k5 = a.t[5];
+
+  auto walk = [&](const int32_t* in, int n, int32_t* out) -> int {
+    __syncthreads();
+    if (wave == 0) {
+      const int c = wave_walk<LDSBM>(in, n, bm, a.n_items, out, &misc[1]);
+      if (lane == 0) misc[0] = c;
+    }
+    __syncthreads();
+    return misc[0];
+  };
+  auto zero_bitmap = [&]() {
+    __syncthreads();
+    wg_zero_words(bm, a.bm_words);
+    __syncthreads();
+  };
+
+  for (int k = tid; k < a.d; k += kNT) qv[k] = a.q[(size_t)qi * a.d + k];
+  if (tid == 0) misc[1] = 0;
+  __syncthreads();
+
+  // ---- level 2 (entry layer): build_opt_graph.py:111-112 -------------------
+  const int E = a.n_enter;
+  if (E == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+  wg_score_l2<LPR, DT, kNT>(a.emb, a.d, a.enter, E, qv, sv.cand_scores);
+  if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
+  if (E == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
+  __syncthreads();
+  int st = wg_topk(a.enter, sv.cand_scores, E, a.t[0], nullptr, sv.beam_ids, sv.beam_scores,
+                   nullptr, nullptr, scratch);
+  if (st) return st;
+  const int nR = a.t[0];
+
+  // ---- level 1: build_opt_graph.py:114-127 ----------------------------------
+  zero_bitmap();                                           // :115-118
+  int kept = walk(sv.beam_ids, nR, sv.cand_ids);           // :119-120 marks the winners
+  if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+  if (kept != nR) return NANN_ERR_BAD_ARGUMENT;            // duplicate enter points
+  for (int i = tid; i < nR; i += kNT) sv.cand_scores[i] = sv.beam_scores[i];
+  int G = wg_expand(sv.beam_ids, nR, a.nbv[1], a.nbrs[1], a.n_items, sv.raw, scratch);  // :116
+  if (G < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
+  int nC = walk(sv.raw, G, sv.cand_ids + nR);              // :121-122
+  if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+  if (tid == 0) { ctr[0 * 5 + 1] = nR; ctr[1 * 5 + 1] = G; ctr[2 * 5 + 1] = nC; }
+  if (nC == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+  wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sv.cand_ids + nR, nC, qv, sv.cand_scores + nR);  // :124
+  if (nC == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
+  __syncthreads();
+  st = wg_topk(sv.cand_ids, sv.cand_scores, nR + nC, a.t[1], nullptr, sv.pool_ids, sv.pool_scores,
+               nullptr, nullptr, scratch);                 // :125-127
+  if (st) return st;
+  int nP = a.t[1];
+
+  // ---- level 0: build_opt_graph.py:129-141 -----------------------------------
+  zero_bitmap();                                           // :131
+  int nB = walk(sv.pool_ids, nP, sv.beam_ids);             // :132-133
+  if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+  const int32_t* frontier = sv.beam_ids;
+  for (int r = 0; r < 3; ++r) {
+    G = wg_expand(frontier, nB, a.nbv[0], a.nbrs[0], a.n_items, sv.raw, scratch);       // :136
+    if (G < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
+    nC = walk(sv.raw, G, sv.cand_ids);                     // :137
+    if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+    if (tid == 0) { ctr[0 * 5 + 2 + r] = nB; ctr[1 * 5 + 2 + r] = G; ctr[2 * 5 + 2 + r] = nC; }
+    if (nC == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+    wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sv.cand_ids, nC, qv, sv.cand_scores);          // :138
+    if (nC == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
+    __syncthreads();
+    st = wg_topk(sv.cand_ids, sv.cand_scores, nC, a.t[2 + r], nullptr, sv.pool_ids + nP,
+                 sv.pool_scores + nP, nullptr, nullptr, scratch);                         // :139-141
+    if (st) return st;
+    frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
+    nB = a.t[2 + r];
+    nP += nB;
+  }
+  // ---- final: build_opt_graph.py:143-149 --------------------------------------
+  st = wg_topk(sv.pool_ids, sv.pool_scores, nP, k5, nullptr,
+               a.out_index ? a.out_index + (size_t)qi * k5 : nullptr,
+               a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr, a.item_ids,
+               a.out_ids + (size_t)qi * k5, scratch);
+  return st;
+}
+
+template <int LPR, int DT, bool LDSBM>
+__global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
+  unsigned char* scratch = smem + (LDSBM ? (size_t)a.bm_words * 4 : 0);
+  float* qv = reinterpret_cast<float*>(scratch + kPhaseScratch);
+  int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] walk count, [1] range error
+  int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
+
+  unsigned long long off[8];
+  slot_layout(a.max_cand, a.max_raw, a.pool_cap, LDSBM ? 0u : a.bm_words, off);
+  unsigned char* slot = a.ws + (unsigned long long)blockIdx.x * a.slot_bytes;
+  SlotView sv;
+  sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
+  sv.cand_scores = reinterpret_cast<float*>(slot + off[1]);
+  sv.raw = reinterpret_cast<int32_t*>(slot + off[2]);
+  sv.beam_ids = reinterpret_cast<int32_t*>(slot + off[3]);
+  sv.beam_scores = reinterpret_cast<float*>(slot + off[4]);
+  sv.pool_ids = reinterpret_cast<int32_t*>(slot + off[5]);
+  sv.pool_scores = reinterpret_cast<float*>(slot + off[6]);
+  sv.gbitmap = reinterpret_cast<uint32_t*>(slot + off[7]);
+  uint32_t* bm = LDSBM ? bm_lds : sv.gbitmap;
+  const int k5 = a.t[5];
+
+  for (int qi = blockIdx.x; qi < a.n_queries; qi += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    const int st = search_one<LPR, DT, LDSBM>(a, qi, sv, bm, scratch, qv, misc, s_ctr);
+    __syncthreads();
+    if (st) {  // a request the reference would fail: zeroed outputs + its code
+      for (int i = threadIdx.x; i < k5; i += kNT) {
+        a.out_ids[(size_t)qi * k5 + i] = 0;
+        if (a.out_scores) a.out_scores[(size_t)qi * k5 + i] = 0.0f;
+        if (a.out_index) a.out_index[(size_t)qi * k5 + i] = 0;
+      }
+    }
+    if (threadIdx.x == 0) a.status[qi] = st;
+    if (a.counters && threadIdx.x < 3 * NANN_NUM_ROUNDS)
+      a.counters[(size_t)qi * 3 * NANN_NUM_ROUNDS + threadIdx.x] = s_ctr[threadIdx.x];
+  }
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+struct nann_scorer {
+  nann_scorer_desc desc;
+  float* dev_weights = nullptr;  // MLP weights block in HBM
+};
+
+struct nann_index {
+  nann_index_desc desc;  // device pointers
+  bool owns = false;
+  std::vector<void*> owned;
+  int64_t max_deg[2] = {0, 0};
+  uint32_t bm_words = 0;  // ceil(N/32) padded to a multiple of 4
+};
+
+extern "C" {
+
+int nann_abi_version(void) { return NANN_ABI_VERSION; }
+const char* nann_last_error(void) { return g_err.c_str(); }
+
+int nann_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int nann_malloc(void** dev_ptr, int64_t nbytes) {
+  if (!dev_ptr || nbytes < 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_malloc: bad argument");
+  HIP_TRY(hipMalloc(dev_ptr, (size_t)std::max<int64_t>(nbytes, 1)));
+  return NANN_OK;
+}
+
+int nann_free(void* dev_ptr) {
+  if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+  return NANN_OK;
+}
+
+int nann_memcpy(void* dst, const void* src, int64_t nbytes, int kind, nann_stream_t stream) {
+  static const hipMemcpyKind kinds[3] = {hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
+                                         hipMemcpyDeviceToDevice};
+  if (kind < 0 || kind > 2 || nbytes < 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_memcpy: bad argument");
+  if (nbytes == 0) return NANN_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, (size_t)nbytes, kinds[kind], as_stream(stream)));
+  return NANN_OK;
+}
+
+int nann_stream_synchronize(nann_stream_t stream) {
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  return NANN_OK;
+}
+
+// ---- HugeConst -------------------------------------------------------------
+static const char* npy_descr(int dtype) {
+  switch (dtype) {
+    case NANN_F16: return "<f2";
+    case NANN_F32: return "<f4";
+    case NANN_F64: return "<f8";
+    case NANN_I32: return "<i4";
+    case NANN_I64: return "<i8";
+    default: return nullptr;
+  }
+}
+
+int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
+                         int expect_rank, void** dev_ptr, int64_t* nbytes) {
+  if (!path || !dev_ptr) return fail(NANN_ERR_BAD_ARGUMENT, "nann_huge_const_load: null argument");
+  std::ifstream f(path, std::ifstream::binary);
+  if (!f) return fail(NANN_ERR_IO, std::string("Fail to open file: ") + path);  // huge_const_op.cc:96-98
+  unsigned char head[12];
+  f.read(reinterpret_cast<char*>(head), 10);
+  if (!f || std::memcmp(head, "\x93NUMPY", 6) != 0) return fail(NANN_ERR_IO, "not an npy file");
+  const int major = head[6];
+  size_t hlen = 0;
+  if (major == 1) {
+    hlen = head[8] | (head[9] << 8);
+  } else if (major == 2) {  // npy.h:541-571 accepts 1.0 and 2.0
+    f.read(reinterpret_cast<char*>(head + 10), 2);
+    hlen = (size_t)head[8] | ((size_t)head[9] << 8) | ((size_t)head[10] << 16) | ((size_t)head[11] << 24);
+  } else {
+    return fail(NANN_ERR_IO, "unsupported npy version");
+  }
+  std::string hdr(hlen, '\0');
+  f.read(&hdr[0], (std::streamsize)hlen);
+  if (!f) return fail(NANN_ERR_IO, "truncated npy header");
+  auto find_val = [&](const char* key) -> size_t {
+    const size_t p = hdr.find(key);
+    if (p == std::string::npos) return p;
+    return hdr.find(':', p) + 1;
+  };
+  size_t p = find_val("'descr'");
+  if (p == std::string::npos) return fail(NANN_ERR_IO, "npy header without descr");
+  const size_t q0 = hdr.find('\'', p), q1 = hdr.find('\'', q0 + 1);
+  std::string descr = hdr.substr(q0 + 1, q1 - q0 - 1);
+  if (!descr.empty() && descr[0] == '|') descr[0] = '<';
+  p = find_val("'fortran_order'");
+  if (p == std::string::npos) return fail(NANN_ERR_IO, "npy header without fortran_order");
+  if (hdr.compare(hdr.find_first_not_of(' ', p), 4, "True") == 0)
+    return fail(NANN_ERR_UNSUPPORTED, "Fortran order NOT supported.");  // huge_const_op.cc:108-109
+  p = find_val("'shape'");
+  if (p == std::string::npos) return fail(NANN_ERR_IO, "npy header without shape");
+  const size_t s0 = hdr.find('(', p), s1 = hdr.find(')', s0);
+  std::vector<int64_t> shape;
+  {
+    const std::string body = hdr.substr(s0 + 1, s1 - s0 - 1);
+    size_t i = 0;
+    while (i < body.size()) {
+      while (i < body.size() && (body[i] == ' ' || body[i] == ',')) ++i;
+      if (i >= body.size()) break;
+      size_t j = i;
+      while (j < body.size() && body[j] >= '0' && body[j] <= '9') ++j;
+      if (j == i) return fail(NANN_ERR_IO, "bad npy shape");
+      shape.push_back(std::strtoll(body.substr(i, j - i).c_str(), nullptr, 10));
+      i = j;
+    }
+  }
+  const char* want = npy_descr(expect_dtype);
+  if (!want) return fail(NANN_ERR_UNSUPPORTED, "Unsupported DataType.");  // huge_const_op.cc:143-146
+  if (descr != want)
+    return fail(NANN_ERR_DTYPE_MISMATCH, "DataType mismatch: " + descr + "!=" + want);  // :117-121
+  if (expect_shape) {
+    if ((int)shape.size() != expect_rank) return fail(NANN_ERR_SHAPE_MISMATCH, "rank mismatch");
+    for (int i = 0; i < expect_rank; ++i)
+      if (shape[i] != expect_shape[i])
+        return fail(NANN_ERR_SHAPE_MISMATCH,
+                    "attr_shape and np_shape NOT match in dim " + std::to_string(i));  // :111-115
+  }
+  static const int esz[6] = {2, 2, 4, 4, 8, 8};
+  int64_t total = esz[expect_dtype];
+  for (int64_t v : shape) total *= v;
+  std::vector<char> host((size_t)std::max<int64_t>(total, 1));
+  f.read(host.data(), (std::streamsize)total);
+  if (f.gcount() != (std::streamsize)total) return fail(NANN_ERR_IO, "truncated npy payload");
+  void* d = nullptr;
+  HIP_TRY(hipMalloc(&d, (size_t)std::max<int64_t>(total, 1)));
+  if (total) HIP_TRY(hipMemcpy(d, host.data(), (size_t)total, hipMemcpyHostToDevice));
+  *dev_ptr = d;
+  if (nbytes) *nbytes = total;
+  return NANN_OK;
+}
+
+// ---- GroupGather -----------------------------------------------------------
+int nann_group_gather_count(const int64_t* params_row_splits, int64_t n_params_splits,
+                            int64_t n_params_values, const int64_t* indices_values,
+                            int64_t n_indices_values, const int64_t* indices_row_splits,
+                            int64_t n_indices_splits, int64_t* ret_row_splits,
+                            int64_t* scratch_offsets, int64_t* n_ret, int64_t* n_ret_splits,
+                            int32_t* ragged_code, nann_stream_t stream) {
+  if (!n_ret || !n_ret_splits) return fail(NANN_ERR_BAD_ARGUMENT, "nann_group_gather_count: null out");
+  ResultBuf* rb;
+  int rc = get_result_buf(&rb);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_group_gather_count, dim3(1), dim3(kNT), 0, st, params_row_splits,
+                     (long long)n_params_splits, (long long)n_params_values, indices_values,
+                     (long long)n_indices_values, indices_row_splits, (long long)n_indices_splits,
+                     ret_row_splits, scratch_offsets, rb->dev);
+  HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  if (ragged_code) *ragged_code = rb->host->code;
+  *n_ret = rb->host->n_out;
+  *n_ret_splits = rb->host->n_out_splits;
+  if (rb->host->err) return fail(rb->host->err, "GroupGather: invalid input, code " +
+                                                    std::to_string(rb->host->code));
+  return NANN_OK;
+}
+
+int nann_group_gather_fill(const int32_t* params_values, const int64_t* params_row_splits,
+                           const int64_t* indices_values, int64_t n_indices_values,
+                           const int64_t* scratch_offsets, int32_t* ret_values,
+                           nann_stream_t stream) {
+  if (n_indices_values <= 0) return NANN_OK;
+  const int waves_per_block = 4;
+  const long long blocks = std::min<long long>((n_indices_values + waves_per_block - 1) / waves_per_block, 4096);
+  hipLaunchKernelGGL(k_group_gather_fill, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     params_values, params_row_splits, indices_values, (long long)n_indices_values,
+                     scratch_offsets, ret_values);
+  HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+// ---- BitmapRefDifference -----------------------------------------------------
+int nann_bitmap_ref_difference(const int32_t* values, int64_t n_values, const int64_t* row_splits,
+                               int64_t n_splits, int32_t* idx_flag, int64_t n_flag_words,
+                               int32_t* c_values, int64_t* c_row_splits, int64_t* n_out,
+                               int64_t* n_out_splits, int32_t* ragged_code, nann_stream_t stream) {
+  if (!n_out || !n_out_splits) return fail(NANN_ERR_BAD_ARGUMENT, "nann_bitmap_ref_difference: null out");
+  if (n_values > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "more than 2^31 candidates");
+  DeviceInfo di;
+  int rc = device_info(&di);
+  if (rc) return rc;
+  ResultBuf* rb;
+  rc = get_result_buf(&rb);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const size_t lds_need = align_up((size_t)n_flag_words * 4, 16) + 16;
+  const bool lds = lds_need <= di.lds_max;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(idx_flag);
+  if (lds) {
+    auto kern = k_bitmap_ref_difference<true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kNT), lds_need, st, values, (long long)n_values, row_splits,
+                       (long long)n_splits, flags, (long long)n_flag_words, c_values, c_row_splits,
+                       rb->dev);
+  } else {
+    hipLaunchKernelGGL(k_bitmap_ref_difference<false>, dim3(1), dim3(kNT), 16, st, values,
+                       (long long)n_values, row_splits, (long long)n_splits, flags,
+                       (long long)n_flag_words, c_values, c_row_splits, rb->dev);
+  }
+  HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  if (ragged_code) *ragged_code = rb->host->code;
+  *n_out = rb->host->n_out;
+  *n_out_splits = rb->host->n_out_splits;
+  if (rb->host->err) return fail(rb->host->err, "BitmapRefDifference: invalid input");
+  return NANN_OK;
+}
+
+// ---- GatherV2 ------------------------------------------------------------------
+int nann_gather_rows(const void* params, int64_t n_rows, int64_t row_bytes, const int32_t* indices,
+                     int64_t n_indices, void* out, int64_t* bad_i, nann_stream_t stream) {
+  if (row_bytes <= 0 || row_bytes % 4) return fail(NANN_ERR_BAD_ARGUMENT, "row_bytes must be a multiple of 4");
+  if (bad_i) *bad_i = -1;
+  if (n_indices <= 0) return NANN_OK;
+  ResultBuf* rb;
+  int rc = get_result_buf(&rb);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, st, rb->dev);
+  const bool vec = row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(params) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+  const long long words = vec ? row_bytes / 16 : row_bytes / 4;
+  const long long total = n_indices * words;
+  const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 8192);
+  if (vec)
+    hipLaunchKernelGGL(k_gather_rows<uint4>, dim3(blocks), dim3(256), 0, st,
+                       static_cast<const uint4*>(params), (long long)n_rows, words, indices,
+                       (long long)n_indices, static_cast<uint4*>(out), rb->dev);
+  else
+    hipLaunchKernelGGL(k_gather_rows<uint32_t>, dim3(blocks), dim3(256), 0, st,
+                       static_cast<const uint32_t*>(params), (long long)n_rows, words, indices,
+                       (long long)n_indices, static_cast<uint32_t*>(out), rb->dev);
+  HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  if (rb->host->bad_i != 0x7fffffffffffffffll) {
+    if (bad_i) *bad_i = rb->host->bad_i;
+    return fail(NANN_ERR_INDEX_OUT_OF_RANGE, "indices[" + std::to_string(rb->host->bad_i) +
+                                                 "] is not in [0, " + std::to_string(n_rows) + ")");
+  }
+  return NANN_OK;
+}
+
+// ---- TopKV2 ----------------------------------------------------------------------
+int nann_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k, float* out_values,
+              int32_t* out_indices, nann_stream_t stream) {
+  if (k < 0) return fail(NANN_ERR_BAD_ARGUMENT, "Need k >= 0, got " + std::to_string(k));  // :60-61
+  if (n_cols < k)
+    return fail(NANN_ERR_TOPK_K_GT_N, "input must have at least k columns. Had " +
+                                          std::to_string(n_cols) + ", needed " + std::to_string(k));
+  if (k > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "k > 1024 not supported");
+  if (n_cols > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "n_cols too large");
+  if (k == 0 || n_rows == 0) return NANN_OK;  // :84-85
+  hipLaunchKernelGGL(k_topk, dim3((unsigned)n_rows), dim3(kNT), 0, as_stream(stream), values,
+                     (long long)n_cols, (int)k, out_values, out_indices);
+  HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+// ---- scorer ------------------------------------------------------------------------
+int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
+  if (!desc || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_scorer_create: null argument");
+  const int d = desc->d;
+  if (!(d == 64 || d == 128 || d == 256 || d == 512))
+    return fail(NANN_ERR_UNSUPPORTED, "embedding dim must be 64, 128, 256 or 512");
+  if (desc->emb_dtype != NANN_F16 && desc->emb_dtype != NANN_BF16 && desc->emb_dtype != NANN_F32)
+    return fail(NANN_ERR_UNSUPPORTED, "embedding dtype must be f16, bf16 or f32");
+  if (desc->kind != NANN_SCORER_L2)
+    return fail(NANN_ERR_UNSUPPORTED, "only the L2 scorer is implemented in this build");
+  nann_scorer* s = new nann_scorer();
+  s->desc = *desc;
+  *out = s;
+  return NANN_OK;
+}
+
+void nann_scorer_destroy(nann_scorer* s) {
+  if (!s) return;
+  if (s->dev_weights) (void)hipFree(s->dev_weights);
+  delete s;
+}
+
+int nann_user_seq_mean(const void* comm_seq_f16, int64_t n_queries, int32_t seq_len, int32_t d,
+                       float* q, nann_stream_t stream) {
+  if (n_queries <= 0) return NANN_OK;
+  if (seq_len <= 0 || d <= 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_user_seq_mean: bad shape");
+  hipLaunchKernelGGL(k_user_seq_mean, dim3((unsigned)n_queries), dim3(std::min(256, (d + 63) / 64 * 64)),
+                     0, as_stream(stream), static_cast<const uint16_t*>(comm_seq_f16), (int)seq_len,
+                     (int)d, q);
+  HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+}  // extern "C"
+
+template <int LPR>
+static void launch_score(int dt, unsigned blocks, hipStream_t st, const void* table, long long nt, int d,
+                         const int32_t* idx, long long n, const float* q, float* out, OpResult* res) {
+  if (dt == NANN_F16)
+    hipLaunchKernelGGL((k_score_l2<LPR, DT_F16>), dim3(blocks), dim3(256), 0, st, table, nt, d, idx, n, q, out, res);
+  else if (dt == NANN_BF16)
+    hipLaunchKernelGGL((k_score_l2<LPR, DT_BF16>), dim3(blocks), dim3(256), 0, st, table, nt, d, idx, n, q, out, res);
+  else
+    hipLaunchKernelGGL((k_score_l2<LPR, DT_F32>), dim3(blocks), dim3(256), 0, st, table, nt, d, idx, n, q, out, res);
+}
+
+extern "C" {
+
+int nann_score(const nann_scorer* scorer, const float* q, const void* table, int64_t n_table_rows,
+               const int32_t* indices, int64_t n, float* out_scores, int64_t* bad_i,
+               nann_stream_t stream) {
+  if (!scorer) return fail(NANN_ERR_BAD_ARGUMENT, "nann_score: null scorer");
+  if (bad_i) *bad_i = -1;
+  if (n <= 0)  // blaze_xla_predictor.cc:259-263
+    return fail(NANN_ERR_EMPTY_SCORE_BATCH, "Error when getting input address or size");
+  ResultBuf* rb;
+  int rc = get_result_buf(&rb);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, st, rb->dev);
+  const int d = scorer->desc.d, lpr = d / 8, dt = scorer->desc.emb_dtype;
+  const long long rows_per_block = 4 * (64 / lpr);
+  const unsigned blocks = (unsigned)std::min<long long>((n + rows_per_block - 1) / rows_per_block, 8192);
+  switch (lpr) {
+    case 8: launch_score<8>(dt, blocks, st, table, n_table_rows, d, indices, n, q, out_scores, rb->dev); break;
+    case 16: launch_score<16>(dt, blocks, st, table, n_table_rows, d, indices, n, q, out_scores, rb->dev); break;
+    case 32: launch_score<32>(dt, blocks, st, table, n_table_rows, d, indices, n, q, out_scores, rb->dev); break;
+    default: launch_score<64>(dt, blocks, st, table, n_table_rows, d, indices, n, q, out_scores, rb->dev); break;
+  }
+  HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  if (rb->host->bad_i != 0x7fffffffffffffffll) {
+    if (bad_i) *bad_i = rb->host->bad_i;
+    return fail(NANN_ERR_INDEX_OUT_OF_RANGE, "indices[" + std::to_string(rb->host->bad_i) +
+                                                 "] is not in [0, " + std::to_string(n_table_rows) + ")");
+  }
+  return NANN_OK;
+}
+
+// ---- index ---------------------------------------------------------------------------
+static int64_t dtype_bytes(int dt) { return dt == NANN_F32 ? 4 : 2; }
+
+int nann_index_create(const nann_index_desc* desc, nann_index** out) {
+  if (!desc || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_index_create: null argument");
+  const nann_index_desc& h = *desc;
+  if (h.n_items <= 0 || h.n_items > 0x7fffffffll) return fail(NANN_ERR_BAD_ARGUMENT, "n_items out of range");
+  if (!(h.d == 64 || h.d == 128 || h.d == 256 || h.d == 512))
+    return fail(NANN_ERR_UNSUPPORTED, "embedding dim must be 64, 128, 256 or 512");
+  if (h.n_enter < 0 || h.n_enter > 0x7fffffffll) return fail(NANN_ERR_BAD_ARGUMENT, "n_enter out of range");
+  for (int l = 0; l < 2; ++l)
+    if (h.nb_nnz[l] < 0 || h.nb_nnz[l] > 0xffffffffll)
+      return fail(NANN_ERR_UNSUPPORTED, "a level holds more than 2^32-1 links");
+  nann_index* ix = new nann_index();
+  ix->desc = h;
+  const int64_t N = h.n_items;
+  // host copies of the small arrays for validation
+  std::vector<int64_t> rs_host[2];
+  std::vector<int32_t> ep_host((size_t)h.n_enter);
+  auto fetch = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (!bytes) return NANN_OK;
+    if (h.on_device) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }
+    else std::memcpy(dst, src, bytes);
+    return NANN_OK;
+  };
+  int rc = NANN_OK;
+  for (int l = 0; l < 2 && !rc; ++l) {
+    rs_host[l].resize((size_t)N + 1);
+    rc = fetch(rs_host[l].data(), h.nb_row_splits[l], (size_t)(N + 1) * 8);
+  }
+  if (!rc) rc = fetch(ep_host.data(), h.enter_points, (size_t)h.n_enter * 4);
+  if (rc) { delete ix; return rc; }
+  for (int l = 0; l < 2; ++l) {
+    const auto& rs = rs_host[l];
+    if (rs[0] != 0 || rs[(size_t)N] != h.nb_nnz[l]) {
+      delete ix;
+      return fail(NANN_ERR_INVALID_RAGGED_PARAMS, "level " + std::to_string(l) + " row_splits do not span its values");
+    }
+    int64_t md = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t len = rs[(size_t)i + 1] - rs[(size_t)i];
+      if (len < 0) { delete ix; return fail(NANN_ERR_INVALID_RAGGED_PARAMS, "row_splits not monotone"); }
+      md = std::max(md, len);
+    }
+    ix->max_deg[l] = md;
+  }
+  for (int64_t i = 0; i < h.n_enter; ++i) {
+    if (ep_host[(size_t)i] < 0 || ep_host[(size_t)i] >= N) { delete ix; return fail(NANN_ERR_INDEX_OUT_OF_RANGE, "enter point out of range"); }
+    if (i && ep_host[(size_t)i] <= ep_host[(size_t)i - 1]) { delete ix; return fail(NANN_ERR_BAD_ARGUMENT, "enter points must be ascending and unique"); }
+  }
+  ix->bm_words = (uint32_t)(((N + 31) / 32 + 3) / 4 * 4);
+  if (!h.on_device) {  // one-time H2D, what HugeConst's GPU kernel does (huge_const_op.cc:187-218)
+    auto up = [&](const void* src, size_t bytes, const void** dst) -> int {
+      void* d = nullptr;
+      HIP_TRY(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+      ix->owned.push_back(d);
+      if (bytes) HIP_TRY(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+      *dst = d;
+      return NANN_OK;
+    };
+    nann_index_desc& dd = ix->desc;
+    rc = up(h.item_embs, (size_t)N * h.d * dtype_bytes(h.emb_dtype), &dd.item_embs);
+    if (!rc) rc = up(h.item_ids, (size_t)N * 8, reinterpret_cast<const void**>(&dd.item_ids));
+    for (int l = 0; l < 2 && !rc; ++l) {
+      rc = up(h.nb_values[l], (size_t)h.nb_nnz[l] * 4, reinterpret_cast<const void**>(&dd.nb_values[l]));
+      if (!rc) rc = up(h.nb_row_splits[l], (size_t)(N + 1) * 8, reinterpret_cast<const void**>(&dd.nb_row_splits[l]));
+    }
+    if (!rc) rc = up(h.enter_points, (size_t)h.n_enter * 4, reinterpret_cast<const void**>(&dd.enter_points));
+    if (rc) { nann_index_destroy(ix); return rc; }
+    ix->owns = true;
+    dd.on_device = 1;
+  }
+  *out = ix;
+  return NANN_OK;
+}
+
+void nann_index_destroy(nann_index* ix) {
+  if (!ix) return;
+  for (void* p : ix->owned) (void)hipFree(p);
+  delete ix;
+}
+
+int nann_index_info(const nann_index* ix, int64_t out[6]) {
+  if (!ix || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_index_info: null argument");
+  out[0] = ix->desc.n_items; out[1] = ix->desc.d; out[2] = ix->desc.n_enter;
+  out[3] = ix->max_deg[0]; out[4] = ix->max_deg[1]; out[5] = ix->bm_words;
+  return NANN_OK;
+}
+
+// ---- fused search -----------------------------------------------------------------------
+struct SearchPlan {
+  int max_cand, max_raw, pool_cap;
+  bool lds_bitmap;
+  size_t lds_bytes;
+  unsigned long long slot_bytes;
+  int slots;
+};
+
+static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, SearchPlan* p) {
+  for (int i = 0; i < 6; ++i)
+    if (t[i] < 0 || t[i] > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "level_topn entries must be in [0, 1024]");
+  DeviceInfo di;
+  int rc = device_info(&di);
+  if (rc) return rc;
+  const int64_t E = ix->desc.n_enter;
+  const int64_t raw1 = (int64_t)t[0] * ix->max_deg[1];
+  const int64_t raw0 = (int64_t)std::max(t[1], std::max(t[2], t[3])) * ix->max_deg[0];
+  const int64_t max_raw = std::max<int64_t>(std::max(raw1, raw0), 1);
+  const int64_t max_cand = std::max<int64_t>(std::max<int64_t>(E, t[0] + raw1), std::max<int64_t>(raw0, 1));
+  if (max_cand > 0x3fffffffll) return fail(NANN_ERR_UNSUPPORTED, "candidate bound too large");
+  p->max_cand = (int)max_cand;
+  p->max_raw = (int)max_raw;
+  p->pool_cap = std::max(t[1] + t[2] + t[3] + t[4], 1);
+  const size_t fixed = kPhaseScratch + kMaxD * 4 + 128;
+  const size_t bm_bytes = (size_t)ix->bm_words * 4;
+  p->lds_bitmap = bm_bytes + fixed <= di.lds_max;
+  p->lds_bytes = fixed + (p->lds_bitmap ? bm_bytes : 0);
+  unsigned long long off[8];
+  p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, p->lds_bitmap ? 0u : ix->bm_words, off);
+  const int per_cu = p->lds_bitmap ? 1 : 2;  // LDS-resident bitmap: one workgroup per CU
+  p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
+  return NANN_OK;
+}
+
+int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6], int64_t n_queries,
+                                int64_t* nbytes) {
+  if (!ix || !level_topn || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_workspace_bytes: null argument");
+  SearchPlan p;
+  const int rc = plan_search(ix, level_topn, n_queries, &p);
+  if (rc) return rc;
+  *nbytes = (int64_t)(p.slot_bytes * (unsigned long long)p.slots);
+  return NANN_OK;
+}
+
+}  // extern "C"
+
+template <int LPR, int DT>
+static int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  if (p.lds_bitmap) {
+    auto kern = k_search<LPR, DT, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(kNT), p.lds_bytes, st, a);
+  } else {
+    auto kern = k_search<LPR, DT, false>;
+    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(kNT), p.lds_bytes, st, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+template <int LPR>
+static int launch_search_dt(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  if (dt == NANN_F16) return launch_search<LPR, DT_F16>(p, a, st);
+  if (dt == NANN_BF16) return launch_search<LPR, DT_BF16>(p, a, st);
+  return launch_search<LPR, DT_F32>(p, a, st);
+}
+
+extern "C" {
+
+int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                int32_t* counters, nann_stream_t stream) {
+  if (!ix || !scorer || !level_topn || !out_item_ids || !status)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
+  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  SearchPlan p;
+  int rc = plan_search(ix, level_topn, n_queries, &p);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < (int64_t)(p.slot_bytes * (unsigned long long)p.slots))
+    return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");
+  SearchArgs a;
+  a.emb = ix->desc.item_embs;
+  a.item_ids = ix->desc.item_ids;
+  for (int l = 0; l < 2; ++l) { a.nbv[l] = ix->desc.nb_values[l]; a.nbrs[l] = ix->desc.nb_row_splits[l]; }
+  a.enter = ix->desc.enter_points;
+  a.n_enter = (int)ix->desc.n_enter;
+  a.n_items = (uint32_t)ix->desc.n_items;
+  a.d = ix->desc.d;
+  a.q = q;
+  a.n_queries = (int)n_queries;
+  for (int i = 0; i < 6; ++i) a.t[i] = level_topn[i];
+  a.ws = static_cast<unsigned char*>(workspace);
+  a.slot_bytes = p.slot_bytes;
+  a.bm_words = ix->bm_words;
+  a.max_cand = p.max_cand; a.max_raw = p.max_raw; a.pool_cap = p.pool_cap;
+  a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index;
+  a.status = status; a.counters = counters;
+  hipStream_t st = as_stream(stream);
+  const int dt = ix->desc.emb_dtype;
+  switch (ix->desc.d / 8) {
+    case 8: return launch_search_dt<8>(dt, p, a, st);
+    case 16: return launch_search_dt<16>(dt, p, a, st);
+    case 32: return launch_search_dt<32>(dt, p, a, st);
+    default: return launch_search_dt<64>(dt, p, a, st);
+  }
+}
+
+// ---- merge ------------------------------------------------------------------------------
+int nann_merge_topk(const float* scores, const int64_t* ids, int64_t n_queries, int32_t n_shards,
+                    int32_t k_in, int32_t k_out, float* out_scores, int64_t* out_ids,
+                    nann_stream_t stream) {
+  const int64_t n_in = (int64_t)n_shards * k_in;
+  if (k_out < 0 || k_out > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "k_out must be in [0, 1024]");
+  if (n_in < k_out) return fail(NANN_ERR_TOPK_K_GT_N, "fewer candidates than k_out");
+  if (n_queries <= 0 || k_out == 0) return NANN_OK;
+  hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)n_queries), dim3(kNT), 0, as_stream(stream), scores,
+                     ids, (int)n_in, (int)k_out, out_scores, out_ids);
+  HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+int nann_merge_topk_host(const float* scores, const int64_t* ids, int64_t n_queries, int32_t n_shards,
+                         int32_t k_in, int32_t k_out, float* out_scores, int64_t* out_ids) {
+  const int64_t n_in = (int64_t)n_shards * k_in;
+  if (k_out < 0) return fail(NANN_ERR_BAD_ARGUMENT, "k_out < 0");
+  if (n_in < k_out) return fail(NANN_ERR_TOPK_K_GT_N, "fewer candidates than k_out");
+  std::vector<int32_t> idx((size_t)n_in);
+  for (int64_t qi = 0; qi < n_queries; ++qi) {
+    const float* s = scores + qi * n_in;
+    for (int64_t i = 0; i < n_in; ++i) idx[(size_t)i] = (int32_t)i;
+    std::partial_sort(idx.begin(), idx.begin() + k_out, idx.end(), [s](int32_t x, int32_t y) {
+      if (s[y] < s[x]) return true;   // value descending
+      if (s[y] > s[x]) return false;
+      return x < y;                   // ties -> lower position (shard-major)
+    });
+    for (int32_t i = 0; i < k_out; ++i) {
+      out_scores[qi * k_out + i] = s[idx[(size_t)i]];
+      out_ids[qi * k_out + i] = ids[qi * n_in + idx[(size_t)i]];
+    }
+  }
+  return NANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's custom-op surface for the retrieval path.
+
+Same op names, argument order/meaning and error behaviour as the TensorFlow
+wrappers the reference generates from its REGISTER_OP blocks
+(`tf.group_gather`, `tf.bitmap_ref_difference`, `tf.huge_const`,
+`tf.blaze_xla_op`; tensorflow/python/user_ops/user_ops.py) plus the two stock
+ops the serving graph chains between them (`tf.gather`, `tf.math.top_k`).
+Every function is a thin call into the C ABI (include/nann_hip.h) on torch
+CUDA tensors -- torch only provides device memory and the stream.
+
+Citations are relative to /root/reference/,
+UO/ = tensorflow/tensorflow/core/user_ops/.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, last_error
+
+
+# ---- errors: the classes the reference raises through tf.errors --------------
+class NannError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"[{_lib.STATUS_NAMES.get(status, status)}] {message}")
+        self.status = status
+
+
+class InvalidArgumentError(NannError):
+    """errors::InvalidArgument (OP_REQUIRES in the reference kernels)."""
+
+
+class InternalError(NannError):
+    """errors::Internal"""
+
+
+class NotFoundError(NannError):
+    """errors::NotFound (huge_const_op.cc:96-98)"""
+
+
+class UnimplementedError(NannError):
+    """errors::Unimplemented"""
+
+
+_INVALID = {1, 2, 3, 4, 5, 7, 8}
+
+
+def _raise(status, what=""):
+    msg = last_error() or what
+    if status in _INVALID:
+        raise InvalidArgumentError(status, msg)
+    if status == 104:
+        raise NotFoundError(status, msg)
+    if status == 102:
+        raise UnimplementedError(status, msg)
+    raise InternalError(status, msg)
+
+
+def _check(status, what=""):
+    if status != _lib.OK:
+        _raise(status, what)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev(t, dtype):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t), dtype=dtype)
+    if not t.is_cuda:
+        t = t.cuda()
+    return t.to(dtype).contiguous()
+
+
+# ---- a1: GroupGather ----------------------------------------------------------
+def group_gather(params_values, params_row_splits, indices_values, indices_row_splits, unique=False):
+    """tf.group_gather (UO/beam_search_op/GroupGather_kernel.cc:18-42): for each
+    group of `indices`, concatenate the CSR rows params[i] in order, duplicates
+    kept.  Returns (ret_values int32, ret_row_splits int64).
+
+    unique=True selects the reference's unordered_set path (:91-131), whose
+    output order is implementation-defined; the serving graph never uses it
+    (build_opt_graph.py:48) and it is not implemented here."""
+    if unique:
+        raise UnimplementedError(102, "GroupGather unique=True is not used by the serving graph")
+    pv = _dev(params_values, torch.int32)
+    prs = _dev(params_row_splits, torch.int64)
+    iv = _dev(indices_values, torch.int64)
+    irs = _dev(indices_row_splits, torch.int64)
+    ret_rs = torch.zeros(max(irs.numel(), 1), dtype=torch.int64, device=pv.device)
+    offsets = torch.empty(iv.numel() + 1, dtype=torch.int64, device=pv.device)
+    n_ret, n_rs, code = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    st = lib().nann_group_gather_count(
+        _ptr(prs), C.c_int64(prs.numel()), C.c_int64(pv.numel()), _ptr(iv), C.c_int64(iv.numel()),
+        _ptr(irs), C.c_int64(irs.numel()), _ptr(ret_rs), _ptr(offsets), C.byref(n_ret),
+        C.byref(n_rs), C.byref(code), _stream())
+    _check(st, "GroupGather")
+    ret_values = torch.empty(n_ret.value, dtype=torch.int32, device=pv.device)
+    if n_ret.value:
+        st = lib().nann_group_gather_fill(_ptr(pv), _ptr(prs), _ptr(iv), C.c_int64(iv.numel()),
+                                          _ptr(offsets), _ptr(ret_values), _stream())
+        _check(st, "GroupGather")
+    return ret_values, ret_rs[: n_rs.value]
+
+
+# ---- a2: BitmapRefDifference ---------------------------------------------------
+def bitmap_ref_difference(idx_next_values, idx_next_row_splits, idx_flag):
+    """tf.bitmap_ref_difference (UO/bitmap_op/bitmap_ops.cc:150-257): ordered
+    first-occurrence filter of ids whose bit is clear; `idx_flag` (int32 CUDA
+    tensor, ceil(N/32) words) is the Ref input and is mutated IN PLACE.
+    Returns (c_values, c_row_splits, idx_flag)."""
+    if not (isinstance(idx_flag, torch.Tensor) and idx_flag.is_cuda and idx_flag.dtype == torch.int32
+            and idx_flag.is_contiguous()):
+        raise InvalidArgumentError(7, "idx_flag must be a contiguous int32 CUDA tensor (Ref input)")
+    v = _dev(idx_next_values, torch.int32)
+    rs = _dev(idx_next_row_splits, torch.int64)
+    out = torch.empty(max(v.numel(), 1), dtype=torch.int32, device=v.device)
+    out_rs = torch.zeros(max(rs.numel(), 1), dtype=torch.int64, device=v.device)
+    n_out, n_rs, code = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    st = lib().nann_bitmap_ref_difference(
+        _ptr(v), C.c_int64(v.numel()), _ptr(rs), C.c_int64(rs.numel()), _ptr(idx_flag),
+        C.c_int64(idx_flag.numel()), _ptr(out), _ptr(out_rs), C.byref(n_out), C.byref(n_rs),
+        C.byref(code), _stream())
+    _check(st, "BitmapRefDifference")
+    return out[: n_out.value], out_rs[: n_rs.value], idx_flag
+
+
+# ---- a3: GatherV2 ---------------------------------------------------------------
+def gather(params, indices):
+    """tf.gather axis 0 (core/kernels/gather_op.cc, gather_functor.h:38-116)."""
+    assert params.is_cuda and params.is_contiguous()
+    idx = _dev(indices, torch.int32)
+    row_bytes = params[0].numel() * params.element_size() if params.dim() > 1 else params.element_size()
+    if row_bytes % 4:
+        raise UnimplementedError(102, "row size must be a multiple of 4 bytes")
+    out = torch.empty((idx.numel(),) + tuple(params.shape[1:]), dtype=params.dtype, device=params.device)
+    bad = C.c_int64(-1)
+    st = lib().nann_gather_rows(_ptr(params), C.c_int64(params.shape[0]), C.c_int64(row_bytes), _ptr(idx),
+                                C.c_int64(idx.numel()), _ptr(out), C.byref(bad), _stream())
+    _check(st, "GatherV2")
+    return out
+
+
+# ---- a5: TopKV2 -------------------------------------------------------------------
+def top_k(values, k):
+    """tf.math.top_k(sorted=True) (core/kernels/topk_op.cc:40-205): returns
+    (values, indices int32); descending, ties -> lower index."""
+    v = _dev(values, torch.float32)
+    squeeze = v.dim() == 1
+    if v.dim() == 0:
+        raise InvalidArgumentError(8, "input must be >= 1-D, got shape []")  # topk_op.cc:63-65
+    v2 = v.reshape(-1, v.shape[-1])
+    ov = torch.empty((v2.shape[0], max(k, 0)), dtype=torch.float32, device=v.device)
+    oi = torch.empty((v2.shape[0], max(k, 0)), dtype=torch.int32, device=v.device)
+    st = lib().nann_topk(_ptr(v2), C.c_int64(v2.shape[0]), C.c_int64(v2.shape[1]), C.c_int32(k), _ptr(ov),
+                         _ptr(oi), _stream())
+    _check(st, "TopKV2")
+    shape = tuple(v.shape[:-1]) + (k,)
+    return (ov.reshape(shape), oi.reshape(shape)) if not squeeze else (ov[0], oi[0])
+
+
+# ---- a4: the scorer behind BlazeXlaOp ----------------------------------------------
+_DT = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
+
+
+class Scorer:
+    """What the frozen scoring GraphDef is to BlazeXlaOp (blaze_xla_kernel.cc:24-33):
+    kind 'l2' (s = -||q - x||^2) or 'mlp' (weights dict as synth.make_mlp_weights)."""
+
+    def __init__(self, kind, d, emb_dtype=torch.float16, weights=None):
+        self.kind, self.d, self.emb_dtype = kind, d, emb_dtype
+        desc = _lib.ScorerDesc()
+        desc.kind = _lib.SCORER_L2 if kind == "l2" else _lib.SCORER_MLP
+        desc.d = d
+        desc.emb_dtype = _DT[emb_dtype]
+        self._keep = {}
+        if kind == "mlp":
+            for name in ("w1", "b1", "alpha1", "w2", "b2", "alpha2", "w3"):
+                a = np.ascontiguousarray(weights[name], dtype=np.float32)
+                self._keep[name] = a
+                setattr(desc, name, a.ctypes.data)
+            desc.h1, desc.h2 = self._keep["w1"].shape[1], self._keep["w2"].shape[1]
+        self.handle = C.c_void_p(0)
+        _check(lib().nann_scorer_create(C.byref(desc), C.byref(self.handle)), "scorer")
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            lib().nann_scorer_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+
+def user_seq_mean(comm_seq):
+    """comm_seq f16[B, L, d] (the `comm_seq` feed reshaped, build_opt_graph.py:76-79)
+    -> q f32[B, d]: mean of the non-pad history rows."""
+    s = _dev(comm_seq, torch.float16)
+    b, l, d = s.shape
+    q = torch.empty((b, d), dtype=torch.float32, device=s.device)
+    _check(lib().nann_user_seq_mean(_ptr(s), C.c_int64(b), C.c_int32(l), C.c_int32(d), _ptr(q), _stream()))
+    return q
+
+
+def blaze_score(scorer, q, item_emb=None, table=None, indices=None):
+    """The BlazeXlaOp contract for one user (forward(), build_opt_graph.py:91-107):
+    f32 logits, one per candidate row, rows scored independently.
+    Either item_emb [n, d] (already gathered, as BlazeXlaOp receives it) or
+    table + indices (fused GatherV2 + score)."""
+    q = _dev(q, torch.float32).reshape(-1)
+    bad = C.c_int64(-1)
+    if item_emb is not None:
+        rows, n_table, idx, n = item_emb.contiguous(), item_emb.shape[0], None, item_emb.shape[0]
+    else:
+        rows, n_table = table, table.shape[0]
+        idx = _dev(indices, torch.int32)
+        n = idx.numel()
+    out = torch.empty(max(n, 1), dtype=torch.float32, device=q.device)
+    st = lib().nann_score(scorer.handle, _ptr(q), _ptr(rows), C.c_int64(n_table), _ptr(idx), C.c_int64(n),
+                          _ptr(out), C.byref(bad), _stream())
+    _check(st, "BlazeXlaOp")
+    return out[:n]
+
+
+# ---- a6: HugeConst ---------------------------------------------------------------------
+_NPY = {np.dtype(np.float16): (_lib.F16, torch.float16), np.dtype(np.float32): (_lib.F32, torch.float32),
+        np.dtype(np.float64): (_lib.F64, torch.float64), np.dtype(np.int32): (_lib.I32, torch.int32),
+        np.dtype(np.int64): (_lib.I64, torch.int64)}
+
+
+class HugeConst:
+    """tf.huge_const (UO/huge_const_op/huge_const_op.cc:58-226): a .npy file
+    loaded into HBM once and held for the lifetime of the object.
+    dtype/shape play the role of the op's attrs and are validated against the
+    npy header (:108-147).  `.tensor` is a zero-copy torch view."""
+
+    def __init__(self, path, dtype, shape):
+        code, tdt = _NPY[np.dtype(dtype)]
+        shp = (C.c_int64 * len(shape))(*shape)
+        ptr, nbytes = C.c_void_p(0), C.c_int64(0)
+        _check(lib().nann_huge_const_load(path.encode(), C.c_int(code), shp, C.c_int(len(shape)),
+                                          C.byref(ptr), C.byref(nbytes)), "HugeConst")
+        self._ptr, self.nbytes = ptr, nbytes.value
+        self.shape, self.dtype = tuple(shape), tdt
+        self.tensor = _wrap_device_pointer(ptr.value, self.shape, tdt, self)
+
+    def __del__(self):
+        if getattr(self, "_ptr", None) and self._ptr.value:
+            lib().nann_free(self._ptr)
+            self._ptr = C.c_void_p(0)
+
+
+def _wrap_device_pointer(ptr, shape, dtype, owner):
+    """torch view of library-owned HBM via __cuda_array_interface__."""
+    typestr = {torch.float16: "<f2", torch.float32: "<f4", torch.float64: "<f8", torch.int32: "<i4",
+               torch.int64: "<i8"}[dtype]
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False),
+                                  "version": 3, "strides": None}
+    h._owner = owner
+    n = int(np.prod(shape)) if len(shape) else 1
+    if n == 0:
+        return torch.empty(shape, dtype=dtype, device="cuda")
+    return torch.as_tensor(h, device="cuda")
+
+
+def huge_const(path, dtype=None):
+    """model_util.huge_constant (NANN_impls/nann/model/model_util.py:107-121)
+    without its in-place rewrite of the file (Appendix C): the header supplies
+    the shape; a dtype different from the file's is an error here."""
+    with open(path, "rb") as f:
+        np.lib.format.read_magic(f)
+        shape, fortran, file_dtype = np.lib.format.read_array_header_1_0(f)
+    hc = HugeConst(path, dtype or file_dtype, shape)
+    return hc

@@ -1,0 +1,185 @@
+"""The traversal schedule of the reference's serving graph on the MI355X.
+
+`build_model()` in NANN_impls/nann/delivery/build_opt_graph.py:69-149 chains
+GroupGather / BitmapRefDifference / GatherV2 / BlazeXlaOp / TopKV2 ~40 times
+per request.  Two equivalent executions of that schedule live here:
+
+  * `search()`        one fused launch for a whole batch of queries
+                      (nann_search in include/nann_hip.h) -- the product path;
+  * `search_per_op()` the same schedule spelled op by op with the drop-in ops
+                      of nann_amd.ops, line for line against build_model(), so
+                      that each op is exercised in the composition the
+                      reference uses it in (plumbing/parity, not performance).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import lib
+from .ops import _check, _ptr, _stream
+
+
+class Index:
+    """Device-resident corpus + graph: what the serving graph's HugeConst nodes
+    hold (build_opt_graph.py:83-90) plus the baked enter_points Const (:70)."""
+
+    def __init__(self, item_embs, item_ids, nb_values, nb_row_splits, enter_points, device=None):
+        dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+        def put(a, dt):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dt).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(a)).to(device=dev, dtype=dt).contiguous()
+
+        if isinstance(item_embs, np.ndarray) and item_embs.dtype == np.uint16:  # bf16 bit patterns
+            self.item_embs = torch.as_tensor(item_embs.view(np.int16)).to(dev).view(torch.bfloat16)
+        elif isinstance(item_embs, torch.Tensor):
+            self.item_embs = item_embs.to(dev).contiguous()
+        else:
+            self.item_embs = torch.as_tensor(np.ascontiguousarray(item_embs)).to(dev)
+        self.item_ids = put(item_ids, torch.int64)
+        self.nb_values = [put(nb_values[l], torch.int32) for l in (0, 1)]
+        self.nb_row_splits = [put(nb_row_splits[l], torch.int64) for l in (0, 1)]
+        self.enter_points = put(enter_points, torch.int32)
+        self.n_items, self.d = self.item_embs.shape
+        desc = _lib.IndexDesc()
+        desc.n_items, desc.d = self.n_items, self.d
+        desc.emb_dtype = ops._DT[self.item_embs.dtype]
+        desc.item_embs = self.item_embs.data_ptr()
+        desc.item_ids = self.item_ids.data_ptr()
+        for l in (0, 1):
+            desc.nb_values[l] = self.nb_values[l].data_ptr()
+            desc.nb_row_splits[l] = self.nb_row_splits[l].data_ptr()
+            desc.nb_nnz[l] = self.nb_values[l].numel()
+        desc.enter_points = self.enter_points.data_ptr()
+        desc.n_enter = self.enter_points.numel()
+        desc.on_device = 1
+        self.handle = C.c_void_p(0)
+        with torch.cuda.device(dev):
+            _check(lib().nann_index_create(C.byref(desc), C.byref(self.handle)), "index")
+        info = (C.c_int64 * 6)()
+        _check(lib().nann_index_info(self.handle, info))
+        self.max_deg = (int(info[3]), int(info[4]))
+        self.bitmap_words = int(math.ceil(self.n_items / 32))  # build_opt_graph.py:114
+        self.device = dev
+        self._ws = None
+
+    @classmethod
+    def from_dict(cls, g, device=None):
+        return cls(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"],
+                   device=device)
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            lib().nann_index_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+    def workspace(self, level_topn, n_queries):
+        t = (C.c_int32 * 6)(*[int(x) for x in level_topn])
+        nbytes = C.c_int64(0)
+        _check(lib().nann_search_workspace_bytes(self.handle, t, C.c_int64(n_queries), C.byref(nbytes)))
+        if self._ws is None or self._ws.numel() < nbytes.value:
+            self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+
+class SearchResult:
+    __slots__ = ("item_ids", "scores", "index", "status", "counters")
+
+    def __init__(self, item_ids, scores, index, status, counters):
+        self.item_ids, self.scores, self.index, self.status, self.counters = (
+            item_ids, scores, index, status, counters)
+
+
+def search(index, scorer, q, level_topn, want_counters=True):
+    """Fused execution of build_model()'s schedule for a batch of queries.
+    q: f32[B, d] CUDA tensor (ops.user_seq_mean of `comm_seq`).  Asynchronous:
+    the returned tensors are valid once the current stream reaches them.
+    status[b] != 0 marks a request the reference would have failed."""
+    q = q.to(device=index.device, dtype=torch.float32).contiguous()
+    b = q.shape[0]
+    t = (C.c_int32 * 6)(*[int(x) for x in level_topn])
+    k = int(level_topn[5])
+    dev = index.device
+    out_ids = torch.empty((b, k), dtype=torch.int64, device=dev)
+    out_scores = torch.empty((b, k), dtype=torch.float32, device=dev)
+    out_index = torch.empty((b, k), dtype=torch.int32, device=dev)
+    status = torch.empty(b, dtype=torch.int32, device=dev)
+    counters = torch.zeros((b, 3, _lib.NUM_ROUNDS), dtype=torch.int32, device=dev) if want_counters else None
+    ws = index.workspace(level_topn, b)
+    with torch.cuda.device(dev):
+        _check(lib().nann_search(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(ws),
+                                 C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
+                                 _ptr(status), _ptr(counters), _stream()), "search")
+    return SearchResult(out_ids, out_scores, out_index, status, counters)
+
+
+# -----------------------------------------------------------------------------
+# build_model() spelled with the per-op drop-ins (one query)
+def _fake_row_splits(x):
+    """build_opt_graph.py:29-30"""
+    return torch.tensor([0, x.numel()], dtype=torch.int64, device=x.device)
+
+
+def _set_difference(a, flags):
+    """build_opt_graph.py:33-36"""
+    values, _, flags = ops.bitmap_ref_difference(a, _fake_row_splits(a), flags)
+    return values, flags
+
+
+def _ragged_gather(values, row_splits, idx):
+    """build_opt_graph.py:39-49"""
+    out, _ = ops.group_gather(values, row_splits, idx.to(torch.int64), _fake_row_splits(idx), unique=False)
+    return out
+
+
+def _top_k(ids, scores, k):
+    """build_opt_graph.py:52-66"""
+    scores, indices = ops.top_k(scores, k)
+    return ops.gather(ids, indices), scores
+
+
+def search_per_op(index, scorer, q, level_topn):
+    """One query through the op-by-op schedule (build_opt_graph.py:109-149).
+    Raises the error the reference graph would raise.  Returns
+    (item_ids i64[k], scores f32[k], internal index i32[k])."""
+    q = q.reshape(-1)
+    t = [int(x) for x in level_topn]
+
+    def forward(idx):  # :91-107
+        if idx.numel() == 0:
+            raise ops.InternalError(6, "Error when getting input address or size")
+        s = ops.blaze_score(scorer, q, table=index.item_embs, indices=idx)
+        if idx.numel() == 1:  # tf.squeeze -> scalar; TopKV2/ConcatV2 reject it
+            raise ops.InvalidArgumentError(8, "input must be >= 1-D, got shape []")
+        return s
+
+    enter_points = index.enter_points
+    # level 2
+    scores = forward(enter_points)                                          # :111
+    idx_results, scores_result = _top_k(enter_points, scores, t[0])         # :112
+    # level 1
+    idx_next = _ragged_gather(index.nb_values[1], index.nb_row_splits[1], idx_results)   # :116
+    flags = torch.zeros(index.bitmap_words, dtype=torch.int32, device=index.device)      # :115-118
+    idx_results, _ = _set_difference(idx_results, flags)                    # :119-120
+    idx_next, _ = _set_difference(idx_next, flags)                          # :121-122
+    scores_next = forward(idx_next)                                         # :124
+    idx_result, scores_result = _top_k(torch.cat([idx_results, idx_next]),
+                                       torch.cat([scores_result, scores_next]), t[1])    # :125-127
+    # level 0
+    idx_candidate = idx_result
+    flags.zero_()                                                           # :131
+    idx_candidate, _ = _set_difference(idx_candidate, flags)                # :132-133
+    for i in range(3):                                                      # :135
+        idx_next = _ragged_gather(index.nb_values[0], index.nb_row_splits[0], idx_candidate)   # :136
+        idx_next, _ = _set_difference(idx_next, flags)                      # :137
+        scores_next = forward(idx_next)                                     # :138
+        idx_candidate, scores_candidate = _top_k(idx_next, scores_next, t[i + 2])   # :139
+        idx_result = torch.cat([idx_result, idx_candidate])                 # :140
+        scores_result = torch.cat([scores_result, scores_candidate])        # :141
+    idx_result, scores_result = _top_k(idx_result, scores_result, t[5])     # :143
+    item_ids = ops.gather(index.item_ids.view(torch.int32).reshape(-1, 2), idx_result)   # :144
+    return item_ids.reshape(-1).view(torch.int64), scores_result, idx_result

@@ -23,14 +23,38 @@ M_DEFAULT = 32  # --hnsw-num-neighbors, build_hnsw_index.py:24
 START_LEVEL = 2  # --hnsw-start-level, build_hnsw_index.py:22
 
 
-def make_corpus(n_items, d, n_clusters=256, noise=0.5, seed=1234):
-    """-> (item_embs f16[N,d], cluster assignment i32[N])"""
-    rng = np.random.default_rng(seed)
-    centres = rng.standard_normal((n_clusters, d), dtype=np.float32)
+def make_centres(d, n_clusters=256, seed=1234):
+    """Cluster centres f32[C, d]; shared by every shard of a sharded corpus."""
+    return np.random.default_rng(seed).standard_normal((n_clusters, d), dtype=np.float32)
+
+
+def make_corpus(n_items, d, n_clusters=256, noise=0.5, seed=1234, item_seed=None):
+    """-> (item_embs f16[N,d], cluster assignment i32[N]).  Centres come from
+    `seed`, the items from `item_seed` (default seed + 100) so that shards of
+    one corpus share centres but not items."""
+    centres = make_centres(d, n_clusters, seed)
+    rng = np.random.default_rng(seed + 100 if item_seed is None else item_seed)
     assign = rng.integers(0, n_clusters, size=n_items, dtype=np.int32)
     x = centres[assign] + noise * rng.standard_normal((n_items, d), dtype=np.float32)
     x *= np.float32(1.0 / math.sqrt(d))
     return x.astype(np.float16), assign
+
+
+def make_queries_from_centres(d, n_queries, n_clusters=256, noise=0.5, seq_len=50, min_len=7,
+                              seed=1234, query_seed=4321):
+    """UserBehavior-shaped `comm_seq` f16[B, seq_len, d] that does not depend on
+    any shard's items: each history is 7..50 fresh draws around one centre,
+    zero-padded tail (convert_UB_to_tfrecord.py:121-137)."""
+    centres = make_centres(d, n_clusters, seed)
+    rng = np.random.default_rng(query_seed)
+    seq = np.zeros((n_queries, seq_len, d), np.float32)
+    lens = rng.integers(min_len, seq_len + 1, size=n_queries)
+    cl = rng.integers(0, n_clusters, size=n_queries)
+    x = centres[cl][:, None, :] + noise * rng.standard_normal((n_queries, seq_len, d), dtype=np.float32)
+    x *= np.float32(1.0 / math.sqrt(d))
+    mask = np.arange(seq_len)[None, :] < lens[:, None]
+    seq[mask] = x[mask]
+    return seq.astype(np.float16)
 
 
 def make_item_ids(n_items, seed=1235):
@@ -225,11 +249,12 @@ def make_mlp_weights(d, h1=256, h2=128, seed=777):
 
 
 def make_index(n_items, d, ef, m=M_DEFAULT, device=None, mode="hnsw", seed=1234,
-               n_clusters=256, noise=0.5):
+               n_clusters=256, noise=0.5, shard=0):
     """One call: corpus + ids + graph.  Guarantees E >= ef."""
-    embs, assign = make_corpus(n_items, d, n_clusters=n_clusters, noise=noise, seed=seed)
-    ids = make_item_ids(n_items, seed=seed + 1)
-    levels = assign_levels(n_items, m=m, seed=seed + 2, min_enter=ef)
+    embs, assign = make_corpus(n_items, d, n_clusters=n_clusters, noise=noise, seed=seed,
+                               item_seed=seed + 100 + 1000 * shard)
+    ids = make_item_ids(n_items, seed=seed + 1 + 1000 * shard) + shard * n_items
+    levels = assign_levels(n_items, m=m, seed=seed + 2 + 1000 * shard, min_enter=ef)
     g = build_graph(embs, levels, m=m, device=device, mode=mode)
     g.update({"item_embs": embs, "item_ids": ids, "assign": assign, "levels": levels})
     return g

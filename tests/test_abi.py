@@ -1,0 +1,57 @@
+"""CPU: libnann_hip.so builds for gfx950, loads without a GPU, and exports every
+symbol include/nann_hip.h declares.  No compute calls here."""
+import ctypes
+import os
+import re
+
+from nann_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nann_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nann_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_the_abi():
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/nann_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_abi_version_and_error_string():
+    L = _lib.lib()
+    assert L.nann_abi_version() == 1
+    assert isinstance(_lib.last_error(), str)
+    assert L.nann_device_count() >= 0
+
+
+def test_status_codes_match_oracle():
+    from oracle import oracle as O
+    hdr = open(os.path.join(ROOT, "include", "nann_hip.h")).read()
+    for name, val in [("INVALID_RAGGED_PARAMS", O.ERR_INVALID_RAGGED_PARAMS),
+                      ("INVALID_RAGGED_INDICES", O.ERR_INVALID_RAGGED_INDICES),
+                      ("INVALID_RAGGED_INPUT", O.ERR_INVALID_RAGGED_INPUT),
+                      ("TOPK_K_GT_N", O.ERR_TOPK_K_GT_N), ("INDEX_OUT_OF_RANGE", O.ERR_INDEX_OUT_OF_RANGE),
+                      ("EMPTY_SCORE_BATCH", O.ERR_EMPTY_SCORE_BATCH), ("BAD_ARGUMENT", O.ERR_BAD_ARGUMENT),
+                      ("TOPK_SCALAR_INPUT", O.ERR_TOPK_SCALAR_INPUT)]:
+        m = re.search(rf"NANN_ERR_{name}\s*=\s*(\d+)", hdr)
+        assert m and int(m.group(1)) == val
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under nann_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "nann_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "from oracle" not in text and "import oracle" not in text, f
+                assert "nann_oracle" not in text or f == "nann_device.h", f

@@ -1,0 +1,266 @@
+"""-m gpu: each drop-in op (C ABI -> HIP kernel) against the CPU oracle and the
+reference's known answers.  Bit-exact for integer/index work and for L2 scores
+(shared canonical summation order)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import bits, cuda, require_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    require_gpu()
+
+
+@pytest.fixture(scope="module")
+def ref_ops(golden_dir):
+    with open(os.path.join(golden_dir, "reference_ops.json")) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------- GroupGather
+def test_group_gather_known_answers(ref_ops):
+    from nann_amd import ops
+    for case in ref_ops["group_gather"]:
+        args = (case["params_values"], case["params_row_splits"], case["indices_values"],
+                case["indices_row_splits"])
+        if case["status"]:
+            with pytest.raises(ops.InvalidArgumentError) as e:
+                ops.group_gather(*args)
+            assert e.value.status == case["status"], case["name"]
+            continue
+        v, rs = ops.group_gather(*args)
+        assert v.cpu().tolist() == case["ret_values"], case["name"]
+        assert rs.cpu().tolist() == case["ret_row_splits"], case["name"]
+
+
+def test_group_gather_random_ragged(oracle):
+    from nann_amd import ops
+    rng = np.random.default_rng(10)
+    for n_rows, n_groups, max_len in [(50, 1, 70), (3000, 7, 200), (20000, 1, 64), (100, 40, 0)]:
+        lens = rng.integers(0, max_len + 1, size=n_rows)
+        lens[rng.random(n_rows) < 0.3] = 0  # absent nodes have empty rows (build_hnsw_index.py:52-54)
+        prs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pv = rng.integers(0, 1 << 20, size=int(prs[-1])).astype(np.int32)
+        glen = rng.integers(0, 300, size=n_groups)
+        irs = np.concatenate([[0], np.cumsum(glen)]).astype(np.int64)
+        iv = rng.integers(0, n_rows, size=int(irs[-1])).astype(np.int64)
+        rc, _, ev, ers = oracle.group_gather(pv, prs, iv, irs)
+        v, rs = ops.group_gather(pv, prs, iv, irs)
+        assert rc == 0
+        assert (v.cpu().numpy() == ev).all() and (rs.cpu().numpy() == ers).all()
+
+
+def test_group_gather_errors():
+    from nann_amd import ops
+    with pytest.raises(ops.InvalidArgumentError) as e:  # indices ragged invalid, code 3
+        ops.group_gather([1, 2], [0, 2], [0, 0], [0, 1])
+    assert e.value.status == 2
+    with pytest.raises(ops.InvalidArgumentError) as e:  # row index out of range (UB in the reference)
+        ops.group_gather([1, 2], [0, 2], [1], [0, 1])
+    assert e.value.status == 5
+    with pytest.raises(ops.UnimplementedError):
+        ops.group_gather([1, 2], [0, 2], [0], [0, 1], unique=True)
+
+
+# ---------------------------------------------------------------- BitmapRefDifference
+def test_bitmap_ref_difference_known_answers(ref_ops):
+    from nann_amd import ops
+    for case in ref_ops["bitmap_ref_difference"]:
+        flags = torch.zeros(case["bitmap_words"], dtype=torch.int32, device="cuda")
+        for call in case["calls"]:
+            v, rs, f = ops.bitmap_ref_difference(call["values"], call["row_splits"], flags)
+            assert f is flags  # Ref input forwarded (bitmap_ops.cc:238)
+            assert v.cpu().tolist() == call["c_values"], case["name"]
+            assert rs.cpu().tolist() == call["c_row_splits"], case["name"]
+        assert flags.cpu().tolist() == case["final_flags"], case["name"]
+
+
+@pytest.mark.parametrize("n_items,n_values,n_groups,dup_range", [
+    (1000, 5000, 1, 300),         # heavy duplication inside 64-id chunks
+    (1_000_000, 8192, 1, 0),      # config-2 sized round, bitmap staged in LDS
+    (1_000_000, 20000, 5, 50000),
+    (8_000_000, 16384, 3, 0),     # 1 MB bitmap: walked in HBM
+    (64, 64, 1, 1),               # every id identical
+])
+def test_bitmap_ref_difference_random(oracle, n_items, n_values, n_groups, dup_range):
+    from nann_amd import ops
+    rng = np.random.default_rng(n_items + n_values)
+    hi = dup_range if dup_range else n_items
+    base = rng.integers(0, n_items - hi + 1)
+    vals = (base + rng.integers(0, hi, size=n_values)).astype(np.int32)
+    cuts = np.sort(rng.integers(0, n_values + 1, size=n_groups - 1))
+    rs = np.concatenate([[0], cuts, [n_values]]).astype(np.int64)
+    words = (n_items + 31) // 32
+    bm = rng.integers(-2**31, 2**31, size=words, dtype=np.int64).astype(np.int32) & rng.integers(
+        -2**31, 2**31, size=words, dtype=np.int64).astype(np.int32)  # ~25 % already visited
+    flags = cuda(bm)
+    for _ in range(2):  # second call on the updated bitmap keeps nothing new but must agree too
+        rc, _, ev, ers = oracle.bitmap_ref_difference(vals, rs, bm)
+        v, out_rs, _ = ops.bitmap_ref_difference(vals, rs, flags)
+        assert rc == 0
+        assert (v.cpu().numpy() == ev).all()
+        assert (out_rs.cpu().numpy() == ers).all()
+        assert (flags.cpu().numpy() == bm).all()
+
+
+def test_bitmap_ref_difference_errors(oracle):
+    from nann_amd import ops
+    flags = torch.zeros(2, dtype=torch.int32, device="cuda")
+    with pytest.raises(ops.InvalidArgumentError) as e:
+        ops.bitmap_ref_difference([1, 2, 3], [0, 2], flags)
+    assert e.value.status == 3
+    with pytest.raises(ops.InvalidArgumentError) as e:
+        ops.bitmap_ref_difference([1, 64], [0, 2], flags)
+    assert e.value.status == 5 and not flags.any()  # bitmap untouched
+
+
+# ---------------------------------------------------------------- GatherV2
+def test_gather():
+    from nann_amd import ops
+    rng = np.random.default_rng(11)
+    emb = cuda(rng.standard_normal((5000, 128)).astype(np.float16))
+    idx = rng.integers(0, 5000, size=3000).astype(np.int32)
+    assert torch.equal(ops.gather(emb, idx), emb[torch.as_tensor(idx).long().cuda()])
+    ids = cuda(rng.integers(1, 1 << 40, size=5000).astype(np.int64))
+    got = ops.gather(ids.view(torch.int32).reshape(-1, 2), idx).reshape(-1).view(torch.int64)
+    assert torch.equal(got, ids[torch.as_tensor(idx).long().cuda()])
+    assert ops.gather(emb, np.zeros(0, np.int32)).shape == (0, 128)
+    with pytest.raises(ops.InvalidArgumentError) as e:  # gather_op.cc:170-175
+        ops.gather(emb, [1, 2, 5000, 7000])
+    assert e.value.status == 5 and "indices[2]" in str(e.value)
+
+
+# ---------------------------------------------------------------- TopKV2
+@pytest.mark.parametrize("n,k", [(977, 128), (8192, 128), (512, 200), (300, 300), (64, 1), (5, 5),
+                                 (40000, 400), (8192, 1024), (130, 128)])
+def test_topk_random_with_ties(oracle, n, k):
+    from nann_amd import ops
+    rng = np.random.default_rng(n * 7 + k)
+    for x in (rng.standard_normal(n).astype(np.float32),
+              rng.integers(0, 40, size=n).astype(np.float32) - 20.0,       # many exact ties, +-0
+              -np.abs(rng.standard_normal(n)).astype(np.float32) * 1e-3):  # L2-like: all negative
+        rc, ev, ei = oracle.topk(x, k)
+        v, i = ops.top_k(cuda(x), k)
+        assert rc == 0
+        assert (i.cpu().numpy() == ei).all()
+        assert (bits(v.cpu().numpy()) == bits(ev)).all()
+
+
+def test_topk_rows_and_errors(oracle):
+    from nann_amd import ops
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 9, size=(6, 700)).astype(np.float32)
+    v, i = ops.top_k(cuda(x), 50)
+    for r in range(6):
+        _, ev, ei = oracle.topk(x[r], 50)
+        assert (i[r].cpu().numpy() == ei).all() and (v[r].cpu().numpy() == ev).all()
+    with pytest.raises(ops.InvalidArgumentError) as e:  # topk_op.cc:67-71
+        ops.top_k(cuda(x[0]), 701)
+    assert e.value.status == 4
+    v, i = ops.top_k(cuda(x[0]), 0)
+    assert v.numel() == 0
+    z = np.array([0.0, -0.0, 0.0, -0.0], np.float32)  # -0 == +0: position decides
+    assert ops.top_k(cuda(z), 4)[1].cpu().tolist() == [0, 1, 2, 3]
+
+
+# ---------------------------------------------------------------- scorer / user side
+def test_user_seq_mean_bitwise(oracle):
+    from nann_amd import ops
+    rng = np.random.default_rng(13)
+    for d in (64, 128):
+        seq = np.zeros((9, 50, d), np.float16)
+        for b in range(9):
+            L = 0 if b == 0 else rng.integers(7, 51)
+            seq[b, :L] = (rng.standard_normal((L, d)) * 0.3).astype(np.float16)
+        q = ops.user_seq_mean(cuda(seq)).cpu().numpy()
+        exp = np.stack([oracle.user_seq_mean(s) for s in seq])
+        assert (bits(q) == bits(exp)).all()
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+def test_l2_score_bitwise(oracle, d, dtype):
+    from nann_amd import ops
+    rng = np.random.default_rng(d)
+    n_table, n = 4000, 1777
+    x = (rng.standard_normal((n_table, d)) / np.sqrt(d)).astype(np.float32)
+    q = (rng.standard_normal(d) / np.sqrt(d)).astype(np.float32)
+    idx = rng.integers(0, n_table, size=n).astype(np.int32)
+    if dtype == "f16":
+        host, dev, code, tdt = x.astype(np.float16), None, oracle.EMB_F16, torch.float16
+        dev = cuda(host)
+    elif dtype == "bf16":
+        dev = cuda(x).to(torch.bfloat16)
+        host = dev.view(torch.int16).cpu().numpy().view(np.uint16)
+        code, tdt = oracle.EMB_BF16, torch.bfloat16
+    else:
+        host, dev, code, tdt = x, cuda(x), oracle.EMB_F32, torch.float32
+    rc, exp = oracle.score_rows(oracle.Scorer("l2", d, code), q, host[idx])
+    sc = ops.Scorer("l2", d, tdt)
+    got = ops.blaze_score(sc, cuda(q), table=dev, indices=idx).cpu().numpy()
+    assert rc == 0 and (bits(got) == bits(exp)).all()
+    got2 = ops.blaze_score(sc, cuda(q), item_emb=dev[torch.as_tensor(idx).long().cuda()]).cpu().numpy()
+    assert (bits(got2) == bits(exp)).all()
+    with pytest.raises(ops.InvalidArgumentError) as e:
+        ops.blaze_score(sc, cuda(q), table=dev, indices=[0, n_table])
+    assert e.value.status == 5
+    with pytest.raises(ops.InternalError) as e:  # blaze_xla_predictor.cc:259-263
+        ops.blaze_score(sc, cuda(q), table=dev, indices=np.zeros(0, np.int32))
+    assert e.value.status == 6
+
+
+# ---------------------------------------------------------------- HugeConst
+def test_huge_const(tmp_path):
+    from nann_amd import ops
+    rng = np.random.default_rng(14)
+    a = rng.standard_normal((300, 64)).astype(np.float16)
+    p = str(tmp_path / "item_embs.npy")
+    np.save(p, a)
+    hc = ops.huge_const(p)
+    assert hc.tensor.dtype == torch.float16 and tuple(hc.tensor.shape) == (300, 64)
+    assert (hc.tensor.cpu().numpy() == a).all()
+    ids = rng.integers(1, 1 << 50, size=1000).astype(np.int64)
+    p2 = str(tmp_path / "item_ids.npy")
+    np.save(p2, ids)
+    assert (ops.HugeConst(p2, np.int64, (1000,)).tensor.cpu().numpy() == ids).all()
+    with pytest.raises(ops.InternalError) as e:  # huge_const_op.cc:117-121
+        ops.HugeConst(p2, np.int32, (1000,))
+    assert e.value.status == 105
+    with pytest.raises(ops.InternalError) as e:  # :111-115
+        ops.HugeConst(p2, np.int64, (999,))
+    assert e.value.status == 106
+    with pytest.raises(ops.NotFoundError):  # :96-98
+        ops.HugeConst(str(tmp_path / "missing.npy"), np.int64, (1,))
+
+
+# ---------------------------------------------------------------- shard merge
+def test_merge_topk(oracle):
+    import ctypes as C
+    from nann_amd import _lib
+    rng = np.random.default_rng(15)
+    nq, shards, k = 37, 8, 200
+    s = -np.sort(rng.integers(0, 500, size=(nq, shards, k)).astype(np.float32), axis=2)
+    ids = rng.integers(1, 1 << 40, size=(nq, shards, k)).astype(np.int64)
+    ds, di = cuda(s), cuda(ids)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    st = _lib.lib().nann_merge_topk(C.c_void_p(ds.data_ptr()), C.c_void_p(di.data_ptr()), C.c_int64(nq),
+                                    C.c_int32(shards), C.c_int32(k), C.c_int32(k),
+                                    C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()), None)
+    assert st == 0
+    hs = np.empty((nq, k), np.float32); hi = np.empty((nq, k), np.int64)
+    st = _lib.lib().nann_merge_topk_host(s.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                         C.c_int64(nq), C.c_int32(shards), C.c_int32(k), C.c_int32(k),
+                                         hs.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p))
+    assert st == 0
+    for b in range(nq):
+        rc, es, ei = oracle.merge_topk(s[b], ids[b], k)
+        assert (oi[b].cpu().numpy() == ei).all() and (os_[b].cpu().numpy() == es).all()
+        assert (hi[b] == ei).all() and (hs[b] == es).all()

@@ -1,0 +1,126 @@
+"""-m gpu: the fused traversal (nann_search) and the op-by-op schedule against the
+CPU oracle: bit-exact neighbour indices, top-k item ids, scores and per-round
+counters; per-query failure codes; independence from batch size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import bits, cuda, queries_for, require_gpu, synth_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    require_gpu()
+
+
+def _run(dix, q, topn):
+    from nann_amd import ops, retrieval
+    sc = ops.Scorer("l2", dix.d, dix.item_embs.dtype)
+    r = retrieval.search(dix, sc, cuda(q), topn)
+    torch.cuda.synchronize()
+    return (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+            r.index.cpu().numpy(), r.counters.cpu().numpy())
+
+
+def _assert_same(got, exp):
+    st, ids, scores, idx, ctr = got
+    est, eids, escores, eidx, ectr = exp
+    assert (st == est).all(), (st, est)
+    ok = est == 0
+    assert (idx[ok] == eidx[ok]).all()
+    assert (ids[ok] == eids[ok]).all()
+    assert (bits(scores[ok]) == bits(escores[ok])).all()
+    assert (ctr[ok] == ectr[ok]).all()
+    assert (ids[~ok] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["small_l2_d64.npz", "small_l2_d128.npz"])
+def test_committed_vectors(golden_dir, name):
+    from nann_amd import ops, retrieval
+    z = np.load(os.path.join(golden_dir, name))
+    dix = retrieval.Index(z["item_embs"], z["item_ids"], [z["nb_values_0"], z["nb_values_1"]],
+                          [z["nb_row_splits_0"], z["nb_row_splits_1"]], z["enter_points"])
+    q = ops.user_seq_mean(cuda(z["comm_seq"])).cpu().numpy()
+    assert (bits(q) == bits(z["q"])).all()
+    got = _run(dix, q, z["level_topn"])
+    _assert_same(got, (z["status"], z["out_item_ids"], z["out_scores"], z["out_index"], z["counters"]))
+
+
+@pytest.mark.parametrize("n,d,ef,k,nq", [(20000, 64, 32, 20, 300), (60000, 128, 64, 50, 64)])
+def test_search_matches_oracle(oracle, n, d, ef, k, nq):
+    g, oix, dix = synth_index(n, d, ef)
+    seq = queries_for(g, nq)
+    q = np.stack([oracle.user_seq_mean(s) for s in seq])
+    topn = [ef] * 5 + [k]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", d, oracle.EMB_F16), q, topn, n_threads=8)
+    assert (exp[0] == 0).mean() > 0.5, "workload should be mostly valid requests"
+    got = _run(dix, q, topn)
+    _assert_same(got, exp)
+    # uneven level_topn, as in the reference's own benchmark feed (gen_runmeta.py:23)
+    topn2 = [ef // 2, ef, 2 * ef, 2 * ef, 2 * ef, k]
+    exp2 = oracle.search_batch(oix, oracle.Scorer("l2", d, oracle.EMB_F16), q[:40], topn2, n_threads=8)
+    _assert_same(_run(dix, q[:40], topn2), exp2)
+
+
+def test_batch_size_independence(oracle):
+    g, oix, dix = synth_index(20000, 64, 32)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 700, seed=99)])
+    topn = [32] * 5 + [20]
+    full = _run(dix, q, topn)  # more queries than workgroup slots: slots are reused
+    for b in (0, 255, 256, 699):
+        one = _run(dix, q[b:b + 1], topn)
+        assert (one[1][0] == full[1][b]).all() and (bits(one[2][0]) == bits(full[2][b])).all()
+
+
+def test_failing_requests_get_reference_codes(oracle):
+    g, oix, dix = synth_index(20000, 64, 32)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 8, seed=5)])
+    E = len(g["enter_points"])
+    sc = oracle.Scorer("l2", 64, oracle.EMB_F16)
+    for topn in ([E + 1, 8, 8, 8, 8, 8], [8, 8, 8, 8, 8, 33], [0, 8, 8, 8, 8, 8], [8, 1000, 8, 8, 8, 8]):
+        exp = oracle.search_batch(oix, sc, q, topn)
+        assert (exp[0] != 0).all()
+        got = _run(dix, q, topn)
+        assert (got[0] == exp[0]).all(), (topn, got[0], exp[0])
+        assert (got[1] == 0).all()
+
+
+def test_per_op_schedule_matches_oracle(oracle):
+    """build_model() spelled with the drop-in ops, one query at a time."""
+    from nann_amd import ops, retrieval
+    g, oix, dix = synth_index(20000, 64, 32)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 6, seed=77)])
+    topn = [32] * 5 + [20]
+    sc = ops.Scorer("l2", 64)
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn)
+    for b in range(6):
+        if exp[0][b]:
+            with pytest.raises(ops.NannError) as e:
+                retrieval.search_per_op(dix, sc, cuda(q[b]), topn)
+            assert e.value.status == exp[0][b]
+            continue
+        ids, scores, idx = retrieval.search_per_op(dix, sc, cuda(q[b]), topn)
+        assert (ids.cpu().numpy() == exp[1][b]).all()
+        assert (idx.cpu().numpy() == exp[3][b]).all()
+        assert (bits(scores.cpu().numpy()) == bits(exp[2][b])).all()
+
+
+def test_exact_ties_follow_position_order(oracle):
+    """Duplicate embeddings give exactly equal scores: TopKV2's lower-position rule
+    (topk_op.cc:134-142) must decide, which depends on the serial first-occurrence
+    order of BitmapRefDifference."""
+    from nann_amd import retrieval, synth
+    g = synth.make_index(6000, 64, ef=16, seed=5, noise=1.0, n_clusters=8, device="cuda")
+    embs = g["item_embs"].copy()
+    embs[1::2] = embs[0::2]  # every item has an identical twin
+    g["item_embs"] = embs
+    oix = oracle.Index(embs, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    dix = retrieval.Index.from_dict(g)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 40, seed=3)])
+    topn = [16] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn)
+    _assert_same(_run(dix, q, topn), exp)
