@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merge", default="device", choices=["device", "host"])
+    ap.add_argument("--index-cache", default=None, help="directory to cache the synthetic index in")
+    ap.add_argument("--phase-ticks", action="store_true",
+                    help="one extra instrumented launch: per-phase time attribution")
     return ap.parse_args()
 
 
@@ -72,8 +75,26 @@ def main():
 
     topn = [args.ef] * 5 + [args.topk]
     t0 = time.time()
-    g = synth.make_index(args.items, args.dim, ef=args.ef, mode=args.graph, noise=args.noise,
-                         device=str(dev), shard=rank)
+    g = None
+    cache = None
+    if args.index_cache:
+        os.makedirs(args.index_cache, exist_ok=True)
+        cache = os.path.join(args.index_cache,
+                             f"idx_{args.items}_{args.dim}_{args.ef}_{args.graph}_{args.noise}_{rank}.npz")
+        if os.path.exists(cache):
+            z = np.load(cache)
+            g = {"item_embs": z["item_embs"], "item_ids": z["item_ids"],
+                 "nb_values": [z["nb_values_0"], z["nb_values_1"]],
+                 "nb_row_splits": [z["nb_row_splits_0"], z["nb_row_splits_1"]],
+                 "enter_points": z["enter_points"]}
+    if g is None:
+        g = synth.make_index(args.items, args.dim, ef=args.ef, mode=args.graph, noise=args.noise,
+                             device=str(dev), shard=rank)
+        if cache:
+            np.savez(cache, item_embs=g["item_embs"], item_ids=g["item_ids"],
+                     nb_values_0=g["nb_values"][0], nb_values_1=g["nb_values"][1],
+                     nb_row_splits_0=g["nb_row_splits"][0], nb_row_splits_1=g["nb_row_splits"][1],
+                     enter_points=g["enter_points"])
     index = retrieval.Index.from_dict(g, device=dev)
     scorer = ops.Scorer("l2", args.dim)
     seq_host = synth.make_queries_from_centres(args.dim, args.batch, noise=args.noise)
@@ -148,6 +169,16 @@ def main():
         "qps_end_to_end": round(qps, 1), "valid_queries": n_valid, "setup_s": round(setup_s, 1),
         "roofline": roofline,
     }
+
+    if args.phase_ticks:
+        from nann_amd import _lib
+        rr = retrieval.search(index, scorer, ops.user_seq_mean(comm_seq), topn, want_phase_ticks=True)
+        torch.cuda.synchronize()
+        tk = rr.phase_ticks.cpu().numpy().astype(np.float64)
+        tot = tk.sum()
+        result["phase_breakdown"] = {
+            "ticks_per_query": {n: round(float(tk[:, i].mean()), 1) for i, n in enumerate(_lib.PHASE_NAMES)},
+            "fraction": {n: round(float(tk[:, i].sum() / tot), 4) for i, n in enumerate(_lib.PHASE_NAMES)}}
 
     if rank == 0 and world == 1:
         oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])

@@ -75,9 +75,14 @@ int nann_stream_synchronize(nann_stream_t stream);
  * Loads a .npy (format 1.0/2.0, C order) into HBM once; the GPU kernel of the
  * reference op does the same one-time H2D copy (:187-218).  expect_dtype /
  * expect_shape mirror the op's dtype/shape attrs and are validated against
- * the header (:108-147).  path [host]; expect_shape [host]. */
+ * the header (:108-147); expect_shape may be NULL to accept the file's shape.
+ * allow_cast != 0 reproduces the Python wrapper huge_constant()
+ * (NANN_impls/nann/model/model_util.py:107-121), which casts the array to the
+ * requested dtype (f32->f16, i64->i32, ...) -- here at load time, without
+ * rewriting the file as the wrapper does.  *nbytes = bytes resident in HBM.
+ * path [host]; expect_shape [host]. */
 int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
-                         int expect_rank, void** dev_ptr, int64_t* nbytes);
+                         int expect_rank, int allow_cast, void** dev_ptr, int64_t* nbytes);
 
 /* ---- a1: GroupGather<int32>, unique=false (UO/beam_search_op/
  *          GroupGather_kernel.cc:55-173) -------------------------------------
@@ -215,6 +220,17 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
                 int64_t n_queries, const int32_t level_topn[6], void* workspace,
                 int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
                 int32_t* out_index, int32_t* status, int32_t* counters, nann_stream_t stream);
+
+/* Same, plus per-query time attribution for tuning: phase_ticks
+ * i64[n_queries, NANN_NUM_PHASES] receives shader-clock ticks spent in
+ * {bitmap zeroing, walker, CSR expand, gather+score, top-k, other}; NULL
+ * disables the instrumentation (nann_search passes NULL). */
+#define NANN_NUM_PHASES 6
+int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q,
+                   int64_t n_queries, const int32_t level_topn[6], void* workspace,
+                   int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
+                   int32_t* out_index, int32_t* status, int32_t* counters, int64_t* phase_ticks,
+                   nann_stream_t stream);
 
 /* ---- 8(e): merge of per-shard top-k lists ----------------------------------
  * scores f32[n_queries, n_shards, k_in], ids i64[n_queries, n_shards, k_in]

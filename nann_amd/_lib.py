@@ -20,6 +20,8 @@ STATUS_NAMES = {
 F16, BF16, F32, I32, I64, F64 = 0, 1, 2, 3, 4, 5
 SCORER_L2, SCORER_MLP = 0, 1
 NUM_ROUNDS = 5
+NUM_PHASES = 6
+PHASE_NAMES = ("zero", "walk", "expand", "score", "topk", "other")
 
 # every symbol include/nann_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -28,7 +30,7 @@ SYMBOLS = [
     "nann_group_gather_fill", "nann_bitmap_ref_difference", "nann_gather_rows", "nann_topk",
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
-    "nann_search", "nann_merge_topk", "nann_merge_topk_host",
+    "nann_search", "nann_search_ex", "nann_merge_topk", "nann_merge_topk_host",
 ]
 
 

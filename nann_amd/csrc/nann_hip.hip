@@ -380,7 +380,10 @@ struct SearchArgs {
   int32_t* out_index;
   int32_t* status;
   int32_t* counters;
+  long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
 };
+
+enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER };
 
 struct SlotView {
   int32_t* cand_ids;
@@ -410,24 +413,58 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
 
 template <int LPR, int DT, bool LDSBM>
 __device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
-                          unsigned char* scratch, float* qv, int* misc, int32_t* ctr) {
+                          unsigned char* scratch, float* qv, int* misc, int32_t* ctr,
+                          long long* ticks) {
   const int tid = threadIdx.x;
   const int wave = wave_id(), lane = lane_id();
   const int k5 = a.t[5];
+  const bool timing = a.phase_ticks != nullptr;
+  long long t_last = timing ? (long long)clock64() : 0;
+  // attribute the time since the previous mark to `phase` (thread 0 only; off by default)
+  auto mark = [&](int phase) {
+    if (timing && tid == 0) {
+      const long long now = (long long)clock64();
+      ticks[phase] += now - t_last;
+      t_last = now;
+    }
+  };
 
   auto walk = [&](const int32_t* in, int n, int32_t* out) -> int {
     __syncthreads();
+    mark(PH_OTHER);
     if (wave == 0) {
       const int c = wave_walk<LDSBM>(in, n, bm, a.n_items, out, &misc[1]);
       if (lane == 0) misc[0] = c;
     }
     __syncthreads();
+    mark(PH_WALK);
     return misc[0];
+  };
+  auto score = [&](const int32_t* ids, int n, float* out) {
+    mark(PH_OTHER);
+    wg_score_l2<LPR, DT, kNT>(a.emb, a.d, ids, n, qv, out);
+    __syncthreads();
+    mark(PH_SCORE);
+  };
+  auto expand = [&](const int32_t* frontier, int n, int level) -> int {
+    mark(PH_OTHER);
+    const int g = wg_expand(frontier, n, a.nbv[level], a.nbrs[level], a.n_items, sv.raw, scratch);
+    mark(PH_EXPAND);
+    return g;
+  };
+  auto topk = [&](const int32_t* ids, const float* scores, int n, int k, int32_t* out_ids,
+                  float* out_scores, const int64_t* id_map, int64_t* out_mapped) -> int {
+    mark(PH_OTHER);
+    const int st = wg_topk(ids, scores, n, k, nullptr, out_ids, out_scores, id_map, out_mapped, scratch);
+    mark(PH_TOPK);
+    return st;
   };
   auto zero_bitmap = [&]() {
     __syncthreads();
+    mark(PH_OTHER);
     wg_zero_words(bm, a.bm_words);
     __syncthreads();
+    mark(PH_ZERO);
   };
 
   for (int k = tid; k < a.d; k += kNT) qv[k] = a.q[(size_t)qi * a.d + k];
@@ -437,12 +474,10 @@ __device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint3
   // ---- level 2 (entry layer): build_opt_graph.py:111-112 -------------------
   const int E = a.n_enter;
   if (E == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-  wg_score_l2<LPR, DT, kNT>(a.emb, a.d, a.enter, E, qv, sv.cand_scores);
+  score(a.enter, E, sv.cand_scores);
   if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
   if (E == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-  __syncthreads();
-  int st = wg_topk(a.enter, sv.cand_scores, E, a.t[0], nullptr, sv.beam_ids, sv.beam_scores,
-                   nullptr, nullptr, scratch);
+  int st = topk(a.enter, sv.cand_scores, E, a.t[0], sv.beam_ids, sv.beam_scores, nullptr, nullptr);
   if (st) return st;
   const int nR = a.t[0];
 
@@ -452,17 +487,16 @@ __device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint3
   if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
   if (kept != nR) return NANN_ERR_BAD_ARGUMENT;            // duplicate enter points
   for (int i = tid; i < nR; i += kNT) sv.cand_scores[i] = sv.beam_scores[i];
-  int G = wg_expand(sv.beam_ids, nR, a.nbv[1], a.nbrs[1], a.n_items, sv.raw, scratch);  // :116
+  int G = expand(sv.beam_ids, nR, 1);                      // :116
   if (G < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
   int nC = walk(sv.raw, G, sv.cand_ids + nR);              // :121-122
   if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
   if (tid == 0) { ctr[0 * 5 + 1] = nR; ctr[1 * 5 + 1] = G; ctr[2 * 5 + 1] = nC; }
   if (nC == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-  wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sv.cand_ids + nR, nC, qv, sv.cand_scores + nR);  // :124
+  score(sv.cand_ids + nR, nC, sv.cand_scores + nR);        // :124
   if (nC == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-  __syncthreads();
-  st = wg_topk(sv.cand_ids, sv.cand_scores, nR + nC, a.t[1], nullptr, sv.pool_ids, sv.pool_scores,
-               nullptr, nullptr, scratch);                 // :125-127
+  st = topk(sv.cand_ids, sv.cand_scores, nR + nC, a.t[1], sv.pool_ids, sv.pool_scores, nullptr,
+            nullptr);                                      // :125-127
   if (st) return st;
   int nP = a.t[1];
 
@@ -472,27 +506,26 @@ __device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint3
   if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
   const int32_t* frontier = sv.beam_ids;
   for (int r = 0; r < 3; ++r) {
-    G = wg_expand(frontier, nB, a.nbv[0], a.nbrs[0], a.n_items, sv.raw, scratch);       // :136
+    G = expand(frontier, nB, 0);                           // :136
     if (G < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
     nC = walk(sv.raw, G, sv.cand_ids);                     // :137
     if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
     if (tid == 0) { ctr[0 * 5 + 2 + r] = nB; ctr[1 * 5 + 2 + r] = G; ctr[2 * 5 + 2 + r] = nC; }
     if (nC == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-    wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sv.cand_ids, nC, qv, sv.cand_scores);          // :138
+    score(sv.cand_ids, nC, sv.cand_scores);                // :138
     if (nC == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-    __syncthreads();
-    st = wg_topk(sv.cand_ids, sv.cand_scores, nC, a.t[2 + r], nullptr, sv.pool_ids + nP,
-                 sv.pool_scores + nP, nullptr, nullptr, scratch);                         // :139-141
+    st = topk(sv.cand_ids, sv.cand_scores, nC, a.t[2 + r], sv.pool_ids + nP, sv.pool_scores + nP,
+              nullptr, nullptr);                           // :139-141
     if (st) return st;
     frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
     nB = a.t[2 + r];
     nP += nB;
   }
   // ---- final: build_opt_graph.py:143-149 --------------------------------------
-  st = wg_topk(sv.pool_ids, sv.pool_scores, nP, k5, nullptr,
-               a.out_index ? a.out_index + (size_t)qi * k5 : nullptr,
-               a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr, a.item_ids,
-               a.out_ids + (size_t)qi * k5, scratch);
+  st = topk(sv.pool_ids, sv.pool_scores, nP, k5, a.out_index ? a.out_index + (size_t)qi * k5 : nullptr,
+            a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr, a.item_ids,
+            a.out_ids + (size_t)qi * k5);
+  mark(PH_OTHER);
   return st;
 }
 
@@ -504,6 +537,7 @@ __global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
   float* qv = reinterpret_cast<float*>(scratch + kPhaseScratch);
   int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] walk count, [1] range error
   int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
+  long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
 
   unsigned long long off[8];
   slot_layout(a.max_cand, a.max_raw, a.pool_cap, LDSBM ? 0u : a.bm_words, off);
@@ -523,9 +557,12 @@ __global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
   for (int qi = blockIdx.x; qi < a.n_queries; qi += gridDim.x) {
     __syncthreads();
     if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
+    if (threadIdx.x < NANN_NUM_PHASES) s_ticks[threadIdx.x] = 0;
     __syncthreads();
-    const int st = search_one<LPR, DT, LDSBM>(a, qi, sv, bm, scratch, qv, misc, s_ctr);
+    const int st = search_one<LPR, DT, LDSBM>(a, qi, sv, bm, scratch, qv, misc, s_ctr, s_ticks);
     __syncthreads();
+    if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES)
+      a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x] = s_ticks[threadIdx.x];
     if (st) {  // a request the reference would fail: zeroed outputs + its code
       for (int i = threadIdx.x; i < k5; i += kNT) {
         a.out_ids[(size_t)qi * k5 + i] = 0;
@@ -603,8 +640,65 @@ static const char* npy_descr(int dtype) {
   }
 }
 
+// np.ndarray.astype for the casts the reference's wrapper performs
+static uint16_t f32_to_f16_rne(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t man = x & 0x7fffffu;
+  if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    const int shift = 14 - exp;
+    uint32_t hm = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hm & 1))) ++hm;
+    return (uint16_t)(sign | hm);
+  }
+  uint32_t out = sign | ((uint32_t)exp << 10) | (man >> 13);
+  const uint32_t rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (out & 1))) ++out;
+  return (uint16_t)out;
+}
+
+static bool cast_payload(const std::string& from, int to, const std::vector<char>& in, int64_t count,
+                         std::vector<char>* out) {
+  static const int esz[6] = {2, 2, 4, 4, 8, 8};
+  out->resize((size_t)std::max<int64_t>(count * esz[to], 1));
+  if (from == "<i8" && to == NANN_I32) {
+    const int64_t* a = reinterpret_cast<const int64_t*>(in.data());
+    int32_t* b = reinterpret_cast<int32_t*>(out->data());
+    for (int64_t i = 0; i < count; ++i) b[i] = (int32_t)a[i];
+    return true;
+  }
+  if (from == "<i4" && to == NANN_I64) {
+    const int32_t* a = reinterpret_cast<const int32_t*>(in.data());
+    int64_t* b = reinterpret_cast<int64_t*>(out->data());
+    for (int64_t i = 0; i < count; ++i) b[i] = a[i];
+    return true;
+  }
+  if ((from == "<f4" || from == "<f8") && to == NANN_F16) {
+    uint16_t* b = reinterpret_cast<uint16_t*>(out->data());
+    for (int64_t i = 0; i < count; ++i) {
+      const float v = from == "<f4" ? reinterpret_cast<const float*>(in.data())[i]
+                                     : (float)reinterpret_cast<const double*>(in.data())[i];
+      b[i] = f32_to_f16_rne(v);
+    }
+    return from == "<f4";  // f64 -> f16 through f32 would double-round: not offered
+  }
+  if (from == "<f8" && to == NANN_F32) {
+    float* b = reinterpret_cast<float*>(out->data());
+    for (int64_t i = 0; i < count; ++i) b[i] = (float)reinterpret_cast<const double*>(in.data())[i];
+    return true;
+  }
+  return false;
+}
+
 int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
-                         int expect_rank, void** dev_ptr, int64_t* nbytes) {
+                         int expect_rank, int allow_cast, void** dev_ptr, int64_t* nbytes) {
   if (!path || !dev_ptr) return fail(NANN_ERR_BAD_ARGUMENT, "nann_huge_const_load: null argument");
   std::ifstream f(path, std::ifstream::binary);
   if (!f) return fail(NANN_ERR_IO, std::string("Fail to open file: ") + path);  // huge_const_op.cc:96-98
@@ -657,7 +751,8 @@ int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expe
   }
   const char* want = npy_descr(expect_dtype);
   if (!want) return fail(NANN_ERR_UNSUPPORTED, "Unsupported DataType.");  // huge_const_op.cc:143-146
-  if (descr != want)
+  const bool need_cast = descr != want;
+  if (need_cast && !allow_cast)
     return fail(NANN_ERR_DTYPE_MISMATCH, "DataType mismatch: " + descr + "!=" + want);  // :117-121
   if (expect_shape) {
     if ((int)shape.size() != expect_rank) return fail(NANN_ERR_SHAPE_MISMATCH, "rank mismatch");
@@ -667,11 +762,24 @@ int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expe
                     "attr_shape and np_shape NOT match in dim " + std::to_string(i));  // :111-115
   }
   static const int esz[6] = {2, 2, 4, 4, 8, 8};
-  int64_t total = esz[expect_dtype];
-  for (int64_t v : shape) total *= v;
-  std::vector<char> host((size_t)std::max<int64_t>(total, 1));
-  f.read(host.data(), (std::streamsize)total);
-  if (f.gcount() != (std::streamsize)total) return fail(NANN_ERR_IO, "truncated npy payload");
+  int64_t count = 1;
+  for (int64_t v : shape) count *= v;
+  int file_esz = esz[expect_dtype];
+  if (need_cast) {
+    if (descr.size() != 3 || descr[0] != '<' || descr[2] < '1' || descr[2] > '8')
+      return fail(NANN_ERR_DTYPE_MISMATCH, "DataType mismatch: " + descr + "!=" + want);
+    file_esz = descr[2] - '0';
+  }
+  std::vector<char> host((size_t)std::max<int64_t>(count * file_esz, 1));
+  f.read(host.data(), (std::streamsize)(count * file_esz));
+  if (f.gcount() != (std::streamsize)(count * file_esz)) return fail(NANN_ERR_IO, "truncated npy payload");
+  if (need_cast) {
+    std::vector<char> conv;
+    if (!cast_payload(descr, expect_dtype, host, count, &conv))
+      return fail(NANN_ERR_DTYPE_MISMATCH, "no cast from " + descr + " to " + want);
+    host.swap(conv);
+  }
+  const int64_t total = count * esz[expect_dtype];
   void* d = nullptr;
   HIP_TRY(hipMalloc(&d, (size_t)std::max<int64_t>(total, 1)));
   if (total) HIP_TRY(hipMemcpy(d, host.data(), (size_t)total, hipMemcpyHostToDevice));
@@ -1004,7 +1112,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->max_cand = (int)max_cand;
   p->max_raw = (int)max_raw;
   p->pool_cap = std::max(t[1] + t[2] + t[3] + t[4], 1);
-  const size_t fixed = kPhaseScratch + kMaxD * 4 + 128;
+  const size_t fixed = kPhaseScratch + kMaxD * 4 + 256;
   const size_t bm_bytes = (size_t)ix->bm_words * 4;
   p->lds_bitmap = bm_bytes + fixed <= di.lds_max;
   p->lds_bytes = fixed + (p->lds_bitmap ? bm_bytes : 0);
@@ -1055,6 +1163,14 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
                 const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
                 int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                 int32_t* counters, nann_stream_t stream) {
+  return nann_search_ex(ix, scorer, q, n_queries, level_topn, workspace, workspace_bytes, out_item_ids,
+                        out_scores, out_index, status, counters, nullptr, stream);
+}
+
+int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                   const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                   int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                   int32_t* counters, int64_t* phase_ticks, nann_stream_t stream) {
   if (!ix || !scorer || !level_topn || !out_item_ids || !status)
     return fail(NANN_ERR_BAD_ARGUMENT, "nann_search: null argument");
   if (n_queries <= 0) return NANN_OK;
@@ -1083,6 +1199,7 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
   a.max_cand = p.max_cand; a.max_raw = p.max_raw; a.pool_cap = p.pool_cap;
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index;
   a.status = status; a.counters = counters;
+  a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
   hipStream_t st = as_stream(stream);
   const int dt = ix->desc.emb_dtype;
   switch (ix->desc.d / 8) {

@@ -237,12 +237,13 @@ class HugeConst:
     dtype/shape play the role of the op's attrs and are validated against the
     npy header (:108-147).  `.tensor` is a zero-copy torch view."""
 
-    def __init__(self, path, dtype, shape):
+    def __init__(self, path, dtype, shape, allow_cast=False):
         code, tdt = _NPY[np.dtype(dtype)]
         shp = (C.c_int64 * len(shape))(*shape)
         ptr, nbytes = C.c_void_p(0), C.c_int64(0)
         _check(lib().nann_huge_const_load(path.encode(), C.c_int(code), shp, C.c_int(len(shape)),
-                                          C.byref(ptr), C.byref(nbytes)), "HugeConst")
+                                          C.c_int(1 if allow_cast else 0), C.byref(ptr),
+                                          C.byref(nbytes)), "HugeConst")
         self._ptr, self.nbytes = ptr, nbytes.value
         self.shape, self.dtype = tuple(shape), tdt
         self.tensor = _wrap_device_pointer(ptr.value, self.shape, tdt, self)
@@ -272,11 +273,11 @@ def _wrap_device_pointer(ptr, shape, dtype, owner):
 
 
 def huge_const(path, dtype=None):
-    """model_util.huge_constant (NANN_impls/nann/model/model_util.py:107-121)
-    without its in-place rewrite of the file (Appendix C): the header supplies
-    the shape; a dtype different from the file's is an error here."""
+    """model_util.huge_constant (NANN_impls/nann/model/model_util.py:107-121):
+    the header supplies the shape; a dtype different from the file's is cast
+    (np.load(path).astype(dtype)) -- at load time here, WITHOUT the wrapper's
+    in-place rewrite of the file."""
     with open(path, "rb") as f:
         np.lib.format.read_magic(f)
         shape, fortran, file_dtype = np.lib.format.read_array_header_1_0(f)
-    hc = HugeConst(path, dtype or file_dtype, shape)
-    return hc
+    return HugeConst(path, dtype or file_dtype, shape, allow_cast=dtype is not None)

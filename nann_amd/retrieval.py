@@ -87,14 +87,15 @@ class Index:
 
 
 class SearchResult:
-    __slots__ = ("item_ids", "scores", "index", "status", "counters")
+    __slots__ = ("item_ids", "scores", "index", "status", "counters", "phase_ticks")
 
-    def __init__(self, item_ids, scores, index, status, counters):
+    def __init__(self, item_ids, scores, index, status, counters, phase_ticks=None):
         self.item_ids, self.scores, self.index, self.status, self.counters = (
             item_ids, scores, index, status, counters)
+        self.phase_ticks = phase_ticks
 
 
-def search(index, scorer, q, level_topn, want_counters=True):
+def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=False):
     """Fused execution of build_model()'s schedule for a batch of queries.
     q: f32[B, d] CUDA tensor (ops.user_seq_mean of `comm_seq`).  Asynchronous:
     the returned tensors are valid once the current stream reaches them.
@@ -109,12 +110,15 @@ def search(index, scorer, q, level_topn, want_counters=True):
     out_index = torch.empty((b, k), dtype=torch.int32, device=dev)
     status = torch.empty(b, dtype=torch.int32, device=dev)
     counters = torch.zeros((b, 3, _lib.NUM_ROUNDS), dtype=torch.int32, device=dev) if want_counters else None
+    ticks = (torch.zeros((b, _lib.NUM_PHASES), dtype=torch.int64, device=dev)
+             if want_phase_ticks else None)
     ws = index.workspace(level_topn, b)
     with torch.cuda.device(dev):
-        _check(lib().nann_search(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(ws),
-                                 C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
-                                 _ptr(status), _ptr(counters), _stream()), "search")
-    return SearchResult(out_ids, out_scores, out_index, status, counters)
+        _check(lib().nann_search_ex(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(ws),
+                                    C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores),
+                                    _ptr(out_index), _ptr(status), _ptr(counters), _ptr(ticks),
+                                    _stream()), "search")
+    return SearchResult(out_ids, out_scores, out_index, status, counters, ticks)
 
 
 # -----------------------------------------------------------------------------

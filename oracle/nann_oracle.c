@@ -443,9 +443,27 @@ static int topk_ids(const int32_t* ids, const float* scores, int64_t n, int32_t 
   return ORACLE_OK;
 }
 
-int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
-                  const int32_t t[6], int64_t* out_item_ids, float* out_scores,
-                  int32_t* out_index, oracle_counters_t* ctr) {
+/* per-thread reusable buffers: the reference keeps its tensors in TF's
+ * allocator pools; re-malloc'ing MBs per query would serialise threads on
+ * the kernel's mmap lock and misprice the CPU baseline */
+typedef struct {
+  int32_t* bm; int64_t bm_words;
+  buf_t cand, pool, beam;
+  char* tmp; int64_t tmp_cap;
+  int32_t* tmp_idx; int64_t tmp_idx_cap;
+  int32_t* raw; int64_t raw_cap;
+  int64_t* iv; int64_t iv_cap;
+} search_ws_t;
+
+static void ws_free(search_ws_t* w) {
+  free(w->bm); free(w->cand.ids); free(w->cand.scores); free(w->pool.ids); free(w->pool.scores);
+  free(w->beam.ids); free(w->beam.scores); free(w->tmp); free(w->tmp_idx); free(w->raw); free(w->iv);
+  memset(w, 0, sizeof *w);
+}
+
+static int oracle_search_ws(search_ws_t* W, const oracle_index_t* ix, const oracle_scorer_t* sc,
+                            const float* q, const int32_t t[6], int64_t* out_item_ids,
+                            float* out_scores, int32_t* out_index, oracle_counters_t* ctr) {
   if (!ix || !sc || !scorer_ok(sc) || sc->d != ix->d || sc->emb_dtype != ix->emb_dtype)
     return ORACLE_ERR_BAD_ARGUMENT;
   for (int i = 0; i < 6; ++i)
@@ -454,13 +472,20 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
   memset(&c, 0, sizeof c);
   int rc = ORACLE_OK;
   const int64_t n_words = (ix->n_items + 31) / 32; /* build_opt_graph.py:114 */
-  int32_t* bm = (int32_t*)malloc((size_t)(n_words > 0 ? n_words : 1) * 4);
-  buf_t cand = {0, 0, 0}, pool = {0, 0, 0}, beam = {0, 0, 0};
-  char* tmp = NULL;
-  int64_t tmp_cap = 0;
-  int32_t* tmp_idx = NULL;
-  int32_t* raw = NULL;
-  int64_t raw_cap = 0;
+  if (W->bm_words < n_words) {
+    free(W->bm);
+    W->bm = (int32_t*)malloc((size_t)(n_words > 0 ? n_words : 1) * 4);
+    W->bm_words = W->bm ? n_words : 0;
+  }
+  int32_t* bm = W->bm;
+#define cand (W->cand)
+#define pool (W->pool)
+#define beam (W->beam)
+#define tmp (W->tmp)
+#define tmp_cap (W->tmp_cap)
+#define tmp_idx (W->tmp_idx)
+#define raw (W->raw)
+#define raw_cap (W->raw_cap)
   int64_t rs2[2], ors[2], n_out, n_os;
 
 #define FAIL(code) do { rc = (code); goto done; } while (0)
@@ -476,7 +501,11 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
     for (int i = 0; i < 6; ++i) if (t[i] > maxk) maxk = t[i];
     const int64_t poolcap = (int64_t)t[1] + t[2] + t[3] + t[4] + 1;
     if (poolcap > maxk) maxk = poolcap;
-    tmp_idx = (int32_t*)malloc((size_t)(maxk + 1) * 4);
+    if (W->tmp_idx_cap < maxk + 1) {
+      free(tmp_idx);
+      tmp_idx = (int32_t*)malloc((size_t)(maxk + 1) * 4);
+      W->tmp_idx_cap = tmp_idx ? maxk + 1 : 0;
+    }
     if (!tmp_idx || !ensure(&beam, maxk + 1) || !ensure(&pool, poolcap))
       FAIL(ORACLE_ERR_BAD_ARGUMENT);
   }
@@ -488,7 +517,12 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
   {
     /* C = ragged_gather(NB1, R)  :116 */
     int64_t irs[2] = {0, nR};
-    int64_t* iv = (int64_t*)malloc((size_t)(nR ? nR : 1) * 8);
+    if (W->iv_cap < nR + 1) {
+      free(W->iv);
+      W->iv = (int64_t*)malloc((size_t)(nR + 1) * 8);
+      W->iv_cap = W->iv ? nR + 1 : 0;
+    }
+    int64_t* iv = W->iv;
     if (!iv) FAIL(ORACLE_ERR_BAD_ARGUMENT);
     for (int64_t i = 0; i < nR; ++i) iv[i] = beam.ids[i];
     rc = oracle_group_gather_i32(ix->nb_values[1], ix->nb_nnz[1], ix->nb_row_splits[1],
@@ -504,7 +538,6 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
                                    ix->n_items + 1, iv, nR, irs, 2, raw, raw_cap, ors,
                                    &n_out, &n_os, NULL);
     }
-    free(iv);
     if (rc) goto done;
     const int64_t nG = n_out;
     c.frontier[1] = nR;
@@ -540,7 +573,12 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
   int64_t nB = n_out;
   for (int i = 0; i < 3; ++i) {
     int64_t irs[2] = {0, nB};
-    int64_t* iv = (int64_t*)malloc((size_t)(nB ? nB : 1) * 8);
+    if (W->iv_cap < nB + 1) {
+      free(W->iv);
+      W->iv = (int64_t*)malloc((size_t)(nB + 1) * 8);
+      W->iv_cap = W->iv ? nB + 1 : 0;
+    }
+    int64_t* iv = W->iv;
     if (!iv) FAIL(ORACLE_ERR_BAD_ARGUMENT);
     for (int64_t j = 0; j < nB; ++j) iv[j] = beam.ids[j];
     rc = oracle_group_gather_i32(ix->nb_values[0], ix->nb_nnz[0], ix->nb_row_splits[0],
@@ -556,7 +594,6 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
                                    ix->n_items + 1, iv, nB, irs, 2, raw, raw_cap, ors,
                                    &n_out, &n_os, NULL); /* :136 */
     }
-    free(iv);
     if (rc) goto done;
     const int64_t nG = n_out;
     c.frontier[2 + i] = nB;
@@ -584,12 +621,29 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const flo
   }
 done:
   if (ctr) *ctr = c;
-  free(bm); free(cand.ids); free(cand.scores); free(pool.ids); free(pool.scores);
-  free(beam.ids); free(beam.scores); free(tmp); free(tmp_idx); free(raw);
   return rc;
 #undef FAIL
 #undef CHECK
+#undef cand
+#undef pool
+#undef beam
+#undef tmp
+#undef tmp_cap
+#undef tmp_idx
+#undef raw
+#undef raw_cap
 }
+
+int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                  const int32_t t[6], int64_t* out_item_ids, float* out_scores,
+                  int32_t* out_index, oracle_counters_t* ctr) {
+  search_ws_t W;
+  memset(&W, 0, sizeof W);
+  const int rc = oracle_search_ws(&W, ix, sc, q, t, out_item_ids, out_scores, out_index, ctr);
+  ws_free(&W);
+  return rc;
+}
+
 
 /* ------------------------------------------------------------------------ */
 typedef struct {
@@ -601,15 +655,16 @@ typedef struct {
 static void* batch_worker(void* arg) {
   batch_t* b = (batch_t*)arg;
   const int32_t k = b->t[5];
+  search_ws_t W;
+  memset(&W, 0, sizeof W);
   for (;;) {
-    pthread_mutex_lock(&b->mu);
-    const int64_t i = b->next++;
-    pthread_mutex_unlock(&b->mu);
+    const int64_t i = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
     if (i >= b->nq) break;
-    b->status[i] = oracle_search(b->ix, b->sc, b->q + i * b->ix->d, b->t, b->ids + i * k,
-                                 b->scores + i * k, b->index ? b->index + i * k : NULL,
-                                 b->ctr ? b->ctr + i : NULL);
+    b->status[i] = oracle_search_ws(&W, b->ix, b->sc, b->q + i * b->ix->d, b->t, b->ids + i * k,
+                                    b->scores + i * k, b->index ? b->index + i * k : NULL,
+                                    b->ctr ? b->ctr + i : NULL);
   }
+  ws_free(&W);
   return NULL;
 }
 
