@@ -48,11 +48,12 @@ def merge_device(scores, ids, k_out):
 def all_gather_topk(scores, ids, world, group=None):
     """[nq, k] per rank -> [nq, world, k] on every rank (shard-major per query)."""
     nq, k = scores.shape
-    gs = torch.empty((world, nq, k), dtype=scores.dtype, device=scores.device)
-    gi = torch.empty((world, nq, k), dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)
+    gs = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
+    gi = torch.empty((world * nq, k), dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)  # rank-major concatenation
     dist.all_gather_into_tensor(gi, ids.contiguous(), group=group)
-    return gs.permute(1, 0, 2).contiguous(), gi.permute(1, 0, 2).contiguous()
+    return (gs.view(world, nq, k).permute(1, 0, 2).contiguous(),
+            gi.view(world, nq, k).permute(1, 0, 2).contiguous())
 
 
 class ShardedSearch:
