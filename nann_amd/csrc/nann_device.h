@@ -5,8 +5,8 @@
 // Each block below states which reference loop it replaces (paths relative to
 // /root/reference/, UO/ = tensorflow/tensorflow/core/user_ops/).
 //
-//   wave_walk    BitmapRefDifference::Differ   UO/bitmap_op/bitmap_ops.cc:221-234
-//   wg_expand    GroupGather::Fill             UO/beam_search_op/GroupGather_kernel.cc:137-168
+//   wave_walk_span  BitmapRefDifference::Differ  UO/bitmap_op/bitmap_ops.cc:221-234
+//   wg_expand_walk  GroupGather::Fill + Differ   UO/beam_search_op/GroupGather_kernel.cc:137-168
 //   wg_score     GatherV2 + scorer             core/kernels/gather_functor.h:96-103 + BlazeXlaOp
 //   wg_topk      TopKV2 (+ Gather of ids)      core/kernels/topk_op.cc:104-205
 #pragma once
@@ -20,7 +20,7 @@ constexpr int kNT = 1024;            // threads per traversal workgroup
 constexpr int kNW = kNT / 64;        // 16 wavefronts
 constexpr int kTopkEPT = 16;         // top-k keys held in registers per thread (n <= 16384)
 constexpr int kMaxK = 1024;          // largest k / frontier a workgroup handles
-constexpr int kPhaseScratch = 16384; // LDS bytes shared by the phases below
+constexpr int kPhaseScratch = 24832; // LDS bytes shared by the phases below
 constexpr int kMaxD = 512;
 
 enum : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
@@ -56,69 +56,72 @@ __device__ __forceinline__ void wg_zero_words(uint32_t* p, uint32_t n_words) {
 }
 
 // ---------------------------------------------------------------------------
-// wave_walk: ordered first-occurrence filter against the visited bitmap.
+// wave_walk_span: ordered first-occurrence filter against the visited bitmap.
 //
 // Reference semantics (bitmap_ops.cc:224-232): scan ids in order; keep an id
-// iff its bit is clear, then set the bit.  Here ONE wavefront walks the list 64
-// ids at a time.  Per chunk every lane reads its word (pre), then ORs its bit
-// in (old); LDS executes one wave's instructions in order, so chunk c+1 sees
-// every bit chunk c set -- the serial scan order is preserved across chunks
-// with the atomics still pipelined.  Inside a chunk, lanes holding the same
-// fresh id are resolved to the LOWEST lane with ballots (which lane the LDS
-// arbiter happened to serve first does not matter).  Kept ids are compacted
-// with ballot + popcount (stable), so the output order is the serial order.
+// iff its bit is clear, then set the bit.  Here ONE wavefront walks a span 64
+// ids per step, U steps per batch.  Per step every lane reads its bitmap word
+// (pre) and ORs its bit in (old).  All 2U LDS operations of a batch are issued
+// back to back: the LDS executes one wave's instructions in order, so step
+// c+1 observes every bit step c set -- the serial scan order is preserved
+// across steps while the atomics stay pipelined, and only the ballots below
+// wait for them.  Inside a step, lanes holding the same fresh id are resolved
+// to the LOWEST lane with ballots (which lane the LDS arbiter served first
+// does not matter).  Kept ids are compacted with ballot + popcount (stable),
+// so the output order is the serial order.
 //
-// kLds=false walks a bitmap in global memory (shards too large for LDS): the
-// pre-read is then an atomic OR of 0 so that it is served by L2 like the
-// update, and the dependency on `old` keeps chunks ordered.
+// kLdsBm=false walks a bitmap in global memory (shards too large for LDS):
+// the pre-read is then an atomic OR of 0 so that it is served by L2 like the
+// update, one step at a time.
 //
-// Must be called by all lanes of exactly one wavefront.  Returns the number of
-// ids kept (wave-uniform).  *err is set to 1 if an id is outside [0, n_items).
-template <bool kLds>
-__device__ int wave_walk(const int32_t* in, int n, uint32_t* bm, uint32_t n_items,
-                         int32_t* out, int* err) {
-  constexpr int U = kLds ? 8 : 2;
+// Must be called by all lanes of exactly one wavefront.  `src` may be LDS or
+// global.  Returns base + number of ids kept (wave-uniform).  *err is set to 1
+// if an id is outside [0, n_items).
+template <bool kLdsBm>
+__device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_t* bm,
+                                              uint32_t n_items, int32_t* out, int base, int* err) {
+  constexpr int U = kLdsBm ? 4 : 1;
   const int lane = lane_id();
   const uint64_t lt = lanemask_lt();
-  int base = 0;
   for (int c0 = 0; c0 < n; c0 += 64 * U) {
-    int32_t idv[U];
+    int32_t x[U];
+    uint32_t pre[U], old[U];
+    bool inr[U];
+    // branch-free: out-of-span / out-of-range lanes read word 0 and OR in nothing
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = src[min(c0 + u * 64 + lane, n - 1)];
+    bool bad = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = c0 + u * 64 + lane;
-      idv[u] = (i < n) ? in[i] : -1;
+      const bool valid = (c0 + u * 64 + lane) < n;
+      inr[u] = valid && (uint32_t)x[u] < n_items;
+      bad |= valid && !inr[u];
+      uint32_t* w = bm + (inr[u] ? ((uint32_t)x[u] >> 5) : 0u);
+      const uint32_t bit = inr[u] ? (1u << (x[u] & 31)) : 0u;
+      pre[u] = kLdsBm ? *w : atomicOr(w, 0u);
+      old[u] = atomicOr(w, bit);
+    }
+    if (__ballot(bad) != 0ull) {
+      if (lane == 0) *err = 1;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (c0 + u * 64 >= n) break;
-      const int i = c0 + u * 64 + lane;
-      const int32_t x = idv[u];
-      const bool valid = i < n;
-      const bool inrange = valid && (uint32_t)x < n_items;
-      if (__ballot(valid && !inrange) != 0ull) {
-        if (lane == 0) *err = 1;
-      }
-      const uint32_t word = (uint32_t)x >> 5;
-      const uint32_t bit = 1u << (x & 31);
-      uint32_t pre = 0xffffffffu, old = 0xffffffffu;
-      if (inrange) {
-        pre = kLds ? bm[word] : atomicOr(&bm[word], 0u);
-        old = atomicOr(&bm[word], bit);
-      }
-      const bool fresh = inrange && !(pre & bit);
-      bool keep = inrange && !(old & bit);
+      const uint32_t bit = 1u << (x[u] & 31);
+      const bool fresh = inr[u] && !(pre[u] & bit);
+      bool keep = inr[u] && !(old[u] & bit);
       uint64_t dupl = __ballot(fresh && !keep);
-      while (dupl) {  // duplicate fresh ids inside this chunk: lowest lane wins
+      while (dupl) {  // duplicate fresh ids inside this step: lowest lane wins
         const int l = __ffsll((unsigned long long)dupl) - 1;
-        const int32_t xv = __shfl(x, l);
-        const bool mine = fresh && x == xv;
+        const int32_t xv = __shfl(x[u], l);
+        const bool mine = fresh && x[u] == xv;
         const uint64_t same = __ballot(mine);
         const int first = __ffsll((unsigned long long)same) - 1;
         if (mine) keep = (lane == first);
         dupl &= ~same;
       }
       const uint64_t m = __ballot(keep);
-      if (keep) out[base + popc64(m & lt)] = x;
+      if (keep) out[base + popc64(m & lt)] = x[u];
       base += popc64(m);
     }
   }
@@ -126,31 +129,54 @@ __device__ int wave_walk(const int32_t* in, int n, uint32_t* bm, uint32_t n_item
 }
 
 // ---------------------------------------------------------------------------
-// wg_expand: concatenate the CSR rows of a frontier, in frontier order,
-// duplicates kept (GroupGather with one group, GroupGather_kernel.cc:137-168;
-// build_opt_graph.py:39-49).  All kNT threads.  n_frontier <= kMaxK.
-// Pass 1 (count, :137-145): one thread per frontier node reads its two
-// row_splits and a block-wide exclusive scan turns the lengths into output
-// offsets.  Pass 2 (fill, :152-168): one wavefront per row copies it with a
-// single coalesced load/store per 64 neighbours.
-// Returns the number of neighbours written to `raw` (uniform); -1 if a
-// frontier id is out of range.
-struct ExpandScratch {
+// wg_expand_walk: GroupGather (one group) fused with BitmapRefDifference.
+//
+//   GroupGather_kernel.cc:137-168 -- concatenate the CSR rows of a frontier in
+//   frontier order, duplicates kept (build_opt_graph.py:39-49);
+//   bitmap_ops.cc:221-234        -- ordered visited-set filter of that list.
+//
+// The concatenation is never materialised in HBM.  Pass 1 (count, :137-145):
+// one thread per frontier node reads its two row_splits; a block-wide
+// exclusive scan gives every row its offset in the virtual list.  Pass 2 is a
+// two-stage pipeline over kChunk-id pieces of that list: wavefronts 1..15 copy
+// piece c from the CSR into one of two LDS buffers (one wavefront per row, one
+// coalesced <=256-byte load per row, 8 rows in flight per wavefront) while
+// wavefront 0 walks piece c-1 out of the other buffer; one barrier per piece.
+//
+// List mode (row_splits == nullptr): `values[0..n_frontier)` is itself the
+// list to filter (the "mark" calls, build_opt_graph.py:119-120,132-133).
+//
+// All kNT threads.  n_frontier <= kMaxK in CSR mode.  Outputs (uniform):
+// *gathered = length of the virtual list, return value = ids kept (appended
+// to out[0..)); -1 on an out-of-range frontier id or neighbour id.
+constexpr int kChunk = 2048;
+struct ExpandWalkScratch {
   uint32_t off[kMaxK + 1];
   uint32_t rowstart[kMaxK];
   uint32_t wave_tot[kNW];
   int bad;
+  int kept;
+  int pad[2];
+  int32_t stage[2][kChunk];
 };
 
-__device__ int wg_expand(const int32_t* frontier, int n_frontier, const int32_t* __restrict__ values,
-                         const int64_t* __restrict__ row_splits, uint32_t n_items,
-                         int32_t* raw, unsigned char* scratch) {
-  ExpandScratch* S = reinterpret_cast<ExpandScratch*>(scratch);
+template <bool kLdsBm>
+__device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
+                                              const int32_t* __restrict__ values,
+                                              const int64_t* __restrict__ row_splits,
+                                              uint32_t n_items, uint32_t* bm, int32_t* out,
+                                              unsigned char* scratch, int* gathered) {
+  ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  if (tid == 0) S->bad = 0;
+  const bool list_mode = row_splits == nullptr;
+  const int n_rows = list_mode ? 1 : n_frontier;
+  if (tid == 0) { S->bad = 0; S->kept = 0; }
   __syncthreads();
+  // ---- pass 1: row lengths -> offsets --------------------------------------
   uint32_t len = 0, start = 0;
-  if (tid < n_frontier) {
+  if (list_mode) {
+    if (tid == 0) len = (uint32_t)n_frontier;
+  } else if (tid < n_frontier) {
     const int32_t node = frontier[tid];
     if ((uint32_t)node < n_items) {
       const int64_t s = row_splits[node], e = row_splits[node + 1];
@@ -160,7 +186,6 @@ __device__ int wg_expand(const int32_t* frontier, int n_frontier, const int32_t*
       S->bad = 1;
     }
   }
-  // inclusive scan inside the wavefront
   uint32_t inc = len;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -176,21 +201,76 @@ __device__ int wg_expand(const int32_t* frontier, int n_frontier, const int32_t*
     if (w < wave) wbase += t;
     total += t;
   }
-  if (tid < n_frontier) {
+  if (tid < n_rows) {
     S->off[tid] = wbase + inc - len;
     S->rowstart[tid] = start;
   }
-  if (tid == 0) S->off[n_frontier] = total;
+  if (tid == 0) S->off[n_rows] = total;
   __syncthreads();
-  const int bad = S->bad;
-  if (!bad) {
-    for (int r = wave; r < n_frontier; r += kNW) {
-      const uint32_t o = S->off[r], l = S->off[r + 1] - o, s = S->rowstart[r];
-      for (uint32_t c = lane; c < l; c += 64) raw[o + c] = values[(size_t)s + c];
+  *gathered = (int)total;
+  if (S->bad) return -1;
+  // ---- pass 2: fill || walk pipeline ------------------------------------------
+  const int G = (int)total;
+  const int n_chunks = (G + kChunk - 1) / kChunk;
+  int base = 0;
+  int err = 0;
+  for (int it = 0; it <= n_chunks; ++it) {
+    if (wave > 0) {
+      if (it < n_chunks) {  // producers: piece `it` -> stage[it & 1]
+        const uint32_t lo = (uint32_t)it * kChunk;
+        const uint32_t hi = min((uint32_t)G, lo + kChunk);
+        int32_t* dst = S->stage[it & 1];
+        // first row whose end lies beyond lo: upper_bound over off[1..n_rows]
+        int a = 0, b = n_rows;
+        while (a < b) {
+          const int m = (a + b) >> 1;
+          if (S->off[m + 1] > lo) b = m; else a = m + 1;
+        }
+        constexpr int RB = 8;
+        for (int r0 = a + (wave - 1); r0 < n_rows; r0 += (kNW - 1) * RB) {
+          if (S->off[r0] >= hi) break;
+          uint32_t o[RB], l[RB], st[RB];
+          int32_t v[RB];
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {  // row descriptors (LDS)
+            const int r = r0 + j * (kNW - 1);
+            o[j] = 0; l[j] = 0; st[j] = 0;
+            if (r < n_rows) {
+              o[j] = S->off[r];
+              l[j] = S->off[r + 1] - o[j];
+              st[j] = S->rowstart[r];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {  // RB coalesced row loads in flight
+            v[j] = values[(lane < l[j]) ? (size_t)st[j] + lane : (size_t)0];  // values[0] exists: G > 0
+          }
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            const uint32_t p = o[j] + lane;
+            if (lane < l[j] && p >= lo && p < hi) dst[p - lo] = v[j];
+            if (l[j] > 64) {  // long rows (not produced by HNSW with M <= 32): remaining 64-id pieces
+              for (uint32_t c = 64 + lane; c < l[j]; c += 64) {
+                const uint32_t pp = o[j] + c;
+                if (pp >= lo && pp < hi) dst[pp - lo] = values[(size_t)st[j] + c];
+              }
+            }
+          }
+        }
+      }
+    } else if (it >= 1) {  // walker: piece it-1
+      const int c = it - 1;
+      const int n_c = min(kChunk, G - c * kChunk);
+      base = wave_walk_span<kLdsBm>(S->stage[c & 1], n_c, bm, n_items, out, base, &err);
     }
+    __syncthreads();
   }
+  if (wave == 0 && lane == 0) { S->kept = base; if (err) S->bad = 1; }
   __syncthreads();
-  return bad ? -1 : (int)total;
+  const int kept = S->kept;
+  const int bad = S->bad;
+  __syncthreads();
+  return bad ? -1 : kept;
 }
 
 // ---------------------------------------------------------------------------
@@ -261,38 +341,36 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 // wg_score_l2: scores[i] = -||q - table[ids[i]]||^2 for i < n.  All threads of
 // the workgroup (NTHREADS = blockDim.x).  ids must be in range (the walker and
 // index validation guarantee it on the fused path).  qv: f32[d] (LDS or global).
+// U row loads per lane are in flight at once (U * 16 KB per workgroup), and the
+// candidate ids of the next batch are fetched underneath them.
 template <int LPR, int DT, int NTHREADS>
-__device__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids, int n,
-                            const float* qv, float* scores) {
-  constexpr int U = 4;
+__device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids,
+                                            int n, const float* qv, float* scores) {
+  constexpr int U = (DT == DT_F32) ? 4 : 8;
   constexpr int GPW = 64 / LPR;              // rows per wavefront per load
   constexpr int RPI = (NTHREADS / 64) * GPW;  // rows per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
+  const int slot = wave * GPW + grp;
   float q[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
+  // branch-free: positions past n re-read candidate n-1 and their result is dropped
+  int32_t nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) nxt[u] = ids[min(u * RPI + slot, n - 1)];
   for (int i0 = 0; i0 < n; i0 += RPI * U) {
-    int32_t idv[U];
     RowChunk<DT> ch[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * RPI + wave * GPW + grp;
-      idv[u] = (i < n) ? ids[i] : -1;
-    }
+    for (int u = 0; u < U; ++u) ch[u] = load_chunk<DT>(table, (size_t)nxt[u], d, sub);
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (idv[u] >= 0) ch[u] = load_chunk<DT>(table, (size_t)idv[u], d, sub);
+    for (int u = 0; u < U; ++u)  // ids of the next batch, underneath the row loads
+      nxt[u] = ids[min(i0 + RPI * U + u * RPI + slot, n - 1)];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * RPI + wave * GPW + grp;
+      const int i = i0 + u * RPI + slot;
       float x[8];
-      if (idv[u] >= 0) {
-        chunk_to_float<DT>(ch[u], x);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = 0.0f;
-      }
+      chunk_to_float<DT>(ch[u], x);
       const float s = l2_finish<LPR>(q, x);
       if (sub == 0 && i < n) scores[i] = s;
     }
@@ -321,20 +399,23 @@ struct TopkScratch {
   unsigned long long sel[kMaxK];
 };
 
-template <bool REG>
-__device__ int wg_topk_impl(const int32_t* ids, const float* scores, int n, int k,
+// NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
+template <int NS>
+__device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores, int n, int k,
                             int32_t* out_pos, int32_t* out_ids, float* out_scores,
                             const int64_t* id_map, int64_t* out_mapped, unsigned char* scratch) {
   TopkScratch* S = reinterpret_cast<TopkScratch*>(scratch);
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const uint64_t lt = lanemask_lt();
-  uint32_t key[REG ? kTopkEPT : 1];
+  constexpr bool REG = NS > 0;
+  uint32_t key[REG ? NS : 1];
   if constexpr (REG) {
+    // unconditional (clamped) loads: all NS of them in flight together
+    float raw[NS];
 #pragma unroll
-    for (int j = 0; j < kTopkEPT; ++j) {
-      const int i = j * kNT + tid;
-      key[j] = (i < n) ? score_key(scores[i]) : 0u;
-    }
+    for (int j = 0; j < NS; ++j) raw[j] = scores[min(j * kNT + tid, n - 1)];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) key[j] = (j * kNT + tid < n) ? score_key(raw[j]) : 0u;
   }
   if (tid < 40) S->cnt[tid] = 0;
   if (tid == 0) S->nsel = 0;
@@ -342,8 +423,7 @@ __device__ int wg_topk_impl(const int32_t* ids, const float* scores, int n, int 
 
 #define NANN_FOR_KEYS(...)                                                    \
   if constexpr (REG) {                                                        \
-    _Pragma("unroll") for (int j = 0; j < kTopkEPT; ++j) {                    \
-      if (j * kNT >= n) break;                                                \
+    _Pragma("unroll") for (int j = 0; j < NS; ++j) {                          \
       const int i = j * kNT + tid;                                            \
       const bool valid = i < n;                                               \
       const uint32_t kj = key[j];                                             \
@@ -450,15 +530,21 @@ __device__ int wg_topk_impl(const int32_t* ids, const float* scores, int n, int 
   return 0;
 }
 
-__device__ int wg_topk(const int32_t* ids, const float* scores, int n, int k, int32_t* out_pos,
+__device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, int n, int k, int32_t* out_pos,
                        int32_t* out_ids, float* out_scores, const int64_t* id_map,
                        int64_t* out_mapped, unsigned char* scratch) {
   if (k < 0 || k > kMaxK) return 7;  // NANN_ERR_BAD_ARGUMENT
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;
-  if (n <= kTopkEPT * kNT)
-    return wg_topk_impl<true>(ids, scores, n, k, out_pos, out_ids, out_scores, id_map, out_mapped, scratch);
-  return wg_topk_impl<false>(ids, scores, n, k, out_pos, out_ids, out_scores, id_map, out_mapped, scratch);
+#define NANN_TOPK_CASE(NS_) \
+  return wg_topk_impl<NS_>(ids, scores, n, k, out_pos, out_ids, out_scores, id_map, out_mapped, scratch)
+  if (n <= 1 * kNT) NANN_TOPK_CASE(1);
+  if (n <= 2 * kNT) NANN_TOPK_CASE(2);
+  if (n <= 4 * kNT) NANN_TOPK_CASE(4);
+  if (n <= 8 * kNT) NANN_TOPK_CASE(8);
+  if (n <= kTopkEPT * kNT) NANN_TOPK_CASE(kTopkEPT);
+  NANN_TOPK_CASE(0);
+#undef NANN_TOPK_CASE
 }
 
 }  // namespace nann

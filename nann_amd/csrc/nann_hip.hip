@@ -242,8 +242,7 @@ __global__ __launch_bounds__(kNT) void k_bitmap_ref_difference(
     if (lane_id() == 0) c_row_splits[0] = 0;
     for (long long g = 0; g < groups; ++g) {  // ONE bitmap for all groups
       const long long s = row_splits[g], e = row_splits[g + 1];
-      const int kept = wave_walk<kLds>(values + s, (int)(e - s), bm, n_items, c_values + base, &err);
-      base += kept;
+      base = wave_walk_span<kLds>(values + s, (int)(e - s), bm, n_items, c_values, (int)base, &err);
       if (lane_id() == 0) c_row_splits[g + 1] = base;
     }
     if (lane_id() == 0) { res->n_out = base; res->n_out_splits = n_splits; }
@@ -412,11 +411,10 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
 }
 
 template <int LPR, int DT, bool LDSBM>
-__device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
-                          unsigned char* scratch, float* qv, int* misc, int32_t* ctr,
-                          long long* ticks) {
+__device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
+                                          unsigned char* scratch, float* qv, int32_t* ctr,
+                                          long long* ticks) {
   const int tid = threadIdx.x;
-  const int wave = wave_id(), lane = lane_id();
   const int k5 = a.t[5];
   const bool timing = a.phase_ticks != nullptr;
   long long t_last = timing ? (long long)clock64() : 0;
@@ -429,104 +427,107 @@ __device__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint3
     }
   };
 
-  auto walk = [&](const int32_t* in, int n, int32_t* out) -> int {
-    __syncthreads();
-    mark(PH_OTHER);
-    if (wave == 0) {
-      const int c = wave_walk<LDSBM>(in, n, bm, a.n_items, out, &misc[1]);
-      if (lane == 0) misc[0] = c;
-    }
-    __syncthreads();
-    mark(PH_WALK);
-    return misc[0];
-  };
-  auto score = [&](const int32_t* ids, int n, float* out) {
-    mark(PH_OTHER);
-    wg_score_l2<LPR, DT, kNT>(a.emb, a.d, ids, n, qv, out);
-    __syncthreads();
-    mark(PH_SCORE);
-  };
-  auto expand = [&](const int32_t* frontier, int n, int level) -> int {
-    mark(PH_OTHER);
-    const int g = wg_expand(frontier, n, a.nbv[level], a.nbrs[level], a.n_items, sv.raw, scratch);
-    mark(PH_EXPAND);
-    return g;
-  };
-  auto topk = [&](const int32_t* ids, const float* scores, int n, int k, int32_t* out_ids,
-                  float* out_scores, const int64_t* id_map, int64_t* out_mapped) -> int {
-    mark(PH_OTHER);
-    const int st = wg_topk(ids, scores, n, k, nullptr, out_ids, out_scores, id_map, out_mapped, scratch);
-    mark(PH_TOPK);
-    return st;
-  };
-  auto zero_bitmap = [&]() {
-    __syncthreads();
-    mark(PH_OTHER);
-    wg_zero_words(bm, a.bm_words);
-    __syncthreads();
-    mark(PH_ZERO);
-  };
-
   for (int k = tid; k < a.d; k += kNT) qv[k] = a.q[(size_t)qi * a.d + k];
-  if (tid == 0) misc[1] = 0;
   __syncthreads();
 
-  // ---- level 2 (entry layer): build_opt_graph.py:111-112 -------------------
+  // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
+  // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
+  // 2..4 = the three level-0 rounds (:129-141), 5 = final top-k (:143-149).
   const int E = a.n_enter;
-  if (E == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-  score(a.enter, E, sv.cand_scores);
-  if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
-  if (E == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-  int st = topk(a.enter, sv.cand_scores, E, a.t[0], sv.beam_ids, sv.beam_scores, nullptr, nullptr);
-  if (st) return st;
-  const int nR = a.t[0];
-
-  // ---- level 1: build_opt_graph.py:114-127 ----------------------------------
-  zero_bitmap();                                           // :115-118
-  int kept = walk(sv.beam_ids, nR, sv.cand_ids);           // :119-120 marks the winners
-  if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-  if (kept != nR) return NANN_ERR_BAD_ARGUMENT;            // duplicate enter points
-  for (int i = tid; i < nR; i += kNT) sv.cand_scores[i] = sv.beam_scores[i];
-  int G = expand(sv.beam_ids, nR, 1);                      // :116
-  if (G < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
-  int nC = walk(sv.raw, G, sv.cand_ids + nR);              // :121-122
-  if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-  if (tid == 0) { ctr[0 * 5 + 1] = nR; ctr[1 * 5 + 1] = G; ctr[2 * 5 + 1] = nC; }
-  if (nC == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-  score(sv.cand_ids + nR, nC, sv.cand_scores + nR);        // :124
-  if (nC == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-  st = topk(sv.cand_ids, sv.cand_scores, nR + nC, a.t[1], sv.pool_ids, sv.pool_scores, nullptr,
-            nullptr);                                      // :125-127
-  if (st) return st;
-  int nP = a.t[1];
-
-  // ---- level 0: build_opt_graph.py:129-141 -----------------------------------
-  zero_bitmap();                                           // :131
-  int nB = walk(sv.pool_ids, nP, sv.beam_ids);             // :132-133
-  if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-  const int32_t* frontier = sv.beam_ids;
-  for (int r = 0; r < 3; ++r) {
-    G = expand(frontier, nB, 0);                           // :136
-    if (G < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    nC = walk(sv.raw, G, sv.cand_ids);                     // :137
-    if (misc[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    if (tid == 0) { ctr[0 * 5 + 2 + r] = nB; ctr[1 * 5 + 2 + r] = G; ctr[2 * 5 + 2 + r] = nC; }
-    if (nC == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-    score(sv.cand_ids, nC, sv.cand_scores);                // :138
-    if (nC == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-    st = topk(sv.cand_ids, sv.cand_scores, nC, a.t[2 + r], sv.pool_ids + nP, sv.pool_scores + nP,
-              nullptr, nullptr);                           // :139-141
+  int nP = 0;                         // pool size so far
+  const int32_t* frontier = nullptr;  // beam walked by the next stage
+  int nB = 0;
+  for (int r = 0; r <= NANN_NUM_ROUNDS; ++r) {
+    const int32_t* sc_ids = nullptr;  // what this stage scores
+    float* sc_out = nullptr;
+    int sc_n = 0, base_off = 0;
+    if (r == 0) {
+      sc_ids = a.enter; sc_out = sv.cand_scores; sc_n = E;
+      if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
+    } else if (r < NANN_NUM_ROUNDS) {
+      const int level = (r == 1) ? 1 : 0;
+      int nC = 0, G = 0;
+      // sub-step 0 ("mark", only when a level starts): fresh bitmap, then the current
+      // result set goes through BitmapRefDifference (:115-120, :131-133).
+      // sub-step 1: neighbours of the frontier, filtered (:116,121-122 / :136-137).
+      for (int ss = (r <= 2) ? 0 : 1; ss < 2; ++ss) {
+        const int32_t* src;
+        const int64_t* rs;
+        int n_in;
+        int32_t* dst;
+        if (ss == 0) {
+          mark(PH_OTHER);
+          wg_zero_words(bm, a.bm_words);
+          __syncthreads();
+          mark(PH_ZERO);
+          src = (r == 1) ? sv.beam_ids : sv.pool_ids;
+          n_in = (r == 1) ? a.t[0] : a.t[1];
+          dst = (r == 1) ? sv.cand_ids : sv.beam_ids;
+          rs = nullptr;
+        } else {
+          src = a.nbv[level]; rs = a.nbrs[level]; n_in = nB; dst = sv.cand_ids + base_off;
+        }
+        int gathered = 0;
+        const int kept = wg_expand_walk<LDSBM>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm,
+                                               dst, scratch, &gathered);
+        mark(ss == 0 ? PH_WALK : PH_EXPAND);
+        if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
+        if (ss == 0) {
+          if (r == 1) {
+            if (kept != a.t[0]) return NANN_ERR_BAD_ARGUMENT;  // duplicate enter points
+            for (int i = tid; i < kept; i += kNT) sv.cand_scores[i] = sv.beam_scores[i];
+            base_off = kept;
+          }
+          frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
+          nB = kept;
+        } else {
+          nC = kept; G = gathered;
+        }
+      }
+      if (tid == 0) { ctr[0 * 5 + r] = nB; ctr[1 * 5 + r] = G; ctr[2 * 5 + r] = nC; }
+      sc_ids = sv.cand_ids + base_off; sc_out = sv.cand_scores + base_off; sc_n = nC;
+    }
+    if (r < NANN_NUM_ROUNDS) {  // forward(): GatherV2 + scorer (:91-107)
+      if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+      mark(PH_OTHER);
+      wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out);
+      __syncthreads();
+      mark(PH_SCORE);
+      if (sc_n == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
+    }
+    // top_k(): TopKV2 + Gather of the ids (:52-66)
+    const int32_t* tk_ids; const float* tk_sc; int tk_n, tk_k;
+    int32_t* tk_out_ids; float* tk_out_sc; const int64_t* tk_map = nullptr; int64_t* tk_out_map = nullptr;
+    if (r == 0) {          // R, sR = topk(EP, s, t0)                      :112
+      tk_ids = a.enter; tk_sc = sv.cand_scores; tk_n = E; tk_k = a.t[0];
+      tk_out_ids = sv.beam_ids; tk_out_sc = sv.beam_scores;
+    } else if (r == 1) {   // P, sP = topk(R || C, sR || sC, t1)           :125-127
+      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = base_off + sc_n; tk_k = a.t[1];
+      tk_out_ids = sv.pool_ids; tk_out_sc = sv.pool_scores;
+    } else if (r < NANN_NUM_ROUNDS) {  // B, sB = topk(C, sC, t[r]); appended to the pool  :139-141
+      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = sc_n; tk_k = a.t[r];
+      tk_out_ids = sv.pool_ids + nP; tk_out_sc = sv.pool_scores + nP;
+    } else {               // final: topk(pool, t5) -> item_ids           :143-149
+      tk_ids = sv.pool_ids; tk_sc = sv.pool_scores; tk_n = nP; tk_k = k5;
+      tk_out_ids = a.out_index ? a.out_index + (size_t)qi * k5 : nullptr;
+      tk_out_sc = a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr;
+      tk_map = a.item_ids; tk_out_map = a.out_ids + (size_t)qi * k5;
+    }
+    mark(PH_OTHER);
+    const int st = wg_topk(tk_ids, tk_sc, tk_n, tk_k, nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map,
+                           scratch);
+    mark(PH_TOPK);
     if (st) return st;
-    frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
-    nB = a.t[2 + r];
-    nP += nB;
+    if (r == 1) {
+      nP = a.t[1];
+    } else if (r >= 2 && r < NANN_NUM_ROUNDS) {
+      frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
+      nB = a.t[r];
+      nP += nB;
+    }
   }
-  // ---- final: build_opt_graph.py:143-149 --------------------------------------
-  st = topk(sv.pool_ids, sv.pool_scores, nP, k5, a.out_index ? a.out_index + (size_t)qi * k5 : nullptr,
-            a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr, a.item_ids,
-            a.out_ids + (size_t)qi * k5);
   mark(PH_OTHER);
-  return st;
+  return NANN_OK;
 }
 
 template <int LPR, int DT, bool LDSBM>
@@ -535,13 +536,13 @@ __global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
   uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
   unsigned char* scratch = smem + (LDSBM ? (size_t)a.bm_words * 4 : 0);
   float* qv = reinterpret_cast<float*>(scratch + kPhaseScratch);
-  int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] walk count, [1] range error
+  int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] next query
   int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
   long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
 
   unsigned long long off[8];
   slot_layout(a.max_cand, a.max_raw, a.pool_cap, LDSBM ? 0u : a.bm_words, off);
-  unsigned char* slot = a.ws + (unsigned long long)blockIdx.x * a.slot_bytes;
+  unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
   SlotView sv;
   sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
   sv.cand_scores = reinterpret_cast<float*>(slot + off[1]);
@@ -553,16 +554,20 @@ __global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
   sv.gbitmap = reinterpret_cast<uint32_t*>(slot + off[7]);
   uint32_t* bm = LDSBM ? bm_lds : sv.gbitmap;
   const int k5 = a.t[5];
+  unsigned int* queue = reinterpret_cast<unsigned int*>(a.ws);  // zeroed by the host before launch
 
-  for (int qi = blockIdx.x; qi < a.n_queries; qi += gridDim.x) {
+  // queries are pulled from one device-wide counter: a slot that finishes early takes
+  // the next request instead of idling until the slowest slot is done
+  for (;;) {
     __syncthreads();
+    if (threadIdx.x == 0) misc[0] = (int)atomicAdd(queue, 1u);
     if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
     if (threadIdx.x < NANN_NUM_PHASES) s_ticks[threadIdx.x] = 0;
     __syncthreads();
-    const int st = search_one<LPR, DT, LDSBM>(a, qi, sv, bm, scratch, qv, misc, s_ctr, s_ticks);
+    const int qi = misc[0];
+    if (qi >= a.n_queries) break;
+    const int st = search_one<LPR, DT, LDSBM>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
     __syncthreads();
-    if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES)
-      a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x] = s_ticks[threadIdx.x];
     if (st) {  // a request the reference would fail: zeroed outputs + its code
       for (int i = threadIdx.x; i < k5; i += kNT) {
         a.out_ids[(size_t)qi * k5 + i] = 0;
@@ -573,6 +578,8 @@ __global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
     if (threadIdx.x == 0) a.status[qi] = st;
     if (a.counters && threadIdx.x < 3 * NANN_NUM_ROUNDS)
       a.counters[(size_t)qi * 3 * NANN_NUM_ROUNDS + threadIdx.x] = s_ctr[threadIdx.x];
+    if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES)
+      a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x] = s_ticks[threadIdx.x];
   }
 }
 
@@ -1129,7 +1136,7 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
   SearchPlan p;
   const int rc = plan_search(ix, level_topn, n_queries, &p);
   if (rc) return rc;
-  *nbytes = (int64_t)(p.slot_bytes * (unsigned long long)p.slots);
+  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)p.slots);
   return NANN_OK;
 }
 
@@ -1180,7 +1187,7 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   SearchPlan p;
   int rc = plan_search(ix, level_topn, n_queries, &p);
   if (rc) return rc;
-  if (!workspace || workspace_bytes < (int64_t)(p.slot_bytes * (unsigned long long)p.slots))
+  if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)p.slots))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");
   SearchArgs a;
   a.emb = ix->desc.item_embs;
@@ -1201,6 +1208,7 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   a.status = status; a.counters = counters;
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
   hipStream_t st = as_stream(stream);
+  HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // the query queue head
   const int dt = ix->desc.emb_dtype;
   switch (ix->desc.d / 8) {
     case 8: return launch_search_dt<8>(dt, p, a, st);
