@@ -56,6 +56,18 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     args = parse()
     import torch
@@ -184,7 +196,7 @@ def main():
         oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
         osc = O.Scorer("l2", args.dim, O.EMB_F16)
         qh = ops.user_seq_mean(comm_seq).cpu().numpy()
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         if not args.no_cpu_baseline:
             # bounded sample: grow the chunk until the time budget is used
             n_done, t_cpu, chunk = 0, 0.0, min(args.batch, 4 * cores)

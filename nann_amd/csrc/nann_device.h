@@ -20,8 +20,11 @@ constexpr int kNT = 1024;            // threads per traversal workgroup
 constexpr int kNW = kNT / 64;        // 16 wavefronts
 constexpr int kTopkEPT = 16;         // top-k keys held in registers per thread (n <= 16384)
 constexpr int kMaxK = 1024;          // largest k / frontier a workgroup handles
-constexpr int kPhaseScratch = 24832; // LDS bytes shared by the phases below
+constexpr int kPhaseScratch = 25600; // LDS bytes shared by the phases below
 constexpr int kMaxD = 512;
+// candidate scores of a round are mirrored in LDS behind the top-k scratch
+constexpr int kLdsScoresOff = 8704;
+constexpr int kLdsScores = 4096;
 
 enum : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
 
@@ -80,7 +83,7 @@ __device__ __forceinline__ void wg_zero_words(uint32_t* p, uint32_t n_words) {
 template <bool kLdsBm>
 __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_t* bm,
                                               uint32_t n_items, int32_t* out, int base, int* err) {
-  constexpr int U = kLdsBm ? 4 : 1;
+  constexpr int U = kLdsBm ? 8 : 1;
   const int lane = lane_id();
   const uint64_t lt = lanemask_lt();
   for (int c0 = 0; c0 < n; c0 += 64 * U) {
@@ -160,7 +163,7 @@ struct ExpandWalkScratch {
   int32_t stage[2][kChunk];
 };
 
-template <bool kLdsBm>
+template <bool kLdsBm, int NT = kNT>
 __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits,
@@ -173,37 +176,44 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   if (tid == 0) { S->bad = 0; S->kept = 0; }
   __syncthreads();
   // ---- pass 1: row lengths -> offsets --------------------------------------
-  uint32_t len = 0, start = 0;
-  if (list_mode) {
-    if (tid == 0) len = (uint32_t)n_frontier;
-  } else if (tid < n_frontier) {
-    const int32_t node = frontier[tid];
-    if ((uint32_t)node < n_items) {
-      const int64_t s = row_splits[node], e = row_splits[node + 1];
-      start = (uint32_t)s;
-      len = (uint32_t)(e - s);
-    } else {
-      S->bad = 1;
+  constexpr int NWV = NT / 64;
+  uint32_t total = 0;
+  for (int t0 = 0; t0 < n_rows; t0 += NT) {
+    const int t = t0 + tid;
+    uint32_t len = 0, start = 0;
+    if (list_mode) {
+      if (t == 0) len = (uint32_t)n_frontier;
+    } else if (t < n_frontier) {
+      const int32_t node = frontier[t];
+      if ((uint32_t)node < n_items) {
+        const int64_t s = row_splits[node], e = row_splits[node + 1];
+        start = (uint32_t)s;
+        len = (uint32_t)(e - s);
+      } else {
+        S->bad = 1;
+      }
     }
-  }
-  uint32_t inc = len;
+    uint32_t inc = len;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d);
-    if (lane >= d) inc += t;
-  }
-  if (lane == 63) S->wave_tot[wave] = inc;
-  __syncthreads();
-  uint32_t wbase = 0, total = 0;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = __shfl_up(inc, d);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) S->wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kNW; ++w) {
-    const uint32_t t = S->wave_tot[w];
-    if (w < wave) wbase += t;
-    total += t;
-  }
-  if (tid < n_rows) {
-    S->off[tid] = wbase + inc - len;
-    S->rowstart[tid] = start;
+    for (int w = 0; w < NWV; ++w) {
+      const uint32_t v = S->wave_tot[w];
+      if (w < wave) wbase += v;
+      tot += v;
+    }
+    if (t < n_rows) {
+      S->off[t] = total + wbase + inc - len;
+      S->rowstart[t] = start;
+    }
+    total += tot;
+    __syncthreads();
   }
   if (tid == 0) S->off[n_rows] = total;
   __syncthreads();
@@ -227,13 +237,13 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
           if (S->off[m + 1] > lo) b = m; else a = m + 1;
         }
         constexpr int RB = 8;
-        for (int r0 = a + (wave - 1); r0 < n_rows; r0 += (kNW - 1) * RB) {
+        for (int r0 = a + (wave - 1); r0 < n_rows; r0 += (NWV - 1) * RB) {
           if (S->off[r0] >= hi) break;
           uint32_t o[RB], l[RB], st[RB];
           int32_t v[RB];
 #pragma unroll
           for (int j = 0; j < RB; ++j) {  // row descriptors (LDS)
-            const int r = r0 + j * (kNW - 1);
+            const int r = r0 + j * (NWV - 1);
             o[j] = 0; l[j] = 0; st[j] = 0;
             if (r < n_rows) {
               o[j] = S->off[r];
@@ -343,9 +353,11 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 // index validation guarantee it on the fused path).  qv: f32[d] (LDS or global).
 // U row loads per lane are in flight at once (U * 16 KB per workgroup), and the
 // candidate ids of the next batch are fetched underneath them.
+// lds_scores (nullable, LDS): mirror of scores[] for positions lds_off + i < kLdsScores.
 template <int LPR, int DT, int NTHREADS>
 __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids,
-                                            int n, const float* qv, float* scores) {
+                                            int n, const float* qv, float* scores, float* lds_scores,
+                                            int lds_off) {
   constexpr int U = (DT == DT_F32) ? 4 : 8;
   constexpr int GPW = 64 / LPR;              // rows per wavefront per load
   constexpr int RPI = (NTHREADS / 64) * GPW;  // rows per workgroup iteration
@@ -372,7 +384,10 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
       float x[8];
       chunk_to_float<DT>(ch[u], x);
       const float s = l2_finish<LPR>(q, x);
-      if (sub == 0 && i < n) scores[i] = s;
+      if (sub == 0 && i < n) {
+        scores[i] = s;
+        if (lds_scores != nullptr && lds_off + i < kLdsScores) lds_scores[lds_off + i] = s;
+      }
     }
   }
 }
@@ -393,17 +408,36 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
 // out_pos / out_ids / out_scores / out_mapped may each be null.  ids == null
 // means "ids are positions".  Returns NANN status (uniform).
 struct TopkScratch {
-  uint32_t cnt[40];
-  uint32_t nsel;
+  uint32_t cnt[20][3];
+  uint32_t misc[4];  // [0] nsel, [1] c_gt, [2] unordered append cursor, [3] unused
+  uint32_t orv, andv;
   uint32_t wcnt[kNW];
   unsigned long long sel[kMaxK];
 };
+// candidate scores of the current round, kept in LDS behind the top-k scratch so that
+// the selection does not wait on L2 (positions < kLdsScores only)
+static_assert(sizeof(TopkScratch) <= kLdsScoresOff, "top-k scratch overlaps the LDS scores");
+static_assert(kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
+static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too small");
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v |= __shfl_xor(v, s);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_and(uint32_t v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v &= __shfl_xor(v, s);
+  return v;
+}
 
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
-template <int NS>
-__device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores, int n, int k,
-                            int32_t* out_pos, int32_t* out_ids, float* out_scores,
-                            const int64_t* id_map, int64_t* out_mapped, unsigned char* scratch) {
+// SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
+template <int NS, bool SCL, int NT>
+__device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
+                                            const float* lds_scores, int n, int k, int32_t* out_pos,
+                                            int32_t* out_ids, float* out_scores, const int64_t* id_map,
+                                            int64_t* out_mapped, unsigned char* scratch) {
   TopkScratch* S = reinterpret_cast<TopkScratch*>(scratch);
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const uint64_t lt = lanemask_lt();
@@ -413,24 +447,28 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     // unconditional (clamped) loads: all NS of them in flight together
     float raw[NS];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) raw[j] = scores[min(j * kNT + tid, n - 1)];
+    for (int j = 0; j < NS; ++j) {
+      const int i = min(j * NT + tid, n - 1);
+      raw[j] = SCL ? lds_scores[i] : scores[i];
+    }
 #pragma unroll
-    for (int j = 0; j < NS; ++j) key[j] = (j * kNT + tid < n) ? score_key(raw[j]) : 0u;
+    for (int j = 0; j < NS; ++j) key[j] = (j * NT + tid < n) ? score_key(raw[j]) : 0u;
   }
-  if (tid < 40) S->cnt[tid] = 0;
-  if (tid == 0) S->nsel = 0;
+  if (tid < 60) (&S->cnt[0][0])[tid] = 0;
+  if (tid < 4) S->misc[tid] = 0;
+  if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
   __syncthreads();
 
 #define NANN_FOR_KEYS(...)                                                    \
   if constexpr (REG) {                                                        \
     _Pragma("unroll") for (int j = 0; j < NS; ++j) {                          \
-      const int i = j * kNT + tid;                                            \
+      const int i = j * NT + tid;                                             \
       const bool valid = i < n;                                               \
       const uint32_t kj = key[j];                                             \
       __VA_ARGS__                                                             \
     }                                                                         \
   } else {                                                                    \
-    for (int i0 = 0; i0 < n; i0 += kNT) {                                     \
+    for (int i0 = 0; i0 < n; i0 += NT) {                                      \
       const int i = i0 + tid;                                                 \
       const bool valid = i < n;                                               \
       const uint32_t kj = valid ? score_key(scores[i]) : 0u;                  \
@@ -438,34 +476,67 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     }                                                                         \
   }
 
-  // ---- 2. threshold search ------------------------------------------------
-  uint32_t T = 0, c_ge = (uint32_t)n;
-  int it = 0;
-  for (int bit = 31; bit >= 0; --bit, ++it) {
-    const uint32_t probe = T | (1u << bit);
-    uint32_t c = 0;
-    NANN_FOR_KEYS({ c += (uint32_t)popc64(__ballot(valid && kj >= probe)); })
-    if (lane == 0 && c) atomicAdd(&S->cnt[it], c);
-    __syncthreads();
-    const uint32_t tot = S->cnt[it];
-    if (tot >= (uint32_t)k) {
-      T = probe;
-      c_ge = tot;
-      if (tot == (uint32_t)k) break;
-    }
+  // ---- 2a. common prefix of all keys: the search only has to resolve the bits
+  //          below the highest bit in which any two keys differ
+  {
+    uint32_t lo = 0u, la = 0xffffffffu;
+    NANN_FOR_KEYS({ if (valid) { lo |= kj; la &= kj; } })
+    lo = wave_or(lo);
+    la = wave_and(la);
+    if (lane == 0) { atomicOr(&S->orv, lo); atomicAnd(&S->andv, la); }
   }
-  // c_ge = #keys >= T >= k.  If c_ge > k the loop ran to bit 0 and T is the
-  // exact k-th key: some (not all) keys equal to T are admitted.
+  __syncthreads();
+  const uint32_t diff = S->orv ^ S->andv;
+  // ---- 2b. k-th largest key: two bits per barrier round, early exit as soon as
+  //          exactly k keys are >= a probe
+  uint32_t T = 0, c_ge = (uint32_t)n;
+  bool exact = false;
+  if (diff != 0u) {
+    int b = 31 - __clz((int)diff);  // highest differing bit
+    T = S->andv & ~((b == 31) ? 0xffffffffu : ((2u << b) - 1u));
+    int it = 0;
+    while (b >= 0 && !exact) {
+      const int lowbit = (b >= 1) ? b - 1 : 0;
+      const int nb = (b >= 1) ? 2 : 1;
+      const uint32_t p1 = T | (1u << lowbit);
+      const uint32_t p2 = T | (2u << lowbit);
+      const uint32_t p3 = T | (3u << lowbit);
+      uint32_t c1 = 0, c2 = 0, c3 = 0;
+      NANN_FOR_KEYS({
+        c1 += (uint32_t)popc64(__ballot(valid && kj >= p1));
+        if (nb == 2) {
+          c2 += (uint32_t)popc64(__ballot(valid && kj >= p2));
+          c3 += (uint32_t)popc64(__ballot(valid && kj >= p3));
+        }
+      })
+      if (lane == 0) {
+        if (c1) atomicAdd(&S->cnt[it][0], c1);
+        if (c2) atomicAdd(&S->cnt[it][1], c2);
+        if (c3) atomicAdd(&S->cnt[it][2], c3);
+      }
+      __syncthreads();
+      const uint32_t t1 = S->cnt[it][0], t2 = S->cnt[it][1], t3 = S->cnt[it][2];
+      const uint32_t kk = (uint32_t)k;
+      if (nb == 2 && t3 >= kk) { T = p3; c_ge = t3; }
+      else if (nb == 2 && t2 >= kk) { T = p2; c_ge = t2; }
+      else if (t1 >= kk) { T = p1; c_ge = t1; }
+      exact = (c_ge == kk);
+      b -= nb;
+      ++it;
+    }
+  } else {
+    T = S->andv;  // all keys equal
+  }
+  // c_ge = #keys >= T >= k.  If c_ge > k, T is the exact k-th key and only some of the
+  // keys equal to T are admitted.
   uint32_t c_gt = 0;
   const bool partial_eq = c_ge > (uint32_t)k;
   if (partial_eq) {
     uint32_t c = 0;
     NANN_FOR_KEYS({ c += (uint32_t)popc64(__ballot(valid && kj > T)); })
-    if (lane == 0 && c) atomicAdd(&S->cnt[33], c);
+    if (lane == 0 && c) atomicAdd(&S->misc[1], c);
     __syncthreads();
-    c_gt = S->cnt[33];
-    if (tid == 0) S->nsel = c_gt;  // equal keys take slots [c_gt, k)
-    __syncthreads();
+    c_gt = S->misc[1];
   }
   // ---- 3. collect -----------------------------------------------------------
   if (!partial_eq) {
@@ -474,19 +545,19 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       const uint64_t m = __ballot(s);
       if (m) {
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&S->nsel, (uint32_t)popc64(m));
+        if (lane == 0) b = atomicAdd(&S->misc[0], (uint32_t)popc64(m));
         b = __shfl(b, 0);
         if (s) S->sel[b + popc64(m & lt)] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
       }
     })
   } else {
-    // keys > T: any slot in [0, c_gt) (unordered append through cnt[34])
+    // keys > T: any slot in [0, c_gt) (unordered append)
     NANN_FOR_KEYS({
       const bool s = valid && kj > T;
       const uint64_t m = __ballot(s);
       if (m) {
         uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&S->cnt[34], (uint32_t)popc64(m));
+        if (lane == 0) b = atomicAdd(&S->misc[2], (uint32_t)popc64(m));
         b = __shfl(b, 0);
         if (s) S->sel[b + popc64(m & lt)] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
       }
@@ -501,7 +572,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       if (lane == 0) S->wcnt[wave] = (uint32_t)popc64(m);
       __syncthreads();
       uint32_t wb = 0, tot = 0;
-      for (int w = 0; w < kNW; ++w) {
+      for (int w = 0; w < NT / 64; ++w) {
         const uint32_t t = S->wcnt[w];
         if (w < wave) wb += t;
         tot += t;
@@ -515,7 +586,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
 #undef NANN_FOR_KEYS
   __syncthreads();
   // ---- 4. rank sort + output --------------------------------------------------
-  for (int e = tid; e < k; e += kNT) {
+  for (int e = tid; e < k; e += NT) {
     const unsigned long long mine = S->sel[e];
     int rank = 0;
     for (int o = 0; o < k; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
@@ -523,27 +594,37 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     const int32_t idv = ids ? ids[pos] : pos;
     if (out_pos) out_pos[rank] = pos;
     if (out_ids) out_ids[rank] = idv;
-    if (out_scores) out_scores[rank] = scores[pos];
+    if (out_scores) out_scores[rank] = SCL ? lds_scores[pos] : scores[pos];
     if (out_mapped) out_mapped[rank] = id_map[idv];
   }
   __syncthreads();
   return 0;
 }
 
-__device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, int n, int k, int32_t* out_pos,
-                       int32_t* out_ids, float* out_scores, const int64_t* id_map,
-                       int64_t* out_mapped, unsigned char* scratch) {
+// lds_scores != nullptr: the first n scores are mirrored in LDS (n <= kLdsScores)
+template <int NT = kNT>
+__device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, const float* lds_scores,
+                                       int n, int k, int32_t* out_pos, int32_t* out_ids,
+                                       float* out_scores, const int64_t* id_map, int64_t* out_mapped,
+                                       unsigned char* scratch) {
   if (k < 0 || k > kMaxK) return 7;  // NANN_ERR_BAD_ARGUMENT
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;
-#define NANN_TOPK_CASE(NS_) \
-  return wg_topk_impl<NS_>(ids, scores, n, k, out_pos, out_ids, out_scores, id_map, out_mapped, scratch)
-  if (n <= 1 * kNT) NANN_TOPK_CASE(1);
-  if (n <= 2 * kNT) NANN_TOPK_CASE(2);
-  if (n <= 4 * kNT) NANN_TOPK_CASE(4);
-  if (n <= 8 * kNT) NANN_TOPK_CASE(8);
-  if (n <= kTopkEPT * kNT) NANN_TOPK_CASE(kTopkEPT);
-  NANN_TOPK_CASE(0);
+#define NANN_TOPK_CASE(NS_, SCL_)                                                                   \
+  return wg_topk_impl<NS_, SCL_, NT>(ids, scores, lds_scores, n, k, out_pos, out_ids, out_scores, \
+                                     id_map, out_mapped, scratch)
+  if (lds_scores != nullptr && n <= kLdsScores) {
+    if (n <= 1 * NT) NANN_TOPK_CASE(1, true);
+    if (n <= 2 * NT) NANN_TOPK_CASE(2, true);
+    if (n <= 4 * NT) NANN_TOPK_CASE(4, true);
+    if constexpr (8 * NT <= kLdsScores) NANN_TOPK_CASE(8, true);
+  }
+  if (n <= 1 * NT) NANN_TOPK_CASE(1, false);
+  if (n <= 2 * NT) NANN_TOPK_CASE(2, false);
+  if (n <= 4 * NT) NANN_TOPK_CASE(4, false);
+  if (n <= 8 * NT) NANN_TOPK_CASE(8, false);
+  if (n <= kTopkEPT * NT) NANN_TOPK_CASE(kTopkEPT, false);
+  NANN_TOPK_CASE(0, false);
 #undef NANN_TOPK_CASE
 }
 

@@ -280,9 +280,9 @@ __global__ void k_init_result(OpResult* res) {
 // TopKV2 (topk_op.cc:104-205): one workgroup per row.
 __global__ __launch_bounds__(kNT) void k_topk(const float* values, long long n_cols, int k,
                                               float* out_values, int32_t* out_indices) {
-  __shared__ __attribute__((aligned(16))) unsigned char scratch[kPhaseScratch];
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(TopkScratch)];
   const long long row = blockIdx.x;
-  wg_topk(nullptr, values + row * n_cols, (int)n_cols, k, out_indices + row * k, nullptr,
+  wg_topk(nullptr, values + row * n_cols, nullptr, (int)n_cols, k, out_indices + row * k, nullptr,
           out_values + row * k, nullptr, nullptr, scratch);
 }
 
@@ -291,9 +291,9 @@ __global__ __launch_bounds__(kNT) void k_topk(const float* values, long long n_c
 __global__ __launch_bounds__(kNT) void k_merge_topk(const float* scores, const int64_t* ids,
                                                     int n_in, int k_out, float* out_scores,
                                                     int64_t* out_ids) {
-  __shared__ __attribute__((aligned(16))) unsigned char scratch[kPhaseScratch];
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(TopkScratch)];
   const long long qi = blockIdx.x;
-  wg_topk(nullptr, scores + qi * n_in, n_in, k_out, nullptr, nullptr, out_scores + qi * k_out,
+  wg_topk(nullptr, scores + qi * n_in, nullptr, n_in, k_out, nullptr, nullptr, out_scores + qi * k_out,
           ids + qi * n_in, out_ids + qi * k_out, scratch);
 }
 
@@ -416,6 +416,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                           long long* ticks) {
   const int tid = threadIdx.x;
   const int k5 = a.t[5];
+  float* lds_scores = reinterpret_cast<float*>(scratch + kLdsScoresOff);
   const bool timing = a.phase_ticks != nullptr;
   long long t_last = timing ? (long long)clock64() : 0;
   // attribute the time since the previous mark to `phase` (thread 0 only; off by default)
@@ -475,7 +476,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         if (ss == 0) {
           if (r == 1) {
             if (kept != a.t[0]) return NANN_ERR_BAD_ARGUMENT;  // duplicate enter points
-            for (int i = tid; i < kept; i += kNT) sv.cand_scores[i] = sv.beam_scores[i];
+            for (int i = tid; i < kept; i += kNT) {
+              const float v = sv.beam_scores[i];
+              sv.cand_scores[i] = v;
+              if (i < kLdsScores) lds_scores[i] = v;
+            }
             base_off = kept;
           }
           frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
@@ -490,7 +495,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     if (r < NANN_NUM_ROUNDS) {  // forward(): GatherV2 + scorer (:91-107)
       if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
       mark(PH_OTHER);
-      wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out);
+      wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out, lds_scores, base_off);
       __syncthreads();
       mark(PH_SCORE);
       if (sc_n == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
@@ -514,8 +519,8 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       tk_map = a.item_ids; tk_out_map = a.out_ids + (size_t)qi * k5;
     }
     mark(PH_OTHER);
-    const int st = wg_topk(tk_ids, tk_sc, tk_n, tk_k, nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map,
-                           scratch);
+    const int st = wg_topk(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k, nullptr,
+                           tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch);
     mark(PH_TOPK);
     if (st) return st;
     if (r == 1) {
