@@ -7,8 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libnann_hip.so")
-SOURCES = ["nann_hip.hip"]
-DEPS = ["nann_hip.hip", "nann_device.h", os.path.join("..", "..", "include", "nann_hip.h")]
+# (source, extra flags, object name): compiled in parallel, then linked
+UNITS = [("nann_hip.hip", [], "nann_hip.o"),
+         ("nann_mlp_inst.hip", ["-DNANN_MLP_D=64"], "nann_mlp_d64.o"),
+         ("nann_mlp_inst.hip", ["-DNANN_MLP_D=128"], "nann_mlp_d128.o"),
+         ("nann_mlp_inst.hip", ["-DNANN_MLP_D=256"], "nann_mlp_d256.o")]
+DEPS = ["nann_hip.hip", "nann_mlp_inst.hip", "nann_device.h", "nann_mlp.h", "nann_search.h",
+        os.path.join("..", "..", "include", "nann_hip.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-fast-math", "-ffp-contract=off"]
 
 
 def _hipcc():
@@ -26,16 +32,25 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source into nann_amd/_build/libnann_hip.so.  Returns its path."""
+    """Compile every HIP source for gfx950 into nann_amd/_build/libnann_hip.so (objects in
+    parallel, then one link).  Returns the library path."""
     if not force and not is_stale():
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-fno-fast-math", "-ffp-contract=off",
-           "-o", LIB] + [os.path.join(SRC_DIR, s) for s in SOURCES]
+    procs = []
+    for src, extra, obj in UNITS:
+        cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(SRC_DIR, src), "-o", os.path.join(OUT_DIR, obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + \
+           [os.path.join(OUT_DIR, obj) for _, _, obj in UNITS]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     return LIB
 
 

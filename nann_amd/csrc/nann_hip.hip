@@ -1,8 +1,7 @@
 // nann_hip.hip -- kernels + C ABI of libnann_hip.so (gfx950 only).
 // The ABI is documented in include/nann_hip.h; the workgroup building blocks
 // in nann_device.h.  Reference citations are relative to /root/reference/.
-#include "../../include/nann_hip.h"
-#include "nann_device.h"
+#include "nann_search.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -18,14 +17,15 @@ using namespace nann;
 // ===========================================================================
 // host-side helpers
 // ===========================================================================
-namespace {
-
+namespace nann {
 thread_local std::string g_err;
-
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+}  // namespace nann
+
+namespace {
 
 #define HIP_TRY(expr)                                                                    \
   do {                                                                                   \
@@ -60,16 +60,6 @@ int device_info(DeviceInfo* out) {
   *out = cache[dev];
   return NANN_OK;
 }
-
-// small result block shared between a kernel and the host for calls that
-// return data-dependent counts (they synchronise anyway)
-struct OpResult {
-  long long n_out;
-  long long n_out_splits;
-  long long bad_i;
-  int code;  // ragged validation code 1/2/3
-  int err;   // nann_status
-};
 
 struct ResultBuf {
   OpResult* dev = nullptr;
@@ -356,244 +346,12 @@ __global__ __launch_bounds__(256) void k_score_l2(const void* table, long long n
 }
 
 // ===========================================================================
-// the fused traversal (build_opt_graph.py:109-149)
-// ===========================================================================
-struct SearchArgs {
-  const void* emb;
-  const int64_t* item_ids;
-  const int32_t* nbv[2];
-  const int64_t* nbrs[2];
-  const int32_t* enter;
-  int n_enter;
-  uint32_t n_items;
-  int d;
-  const float* q;
-  int n_queries;
-  int t[6];
-  unsigned char* ws;
-  unsigned long long slot_bytes;
-  uint32_t bm_words;  // padded to a multiple of 4
-  int max_cand, max_raw, pool_cap;
-  int64_t* out_ids;
-  float* out_scores;
-  int32_t* out_index;
-  int32_t* status;
-  int32_t* counters;
-  long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
-};
-
-enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER };
-
-struct SlotView {
-  int32_t* cand_ids;
-  float* cand_scores;
-  int32_t* raw;
-  int32_t* beam_ids;
-  float* beam_scores;
-  int32_t* pool_ids;
-  float* pool_scores;
-  uint32_t* gbitmap;
-};
-
-__host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_raw, int pool_cap,
-                                                          uint32_t gbm_words, unsigned long long off[8]) {
-  unsigned long long o = 0;
-  auto put = [&](int i, unsigned long long bytes) { off[i] = o; o += (bytes + 255ull) & ~255ull; };
-  put(0, 4ull * max_cand);  // cand_ids
-  put(1, 4ull * max_cand);  // cand_scores
-  put(2, 4ull * max_raw);   // raw
-  put(3, 4ull * kMaxK);     // beam_ids
-  put(4, 4ull * kMaxK);     // beam_scores
-  put(5, 4ull * pool_cap);  // pool_ids
-  put(6, 4ull * pool_cap);  // pool_scores
-  put(7, 4ull * gbm_words); // bitmap in HBM (large shards only)
-  return o;
-}
-
-template <int LPR, int DT, bool LDSBM>
-__device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
-                                          unsigned char* scratch, float* qv, int32_t* ctr,
-                                          long long* ticks) {
-  const int tid = threadIdx.x;
-  const int k5 = a.t[5];
-  float* lds_scores = reinterpret_cast<float*>(scratch + kLdsScoresOff);
-  const bool timing = a.phase_ticks != nullptr;
-  long long t_last = timing ? (long long)clock64() : 0;
-  // attribute the time since the previous mark to `phase` (thread 0 only; off by default)
-  auto mark = [&](int phase) {
-    if (timing && tid == 0) {
-      const long long now = (long long)clock64();
-      ticks[phase] += now - t_last;
-      t_last = now;
-    }
-  };
-
-  for (int k = tid; k < a.d; k += kNT) qv[k] = a.q[(size_t)qi * a.d + k];
-  __syncthreads();
-
-  // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
-  // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
-  // 2..4 = the three level-0 rounds (:129-141), 5 = final top-k (:143-149).
-  const int E = a.n_enter;
-  int nP = 0;                         // pool size so far
-  const int32_t* frontier = nullptr;  // beam walked by the next stage
-  int nB = 0;
-  for (int r = 0; r <= NANN_NUM_ROUNDS; ++r) {
-    const int32_t* sc_ids = nullptr;  // what this stage scores
-    float* sc_out = nullptr;
-    int sc_n = 0, base_off = 0;
-    if (r == 0) {
-      sc_ids = a.enter; sc_out = sv.cand_scores; sc_n = E;
-      if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
-    } else if (r < NANN_NUM_ROUNDS) {
-      const int level = (r == 1) ? 1 : 0;
-      int nC = 0, G = 0;
-      // sub-step 0 ("mark", only when a level starts): fresh bitmap, then the current
-      // result set goes through BitmapRefDifference (:115-120, :131-133).
-      // sub-step 1: neighbours of the frontier, filtered (:116,121-122 / :136-137).
-      for (int ss = (r <= 2) ? 0 : 1; ss < 2; ++ss) {
-        const int32_t* src;
-        const int64_t* rs;
-        int n_in;
-        int32_t* dst;
-        if (ss == 0) {
-          mark(PH_OTHER);
-          wg_zero_words(bm, a.bm_words);
-          __syncthreads();
-          mark(PH_ZERO);
-          src = (r == 1) ? sv.beam_ids : sv.pool_ids;
-          n_in = (r == 1) ? a.t[0] : a.t[1];
-          dst = (r == 1) ? sv.cand_ids : sv.beam_ids;
-          rs = nullptr;
-        } else {
-          src = a.nbv[level]; rs = a.nbrs[level]; n_in = nB; dst = sv.cand_ids + base_off;
-        }
-        int gathered = 0;
-        const int kept = wg_expand_walk<LDSBM>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm,
-                                               dst, scratch, &gathered);
-        mark(ss == 0 ? PH_WALK : PH_EXPAND);
-        if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
-        if (ss == 0) {
-          if (r == 1) {
-            if (kept != a.t[0]) return NANN_ERR_BAD_ARGUMENT;  // duplicate enter points
-            for (int i = tid; i < kept; i += kNT) {
-              const float v = sv.beam_scores[i];
-              sv.cand_scores[i] = v;
-              if (i < kLdsScores) lds_scores[i] = v;
-            }
-            base_off = kept;
-          }
-          frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
-          nB = kept;
-        } else {
-          nC = kept; G = gathered;
-        }
-      }
-      if (tid == 0) { ctr[0 * 5 + r] = nB; ctr[1 * 5 + r] = G; ctr[2 * 5 + r] = nC; }
-      sc_ids = sv.cand_ids + base_off; sc_out = sv.cand_scores + base_off; sc_n = nC;
-    }
-    if (r < NANN_NUM_ROUNDS) {  // forward(): GatherV2 + scorer (:91-107)
-      if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-      mark(PH_OTHER);
-      wg_score_l2<LPR, DT, kNT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out, lds_scores, base_off);
-      __syncthreads();
-      mark(PH_SCORE);
-      if (sc_n == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
-    }
-    // top_k(): TopKV2 + Gather of the ids (:52-66)
-    const int32_t* tk_ids; const float* tk_sc; int tk_n, tk_k;
-    int32_t* tk_out_ids; float* tk_out_sc; const int64_t* tk_map = nullptr; int64_t* tk_out_map = nullptr;
-    if (r == 0) {          // R, sR = topk(EP, s, t0)                      :112
-      tk_ids = a.enter; tk_sc = sv.cand_scores; tk_n = E; tk_k = a.t[0];
-      tk_out_ids = sv.beam_ids; tk_out_sc = sv.beam_scores;
-    } else if (r == 1) {   // P, sP = topk(R || C, sR || sC, t1)           :125-127
-      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = base_off + sc_n; tk_k = a.t[1];
-      tk_out_ids = sv.pool_ids; tk_out_sc = sv.pool_scores;
-    } else if (r < NANN_NUM_ROUNDS) {  // B, sB = topk(C, sC, t[r]); appended to the pool  :139-141
-      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = sc_n; tk_k = a.t[r];
-      tk_out_ids = sv.pool_ids + nP; tk_out_sc = sv.pool_scores + nP;
-    } else {               // final: topk(pool, t5) -> item_ids           :143-149
-      tk_ids = sv.pool_ids; tk_sc = sv.pool_scores; tk_n = nP; tk_k = k5;
-      tk_out_ids = a.out_index ? a.out_index + (size_t)qi * k5 : nullptr;
-      tk_out_sc = a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr;
-      tk_map = a.item_ids; tk_out_map = a.out_ids + (size_t)qi * k5;
-    }
-    mark(PH_OTHER);
-    const int st = wg_topk(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k, nullptr,
-                           tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch);
-    mark(PH_TOPK);
-    if (st) return st;
-    if (r == 1) {
-      nP = a.t[1];
-    } else if (r >= 2 && r < NANN_NUM_ROUNDS) {
-      frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
-      nB = a.t[r];
-      nP += nB;
-    }
-  }
-  mark(PH_OTHER);
-  return NANN_OK;
-}
-
-template <int LPR, int DT, bool LDSBM>
-__global__ __launch_bounds__(kNT) void k_search(SearchArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
-  unsigned char* scratch = smem + (LDSBM ? (size_t)a.bm_words * 4 : 0);
-  float* qv = reinterpret_cast<float*>(scratch + kPhaseScratch);
-  int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] next query
-  int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
-  long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
-
-  unsigned long long off[8];
-  slot_layout(a.max_cand, a.max_raw, a.pool_cap, LDSBM ? 0u : a.bm_words, off);
-  unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
-  SlotView sv;
-  sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
-  sv.cand_scores = reinterpret_cast<float*>(slot + off[1]);
-  sv.raw = reinterpret_cast<int32_t*>(slot + off[2]);
-  sv.beam_ids = reinterpret_cast<int32_t*>(slot + off[3]);
-  sv.beam_scores = reinterpret_cast<float*>(slot + off[4]);
-  sv.pool_ids = reinterpret_cast<int32_t*>(slot + off[5]);
-  sv.pool_scores = reinterpret_cast<float*>(slot + off[6]);
-  sv.gbitmap = reinterpret_cast<uint32_t*>(slot + off[7]);
-  uint32_t* bm = LDSBM ? bm_lds : sv.gbitmap;
-  const int k5 = a.t[5];
-  unsigned int* queue = reinterpret_cast<unsigned int*>(a.ws);  // zeroed by the host before launch
-
-  // queries are pulled from one device-wide counter: a slot that finishes early takes
-  // the next request instead of idling until the slowest slot is done
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) misc[0] = (int)atomicAdd(queue, 1u);
-    if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
-    if (threadIdx.x < NANN_NUM_PHASES) s_ticks[threadIdx.x] = 0;
-    __syncthreads();
-    const int qi = misc[0];
-    if (qi >= a.n_queries) break;
-    const int st = search_one<LPR, DT, LDSBM>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
-    __syncthreads();
-    if (st) {  // a request the reference would fail: zeroed outputs + its code
-      for (int i = threadIdx.x; i < k5; i += kNT) {
-        a.out_ids[(size_t)qi * k5 + i] = 0;
-        if (a.out_scores) a.out_scores[(size_t)qi * k5 + i] = 0.0f;
-        if (a.out_index) a.out_index[(size_t)qi * k5 + i] = 0;
-      }
-    }
-    if (threadIdx.x == 0) a.status[qi] = st;
-    if (a.counters && threadIdx.x < 3 * NANN_NUM_ROUNDS)
-      a.counters[(size_t)qi * 3 * NANN_NUM_ROUNDS + threadIdx.x] = s_ctr[threadIdx.x];
-    if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES)
-      a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x] = s_ticks[threadIdx.x];
-  }
-}
-
-// ===========================================================================
 // C ABI
 // ===========================================================================
 struct nann_scorer {
   nann_scorer_desc desc;
   float* dev_weights = nullptr;  // MLP weights block in HBM
+  MlpParams mlp = {};
 };
 
 struct nann_index {
@@ -607,7 +365,7 @@ struct nann_index {
 extern "C" {
 
 int nann_abi_version(void) { return NANN_ABI_VERSION; }
-const char* nann_last_error(void) { return g_err.c_str(); }
+const char* nann_last_error(void) { return nann::g_err.c_str(); }
 
 int nann_device_count(void) {
   int n = 0;
@@ -939,10 +697,45 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
     return fail(NANN_ERR_UNSUPPORTED, "embedding dim must be 64, 128, 256 or 512");
   if (desc->emb_dtype != NANN_F16 && desc->emb_dtype != NANN_BF16 && desc->emb_dtype != NANN_F32)
     return fail(NANN_ERR_UNSUPPORTED, "embedding dtype must be f16, bf16 or f32");
-  if (desc->kind != NANN_SCORER_L2)
-    return fail(NANN_ERR_UNSUPPORTED, "only the L2 scorer is implemented in this build");
+  if (desc->kind != NANN_SCORER_L2 && desc->kind != NANN_SCORER_MLP)
+    return fail(NANN_ERR_BAD_ARGUMENT, "unknown scorer kind");
   nann_scorer* s = new nann_scorer();
   s->desc = *desc;
+  if (desc->kind == NANN_SCORER_MLP) {
+    if (desc->h1 != 256 || desc->h2 != 128 || d > 256) {
+      delete s;
+      return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: this build has the 2d-256-128-1 shape, d <= 256");
+    }
+    if (desc->emb_dtype == NANN_F32) {
+      delete s;
+      return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
+    }
+    if (!desc->w1 || !desc->b1 || !desc->alpha1 || !desc->w2 || !desc->b2 || !desc->alpha2 || !desc->w3) {
+      delete s;
+      return fail(NANN_ERR_BAD_ARGUMENT, "MLP scorer: null weight pointer");
+    }
+    const size_t h1 = 256, h2 = 128;
+    const size_t n_w1 = 2 * (size_t)d * h1, n_w2 = h1 * h2;
+    const size_t total = n_w1 + h1 + h1 + n_w2 + h2 + h2 + h2;
+    std::vector<float> host(total);
+    size_t o = 0;
+    auto put = [&](const float* src, size_t cnt) { std::memcpy(host.data() + o, src, cnt * 4); o += cnt; return o - cnt; };
+    const size_t o_w1 = put(desc->w1, n_w1), o_b1 = put(desc->b1, h1), o_a1 = put(desc->alpha1, h1);
+    const size_t o_w2 = put(desc->w2, n_w2), o_b2 = put(desc->b2, h2), o_a2 = put(desc->alpha2, h2);
+    const size_t o_w3 = put(desc->w3, h2);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->dev_weights), total * 4);
+    if (e == hipSuccess) e = hipMemcpy(s->dev_weights, host.data(), total * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      nann_scorer_destroy(s);
+      return fail(NANN_ERR_HIP, std::string("scorer weights: ") + hipGetErrorString(e));
+    }
+    const float* w = s->dev_weights;
+    s->mlp.w1 = w + o_w1; s->mlp.b1 = w + o_b1; s->mlp.alpha1 = w + o_a1;
+    s->mlp.w2 = w + o_w2; s->mlp.b2 = w + o_b2; s->mlp.alpha2 = w + o_a2; s->mlp.w3 = w + o_w3;
+    s->mlp.d = d; s->mlp.h1 = 256; s->mlp.h2 = 128;
+    // the host pointers of the descriptor are not kept
+    s->desc.w1 = s->desc.b1 = s->desc.alpha1 = s->desc.w2 = s->desc.b2 = s->desc.alpha2 = s->desc.w3 = nullptr;
+  }
   *out = s;
   return NANN_OK;
 }
@@ -992,6 +785,23 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table, int
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, st, rb->dev);
   const int d = scorer->desc.d, lpr = d / 8, dt = scorer->desc.emb_dtype;
+  if (scorer->desc.kind == NANN_SCORER_MLP) {
+    const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    const MlpParams& P = scorer->mlp;
+    if (d == 64) rc = launch_score_mlp_d64(dt, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
+    else if (d == 128) rc = launch_score_mlp_d128(dt, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
+    else rc = launch_score_mlp_d256(dt, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    rc = fetch_result(rb, st);
+    if (rc) return rc;
+    if (rb->host->bad_i != 0x7fffffffffffffffll) {
+      if (bad_i) *bad_i = rb->host->bad_i;
+      return fail(NANN_ERR_INDEX_OUT_OF_RANGE, "indices[" + std::to_string(rb->host->bad_i) +
+                                                   "] is not in [0, " + std::to_string(n_table_rows) + ")");
+    }
+    return NANN_OK;
+  }
   const long long rows_per_block = 4 * (64 / lpr);
   const unsigned blocks = (unsigned)std::min<long long>((n + rows_per_block - 1) / rows_per_block, 8192);
   switch (lpr) {
@@ -1101,14 +911,6 @@ int nann_index_info(const nann_index* ix, int64_t out[6]) {
 }
 
 // ---- fused search -----------------------------------------------------------------------
-struct SearchPlan {
-  int max_cand, max_raw, pool_cap;
-  bool lds_bitmap;
-  size_t lds_bytes;
-  unsigned long long slot_bytes;
-  int slots;
-};
-
 static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, SearchPlan* p) {
   for (int i = 0; i < 6; ++i)
     if (t[i] < 0 || t[i] > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "level_topn entries must be in [0, 1024]");
@@ -1147,26 +949,17 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
 
 }  // extern "C"
 
-template <int LPR, int DT>
-static int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
-  if (p.lds_bitmap) {
-    auto kern = k_search<LPR, DT, true>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(kNT), p.lds_bytes, st, a);
-  } else {
-    auto kern = k_search<LPR, DT, false>;
-    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(kNT), p.lds_bytes, st, a);
-  }
-  HIP_TRY(hipGetLastError());
-  return NANN_OK;
-}
-
 template <int LPR>
-static int launch_search_dt(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
-  if (dt == NANN_F16) return launch_search<LPR, DT_F16>(p, a, st);
-  if (dt == NANN_BF16) return launch_search<LPR, DT_BF16>(p, a, st);
-  return launch_search<LPR, DT_F32>(p, a, st);
+static int launch_search_dt(int dt, int kind, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  if (kind == NANN_SCORER_MLP) {
+    if (LPR == 8) return launch_search_mlp_d64(dt, p, a, st);
+    if (LPR == 16) return launch_search_mlp_d128(dt, p, a, st);
+    if (LPR == 32) return launch_search_mlp_d256(dt, p, a, st);
+    return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256 only");
+  }
+  if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_L2, kNT>(p, a, st);
+  if (dt == NANN_BF16) return launch_search<LPR, DT_BF16, NANN_SCORER_L2, kNT>(p, a, st);
+  return launch_search<LPR, DT_F32, NANN_SCORER_L2, kNT>(p, a, st);
 }
 
 extern "C" {
@@ -1215,11 +1008,13 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   hipStream_t st = as_stream(stream);
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // the query queue head
   const int dt = ix->desc.emb_dtype;
+  const int kind = scorer->desc.kind;
+  a.mlp = scorer->mlp;
   switch (ix->desc.d / 8) {
-    case 8: return launch_search_dt<8>(dt, p, a, st);
-    case 16: return launch_search_dt<16>(dt, p, a, st);
-    case 32: return launch_search_dt<32>(dt, p, a, st);
-    default: return launch_search_dt<64>(dt, p, a, st);
+    case 8: return launch_search_dt<8>(dt, kind, p, a, st);
+    case 16: return launch_search_dt<16>(dt, kind, p, a, st);
+    case 32: return launch_search_dt<32>(dt, kind, p, a, st);
+    default: return launch_search_dt<64>(dt, kind, p, a, st);
   }
 }
 

@@ -1,0 +1,342 @@
+// nann_search.h -- the fused traversal kernel (build_opt_graph.py:109-149) and its launch
+// helper, shared by the translation units that instantiate it (nann_hip.hip: L2 scorer;
+// nann_mlp_inst.hip: MLP scorer, one object per embedding dim so they compile in parallel).
+#pragma once
+#include "../../include/nann_hip.h"
+#include "nann_device.h"
+#include "nann_mlp.h"
+
+#include <string>
+
+namespace nann {
+
+// small result block shared between a kernel and the host for calls that
+// return data-dependent counts (they synchronise anyway)
+struct OpResult {
+  long long n_out;
+  long long n_out_splits;
+  long long bad_i;
+  int code;  // ragged validation code 1/2/3
+  int err;   // nann_status
+};
+
+
+int fail(int code, const std::string& msg);  // sets nann_last_error(); defined in nann_hip.hip
+
+#define NANN_HIP_TRY(expr)                                                                 \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return ::nann::fail(NANN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// stand-alone MLP scorer: one query vector, n rows; each workgroup takes passes of 256 rows
+template <int D, int DT>
+__global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* table, long long n_table_rows,
+                                                      const int32_t* indices, long long n, const float* qv,
+                                                      float* scores, OpResult* res) {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(MlpScratch)];
+  MlpScratch* S = reinterpret_cast<MlpScratch*>(scratch);
+  constexpr int CPP = (kMlpNT / 64) * 32;
+  if (indices) {  // bounds first (gather_op.cc:170-175)
+    for (long long i = (long long)blockIdx.x * kMlpNT + threadIdx.x; i < n; i += (long long)gridDim.x * kMlpNT) {
+      const long long r = indices[i];
+      if (r < 0 || r >= n_table_rows)
+        atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
+    }
+  }
+  wg_mlp_query_setup<kMlpNT>(P, qv, S);
+  for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
+    const int cnt = (int)((n - c0) < CPP ? (n - c0) : CPP);
+    if (indices) {
+      wg_score_mlp<D, 8, 4, DT, kMlpNT>(P, table, (uint32_t)n_table_rows, indices + c0, cnt, S, scores + c0);
+    } else {  // rows c0.. of `table` itself
+      wg_score_mlp<D, 8, 4, DT, kMlpNT>(P, static_cast<const char*>(table) + (size_t)c0 * D * (DT == DT_F32 ? 4 : 2),
+                                        (uint32_t)(n_table_rows - c0), nullptr, cnt, S, scores + c0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the fused traversal (build_opt_graph.py:109-149)
+struct SearchArgs {
+  const void* emb;
+  const int64_t* item_ids;
+  const int32_t* nbv[2];
+  const int64_t* nbrs[2];
+  const int32_t* enter;
+  int n_enter;
+  uint32_t n_items;
+  int d;
+  const float* q;
+  int n_queries;
+  int t[6];
+  unsigned char* ws;
+  unsigned long long slot_bytes;
+  uint32_t bm_words;  // padded to a multiple of 4
+  int max_cand, max_raw, pool_cap;
+  int64_t* out_ids;
+  float* out_scores;
+  int32_t* out_index;
+  int32_t* status;
+  int32_t* counters;
+  long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
+  MlpParams mlp;           // NANN_SCORER_MLP only
+};
+
+enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER };
+
+struct SlotView {
+  int32_t* cand_ids;
+  float* cand_scores;
+  int32_t* raw;
+  int32_t* beam_ids;
+  float* beam_scores;
+  int32_t* pool_ids;
+  float* pool_scores;
+  uint32_t* gbitmap;
+};
+
+__host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_raw, int pool_cap,
+                                                          uint32_t gbm_words, unsigned long long off[8]) {
+  unsigned long long o = 0;
+  auto put = [&](int i, unsigned long long bytes) { off[i] = o; o += (bytes + 255ull) & ~255ull; };
+  put(0, 4ull * max_cand);  // cand_ids
+  put(1, 4ull * max_cand);  // cand_scores
+  put(2, 4ull * max_raw);   // raw
+  put(3, 4ull * kMaxK);     // beam_ids
+  put(4, 4ull * kMaxK);     // beam_scores
+  put(5, 4ull * pool_cap);  // pool_ids
+  put(6, 4ull * pool_cap);  // pool_scores
+  put(7, 4ull * gbm_words); // bitmap in HBM (large shards only)
+  return o;
+}
+
+template <int LPR, int DT, bool LDSBM, int SC, int NT>
+__device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
+                                          unsigned char* scratch, float* qv, int32_t* ctr,
+                                          long long* ticks) {
+  const int tid = threadIdx.x;
+  const int k5 = a.t[5];
+  // L2: candidate scores are mirrored in LDS for the selection; the MLP uses that space
+  // for its weight slices (and its selection time is negligible next to the MFMAs)
+  float* lds_scores = SC == NANN_SCORER_L2 ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
+  const bool timing = a.phase_ticks != nullptr;
+  long long t_last = timing ? (long long)clock64() : 0;
+  // attribute the time since the previous mark to `phase` (thread 0 only; off by default)
+  auto mark = [&](int phase) {
+    if (timing && tid == 0) {
+      const long long now = (long long)clock64();
+      ticks[phase] += now - t_last;
+      t_last = now;
+    }
+  };
+
+  for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
+  __syncthreads();
+  constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
+
+  // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
+  // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
+  // 2..4 = the three level-0 rounds (:129-141), 5 = final top-k (:143-149).
+  const int E = a.n_enter;
+  int nP = 0;                         // pool size so far
+  const int32_t* frontier = nullptr;  // beam walked by the next stage
+  int nB = 0;
+  for (int r = 0; r <= NANN_NUM_ROUNDS; ++r) {
+    const int32_t* sc_ids = nullptr;  // what this stage scores
+    float* sc_out = nullptr;
+    int sc_n = 0, base_off = 0;
+    if (r == 0) {
+      sc_ids = a.enter; sc_out = sv.cand_scores; sc_n = E;
+      if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
+    } else if (r < NANN_NUM_ROUNDS) {
+      const int level = (r == 1) ? 1 : 0;
+      int nC = 0, G = 0;
+      // sub-step 0 ("mark", only when a level starts): fresh bitmap, then the current
+      // result set goes through BitmapRefDifference (:115-120, :131-133).
+      // sub-step 1: neighbours of the frontier, filtered (:116,121-122 / :136-137).
+      for (int ss = (r <= 2) ? 0 : 1; ss < 2; ++ss) {
+        const int32_t* src;
+        const int64_t* rs;
+        int n_in;
+        int32_t* dst;
+        if (ss == 0) {
+          mark(PH_OTHER);
+          wg_zero_words(bm, a.bm_words);
+          __syncthreads();
+          mark(PH_ZERO);
+          src = (r == 1) ? sv.beam_ids : sv.pool_ids;
+          n_in = (r == 1) ? a.t[0] : a.t[1];
+          dst = (r == 1) ? sv.cand_ids : sv.beam_ids;
+          rs = nullptr;
+        } else {
+          src = a.nbv[level]; rs = a.nbrs[level]; n_in = nB; dst = sv.cand_ids + base_off;
+        }
+        int gathered = 0;
+        const int kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items,
+                                                   bm, dst, scratch, &gathered);
+        mark(ss == 0 ? PH_WALK : PH_EXPAND);
+        if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
+        if (ss == 0) {
+          if (r == 1) {
+            if (kept != a.t[0]) return NANN_ERR_BAD_ARGUMENT;  // duplicate enter points
+            base_off = kept;
+          }
+          frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
+          nB = kept;
+        } else {
+          nC = kept; G = gathered;
+        }
+      }
+      if (r == 1) {  // sR in front of sC (:125-126); after the walk, whose staging shares this LDS
+        for (int i = tid; i < base_off; i += NT) {
+          const float v = sv.beam_scores[i];
+          sv.cand_scores[i] = v;
+          if (lds_scores != nullptr && i < kLdsScores) lds_scores[i] = v;
+        }
+      }
+      if (tid == 0) { ctr[0 * 5 + r] = nB; ctr[1 * 5 + r] = G; ctr[2 * 5 + r] = nC; }
+      sc_ids = sv.cand_ids + base_off; sc_out = sv.cand_scores + base_off; sc_n = nC;
+    }
+    if (r < NANN_NUM_ROUNDS) {  // forward(): GatherV2 + scorer (:91-107)
+      if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+      mark(PH_OTHER);
+      if constexpr (SC == NANN_SCORER_L2) {
+        wg_score_l2<LPR, DT, NT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out, lds_scores, base_off);
+      } else {
+        MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
+        wg_mlp_query_setup<NT>(a.mlp, qv, M);  // the phase scratch was reused since the last stage
+        wg_score_mlp<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
+      }
+      __syncthreads();
+      mark(PH_SCORE);
+      if (sc_n == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
+    }
+    // top_k(): TopKV2 + Gather of the ids (:52-66)
+    const int32_t* tk_ids; const float* tk_sc; int tk_n, tk_k;
+    int32_t* tk_out_ids; float* tk_out_sc; const int64_t* tk_map = nullptr; int64_t* tk_out_map = nullptr;
+    if (r == 0) {          // R, sR = topk(EP, s, t0)                      :112
+      tk_ids = a.enter; tk_sc = sv.cand_scores; tk_n = E; tk_k = a.t[0];
+      tk_out_ids = sv.beam_ids; tk_out_sc = sv.beam_scores;
+    } else if (r == 1) {   // P, sP = topk(R || C, sR || sC, t1)           :125-127
+      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = base_off + sc_n; tk_k = a.t[1];
+      tk_out_ids = sv.pool_ids; tk_out_sc = sv.pool_scores;
+    } else if (r < NANN_NUM_ROUNDS) {  // B, sB = topk(C, sC, t[r]); appended to the pool  :139-141
+      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = sc_n; tk_k = a.t[r];
+      tk_out_ids = sv.pool_ids + nP; tk_out_sc = sv.pool_scores + nP;
+    } else {               // final: topk(pool, t5) -> item_ids           :143-149
+      tk_ids = sv.pool_ids; tk_sc = sv.pool_scores; tk_n = nP; tk_k = k5;
+      tk_out_ids = a.out_index ? a.out_index + (size_t)qi * k5 : nullptr;
+      tk_out_sc = a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr;
+      tk_map = a.item_ids; tk_out_map = a.out_ids + (size_t)qi * k5;
+    }
+    mark(PH_OTHER);
+    const int st = wg_topk<NT>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
+                               nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch);
+    mark(PH_TOPK);
+    if (st) return st;
+    if (r == 1) {
+      nP = a.t[1];
+    } else if (r >= 2 && r < NANN_NUM_ROUNDS) {
+      frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
+      nB = a.t[r];
+      nP += nB;
+    }
+  }
+  mark(PH_OTHER);
+  return NANN_OK;
+}
+
+template <int LPR, int DT, bool LDSBM, int SC, int NT>
+__global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
+  unsigned char* scratch = smem + (LDSBM ? (size_t)a.bm_words * 4 : 0);
+  float* qv = reinterpret_cast<float*>(scratch + kPhaseScratch);
+  int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] next query
+  int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
+  long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
+
+  unsigned long long off[8];
+  slot_layout(a.max_cand, a.max_raw, a.pool_cap, LDSBM ? 0u : a.bm_words, off);
+  unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
+  SlotView sv;
+  sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
+  sv.cand_scores = reinterpret_cast<float*>(slot + off[1]);
+  sv.raw = reinterpret_cast<int32_t*>(slot + off[2]);
+  sv.beam_ids = reinterpret_cast<int32_t*>(slot + off[3]);
+  sv.beam_scores = reinterpret_cast<float*>(slot + off[4]);
+  sv.pool_ids = reinterpret_cast<int32_t*>(slot + off[5]);
+  sv.pool_scores = reinterpret_cast<float*>(slot + off[6]);
+  sv.gbitmap = reinterpret_cast<uint32_t*>(slot + off[7]);
+  uint32_t* bm = LDSBM ? bm_lds : sv.gbitmap;
+  const int k5 = a.t[5];
+  unsigned int* queue = reinterpret_cast<unsigned int*>(a.ws);  // zeroed by the host before launch
+
+  // queries are pulled from one device-wide counter: a slot that finishes early takes
+  // the next request instead of idling until the slowest slot is done
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) misc[0] = (int)atomicAdd(queue, 1u);
+    if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
+    if (threadIdx.x < NANN_NUM_PHASES) s_ticks[threadIdx.x] = 0;
+    __syncthreads();
+    const int qi = misc[0];
+    if (qi >= a.n_queries) break;
+    const int st = search_one<LPR, DT, LDSBM, SC, NT>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
+    __syncthreads();
+    if (st) {  // a request the reference would fail: zeroed outputs + its code
+      for (int i = threadIdx.x; i < k5; i += NT) {
+        a.out_ids[(size_t)qi * k5 + i] = 0;
+        if (a.out_scores) a.out_scores[(size_t)qi * k5 + i] = 0.0f;
+        if (a.out_index) a.out_index[(size_t)qi * k5 + i] = 0;
+      }
+    }
+    if (threadIdx.x == 0) a.status[qi] = st;
+    if (a.counters && threadIdx.x < 3 * NANN_NUM_ROUNDS)
+      a.counters[(size_t)qi * 3 * NANN_NUM_ROUNDS + threadIdx.x] = s_ctr[threadIdx.x];
+    if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES)
+      a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x] = s_ticks[threadIdx.x];
+  }
+}
+
+struct SearchPlan {
+  int max_cand, max_raw, pool_cap;
+  bool lds_bitmap;
+  size_t lds_bytes;
+  unsigned long long slot_bytes;
+  int slots;
+};
+
+template <int LPR, int DT, int SC, int NT>
+inline int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  if (p.lds_bitmap) {
+    auto kern = k_search<LPR, DT, true, SC, NT>;
+    NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
+  } else {
+    auto kern = k_search<LPR, DT, false, SC, NT>;
+    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
+  }
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+
+// MLP instantiations live in nann_mlp_inst.hip (one object per embedding dim)
+int launch_search_mlp_d64(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_d128(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_d256(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
+int launch_score_mlp_d64(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
+                         long long n_table_rows, const int32_t* indices, long long n, const float* q,
+                         float* out, OpResult* res);
+int launch_score_mlp_d128(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
+                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
+                          float* out, OpResult* res);
+int launch_score_mlp_d256(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
+                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
+                          float* out, OpResult* res);
+
+}  // namespace nann

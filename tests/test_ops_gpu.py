@@ -264,3 +264,38 @@ def test_merge_topk(oracle):
         rc, es, ei = oracle.merge_topk(s[b], ids[b], k)
         assert (oi[b].cpu().numpy() == ei).all() and (os_[b].cpu().numpy() == es).all()
         assert (hi[b] == ei).all() and (hs[b] == es).all()
+
+
+# ---------------------------------------------------------------- MLP scorer on MFMA
+@pytest.mark.parametrize("d,dtype", [(128, "f16"), (64, "f16"), (256, "bf16")])
+def test_mlp_score(oracle, d, dtype):
+    """x=[q;e] -> 256 -> PReLU -> 128 -> PReLU -> 1 on v_mfma_f32_32x32x2_f32: the f32 MFMA is a
+    k-ordered fmaf chain and the oracle walks k in the same order, so scores must agree
+    bit for bit (and a fortiori within north_star's 1e-5 relative)."""
+    from nann_amd import ops, synth
+    rng = np.random.default_rng(d + 1)
+    n_table, n = 3000, 1000
+    w = synth.make_mlp_weights(d)
+    w["alpha1"] = rng.uniform(0.05, 0.4, 256).astype(np.float32)  # per-channel slopes
+    w["alpha2"] = rng.uniform(0.05, 0.4, 128).astype(np.float32)
+    x = (rng.standard_normal((n_table, d)) / np.sqrt(d)).astype(np.float32)
+    q = (rng.standard_normal(d) / np.sqrt(d)).astype(np.float32)
+    idx = rng.integers(0, n_table, size=n).astype(np.int32)
+    if dtype == "f16":
+        host = x.astype(np.float16); dev = cuda(host); code, tdt = oracle.EMB_F16, torch.float16
+    else:
+        dev = cuda(x).to(torch.bfloat16)
+        host = dev.view(torch.int16).cpu().numpy().view(np.uint16)
+        code, tdt = oracle.EMB_BF16, torch.bfloat16
+    rc, exp = oracle.score_rows(oracle.Scorer("mlp", d, code, w), q, host[idx])
+    sc = ops.Scorer("mlp", d, tdt, w)
+    got = ops.blaze_score(sc, cuda(q), table=dev, indices=idx).cpu().numpy()
+    assert rc == 0
+    np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-6)
+    assert (bits(got) == bits(exp)).all(), "f32 MFMA chain differs from the fmaf chain of the oracle"
+    got2 = ops.blaze_score(sc, cuda(q), item_emb=dev[torch.as_tensor(idx).long().cuda()]).cpu().numpy()
+    assert (bits(got2) == bits(exp)).all()
+    got3 = ops.blaze_score(sc, cuda(q), table=dev, indices=idx[:37]).cpu().numpy()  # partial pass
+    assert (bits(got3) == bits(exp[:37])).all()
+    with pytest.raises(ops.InvalidArgumentError):
+        ops.blaze_score(sc, cuda(q), table=dev, indices=[0, n_table])

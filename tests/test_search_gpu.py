@@ -124,3 +124,20 @@ def test_exact_ties_follow_position_order(oracle):
     topn = [16] * 5 + [20]
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn)
     _assert_same(_run(dix, q, topn), exp)
+
+
+def test_mlp_search_matches_oracle(oracle):
+    """BASELINE configs[2] shape at test size: the traversal with the 256-128-1 MLP scorer."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 128, 32)
+    w = synth.make_mlp_weights(128)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 48, seed=11)])
+    topn = [32] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q, topn, n_threads=8)
+    sc = ops.Scorer("mlp", 128, torch.float16, w)
+    r = retrieval.search(dix, sc, cuda(q), topn)
+    torch.cuda.synchronize()
+    got = (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+           r.index.cpu().numpy(), r.counters.cpu().numpy())
+    assert (exp[0] == 0).mean() > 0.5
+    _assert_same(got, exp)
