@@ -187,7 +187,7 @@ def main():
         rr = retrieval.search(index, scorer, ops.user_seq_mean(comm_seq), topn, want_phase_ticks=True)
         torch.cuda.synchronize()
         tk = rr.phase_ticks.cpu().numpy().astype(np.float64)
-        tot = tk.sum()
+        tot = tk[:, :6].sum()  # the first six phases partition the query; the rest are sub-phases
         result["phase_breakdown"] = {
             "ticks_per_query": {n: round(float(tk[:, i].mean()), 1) for i, n in enumerate(_lib.PHASE_NAMES)},
             "fraction": {n: round(float(tk[:, i].sum() / tot), 4) for i, n in enumerate(_lib.PHASE_NAMES)}}

@@ -223,9 +223,10 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
 
 /* Same, plus per-query time attribution for tuning: phase_ticks
  * i64[n_queries, NANN_NUM_PHASES] receives shader-clock ticks spent in
- * {bitmap zeroing, walker, CSR expand, gather+score, top-k, other}; NULL
+ * {bitmap zeroing, mark walks, CSR expand+walk, gather+score, top-k, other} followed by
+ * sub-phases {top-k: load, search, collect, sort; expand: pass 1, pipeline loop}; NULL
  * disables the instrumentation (nann_search passes NULL). */
-#define NANN_NUM_PHASES 6
+#define NANN_NUM_PHASES 12
 int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q,
                    int64_t n_queries, const int32_t level_topn[6], void* workspace,
                    int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,

@@ -20,10 +20,10 @@ constexpr int kNT = 1024;            // threads per traversal workgroup
 constexpr int kNW = kNT / 64;        // 16 wavefronts
 constexpr int kTopkEPT = 16;         // top-k keys held in registers per thread (n <= 16384)
 constexpr int kMaxK = 1024;          // largest k / frontier a workgroup handles
-constexpr int kPhaseScratch = 25600; // LDS bytes shared by the phases below
+constexpr int kPhaseScratch = 27648; // LDS bytes shared by the phases below
 constexpr int kMaxD = 512;
 // candidate scores of a round are mirrored in LDS behind the top-k scratch
-constexpr int kLdsScoresOff = 8704;
+constexpr int kLdsScoresOff = 10752;
 constexpr int kLdsScores = 4096;
 
 enum : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
@@ -32,6 +32,36 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
+
+// ---------------------------------------------------------------------------
+// optional per-phase time attribution (thread 0 only; off unless a buffer is given)
+enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER,
+       PH_TK_LOAD, PH_TK_SEARCH, PH_TK_COLLECT, PH_TK_SORT, PH_EX_PASS1, PH_EX_LOOP, PH_COUNT };
+struct PhaseTimer {
+  long long* ticks;  // LDS, [PH_COUNT]
+  long long last;
+  bool on;
+  __device__ __forceinline__ void start(long long* t, bool enable) {
+    ticks = t; on = enable; last = enable ? (long long)clock64() : 0;
+  }
+  // attribute the time since the previous mark to `phase`; sub-phases (>= PH_TK_LOAD)
+  // do not reset the clock of the enclosing phase
+  __device__ __forceinline__ void mark(int phase) {
+    if (on && threadIdx.x == 0) {
+      const long long now = (long long)clock64();
+      ticks[phase] += now - last;
+      last = now;
+    }
+  }
+  __device__ __forceinline__ void sub(int phase, long long& t0) {
+    if (on && threadIdx.x == 0) {
+      const long long now = (long long)clock64();
+      ticks[phase] += now - t0;
+      t0 = now;
+    }
+  }
+  __device__ __forceinline__ long long now() const { return on ? (long long)clock64() : 0; }
+};
 
 // ---------------------------------------------------------------------------
 // scalar conversions (exact)
@@ -168,8 +198,10 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
-                                              unsigned char* scratch, int* gathered) {
+                                              unsigned char* scratch, int* gathered,
+                                              PhaseTimer* pt = nullptr) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
+  long long tsub = pt ? pt->now() : 0;
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
@@ -218,6 +250,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   if (tid == 0) S->off[n_rows] = total;
   __syncthreads();
   *gathered = (int)total;
+  if (pt) pt->sub(PH_EX_PASS1, tsub);
   if (S->bad) return -1;
   // ---- pass 2: fill || walk pipeline ------------------------------------------
   const int G = (int)total;
@@ -275,6 +308,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
     }
     __syncthreads();
   }
+  if (pt) pt->sub(PH_EX_LOOP, tsub);
   if (wave == 0 && lane == 0) { S->kept = base; if (err) S->bad = 1; }
   __syncthreads();
   const int kept = S->kept;
@@ -413,6 +447,7 @@ struct TopkScratch {
   uint32_t orv, andv;
   uint32_t wcnt[kNW];
   unsigned long long sel[kMaxK];
+  unsigned short prank[kNT];  // partial ranks of the rank sort: [segment][element]
 };
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
 // the selection does not wait on L2 (positions < kLdsScores only)
@@ -437,8 +472,9 @@ template <int NS, bool SCL, int NT>
 __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
                                             const float* lds_scores, int n, int k, int32_t* out_pos,
                                             int32_t* out_ids, float* out_scores, const int64_t* id_map,
-                                            int64_t* out_mapped, unsigned char* scratch) {
+                                            int64_t* out_mapped, unsigned char* scratch, PhaseTimer* pt) {
   TopkScratch* S = reinterpret_cast<TopkScratch*>(scratch);
+  long long tsub = pt ? pt->now() : 0;
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const uint64_t lt = lanemask_lt();
   constexpr bool REG = NS > 0;
@@ -458,6 +494,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   if (tid < 4) S->misc[tid] = 0;
   if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
   __syncthreads();
+  if (pt) pt->sub(PH_TK_LOAD, tsub);
 
 #define NANN_FOR_KEYS(...)                                                    \
   if constexpr (REG) {                                                        \
@@ -527,6 +564,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   } else {
     T = S->andv;  // all keys equal
   }
+  if (pt) pt->sub(PH_TK_SEARCH, tsub);
   // c_ge = #keys >= T >= k.  If c_ge > k, T is the exact k-th key and only some of the
   // keys equal to T are admitted.
   uint32_t c_gt = 0;
@@ -585,11 +623,34 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   }
 #undef NANN_FOR_KEYS
   __syncthreads();
+  if (pt) pt->sub(PH_TK_COLLECT, tsub);
   // ---- 4. rank sort + output --------------------------------------------------
+  // rank(e) = #{o : sel[o] > sel[e]} (pairs are distinct).  The k x k comparisons are
+  // spread over all threads: element e = tid % K2, comparison segment = tid / K2.
+  int K2 = 64;
+  while (K2 < k) K2 <<= 1;
+  const bool split = K2 <= NT;  // else (k > NT, only for NT < kMaxK): one thread per element
+  if (split) {
+    const int segs = NT / K2;
+    const int e = tid & (K2 - 1), seg = tid / K2;
+    const int len = (k + segs - 1) / segs;
+    const int o0 = seg * len, o1 = min(k, o0 + len);
+    int pr = 0;
+    if (e < k) {
+      const unsigned long long mine = S->sel[e];
+      for (int o = o0; o < o1; ++o) pr += (S->sel[o] > mine) ? 1 : 0;
+    }
+    S->prank[tid] = (unsigned short)pr;
+    __syncthreads();
+  }
   for (int e = tid; e < k; e += NT) {
     const unsigned long long mine = S->sel[e];
     int rank = 0;
-    for (int o = 0; o < k; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
+    if (split) {
+      for (int sg = 0; sg < NT / K2; ++sg) rank += S->prank[sg * K2 + e];
+    } else {
+      for (int o = 0; o < k; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
+    }
     const int pos = (int)(~(uint32_t)(mine & 0xffffffffull));
     const int32_t idv = ids ? ids[pos] : pos;
     if (out_pos) out_pos[rank] = pos;
@@ -598,6 +659,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     if (out_mapped) out_mapped[rank] = id_map[idv];
   }
   __syncthreads();
+  if (pt) pt->sub(PH_TK_SORT, tsub);
   return 0;
 }
 
@@ -606,13 +668,13 @@ template <int NT = kNT>
 __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, const float* lds_scores,
                                        int n, int k, int32_t* out_pos, int32_t* out_ids,
                                        float* out_scores, const int64_t* id_map, int64_t* out_mapped,
-                                       unsigned char* scratch) {
+                                       unsigned char* scratch, PhaseTimer* pt = nullptr) {
   if (k < 0 || k > kMaxK) return 7;  // NANN_ERR_BAD_ARGUMENT
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;
 #define NANN_TOPK_CASE(NS_, SCL_)                                                                   \
   return wg_topk_impl<NS_, SCL_, NT>(ids, scores, lds_scores, n, k, out_pos, out_ids, out_scores, \
-                                     id_map, out_mapped, scratch)
+                                     id_map, out_mapped, scratch, pt)
   if (lds_scores != nullptr && n <= kLdsScores) {
     if (n <= 1 * NT) NANN_TOPK_CASE(1, true);
     if (n <= 2 * NT) NANN_TOPK_CASE(2, true);

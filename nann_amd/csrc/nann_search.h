@@ -84,7 +84,7 @@ struct SearchArgs {
   MlpParams mlp;           // NANN_SCORER_MLP only
 };
 
-enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER };
+static_assert(PH_COUNT == NANN_NUM_PHASES, "phase list out of sync with include/nann_hip.h");
 
 struct SlotView {
   int32_t* cand_ids;
@@ -121,16 +121,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   // L2: candidate scores are mirrored in LDS for the selection; the MLP uses that space
   // for its weight slices (and its selection time is negligible next to the MFMAs)
   float* lds_scores = SC == NANN_SCORER_L2 ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
-  const bool timing = a.phase_ticks != nullptr;
-  long long t_last = timing ? (long long)clock64() : 0;
-  // attribute the time since the previous mark to `phase` (thread 0 only; off by default)
-  auto mark = [&](int phase) {
-    if (timing && tid == 0) {
-      const long long now = (long long)clock64();
-      ticks[phase] += now - t_last;
-      t_last = now;
-    }
-  };
+  PhaseTimer timer;
+  timer.start(ticks, a.phase_ticks != nullptr);
+  PhaseTimer* pt = a.phase_ticks ? &timer : nullptr;
+  auto mark = [&](int phase) { timer.mark(phase); };
 
   for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
   __syncthreads();
@@ -175,7 +169,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         }
         int gathered = 0;
         const int kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items,
-                                                   bm, dst, scratch, &gathered);
+                                                   bm, dst, scratch, &gathered, ss == 0 ? nullptr : pt);
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {
@@ -233,7 +227,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     }
     mark(PH_OTHER);
     const int st = wg_topk<NT>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
-                               nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch);
+                               nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch, pt);
     mark(PH_TOPK);
     if (st) return st;
     if (r == 1) {
