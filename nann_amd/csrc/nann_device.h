@@ -269,33 +269,41 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
           const int m = (a + b) >> 1;
           if (S->off[m + 1] > lo) b = m; else a = m + 1;
         }
-        constexpr int RB = 8;
+        constexpr int RB = 16;  // rows in flight per wavefront: a 2048-id piece is one batch
         for (int r0 = a + (wave - 1); r0 < n_rows; r0 += (NWV - 1) * RB) {
           if (S->off[r0] >= hi) break;
-          uint32_t o[RB], l[RB], st[RB];
+          uint32_t src_off[RB];  // index into values[] (0 when the lane has nothing to copy)
+          int dst_off[RB];       // index into the staging buffer, -1 = nothing
           int32_t v[RB];
+          uint32_t long_rows = 0;
 #pragma unroll
           for (int j = 0; j < RB; ++j) {  // row descriptors (LDS)
             const int r = r0 + j * (NWV - 1);
-            o[j] = 0; l[j] = 0; st[j] = 0;
+            src_off[j] = 0; dst_off[j] = -1;
             if (r < n_rows) {
-              o[j] = S->off[r];
-              l[j] = S->off[r + 1] - o[j];
-              st[j] = S->rowstart[r];
+              const uint32_t o = S->off[r];
+              const uint32_t l = S->off[r + 1] - o;
+              const uint32_t p = o + lane;
+              if (lane < l && p >= lo && p < hi) {
+                src_off[j] = S->rowstart[r] + lane;
+                dst_off[j] = (int)(p - lo);
+              }
+              if (l > 64) long_rows |= 1u << j;
             }
           }
 #pragma unroll
-          for (int j = 0; j < RB; ++j) {  // RB coalesced row loads in flight
-            v[j] = values[(lane < l[j]) ? (size_t)st[j] + lane : (size_t)0];  // values[0] exists: G > 0
-          }
+          for (int j = 0; j < RB; ++j) v[j] = values[src_off[j]];  // RB coalesced row loads in flight
 #pragma unroll
-          for (int j = 0; j < RB; ++j) {
-            const uint32_t p = o[j] + lane;
-            if (lane < l[j] && p >= lo && p < hi) dst[p - lo] = v[j];
-            if (l[j] > 64) {  // long rows (not produced by HNSW with M <= 32): remaining 64-id pieces
-              for (uint32_t c = 64 + lane; c < l[j]; c += 64) {
-                const uint32_t pp = o[j] + c;
-                if (pp >= lo && pp < hi) dst[pp - lo] = values[(size_t)st[j] + c];
+          for (int j = 0; j < RB; ++j)
+            if (dst_off[j] >= 0) dst[dst_off[j]] = v[j];
+          if (long_rows) {  // rows longer than 64 (not produced by HNSW with M <= 32): remaining pieces
+            for (int j = 0; j < RB; ++j) {
+              if (!((long_rows >> j) & 1u)) continue;
+              const int r = r0 + j * (NWV - 1);
+              const uint32_t o = S->off[r], l = S->off[r + 1] - o, st = S->rowstart[r];
+              for (uint32_t c = 64 + lane; c < l; c += 64) {
+                const uint32_t pp = o + c;
+                if (pp >= lo && pp < hi) dst[pp - lo] = values[(size_t)st + c];
               }
             }
           }
@@ -442,8 +450,8 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
 // out_pos / out_ids / out_scores / out_mapped may each be null.  ids == null
 // means "ids are positions".  Returns NANN status (uniform).
 struct TopkScratch {
-  uint32_t cnt[20][3];
-  uint32_t misc[4];  // [0] nsel, [1] c_gt, [2] unordered append cursor, [3] unused
+  uint32_t sel_bin, sel_above, sel_inbin, pad0;
+  uint32_t misc[4];  // [0] nsel, [2] unordered append cursor
   uint32_t orv, andv;
   uint32_t wcnt[kNW];
   unsigned long long sel[kMaxK];
@@ -490,7 +498,8 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
 #pragma unroll
     for (int j = 0; j < NS; ++j) key[j] = (j * NT + tid < n) ? score_key(raw[j]) : 0u;
   }
-  if (tid < 60) (&S->cnt[0][0])[tid] = 0;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(S->sel);  // [4][256]; sel is not in use before step 3
+  for (int i = tid; i < 4 * 256; i += NT) hist[i] = 0;
   if (tid < 4) S->misc[tid] = 0;
   if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
   __syncthreads();
@@ -524,58 +533,64 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   }
   __syncthreads();
   const uint32_t diff = S->orv ^ S->andv;
-  // ---- 2b. k-th largest key: two bits per barrier round, early exit as soon as
-  //          exactly k keys are >= a probe
-  uint32_t T = 0, c_ge = (uint32_t)n;
-  bool exact = false;
+  // ---- 2b. k-th largest key: radix select over the undecided bits, 8 bits per pass
+  //          (LDS histogram -> 256-bin suffix scan).  A pass ends the search early when the
+  //          bin holding the k-th key is needed in full.
+  uint32_t T = 0, c_ge = (uint32_t)n, c_gt = 0;
   if (diff != 0u) {
-    int b = 31 - __clz((int)diff);  // highest differing bit
-    T = S->andv & ~((b == 31) ? 0xffffffffu : ((2u << b) - 1u));
-    int it = 0;
-    while (b >= 0 && !exact) {
-      const int lowbit = (b >= 1) ? b - 1 : 0;
-      const int nb = (b >= 1) ? 2 : 1;
-      const uint32_t p1 = T | (1u << lowbit);
-      const uint32_t p2 = T | (2u << lowbit);
-      const uint32_t p3 = T | (3u << lowbit);
-      uint32_t c1 = 0, c2 = 0, c3 = 0;
+    const int hb = 31 - __clz((int)diff);  // highest differing bit
+    T = S->andv & ~((hb == 31) ? 0xffffffffu : ((2u << hb) - 1u));
+    int top = hb + 1;          // undecided low bits
+    uint32_t kk = (uint32_t)k;  // still to find among keys that match T above `top`
+    bool exact = false;
+    for (int pass = 0; top > 0 && !exact; ++pass) {
+      const int nb = top < 8 ? top : 8;
+      const int shift = top - nb;
+      const uint32_t dmask = (1u << nb) - 1u;
+      uint32_t* h = hist + pass * 256;
       NANN_FOR_KEYS({
-        c1 += (uint32_t)popc64(__ballot(valid && kj >= p1));
-        if (nb == 2) {
-          c2 += (uint32_t)popc64(__ballot(valid && kj >= p2));
-          c3 += (uint32_t)popc64(__ballot(valid && kj >= p3));
-        }
+        if (valid && (top >= 32 || (kj >> top) == (T >> top))) atomicAdd(&h[(kj >> shift) & dmask], 1u);
       })
-      if (lane == 0) {
-        if (c1) atomicAdd(&S->cnt[it][0], c1);
-        if (c2) atomicAdd(&S->cnt[it][1], c2);
-        if (c3) atomicAdd(&S->cnt[it][2], c3);
+      __syncthreads();
+      // thread t < 256 owns bin 255 - t: inclusive scan = #keys with digit >= bin
+      uint32_t v = 0, inc = 0;
+      if (tid < 256) {
+        v = h[255 - tid];
+        inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(inc, d);
+          if (lane >= d) inc += t;
+        }
+        if (lane == 63) S->wcnt[wave] = inc;
       }
       __syncthreads();
-      const uint32_t t1 = S->cnt[it][0], t2 = S->cnt[it][1], t3 = S->cnt[it][2];
-      const uint32_t kk = (uint32_t)k;
-      if (nb == 2 && t3 >= kk) { T = p3; c_ge = t3; }
-      else if (nb == 2 && t2 >= kk) { T = p2; c_ge = t2; }
-      else if (t1 >= kk) { T = p1; c_ge = t1; }
-      exact = (c_ge == kk);
-      b -= nb;
-      ++it;
+      if (tid < 256) {
+        uint32_t wb = 0;
+        for (int w = 0; w < 4; ++w) wb += (w < wave) ? S->wcnt[w] : 0u;
+        const uint32_t incl = wb + inc, excl = incl - v;
+        if (excl < kk && kk <= incl) {  // exactly one bin
+          S->sel_bin = 255u - (uint32_t)tid;
+          S->sel_above = excl;
+          S->sel_inbin = v;
+        }
+      }
+      __syncthreads();
+      const uint32_t above = S->sel_above, inbin = S->sel_inbin;
+      T |= S->sel_bin << shift;
+      c_gt += above;
+      kk -= above;
+      c_ge = c_gt + inbin;
+      exact = (inbin == kk);
+      top = shift;
     }
   } else {
     T = S->andv;  // all keys equal
   }
+  // c_ge = #keys >= T >= k; c_gt = #keys > T (when the search ran to the last bit).  If
+  // c_ge > k, T is the exact k-th key and only some of the keys equal to T are admitted.
   if (pt) pt->sub(PH_TK_SEARCH, tsub);
-  // c_ge = #keys >= T >= k.  If c_ge > k, T is the exact k-th key and only some of the
-  // keys equal to T are admitted.
-  uint32_t c_gt = 0;
   const bool partial_eq = c_ge > (uint32_t)k;
-  if (partial_eq) {
-    uint32_t c = 0;
-    NANN_FOR_KEYS({ c += (uint32_t)popc64(__ballot(valid && kj > T)); })
-    if (lane == 0 && c) atomicAdd(&S->misc[1], c);
-    __syncthreads();
-    c_gt = S->misc[1];
-  }
   // ---- 3. collect -----------------------------------------------------------
   if (!partial_eq) {
     NANN_FOR_KEYS({
