@@ -226,7 +226,7 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
  * {bitmap zeroing, mark walks, CSR expand+walk, gather+score, top-k, other} followed by
  * sub-phases {top-k: load, search, collect, sort; expand: pass 1, pipeline loop}; NULL
  * disables the instrumentation (nann_search passes NULL). */
-#define NANN_NUM_PHASES 12
+#define NANN_NUM_PHASES 13
 int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q,
                    int64_t n_queries, const int32_t level_topn[6], void* workspace,
                    int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,

@@ -20,9 +20,9 @@ STATUS_NAMES = {
 F16, BF16, F32, I32, I64, F64 = 0, 1, 2, 3, 4, 5
 SCORER_L2, SCORER_MLP = 0, 1
 NUM_ROUNDS = 5
-NUM_PHASES = 12
+NUM_PHASES = 13
 PHASE_NAMES = ("zero", "walk", "expand", "score", "topk", "other", "tk_load", "tk_search",
-               "tk_collect", "tk_sort", "ex_pass1", "ex_loop")
+               "tk_collect", "tk_sort", "ex_pass1", "ex_loop", "ex_walkbusy")
 
 # every symbol include/nann_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

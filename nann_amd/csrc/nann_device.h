@@ -36,7 +36,8 @@ __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 // ---------------------------------------------------------------------------
 // optional per-phase time attribution (thread 0 only; off unless a buffer is given)
 enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER,
-       PH_TK_LOAD, PH_TK_SEARCH, PH_TK_COLLECT, PH_TK_SORT, PH_EX_PASS1, PH_EX_LOOP, PH_COUNT };
+       PH_TK_LOAD, PH_TK_SEARCH, PH_TK_COLLECT, PH_TK_SORT, PH_EX_PASS1, PH_EX_LOOP, PH_EX_WALKBUSY,
+       PH_COUNT };
 struct PhaseTimer {
   long long* ticks;  // LDS, [PH_COUNT]
   long long last;
@@ -145,8 +146,8 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
       bool keep = inr[u] && !(old[u] & bit);
       uint64_t dupl = __ballot(fresh && !keep);
       while (dupl) {  // duplicate fresh ids inside this step: lowest lane wins
-        const int l = __ffsll((unsigned long long)dupl) - 1;
-        const int32_t xv = __shfl(x[u], l);
+        const int l = __ffsll((unsigned long long)dupl) - 1;  // wave-uniform (scalar)
+        const int32_t xv = __builtin_amdgcn_readlane(x[u], l);  // v_readlane: no LDS round trip
         const bool mine = fresh && x[u] == xv;
         const uint64_t same = __ballot(mine);
         const int first = __ffsll((unsigned long long)same) - 1;
@@ -312,7 +313,9 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
     } else if (it >= 1) {  // walker: piece it-1
       const int c = it - 1;
       const int n_c = min(kChunk, G - c * kChunk);
+      long long tw = pt ? pt->now() : 0;
       base = wave_walk_span<kLdsBm>(S->stage[c & 1], n_c, bm, n_items, out, base, &err);
+      if (pt) pt->sub(PH_EX_WALKBUSY, tw);
     }
     __syncthreads();
   }
@@ -400,7 +403,7 @@ template <int LPR, int DT, int NTHREADS>
 __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids,
                                             int n, const float* qv, float* scores, float* lds_scores,
                                             int lds_off) {
-  constexpr int U = (DT == DT_F32) ? 4 : 8;
+  constexpr int U = ((DT == DT_F32) ? 4 : 8) * (NTHREADS <= 512 ? 2 : 1);  // same bytes in flight per CU
   constexpr int GPW = 64 / LPR;              // rows per wavefront per load
   constexpr int RPI = (NTHREADS / 64) * GPW;  // rows per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -450,12 +453,11 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
 // out_pos / out_ids / out_scores / out_mapped may each be null.  ids == null
 // means "ids are positions".  Returns NANN status (uniform).
 struct TopkScratch {
-  uint32_t sel_bin, sel_above, sel_inbin, pad0;
-  uint32_t misc[4];  // [0] nsel, [2] unordered append cursor
+  unsigned long long sel[kMaxK];  // first: 16-byte aligned (the radix histograms alias it)
+  unsigned short prank[kNT];      // partial ranks of the rank sort: [segment][element]
+  uint32_t misc[4];               // [0] nsel, [2] unordered append cursor
   uint32_t orv, andv;
   uint32_t wcnt[kNW];
-  unsigned long long sel[kMaxK];
-  unsigned short prank[kNT];  // partial ranks of the rank sort: [segment][element]
 };
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
 // the selection does not wait on L2 (positions < kLdsScores only)
@@ -552,32 +554,33 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
         if (valid && (top >= 32 || (kj >> top) == (T >> top))) atomicAdd(&h[(kj >> shift) & dmask], 1u);
       })
       __syncthreads();
-      // thread t < 256 owns bin 255 - t: inclusive scan = #keys with digit >= bin
-      uint32_t v = 0, inc = 0;
-      if (tid < 256) {
-        v = h[255 - tid];
-        inc = v;
+      // every wavefront scans the 256 bins on its own (no further barrier): lane l owns bins
+      // 4l..4l+3; suffix sums over lanes give #keys with a larger digit
+      const uint4 hv = reinterpret_cast<const uint4*>(h)[lane];
+      const uint32_t s_l = hv.x + hv.y + hv.z + hv.w;
+      uint32_t suf = s_l;  // inclusive suffix sum over lanes >= l
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t t = __shfl_up(inc, d);
-          if (lane >= d) inc += t;
-        }
-        if (lane == 63) S->wcnt[wave] = inc;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_down(suf, d);
+        if (lane + d < 64) suf += t;
       }
-      __syncthreads();
-      if (tid < 256) {
-        uint32_t wb = 0;
-        for (int w = 0; w < 4; ++w) wb += (w < wave) ? S->wcnt[w] : 0u;
-        const uint32_t incl = wb + inc, excl = incl - v;
-        if (excl < kk && kk <= incl) {  // exactly one bin
-          S->sel_bin = 255u - (uint32_t)tid;
-          S->sel_above = excl;
-          S->sel_inbin = v;
-        }
-      }
-      __syncthreads();
-      const uint32_t above = S->sel_above, inbin = S->sel_inbin;
-      T |= S->sel_bin << shift;
+      const uint32_t ab3 = suf - s_l;   // #keys with digit > 4l+3
+      const uint32_t ab2 = ab3 + hv.w;  // > 4l+2
+      const uint32_t ab1 = ab2 + hv.z;  // > 4l+1
+      const uint32_t ab0 = ab1 + hv.y;  // > 4l
+      int hit = -1;
+      if (ab3 < kk && kk <= ab3 + hv.w) hit = 3;
+      else if (ab2 < kk && kk <= ab2 + hv.z) hit = 2;
+      else if (ab1 < kk && kk <= ab1 + hv.y) hit = 1;
+      else if (ab0 < kk && kk <= ab0 + hv.x) hit = 0;
+      const uint64_t hm = __ballot(hit >= 0);  // exactly one lane
+      const int src = __ffsll((unsigned long long)hm) - 1;
+      const uint32_t my_above = hit == 3 ? ab3 : hit == 2 ? ab2 : hit == 1 ? ab1 : ab0;
+      const uint32_t my_inbin = hit == 3 ? hv.w : hit == 2 ? hv.z : hit == 1 ? hv.y : hv.x;
+      const uint32_t sel_bin = (uint32_t)__builtin_amdgcn_readlane((int)(4 * lane + (hit < 0 ? 0 : hit)), src);
+      const uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)my_above, src);
+      const uint32_t inbin = (uint32_t)__builtin_amdgcn_readlane((int)my_inbin, src);
+      T |= sel_bin << shift;
       c_gt += above;
       kk -= above;
       c_ge = c_gt + inbin;
@@ -589,6 +592,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   }
   // c_ge = #keys >= T >= k; c_gt = #keys > T (when the search ran to the last bit).  If
   // c_ge > k, T is the exact k-th key and only some of the keys equal to T are admitted.
+  __syncthreads();  // the histograms alias sel: every wavefront is done scanning them
   if (pt) pt->sub(PH_TK_SEARCH, tsub);
   const bool partial_eq = c_ge > (uint32_t)k;
   // ---- 3. collect -----------------------------------------------------------
@@ -599,7 +603,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       if (m) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(&S->misc[0], (uint32_t)popc64(m));
-        b = __shfl(b, 0);
+        b = __builtin_amdgcn_readfirstlane(b);
         if (s) S->sel[b + popc64(m & lt)] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
       }
     })
@@ -611,7 +615,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       if (m) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(&S->misc[2], (uint32_t)popc64(m));
-        b = __shfl(b, 0);
+        b = __builtin_amdgcn_readfirstlane(b);
         if (s) S->sel[b + popc64(m & lt)] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
       }
     })
@@ -645,6 +649,9 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   int K2 = 64;
   while (K2 < k) K2 <<= 1;
   const bool split = K2 <= NT;  // else (k > NT, only for NT < kMaxK): one thread per element
+  // the id of "my" element (e = tid) is fetched now so that its latency hides under the ranking
+  int32_t my_id = 0;
+  if (tid < k && ids) my_id = ids[(int)(~(uint32_t)(S->sel[tid] & 0xffffffffull))];
   if (split) {
     const int segs = NT / K2;
     const int e = tid & (K2 - 1), seg = tid / K2;
@@ -667,7 +674,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       for (int o = 0; o < k; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
     }
     const int pos = (int)(~(uint32_t)(mine & 0xffffffffull));
-    const int32_t idv = ids ? ids[pos] : pos;
+    const int32_t idv = ids ? (e == tid ? my_id : ids[pos]) : pos;
     if (out_pos) out_pos[rank] = pos;
     if (out_ids) out_ids[rank] = idv;
     if (out_scores) out_scores[rank] = SCL ? lds_scores[pos] : scores[pos];

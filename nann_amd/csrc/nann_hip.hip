@@ -957,6 +957,13 @@ static int launch_search_dt(int dt, int kind, const SearchPlan& p, const SearchA
     if (LPR == 32) return launch_search_mlp_d256(dt, p, a, st);
     return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256 only");
   }
+  // tuning knob: NANN_L2_THREADS=512 runs the L2 traversal with 8 wavefronts per workgroup
+  static const int l2_threads = [] { const char* e = std::getenv("NANN_L2_THREADS"); return e ? std::atoi(e) : kNT; }();
+  if (l2_threads == 512) {
+    if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_L2, 512>(p, a, st);
+    if (dt == NANN_BF16) return launch_search<LPR, DT_BF16, NANN_SCORER_L2, 512>(p, a, st);
+    return launch_search<LPR, DT_F32, NANN_SCORER_L2, 512>(p, a, st);
+  }
   if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_L2, kNT>(p, a, st);
   if (dt == NANN_BF16) return launch_search<LPR, DT_BF16, NANN_SCORER_L2, kNT>(p, a, st);
   return launch_search<LPR, DT_F32, NANN_SCORER_L2, kNT>(p, a, st);
