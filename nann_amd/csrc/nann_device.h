@@ -34,6 +34,51 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 
 // ---------------------------------------------------------------------------
+// cross-lane primitives on DPP (a VALU modifier, a few cycles) instead of ds_bpermute
+// (an LDS round trip of ~100 cycles per step): row_shr within rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 to carry across rows (gfx9 family, incl. gfx950).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive prefix sum over the 64 lanes (lane 63 = total)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  v += dpp_u32<0x111>(0, v);
+  v += dpp_u32<0x112>(0, v);
+  v += dpp_u32<0x114>(0, v);
+  v += dpp_u32<0x118>(0, v);
+  v += dpp_u32<0x142, 0xA>(0, v);
+  v += dpp_u32<0x143, 0xC>(0, v);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_total(uint32_t scanned) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)scanned, 63);
+}
+// OR / AND of a value over the wavefront (result valid in lane 63, broadcast by readlane)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+  v |= dpp_u32<0x111>(0, v);
+  v |= dpp_u32<0x112>(0, v);
+  v |= dpp_u32<0x114>(0, v);
+  v |= dpp_u32<0x118>(0, v);
+  v |= dpp_u32<0x142, 0xA>(0, v);
+  v |= dpp_u32<0x143, 0xC>(0, v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_and(uint32_t v) {
+  v &= dpp_u32<0x111>(0xffffffffu, v);
+  v &= dpp_u32<0x112>(0xffffffffu, v);
+  v &= dpp_u32<0x114>(0xffffffffu, v);
+  v &= dpp_u32<0x118>(0xffffffffu, v);
+  v &= dpp_u32<0x142, 0xA>(0xffffffffu, v);
+  v &= dpp_u32<0x143, 0xC>(0xffffffffu, v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// ---------------------------------------------------------------------------
 // optional per-phase time attribution (thread 0 only; off unless a buffer is given)
 enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER,
        PH_TK_LOAD, PH_TK_SEARCH, PH_TK_COLLECT, PH_TK_SORT, PH_EX_PASS1, PH_EX_LOOP, PH_EX_WALKBUSY,
@@ -226,12 +271,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
         S->bad = 1;
       }
     }
-    uint32_t inc = len;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t v = __shfl_up(inc, d);
-      if (lane >= d) inc += v;
-    }
+    const uint32_t inc = wave_scan_add(len);
     if (lane == 63) S->wave_tot[wave] = inc;
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
@@ -314,7 +354,9 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
       const int c = it - 1;
       const int n_c = min(kChunk, G - c * kChunk);
       long long tw = pt ? pt->now() : 0;
+      __builtin_amdgcn_s_setprio(3);  // the serial wavefront: issue ahead of the copying ones
       base = wave_walk_span<kLdsBm>(S->stage[c & 1], n_c, bm, n_items, out, base, &err);
+      __builtin_amdgcn_s_setprio(0);
       if (pt) pt->sub(PH_EX_WALKBUSY, tw);
     }
     __syncthreads();
@@ -388,8 +430,15 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
     const float t = q[k] - x[k];
     acc = __fmaf_rn(t, t, acc);
   }
-#pragma unroll
-  for (int s = 1; s < LPR; s <<= 1) acc = acc + __shfl_xor(acc, s);
+  // xor butterfly over the LPR lanes of the row.  Strides 1 and 2 are quad permutes; for
+  // strides 4 and 8 the mirror patterns pair every lane with a lane of the partner group,
+  // all of whose lanes already hold the same partial sum -- the same tree as p[l] + p[l^s].
+  acc = acc + dpp_f32<0xB1>(acc);                      // quad_perm [1,0,3,2]  (l ^ 1)
+  acc = acc + dpp_f32<0x4E>(acc);                      // quad_perm [2,3,0,1]  (l ^ 2)
+  if constexpr (LPR >= 8) acc = acc + dpp_f32<0x141>(acc);   // row_half_mirror      (l ^ 4)
+  if constexpr (LPR >= 16) acc = acc + dpp_f32<0x140>(acc);  // row_mirror           (l ^ 8)
+  if constexpr (LPR >= 32) acc = acc + __shfl_xor(acc, 16);
+  if constexpr (LPR >= 64) acc = acc + __shfl_xor(acc, 32);
   return 0.0f - acc;
 }
 
@@ -464,17 +513,6 @@ struct TopkScratch {
 static_assert(sizeof(TopkScratch) <= kLdsScoresOff, "top-k scratch overlaps the LDS scores");
 static_assert(kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
 static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too small");
-
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) v |= __shfl_xor(v, s);
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_and(uint32_t v) {
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) v &= __shfl_xor(v, s);
-  return v;
-}
 
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
 // SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
@@ -558,12 +596,8 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       // 4l..4l+3; suffix sums over lanes give #keys with a larger digit
       const uint4 hv = reinterpret_cast<const uint4*>(h)[lane];
       const uint32_t s_l = hv.x + hv.y + hv.z + hv.w;
-      uint32_t suf = s_l;  // inclusive suffix sum over lanes >= l
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_down(suf, d);
-        if (lane + d < 64) suf += t;
-      }
+      const uint32_t pre = wave_scan_add(s_l);              // inclusive prefix over lanes <= l
+      const uint32_t suf = wave_total(pre) - pre + s_l;      // inclusive suffix over lanes >= l
       const uint32_t ab3 = suf - s_l;   // #keys with digit > 4l+3
       const uint32_t ab2 = ab3 + hv.w;  // > 4l+2
       const uint32_t ab1 = ab2 + hv.z;  // > 4l+1
