@@ -166,37 +166,49 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
     int32_t x[U];
     uint32_t pre[U], old[U];
     bool inr[U];
-    // branch-free: out-of-span / out-of-range lanes read word 0 and OR in nothing
+    // branch-free loads: out-of-span / out-of-range lanes read word 0
 #pragma unroll
     for (int u = 0; u < U; ++u) x[u] = src[min(c0 + u * 64 + lane, n - 1)];
     bool bad = false;
+    uint32_t* w[U];
+    uint32_t bit[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool valid = (c0 + u * 64 + lane) < n;
       inr[u] = valid && (uint32_t)x[u] < n_items;
       bad |= valid && !inr[u];
-      uint32_t* w = bm + (inr[u] ? ((uint32_t)x[u] >> 5) : 0u);
-      const uint32_t bit = inr[u] ? (1u << (x[u] & 31)) : 0u;
-      pre[u] = kLdsBm ? *w : atomicOr(w, 0u);
-      old[u] = atomicOr(w, bit);
+      w[u] = bm + (inr[u] ? ((uint32_t)x[u] >> 5) : 0u);
+      bit[u] = inr[u] ? (1u << (x[u] & 31)) : 0u;
+      pre[u] = kLdsBm ? *w[u] : atomicOr(w[u], 0u);
     }
     if (__ballot(bad) != 0ull) {
       if (lane == 0) *err = 1;
     }
+    // only lanes whose bit was clear at the pre-read need the atomic; the pre-reads of a
+    // batch are issued before its atomics, so an id that an EARLIER step of this batch
+    // claims still looks fresh here -- the returned word then shows it taken, and no lane
+    // of this step holds the claim (see the resolution below)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      old[u] = 0xffffffffu;
+      if (inr[u] && !(pre[u] & bit[u])) old[u] = atomicOr(w[u], bit[u]);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (c0 + u * 64 >= n) break;
-      const uint32_t bit = 1u << (x[u] & 31);
-      const bool fresh = inr[u] && !(pre[u] & bit);
-      bool keep = inr[u] && !(old[u] & bit);
+      const bool fresh = inr[u] && !(pre[u] & bit[u]);
+      bool keep = fresh && !(old[u] & bit[u]);
       uint64_t dupl = __ballot(fresh && !keep);
-      while (dupl) {  // duplicate fresh ids inside this step: lowest lane wins
+      while (dupl) {  // a fresh id that lost its claim
         const int l = __ffsll((unsigned long long)dupl) - 1;  // wave-uniform (scalar)
         const int32_t xv = __builtin_amdgcn_readlane(x[u], l);  // v_readlane: no LDS round trip
         const bool mine = fresh && x[u] == xv;
         const uint64_t same = __ballot(mine);
+        // claimed by a lane of this step -> the LOWEST lane of the group keeps it;
+        // claimed by an earlier step of the batch -> nobody here does
+        const bool claimed_here = __ballot(mine && keep) != 0ull;
         const int first = __ffsll((unsigned long long)same) - 1;
-        if (mine) keep = (lane == first);
+        if (mine) keep = claimed_here && (lane == first);
         dupl &= ~same;
       }
       const uint64_t m = __ballot(keep);
