@@ -159,62 +159,84 @@ __device__ __forceinline__ void wg_zero_words(uint32_t* p, uint32_t n_words) {
 template <bool kLdsBm>
 __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_t* bm,
                                               uint32_t n_items, int32_t* out, int base, int* err) {
-  constexpr int U = kLdsBm ? 8 : 1;
+  constexpr int U = kLdsBm ? 4 : 1;  // steps per batch
+  constexpr int B = 64 * U;          // ids per batch
+  if (n <= 0) return base;
   const int lane = lane_id();
   const uint64_t lt = lanemask_lt();
-  for (int c0 = 0; c0 < n; c0 += 64 * U) {
-    int32_t x[U];
-    uint32_t pre[U], old[U];
-    bool inr[U];
-    // branch-free loads: out-of-span / out-of-range lanes read word 0
+  bool bad = false;
+
+  // ids of the batch starting at c (clamped: lanes past the span re-read id n-1 and are masked)
+  auto load_ids = [&](int c, int32_t (&x)[U]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) x[u] = src[min(c0 + u * 64 + lane, n - 1)];
-    bool bad = false;
-    uint32_t* w[U];
-    uint32_t bit[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool valid = (c0 + u * 64 + lane) < n;
-      inr[u] = valid && (uint32_t)x[u] < n_items;
-      bad |= valid && !inr[u];
-      w[u] = bm + (inr[u] ? ((uint32_t)x[u] >> 5) : 0u);
-      bit[u] = inr[u] ? (1u << (x[u] & 31)) : 0u;
-      pre[u] = kLdsBm ? *w[u] : atomicOr(w[u], 0u);
-    }
-    if (__ballot(bad) != 0ull) {
-      if (lane == 0) *err = 1;
-    }
-    // only lanes whose bit was clear at the pre-read need the atomic; the pre-reads of a
-    // batch are issued before its atomics, so an id that an EARLIER step of this batch
-    // claims still looks fresh here -- the returned word then shows it taken, and no lane
-    // of this step holds the claim (see the resolution below)
+    for (int u = 0; u < U; ++u) x[u] = src[min(c + u * 64 + lane, n - 1)];
+  };
+  // pre-read + OR for every step of the batch, issued back to back and in step order.
+  // Branch-free: lanes with nothing to do read word 0 and OR in nothing.
+  auto issue = [&](int c, const int32_t (&x)[U], uint32_t (&pre)[U], uint32_t (&old)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      old[u] = 0xffffffffu;
-      if (inr[u] && !(pre[u] & bit[u])) old[u] = atomicOr(w[u], bit[u]);
+      const bool valid = (c + u * 64 + lane) < n;
+      const bool inr = valid && (uint32_t)x[u] < n_items;
+      bad |= valid && !inr;
+      uint32_t* w = bm + (inr ? ((uint32_t)x[u] >> 5) : 0u);
+      const uint32_t bit = inr ? (1u << (x[u] & 31)) : 0u;
+      pre[u] = kLdsBm ? *w : atomicOr(w, 0u);
+      old[u] = atomicOr(w, bit);
     }
+  };
+  // ballots, in-step duplicate resolution (lowest lane wins) and stable compaction
+  auto resolve = [&](int c, const int32_t (&x)[U], const uint32_t (&pre)[U], const uint32_t (&old)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (c0 + u * 64 >= n) break;
-      const bool fresh = inr[u] && !(pre[u] & bit[u]);
-      bool keep = fresh && !(old[u] & bit[u]);
+      const bool valid = (c + u * 64 + lane) < n;
+      const bool inr = valid && (uint32_t)x[u] < n_items;
+      const uint32_t bit = 1u << (x[u] & 31);
+      const bool fresh = inr && !(pre[u] & bit);
+      bool keep = inr && !(old[u] & bit);
       uint64_t dupl = __ballot(fresh && !keep);
-      while (dupl) {  // a fresh id that lost its claim
-        const int l = __ffsll((unsigned long long)dupl) - 1;  // wave-uniform (scalar)
-        const int32_t xv = __builtin_amdgcn_readlane(x[u], l);  // v_readlane: no LDS round trip
+      while (dupl) {  // duplicate fresh ids inside this step
+        const int l = __ffsll((unsigned long long)dupl) - 1;     // wave-uniform (scalar)
+        const int32_t xv = __builtin_amdgcn_readlane(x[u], l);   // v_readlane: no LDS round trip
         const bool mine = fresh && x[u] == xv;
         const uint64_t same = __ballot(mine);
-        // claimed by a lane of this step -> the LOWEST lane of the group keeps it;
-        // claimed by an earlier step of the batch -> nobody here does
-        const bool claimed_here = __ballot(mine && keep) != 0ull;
         const int first = __ffsll((unsigned long long)same) - 1;
-        if (mine) keep = claimed_here && (lane == first);
+        if (mine) keep = (lane == first);
         dupl &= ~same;
       }
       const uint64_t m = __ballot(keep);
       if (keep) out[base + popc64(m & lt)] = x[u];
       base += popc64(m);
     }
+  };
+
+  if constexpr (!kLdsBm) {  // bitmap in HBM: one step at a time, each waits for its atomics
+    for (int c = 0; c < n; c += B) {
+      int32_t x[U];
+      uint32_t pre[U], old[U];
+      load_ids(c, x);
+      issue(c, x, pre, old);
+      resolve(c, x, pre, old);
+    }
+  } else {
+    // three batches in flight: while batch c is resolved (VALU/SALU only), the LDS already
+    // works on the bitmap operations of batch c+B and on the id reads of batch c+2B.  The
+    // LDS runs one wavefront's operations in order, so the serial semantics hold.
+    int32_t x0[U], x1[U], x2[U];
+    uint32_t p0[U], o0[U], p1[U], o1[U];
+    load_ids(0, x0);
+    issue(0, x0, p0, o0);
+    load_ids(B, x1);
+    for (int c = 0; c < n; c += B) {
+      issue(c + B, x1, p1, o1);   // no-ops past the span
+      load_ids(c + 2 * B, x2);
+      resolve(c, x0, p0, o0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) { x0[u] = x1[u]; p0[u] = p1[u]; o0[u] = o1[u]; x1[u] = x2[u]; }
+    }
+  }
+  if (__ballot(bad) != 0ull) {
+    if (lane == 0) *err = 1;
   }
   return base;
 }
