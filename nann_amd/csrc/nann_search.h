@@ -82,6 +82,7 @@ struct SearchArgs {
   int32_t* counters;
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
+  int rows_le_64[2];       // per level: every CSR row holds <= 64 ids
 };
 
 static_assert(PH_COUNT == NANN_NUM_PHASES, "phase list out of sync with include/nann_hip.h");
@@ -168,8 +169,14 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           src = a.nbv[level]; rs = a.nbrs[level]; n_in = nB; dst = sv.cand_ids + base_off;
         }
         int gathered = 0;
-        const int kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items,
-                                                   bm, dst, scratch, &gathered, ss == 0 ? nullptr : pt);
+        int kept;
+        if (ss == 1 && a.rows_le_64[level]) {  // HNSW rows (<= 64 links): one row per walker step
+          kept = wg_expand_walk_rows<LDSBM, NT>(frontier, n_in, src, rs, a.n_items, bm, dst, scratch,
+                                                &gathered, pt);
+        } else {
+          kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm,
+                                           dst, scratch, &gathered, ss == 0 ? nullptr : pt);
+        }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {

@@ -141,3 +141,35 @@ def test_mlp_search_matches_oracle(oracle):
            r.index.cpu().numpy(), r.counters.cpu().numpy())
     assert (exp[0] == 0).mean() > 0.5
     _assert_same(got, exp)
+
+
+def test_long_rows_with_repeated_ids(oracle):
+    """A CSR whose rows exceed 64 ids and repeat ids inside a row (legal input for
+    GroupGather / BitmapRefDifference, cf. group_gather_test.py's [0,1,1,2,...]): takes the
+    flat 64-ids-per-step walker with its in-step duplicate resolution instead of the
+    row-per-step one."""
+    from nann_amd import retrieval
+    g, _, _ = synth_index(20000, 64, 32)
+    rng = np.random.default_rng(8)
+    g2 = dict(g)
+    nbv, nbrs = [], []
+    for level in (0, 1):
+        v, rs = g["nb_values"][level], g["nb_row_splits"][level]
+        rows = []
+        for i in range(len(rs) - 1):
+            row = v[rs[i]:rs[i + 1]]
+            if len(row) and level == 0:
+                hop2 = np.concatenate([v[rs[j]:rs[j + 1]] for j in row[:6]])  # neighbours of neighbours
+                row = np.concatenate([row, row[:3], hop2])[:150]               # > 64 ids, with repeats
+            rows.append(row)
+        nbv.append(np.concatenate(rows).astype(np.int32))
+        nbrs.append(np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64))
+    g2["nb_values"], g2["nb_row_splits"] = nbv, nbrs
+    assert np.diff(nbrs[0]).max() > 64
+    oix = oracle.Index(g2["item_embs"], g2["item_ids"], nbv, nbrs, g2["enter_points"])
+    dix = retrieval.Index.from_dict(g2)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 64, seed=21)])
+    topn = [32] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
+    assert (exp[0] == 0).mean() > 0.5
+    _assert_same(_run(dix, q, topn), exp)
