@@ -159,24 +159,20 @@ __device__ __forceinline__ void wg_zero_words(uint32_t* p, uint32_t n_words) {
 template <bool kLdsBm>
 __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_t* bm,
                                               uint32_t n_items, int32_t* out, int base, int* err) {
-  constexpr int U = kLdsBm ? 4 : 1;  // steps per batch
-  constexpr int B = 64 * U;          // ids per batch
+  constexpr int U = kLdsBm ? 8 : 1;  // steps per batch
   if (n <= 0) return base;
   const int lane = lane_id();
   const uint64_t lt = lanemask_lt();
   bool bad = false;
-
-  // ids of the batch starting at c (clamped: lanes past the span re-read id n-1 and are masked)
-  auto load_ids = [&](int c, int32_t (&x)[U]) {
+  for (int c0 = 0; c0 < n; c0 += 64 * U) {
+    int32_t x[U];
+    uint32_t pre[U], old[U];
+    // branch-free: lanes past the span / out of range read word 0 and OR in nothing
 #pragma unroll
-    for (int u = 0; u < U; ++u) x[u] = src[min(c + u * 64 + lane, n - 1)];
-  };
-  // pre-read + OR for every step of the batch, issued back to back and in step order.
-  // Branch-free: lanes with nothing to do read word 0 and OR in nothing.
-  auto issue = [&](int c, const int32_t (&x)[U], uint32_t (&pre)[U], uint32_t (&old)[U]) {
+    for (int u = 0; u < U; ++u) x[u] = src[min(c0 + u * 64 + lane, n - 1)];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool valid = (c + u * 64 + lane) < n;
+      const bool valid = (c0 + u * 64 + lane) < n;
       const bool inr = valid && (uint32_t)x[u] < n_items;
       bad |= valid && !inr;
       uint32_t* w = bm + (inr ? ((uint32_t)x[u] >> 5) : 0u);
@@ -184,55 +180,38 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
       pre[u] = kLdsBm ? *w : atomicOr(w, 0u);
       old[u] = atomicOr(w, bit);
     }
-  };
-  // ballots, in-step duplicate resolution (lowest lane wins) and stable compaction
-  auto resolve = [&](int c, const int32_t (&x)[U], const uint32_t (&pre)[U], const uint32_t (&old)[U]) {
+    bool fresh[U], keep[U];
+    uint64_t dm[U];
+    uint64_t any_dup = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool valid = (c + u * 64 + lane) < n;
-      const bool inr = valid && (uint32_t)x[u] < n_items;
+      const bool inr = (c0 + u * 64 + lane) < n && (uint32_t)x[u] < n_items;
       const uint32_t bit = 1u << (x[u] & 31);
-      const bool fresh = inr && !(pre[u] & bit);
-      bool keep = inr && !(old[u] & bit);
-      uint64_t dupl = __ballot(fresh && !keep);
-      while (dupl) {  // duplicate fresh ids inside this step
-        const int l = __ffsll((unsigned long long)dupl) - 1;     // wave-uniform (scalar)
-        const int32_t xv = __builtin_amdgcn_readlane(x[u], l);   // v_readlane: no LDS round trip
-        const bool mine = fresh && x[u] == xv;
-        const uint64_t same = __ballot(mine);
-        const int first = __ffsll((unsigned long long)same) - 1;
-        if (mine) keep = (lane == first);
-        dupl &= ~same;
-      }
-      const uint64_t m = __ballot(keep);
-      if (keep) out[base + popc64(m & lt)] = x[u];
-      base += popc64(m);
+      fresh[u] = inr && !(pre[u] & bit);
+      keep[u] = inr && !(old[u] & bit);
+      dm[u] = __ballot(fresh[u] && !keep[u]);
+      any_dup |= dm[u];
     }
-  };
-
-  if constexpr (!kLdsBm) {  // bitmap in HBM: one step at a time, each waits for its atomics
-    for (int c = 0; c < n; c += B) {
-      int32_t x[U];
-      uint32_t pre[U], old[U];
-      load_ids(c, x);
-      issue(c, x, pre, old);
-      resolve(c, x, pre, old);
-    }
-  } else {
-    // three batches in flight: while batch c is resolved (VALU/SALU only), the LDS already
-    // works on the bitmap operations of batch c+B and on the id reads of batch c+2B.  The
-    // LDS runs one wavefront's operations in order, so the serial semantics hold.
-    int32_t x0[U], x1[U], x2[U];
-    uint32_t p0[U], o0[U], p1[U], o1[U];
-    load_ids(0, x0);
-    issue(0, x0, p0, o0);
-    load_ids(B, x1);
-    for (int c = 0; c < n; c += B) {
-      issue(c + B, x1, p1, o1);   // no-ops past the span
-      load_ids(c + 2 * B, x2);
-      resolve(c, x0, p0, o0);
+    if (any_dup) {  // some step holds the same fresh id twice: the lowest lane keeps it
 #pragma unroll
-      for (int u = 0; u < U; ++u) { x0[u] = x1[u]; p0[u] = p1[u]; o0[u] = o1[u]; x1[u] = x2[u]; }
+      for (int u = 0; u < U; ++u) {
+        uint64_t dupl = dm[u];
+        while (dupl) {
+          const int l = __ffsll((unsigned long long)dupl) - 1;     // wave-uniform (scalar)
+          const int32_t xv = __builtin_amdgcn_readlane(x[u], l);   // v_readlane: no LDS round trip
+          const bool mine = fresh[u] && x[u] == xv;
+          const uint64_t same = __ballot(mine);
+          const int first = __ffsll((unsigned long long)same) - 1;
+          if (mine) keep[u] = (lane == first);
+          dupl &= ~same;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // stable compaction
+      const uint64_t m = __ballot(keep[u]);
+      if (keep[u]) out[base + popc64(m & lt)] = x[u];
+      base += popc64(m);
     }
   }
   if (__ballot(bad) != 0ull) {
@@ -269,9 +248,7 @@ struct ExpandWalkScratch {
   uint32_t wave_tot[kNW];
   int bad;
   int kept;
-  int n_pieces;
-  int pad;
-  unsigned short first_row[48];  // row-step mode: first row of every piece (+ end marker)
+  int pad[2];
   int32_t stage[2][kChunk];
 };
 
@@ -399,219 +376,6 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   }
   if (pt) pt->sub(PH_EX_LOOP, tsub);
   if (wave == 0 && lane == 0) { S->kept = base; if (err) S->bad = 1; }
-  __syncthreads();
-  const int kept = S->kept;
-  const int bad = S->bad;
-  __syncthreads();
-  return bad ? -1 : kept;
-}
-
-// ---------------------------------------------------------------------------
-// Row-step variant of the fused expand + walk, for CSR levels whose rows hold at most 64
-// ids (HNSW with M <= 32: 2M = 64 links at level 0).  Same pipeline and same staging as
-// wg_expand_walk, but the walker takes ONE ROW per 64-lane step instead of 64 consecutive
-// ids of the concatenation.  A neighbour list never repeats an id, so the in-step
-// duplicate resolution -- measured at ~150 cycles per duplicated id, i.e. the bulk of the
-// serial wavefront's time when steps span several rows of neighbouring nodes -- has
-// nothing to do (it stays in place for inputs that do repeat ids inside a row).
-// A row belongs to the piece in which it starts; pieces are kRowPiece ids so that a
-// row starting at the very end of a piece still fits the kChunk-id staging buffer.
-constexpr int kRowPiece = kChunk - 64;
-
-template <bool kLdsBm>
-__device__ __forceinline__ int wave_walk_rows(const int32_t* stage, const uint32_t* off, int r_lo,
-                                              int r_hi, uint32_t lo, uint32_t* bm, uint32_t n_items,
-                                              int32_t* out, int base, bool* bad_out) {
-  constexpr int U = kLdsBm ? 4 : 1;  // rows per batch
-  if (r_hi <= r_lo) return base;
-  const int lane = lane_id();
-  const uint64_t lt = lanemask_lt();
-  bool bad = false;
-  auto load_rows = [&](int rb, int32_t (&x)[U], uint32_t (&cnt)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = rb + u;
-      const int rr = min(r, r_hi - 1);
-      const uint32_t o = off[rr];
-      cnt[u] = (r < r_hi) ? off[rr + 1] - o : 0u;
-      x[u] = stage[o - lo + lane];  // lanes >= cnt read the following row / padding: masked below
-    }
-  };
-  auto issue = [&](const int32_t (&x)[U], const uint32_t (&cnt)[U], uint32_t (&pre)[U], uint32_t (&old)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool valid = (uint32_t)lane < cnt[u];
-      const bool inr = valid && (uint32_t)x[u] < n_items;
-      bad |= valid && !inr;
-      uint32_t* w = bm + (inr ? ((uint32_t)x[u] >> 5) : 0u);
-      const uint32_t bit = inr ? (1u << (x[u] & 31)) : 0u;
-      pre[u] = kLdsBm ? *w : atomicOr(w, 0u);
-      old[u] = atomicOr(w, bit);
-    }
-  };
-  auto resolve = [&](const int32_t (&x)[U], const uint32_t (&cnt)[U], const uint32_t (&pre)[U],
-                     const uint32_t (&old)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool inr = (uint32_t)lane < cnt[u] && (uint32_t)x[u] < n_items;
-      const uint32_t bit = 1u << (x[u] & 31);
-      const bool fresh = inr && !(pre[u] & bit);
-      bool keep = inr && !(old[u] & bit);
-      uint64_t dupl = __ballot(fresh && !keep);
-      while (dupl) {  // only for rows that repeat an id
-        const int l = __ffsll((unsigned long long)dupl) - 1;
-        const int32_t xv = __builtin_amdgcn_readlane(x[u], l);
-        const bool mine = fresh && x[u] == xv;
-        const uint64_t same = __ballot(mine);
-        const int first = __ffsll((unsigned long long)same) - 1;
-        if (mine) keep = (lane == first);
-        dupl &= ~same;
-      }
-      const uint64_t m = __ballot(keep);
-      if (keep) out[base + popc64(m & lt)] = x[u];
-      base += popc64(m);
-    }
-  };
-  if constexpr (!kLdsBm) {
-    for (int rb = r_lo; rb < r_hi; rb += U) {
-      int32_t x[U];
-      uint32_t cnt[U], pre[U], old[U];
-      load_rows(rb, x, cnt);
-      issue(x, cnt, pre, old);
-      resolve(x, cnt, pre, old);
-    }
-  } else {
-    int32_t x0[U], x1[U], x2[U];
-    uint32_t n0[U], n1[U], n2[U], p0[U], o0[U], p1[U], o1[U];
-    load_rows(r_lo, x0, n0);
-    issue(x0, n0, p0, o0);
-    load_rows(r_lo + U, x1, n1);
-    for (int rb = r_lo; rb < r_hi; rb += U) {
-      issue(x1, n1, p1, o1);  // no-ops past the last row
-      load_rows(rb + 2 * U, x2, n2);
-      resolve(x0, n0, p0, o0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        x0[u] = x1[u]; n0[u] = n1[u]; p0[u] = p1[u]; o0[u] = o1[u];
-        x1[u] = x2[u]; n1[u] = n2[u];
-      }
-    }
-  }
-  if (__ballot(bad) != 0ull) *bad_out = true;
-  return base;
-}
-
-// Returns ids kept, -1 on an out-of-range id, -2 if a row is longer than 64 (caller picked
-// the wrong variant).  All NT threads; n_frontier <= kMaxK.
-template <bool kLdsBm, int NT = kNT>
-__device__ __forceinline__ int wg_expand_walk_rows(const int32_t* frontier, int n_frontier,
-                                                   const int32_t* __restrict__ values,
-                                                   const int64_t* __restrict__ row_splits,
-                                                   uint32_t n_items, uint32_t* bm, int32_t* out,
-                                                   unsigned char* scratch, int* gathered,
-                                                   PhaseTimer* pt = nullptr) {
-  ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
-  long long tsub = pt ? pt->now() : 0;
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  constexpr int NWV = NT / 64;
-  const int n_rows = n_frontier;
-  if (tid == 0) { S->bad = 0; S->kept = 0; S->n_pieces = 0; }
-  __syncthreads();
-  // ---- pass 1 (count, GroupGather_kernel.cc:137-145): row lengths -> offsets ------------
-  uint32_t total = 0;
-  for (int t0 = 0; t0 < n_rows; t0 += NT) {
-    const int t = t0 + tid;
-    uint32_t len = 0, start = 0;
-    if (t < n_rows) {
-      const int32_t node = frontier[t];
-      if ((uint32_t)node < n_items) {
-        const int64_t s = row_splits[node], e = row_splits[node + 1];
-        start = (uint32_t)s;
-        len = (uint32_t)(e - s);
-        if (len > 64u) S->bad = 2;
-      } else {
-        S->bad = 1;
-      }
-    }
-    const uint32_t inc = wave_scan_add(len);
-    if (lane == 63) S->wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-      const uint32_t v = S->wave_tot[w];
-      if (w < wave) wbase += v;
-      tot += v;
-    }
-    if (t < n_rows) {
-      S->off[t] = total + wbase + inc - len;
-      S->rowstart[t] = start;
-    }
-    total += tot;
-    __syncthreads();
-  }
-  if (tid == 0) S->off[n_rows] = total;
-  __syncthreads();
-  // piece table: row t opens piece off[t] / kRowPiece if the previous row started in an earlier one
-  for (int t = tid; t < n_rows; t += NT) {
-    const int c = (int)(S->off[t] / kRowPiece);
-    const int cp = t ? (int)(S->off[t - 1] / kRowPiece) : -1;
-    for (int cc = cp + 1; cc <= c; ++cc) S->first_row[cc] = (unsigned short)t;
-    if (t == n_rows - 1) {
-      S->first_row[c + 1] = (unsigned short)n_rows;
-      S->n_pieces = c + 1;
-    }
-  }
-  __syncthreads();
-  *gathered = (int)total;
-  if (pt) pt->sub(PH_EX_PASS1, tsub);
-  if (S->bad) return S->bad == 2 ? -2 : -1;
-  // ---- pass 2 (fill, :152-168) || walk pipeline -------------------------------------------
-  const int n_pieces = S->n_pieces;
-  int base = 0;
-  bool bad_id = false;
-  for (int it = 0; it <= n_pieces; ++it) {
-    if (wave > 0) {
-      if (it < n_pieces) {  // producers: rows of piece `it` -> stage[it & 1]
-        const int r_lo = S->first_row[it], r_hi = S->first_row[it + 1];
-        const uint32_t lo = (uint32_t)it * kRowPiece;
-        int32_t* dst = S->stage[it & 1];
-        constexpr int RB = 8;  // rows in flight per wavefront
-        for (int r0 = r_lo + (wave - 1); r0 < r_hi; r0 += (NWV - 1) * RB) {
-          uint32_t src_off[RB];
-          int dst_off[RB];
-          int32_t v[RB];
-#pragma unroll
-          for (int j = 0; j < RB; ++j) {
-            const int r = r0 + j * (NWV - 1);
-            src_off[j] = 0; dst_off[j] = -1;
-            if (r < r_hi) {
-              const uint32_t o = S->off[r];
-              const uint32_t l = S->off[r + 1] - o;
-              if ((uint32_t)lane < l) {
-                src_off[j] = S->rowstart[r] + lane;
-                dst_off[j] = (int)(o - lo) + lane;
-              }
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < RB; ++j) v[j] = values[src_off[j]];
-#pragma unroll
-          for (int j = 0; j < RB; ++j)
-            if (dst_off[j] >= 0) dst[dst_off[j]] = v[j];
-        }
-      }
-    } else if (it >= 1) {  // walker: rows of piece it-1
-      const int c = it - 1;
-      long long tw = pt ? pt->now() : 0;
-      base = wave_walk_rows<kLdsBm>(S->stage[c & 1], S->off, S->first_row[c], S->first_row[c + 1],
-                                    (uint32_t)c * kRowPiece, bm, n_items, out, base, &bad_id);
-      if (pt) pt->sub(PH_EX_WALKBUSY, tw);
-    }
-    __syncthreads();
-  }
-  if (pt) pt->sub(PH_EX_LOOP, tsub);
-  if (wave == 0 && lane == 0) { S->kept = base; if (bad_id) S->bad = 1; }
   __syncthreads();
   const int kept = S->kept;
   const int bad = S->bad;

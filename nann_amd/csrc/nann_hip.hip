@@ -1017,7 +1017,6 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   const int dt = ix->desc.emb_dtype;
   const int kind = scorer->desc.kind;
   a.mlp = scorer->mlp;
-  for (int l = 0; l < 2; ++l) a.rows_le_64[l] = ix->max_deg[l] <= 64 ? 1 : 0;
   switch (ix->desc.d / 8) {
     case 8: return launch_search_dt<8>(dt, kind, p, a, st);
     case 16: return launch_search_dt<16>(dt, kind, p, a, st);

@@ -82,7 +82,6 @@ struct SearchArgs {
   int32_t* counters;
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
-  int rows_le_64[2];       // per level: every CSR row holds <= 64 ids
 };
 
 static_assert(PH_COUNT == NANN_NUM_PHASES, "phase list out of sync with include/nann_hip.h");
@@ -169,14 +168,39 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           src = a.nbv[level]; rs = a.nbrs[level]; n_in = nB; dst = sv.cand_ids + base_off;
         }
         int gathered = 0;
-        int kept;
-        if (ss == 1 && a.rows_le_64[level]) {  // HNSW rows (<= 64 links): one row per walker step
-          kept = wg_expand_walk_rows<LDSBM, NT>(frontier, n_in, src, rs, a.n_items, bm, dst, scratch,
-                                                &gathered, pt);
-        } else {
-          kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm,
-                                           dst, scratch, &gathered, ss == 0 ? nullptr : pt);
+        int kept = -2;
+        if (ss == 0) {
+          // The list to mark is a TopKV2 output over distinct nodes, hence duplicate-free, and
+          // the bitmap is empty: BitmapRefDifference returns the list unchanged and the order
+          // in which bits are set does not matter -> every thread ORs its bit.  The returned
+          // words prove the premise; if it ever failed, redo the step with the serial walker.
+          int* flags = reinterpret_cast<int*>(scratch);  // [0] duplicate seen, [1] id out of range
+          if (tid < 2) flags[tid] = 0;
+          __syncthreads();
+          for (int i = tid; i < n_in; i += NT) {
+            const int32_t id = src[i];
+            if ((uint32_t)id < a.n_items) {
+              const uint32_t bit = 1u << (id & 31);
+              if (atomicOr(&bm[(uint32_t)id >> 5], bit) & bit) flags[0] = 1;
+              dst[i] = id;
+            } else {
+              flags[1] = 1;
+            }
+          }
+          __syncthreads();
+          const int dup = flags[0], oob = flags[1];
+          __syncthreads();
+          if (oob) return NANN_ERR_INDEX_OUT_OF_RANGE;
+          if (!dup) {
+            kept = n_in;
+          } else {
+            wg_zero_words(bm, a.bm_words);
+            __syncthreads();
+          }
         }
+        if (kept == -2)
+          kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
+                                           scratch, &gathered, ss == 0 ? nullptr : pt);
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {
