@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merge", default="device", choices=["device", "host"])
+    ap.add_argument("--scorer", default="l2", choices=["l2", "mlp"],
+                    help="l2 = BASELINE configs[1] (the headline metric); mlp = configs[2]: 256-128-1 MLP on MFMA")
     ap.add_argument("--index-cache", default=None, help="directory to cache the synthetic index in")
     ap.add_argument("--phase-ticks", action="store_true",
                     help="one extra instrumented launch: per-phase time attribution")
@@ -108,7 +110,8 @@ def main():
                      nb_row_splits_0=g["nb_row_splits"][0], nb_row_splits_1=g["nb_row_splits"][1],
                      enter_points=g["enter_points"])
     index = retrieval.Index.from_dict(g, device=dev)
-    scorer = ops.Scorer("l2", args.dim)
+    mlp_w = synth.make_mlp_weights(args.dim) if args.scorer == "mlp" else None
+    scorer = ops.Scorer(args.scorer, args.dim, weights=mlp_w)
     seq_host = synth.make_queries_from_centres(args.dim, args.batch, noise=args.noise)
     comm_seq = torch.as_tensor(seq_host).to(dev)
     setup_s = time.time() - t0
@@ -161,6 +164,15 @@ def main():
                 "traffic": None, "kernel_ms": round(kern_ms, 4),
                 "algorithmic_bytes_per_query": round(bytes_per_launch / args.batch, 1),
                 "rows_scored_per_query": round(float(counters[:, 2, :].sum(1).mean()), 1)}
+    if args.scorer == "mlp":
+        # 2*(256*256 + 256*128 + 128) flop per scored row; f32-input MFMA dense
+        # peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The HBM figure is kept alongside.
+        flops = float(counters[:, 2, :].sum()) * 2.0 * (2 * args.dim * 256 + 256 * 128 + 128)
+        tf = flops / (kern_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer)", "achieved": round(tf, 2), "peak": 157.3,
+                    "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
+                    "kernel_ms": round(kern_ms, 4), "hbm_algorithmic_GBps": round(achieved, 1),
+                    "rows_scored_per_query": roofline["rows_scored_per_query"]}
 
     # ---- whole-job throughput: every rank searched every query on its 1M-item shard
     qps = args.batch * args.steps / elapsed
@@ -170,10 +182,12 @@ def main():
         "value": round(value, 1), "unit": "queries/s x 1M-item shards searched",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16 rows / f32 L2",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 rows / f32 L2" if args.scorer == "l2" else "f16 rows / f32 MFMA MLP",
         "data": "synthetic",
         "config": {"workload": f"{args.items} items/GPU x {args.dim}-d f16, M=32 {args.graph} graph, "
-                               f"ef_search={args.ef}, top-{args.topk}, L2 scoring (BASELINE configs[1]"
+                               f"ef_search={args.ef}, top-{args.topk}, "
+                               + ("L2 scoring (BASELINE configs[1]" if args.scorer == "l2"
+                                  else "3-layer MLP 256-128-1 scorer on MFMA (BASELINE configs[2]")
                                + (", sharded as configs[3]" if world > 1 else "") + ")",
                    "level_topn": topn, "batch": args.batch, "items_total": args.items * world,
                    "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
@@ -194,7 +208,7 @@ def main():
 
     if rank == 0 and world == 1:
         oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
-        osc = O.Scorer("l2", args.dim, O.EMB_F16)
+        osc = O.Scorer(args.scorer, args.dim, O.EMB_F16, mlp_w)
         qh = ops.user_seq_mean(comm_seq).cpu().numpy()
         cores = usable_cores()
         if not args.no_cpu_baseline:
