@@ -949,24 +949,19 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
 
 }  // extern "C"
 
-template <int LPR>
-static int launch_search_dt(int dt, int kind, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+// L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
+// nann_mlp_inst.hip (one per embedding dim): the heavy kernels compile in parallel.
+static int launch_search_any(int lpr, int dt, int kind, const SearchPlan& p, const SearchArgs& a,
+                             hipStream_t st) {
   if (kind == NANN_SCORER_MLP) {
-    if (LPR == 8) return launch_search_mlp_d64(dt, p, a, st);
-    if (LPR == 16) return launch_search_mlp_d128(dt, p, a, st);
-    if (LPR == 32) return launch_search_mlp_d256(dt, p, a, st);
+    if (lpr == 8) return launch_search_mlp_d64(dt, p, a, st);
+    if (lpr == 16) return launch_search_mlp_d128(dt, p, a, st);
+    if (lpr == 32) return launch_search_mlp_d256(dt, p, a, st);
     return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256 only");
   }
-  // tuning knob: NANN_L2_THREADS=512 runs the L2 traversal with 8 wavefronts per workgroup
-  static const int l2_threads = [] { const char* e = std::getenv("NANN_L2_THREADS"); return e ? std::atoi(e) : kNT; }();
-  if (l2_threads == 512) {
-    if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_L2, 512>(p, a, st);
-    if (dt == NANN_BF16) return launch_search<LPR, DT_BF16, NANN_SCORER_L2, 512>(p, a, st);
-    return launch_search<LPR, DT_F32, NANN_SCORER_L2, 512>(p, a, st);
-  }
-  if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_L2, kNT>(p, a, st);
-  if (dt == NANN_BF16) return launch_search<LPR, DT_BF16, NANN_SCORER_L2, kNT>(p, a, st);
-  return launch_search<LPR, DT_F32, NANN_SCORER_L2, kNT>(p, a, st);
+  if (dt == NANN_F16) return launch_search_l2_f16(lpr, p, a, st);
+  if (dt == NANN_BF16) return launch_search_l2_bf16(lpr, p, a, st);
+  return launch_search_l2_f32(lpr, p, a, st);
 }
 
 extern "C" {
@@ -1017,12 +1012,7 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   const int dt = ix->desc.emb_dtype;
   const int kind = scorer->desc.kind;
   a.mlp = scorer->mlp;
-  switch (ix->desc.d / 8) {
-    case 8: return launch_search_dt<8>(dt, kind, p, a, st);
-    case 16: return launch_search_dt<16>(dt, kind, p, a, st);
-    case 32: return launch_search_dt<32>(dt, kind, p, a, st);
-    default: return launch_search_dt<64>(dt, kind, p, a, st);
-  }
+  return launch_search_any(ix->desc.d / 8, dt, kind, p, a, st);
 }
 
 // ---- merge ------------------------------------------------------------------------------

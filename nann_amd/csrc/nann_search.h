@@ -350,6 +350,10 @@ inline int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t s
 }
 
 
+// L2 instantiations live in nann_l2_inst.hip (one object per row dtype)
+int launch_search_l2_f16(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
+int launch_search_l2_bf16(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
+int launch_search_l2_f32(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
 // MLP instantiations live in nann_mlp_inst.hip (one object per embedding dim)
 int launch_search_mlp_d64(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d128(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);

@@ -1,0 +1,36 @@
+"""CPU: the TensorFlow op-kernel shim (nann_amd/tf_ops/nann_tf_ops.cc) keeps the reference's
+op surface and compiles against the op-kernel API (syntax check against tests/tf_stub, a
+compile-only stub of the few TF classes the shim touches -- TensorFlow is not in the image)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "nann_amd", "tf_ops", "nann_tf_ops.cc")
+
+
+def test_shim_compiles_against_the_op_kernel_api():
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "tests", "tf_stub"),
+           "-I", os.path.join(ROOT, "include"), SHIM]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_shim_registers_the_reference_op_surface():
+    """Same op / input / output / attr names and dtypes as the reference's REGISTER_OP blocks
+    (GroupGather_kernel.cc:18-26, bitmap_ops.cc:150-157)."""
+    text = open(SHIM).read()
+    gg = text[text.index('REGISTER_OP("GroupGather")'):]
+    for frag in ['.Input("params_values: T")', '.Input("params_row_splits: int64")',
+                 '.Input("indices_values: int64")', '.Input("indices_row_splits: int64")',
+                 '.Output("ret_values: T")', '.Output("ret_row_splits: int64")',
+                 '.Attr("T: {int32, int64}")', '.Attr("unique: bool = false")']:
+        assert frag in gg[:900], frag
+    bm = text[text.index('REGISTER_OP("BitmapRefDifference")'):]
+    for frag in ['.Input("idx_next_values: T")', '.Input("idx_next_row_splits: int64")',
+                 '.Input("idx_flag: Ref (int32)")', '.Output("c_values: T")',
+                 '.Output("c_row_splits: int64")', '.Output("idx_flag_new: Ref (int32)")',
+                 '.Attr("T: {int32, int64}")']:
+        assert frag in bm[:900], frag
+    assert re.search(r'Name\("GroupGather"\)\.Device\(DEVICE_CPU\)\.TypeConstraint<int32>\("T"\)', text)
+    assert re.search(r'Name\("BitmapRefDifference"\)\.Device\(DEVICE_CPU\)\.TypeConstraint<int32>\("T"\)', text)
