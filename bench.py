@@ -237,14 +237,19 @@ def main():
                                 "status_equal": bool((status[sel] == st).all()),
                                 "ids_equal": bool((gi[ok] == ids[ok]).all()),
                                 "scores_bitwise_equal": bool((gs[ok].view(np.uint32) == scores[ok].view(np.uint32)).all())}
-        # recall@k of the traversal vs brute force under the same scorer (test_all, main.py:194-237)
+    if rank == 0 and world == 1:
+        # recall@k of the traversal vs brute force under the same scorer (test_all,
+        # main.py:194-237).  Brute force = score ALL items with the device scorer (parity-tested
+        # against the oracle) + TopKV2 on the device; 16 queries.
         hits, nrec = 0, 0
         gidx = r.index.cpu().numpy()
+        qd = ops.user_seq_mean(comm_seq)
         for b in range(min(16, args.batch)):
             if status[b]:
                 continue
-            rc, bi, _ = O.brute_force(oix, osc, qh[b], args.topk)
-            hits += len(set(bi.tolist()) & set(gidx[b].tolist()))
+            sc_all = ops.blaze_score(scorer, qd[b], item_emb=index.item_embs)
+            _, bi = ops.top_k(sc_all, args.topk)
+            hits += len(set(bi.cpu().tolist()) & set(gidx[b].tolist()))
             nrec += args.topk
         result["recall_at_k_vs_bruteforce"] = round(hits / max(nrec, 1), 4)
     if rank == 0:
