@@ -248,23 +248,32 @@ struct ExpandWalkScratch {
   uint32_t wave_tot[kNW];
   int bad;
   int kept;
-  int pad[2];
+  int kept_pub[2];  // ids the walker had produced at the end of the previous pipeline step
   int32_t stage[2][kChunk];
 };
 
-template <bool kLdsBm, int NT = kNT>
+// `consume(begin, end, wave_rel, n_waves)` (optional): called by the n_waves = NT/64 - 1
+// copying wavefronts of every pipeline step for the ids out[begin..end) the walker has
+// published so far, and by all wavefronts (n_waves = NT/64) for the tail after the last
+// piece -- the scorer runs underneath the serial walk instead of after it.  Must not
+// contain workgroup barriers.
+struct NoConsume {
+  __device__ __forceinline__ void operator()(int, int, int, int) const {}
+};
+
+template <bool kLdsBm, int NT = kNT, typename Consume = NoConsume>
 __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
-                                              PhaseTimer* pt = nullptr) {
+                                              PhaseTimer* pt = nullptr, Consume consume = Consume()) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
   long long tsub = pt ? pt->now() : 0;
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
-  if (tid == 0) { S->bad = 0; S->kept = 0; }
+  if (tid == 0) { S->bad = 0; S->kept = 0; S->kept_pub[0] = 0; S->kept_pub[1] = 0; }
   __syncthreads();
   // ---- pass 1: row lengths -> offsets --------------------------------------
   constexpr int NWV = NT / 64;
@@ -311,7 +320,9 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   const int n_chunks = (G + kChunk - 1) / kChunk;
   int base = 0;
   int err = 0;
+  int consumed = 0;  // ids already handed to `consume` (same value in every wavefront)
   for (int it = 0; it <= n_chunks; ++it) {
+    const int pub = S->kept_pub[(it + 1) & 1];  // walker's output count after step it-1
     if (wave > 0) {
       if (it < n_chunks) {  // producers: piece `it` -> stage[it & 1]
         const uint32_t lo = (uint32_t)it * kChunk;
@@ -363,6 +374,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
           }
         }
       }
+      consume(consumed, pub, wave - 1, NWV - 1);  // score what the walker has released so far
     } else if (it >= 1) {  // walker: piece it-1
       const int c = it - 1;
       const int n_c = min(kChunk, G - c * kChunk);
@@ -371,7 +383,9 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
       base = wave_walk_span<kLdsBm>(S->stage[c & 1], n_c, bm, n_items, out, base, &err);
       __builtin_amdgcn_s_setprio(0);
       if (pt) pt->sub(PH_EX_WALKBUSY, tw);
+      if (lane == 0) S->kept_pub[it & 1] = base;
     }
+    consumed = pub;
     __syncthreads();
   }
   if (pt) pt->sub(PH_EX_LOOP, tsub);
@@ -380,6 +394,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   const int kept = S->kept;
   const int bad = S->bad;
   __syncthreads();
+  if (!bad) consume(consumed, kept, wave, NWV);  // the tail, by every wavefront
   return bad ? -1 : kept;
 }
 
@@ -455,48 +470,53 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
   return 0.0f - acc;
 }
 
-// wg_score_l2: scores[i] = -||q - table[ids[i]]||^2 for i < n.  All threads of
-// the workgroup (NTHREADS = blockDim.x).  ids must be in range (the walker and
-// index validation guarantee it on the fused path).  qv: f32[d] (LDS or global).
-// U row loads per lane are in flight at once (U * 16 KB per workgroup), and the
-// candidate ids of the next batch are fetched underneath them.
-// lds_scores (nullable, LDS): mirror of scores[] for positions lds_off + i < kLdsScores.
-template <int LPR, int DT, int NTHREADS>
-__device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids,
-                                            int n, const float* qv, float* scores, float* lds_scores,
-                                            int lds_off) {
-  constexpr int U = ((DT == DT_F32) ? 4 : 8) * (NTHREADS <= 512 ? 2 : 1);  // same bytes in flight per CU
-  constexpr int GPW = 64 / LPR;              // rows per wavefront per load
-  constexpr int RPI = (NTHREADS / 64) * GPW;  // rows per workgroup iteration
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
+// NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
+// inside, so a subset of the workgroup can run it while the walker wavefront keeps walking.
+// ids must be in range (the walker and index validation guarantee it on the fused path).
+// qv: f32[d] (LDS or global).  U row loads per lane are in flight at once (U * 16 KB per
+// workgroup), and the candidate ids of the next batch are fetched underneath them.
+template <int LPR, int DT, int NWAVES>
+__device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table, int d, const int32_t* ids,
+                                                 int begin, int end, const float* qv, float* scores,
+                                                 int wave_rel) {
+  constexpr int U = (DT == DT_F32) ? 4 : 8;
+  constexpr int GPW = 64 / LPR;      // rows per wavefront per load
+  constexpr int RPI = NWAVES * GPW;  // rows per iteration of the participating wavefronts
+  if (end <= begin) return;
+  const int lane = threadIdx.x & 63;
   const int sub = lane % LPR, grp = lane / LPR;
-  const int slot = wave * GPW + grp;
+  const int slot = wave_rel * GPW + grp;
   float q[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
-  // branch-free: positions past n re-read candidate n-1 and their result is dropped
+  // branch-free: positions past `end` re-read candidate end-1 and their result is dropped
   int32_t nxt[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) nxt[u] = ids[min(u * RPI + slot, n - 1)];
-  for (int i0 = 0; i0 < n; i0 += RPI * U) {
+  for (int u = 0; u < U; ++u) nxt[u] = ids[min(begin + u * RPI + slot, end - 1)];
+  for (int i0 = begin; i0 < end; i0 += RPI * U) {
     RowChunk<DT> ch[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) ch[u] = load_chunk<DT>(table, (size_t)nxt[u], d, sub);
 #pragma unroll
     for (int u = 0; u < U; ++u)  // ids of the next batch, underneath the row loads
-      nxt[u] = ids[min(i0 + RPI * U + u * RPI + slot, n - 1)];
+      nxt[u] = ids[min(i0 + RPI * U + u * RPI + slot, end - 1)];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * RPI + slot;
       float x[8];
       chunk_to_float<DT>(ch[u], x);
       const float s = l2_finish<LPR>(q, x);
-      if (sub == 0 && i < n) {
-        scores[i] = s;
-        if (lds_scores != nullptr && lds_off + i < kLdsScores) lds_scores[lds_off + i] = s;
-      }
+      if (sub == 0 && i < end) scores[i] = s;
     }
   }
+}
+
+// whole workgroup, i < n
+template <int LPR, int DT, int NTHREADS>
+__device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids,
+                                            int n, const float* qv, float* scores) {
+  wg_score_l2_part<LPR, DT, NTHREADS / 64>(table, d, ids, 0, n, qv, scores, threadIdx.x >> 6);
 }
 
 // ---------------------------------------------------------------------------

@@ -198,9 +198,25 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
             __syncthreads();
           }
         }
-        if (kept == -2)
-          kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
-                                           scratch, &gathered, ss == 0 ? nullptr : pt);
+        if (kept == -2) {
+          if constexpr (SC == NANN_SCORER_L2) {
+            // the L2 scorer runs underneath the walk: the copying wavefronts score every id the
+            // walker has released (GatherV2 + scorer of forward(), :91-107 / :124,138)
+            float* sc_dst = sv.cand_scores + base_off;
+            auto stream_score = [&](int begin, int end, int wave_rel, int n_waves) {
+              if (ss == 0) return;
+              if (n_waves == NT / 64)
+                wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, dst, begin, end, qv, sc_dst, wave_rel);
+              else
+                wg_score_l2_part<LPR, DT, NT / 64 - 1>(a.emb, a.d, dst, begin, end, qv, sc_dst, wave_rel);
+            };
+            kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
+                                             scratch, &gathered, ss == 0 ? nullptr : pt, stream_score);
+          } else {
+            kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
+                                             scratch, &gathered, ss == 0 ? nullptr : pt);
+          }
+        }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {
@@ -228,7 +244,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
       mark(PH_OTHER);
       if constexpr (SC == NANN_SCORER_L2) {
-        wg_score_l2<LPR, DT, NT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out, lds_scores, base_off);
+        // stage 0 scores the entry points here; later stages were scored underneath the walk
+        if (r == 0) wg_score_l2<LPR, DT, NT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out);
+        __syncthreads();
+        for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
+          lds_scores[base_off + i] = sc_out[i];
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         wg_mlp_query_setup<NT>(a.mlp, qv, M);  // the phase scratch was reused since the last stage
