@@ -131,6 +131,61 @@ def bitmap_ref_difference(idx_next_values, idx_next_row_splits, idx_flag):
     return out[: n_out.value], out_rs[: n_rs.value], idx_flag
 
 
+# ---- a8: sibling ops the reference registers next to these (not wired into the serving
+# graph), expressed with the kernels above ------------------------------
+def bitmap_init(idx, length):
+    """tf.bitmap_init (UO/bitmap_op/bitmap_ops.cc:28-75): int32[length] bitmap with the bits
+    of `idx` set."""
+    idx = _dev(idx, torch.int32)
+    if length < 0 or idx.numel() > length:  # the reference's own check (:56-57)
+        raise InvalidArgumentError(7, f"require: length >= idx.size() and length >=0 but length:{length}"
+                                      f"idx.size():{idx.numel()}")
+    flags = torch.zeros(max(length, 0), dtype=torch.int32, device=idx.device)
+    if idx.numel():
+        bitmap_ref_difference(idx, [0, idx.numel()], flags)
+    return flags
+
+
+def bitmap_difference(idx_next, idx_flag):
+    """tf.bitmap_difference (bitmap_ops.cc:83-143): value-semantics variant of
+    bitmap_ref_difference over one flat list; returns (idx_next_new, idx_flag_new) and
+    leaves `idx_flag` untouched."""
+    idx = _dev(idx_next, torch.int32)
+    flags = _dev(idx_flag, torch.int32).clone()
+    if idx.numel() == 0:
+        return idx, flags
+    out, _, flags = bitmap_ref_difference(idx, [0, idx.numel()], flags)
+    return out, flags
+
+
+def batch_top_k_on_rt(values, row_splits, k, ascending=False):
+    """tf.batch_top_k_on_rt (UO/topk_op/BatchTopKOnRT_kernel.cc:24-155): per ragged row the
+    min(k, len) best values, row-local int64 indices and the output row_splits.  Equal values
+    keep their input order (the reference's std::partial_sort_copy leaves it unspecified)."""
+    v = _dev(values, torch.float32)
+    rs = torch.as_tensor(np.asarray(row_splits.cpu() if isinstance(row_splits, torch.Tensor) else row_splits),
+                         dtype=torch.int64)
+    if rs.numel() == 0 or int(rs[0]) != 0 or int(rs[-1]) != v.numel():
+        code = 1 if rs.numel() == 0 else (2 if int(rs[0]) != 0 else 3)
+        raise InvalidArgumentError(3, f"Invalid RaggedTensor input, code: {code}")
+    groups = rs.numel() - 1
+    ks = [int(k)] * groups if np.ndim(k) == 0 else [int(x) for x in k]
+    if len(ks) != groups:
+        raise InvalidArgumentError(7, f"Size of k vector does NOT match number of groups: {len(ks)}!={groups}")
+    vals, idxs, out_rs = [], [], [0]
+    for g in range(groups):
+        s, e = int(rs[g]), int(rs[g + 1])
+        kk = max(0, min(ks[g], e - s))
+        if kk:
+            row = v[s:e]
+            tv, ti = top_k(-row if ascending else row, kk)
+            vals.append(row[ti.long()])
+            idxs.append(ti.to(torch.int64))
+        out_rs.append(out_rs[-1] + kk)
+    cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=v.device)
+    return cat(vals, torch.float32), cat(idxs, torch.int64), torch.tensor(out_rs, dtype=torch.int64)
+
+
 # ---- a3: GatherV2 ---------------------------------------------------------------
 def gather(params, indices):
     """tf.gather axis 0 (core/kernels/gather_op.cc, gather_functor.h:38-116)."""

@@ -68,6 +68,27 @@ class Index:
         self._ws = None
 
     @classmethod
+    def from_files(cls, index_dir, item_embs_dir, start_level=2):
+        """Load the reference's on-disk artefacts straight into HBM through HugeConst, with the
+        dtype casts build_model() requests (build_opt_graph.py:70,83-90): `item_embs.npy` -> f16,
+        `item_ids.npy` i64, `neighbors_level_{l}_values.npy` -> i32, `..._row_splits.npy` i64,
+        `enter_points.npy` -> i32 (files as written by build_hnsw_index.py:41-67)."""
+        import os
+        assert start_level == 2, "the serving graph walks levels 1 and 0 below the entry layer"
+        hc = {
+            "embs": ops.huge_const(os.path.join(item_embs_dir, "item_embs.npy"), np.float16),
+            "ids": ops.huge_const(os.path.join(item_embs_dir, "item_ids.npy"), np.int64),
+            "ep": ops.huge_const(os.path.join(index_dir, "enter_points.npy"), np.int32),
+        }
+        for l in (0, 1):
+            hc[f"v{l}"] = ops.huge_const(os.path.join(index_dir, f"neighbors_level_{l}_values.npy"), np.int32)
+            hc[f"rs{l}"] = ops.huge_const(os.path.join(index_dir, f"neighbors_level_{l}_row_splits.npy"), np.int64)
+        ix = cls(hc["embs"].tensor, hc["ids"].tensor, [hc["v0"].tensor, hc["v1"].tensor],
+                 [hc["rs0"].tensor, hc["rs1"].tensor], hc["ep"].tensor)
+        ix._huge_consts = hc  # the HugeConst objects own the HBM the tensors view
+        return ix
+
+    @classmethod
     def from_dict(cls, g, device=None):
         return cls(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"],
                    device=device)

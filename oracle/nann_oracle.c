@@ -140,6 +140,86 @@ int oracle_bitmap_ref_difference_i32(const int32_t* values, int64_t n_values,
 }
 
 /* ------------------------------------------------------------------------ */
+/* sibling ops                                              */
+int oracle_bitmap_init_i32(const int32_t* idx, int64_t n_idx, int32_t length, int32_t* bitmap) {
+  if (length < 0 || n_idx > length) return ORACLE_ERR_BAD_ARGUMENT; /* bitmap_ops.cc:56-57 */
+  memset(bitmap, 0, (size_t)length * 4);
+  for (int64_t i = 0; i < n_idx; ++i) { /* :65-72 */
+    const int32_t node = idx[i];
+    if (node < 0 || (node >> 5) >= length) return ORACLE_ERR_INDEX_OUT_OF_RANGE; /* UB in the reference */
+    ((uint32_t*)bitmap)[node >> 5] |= 1u << (node & 31);
+  }
+  return ORACLE_OK;
+}
+
+int oracle_bitmap_difference_i32(const int32_t* idx_next, int64_t n, const int32_t* idx_flag,
+                                 int64_t n_words, int32_t* idx_next_new, int64_t* n_out,
+                                 int32_t* idx_flag_new) {
+  for (int64_t i = 0; i < n; ++i)
+    if (idx_next[i] < 0 || (idx_next[i] >> 5) >= n_words) return ORACLE_ERR_INDEX_OUT_OF_RANGE;
+  memcpy(idx_flag_new, idx_flag, (size_t)n_words * 4); /* :117-121 */
+  uint32_t* bm = (uint32_t*)idx_flag_new;
+  int64_t w = 0;
+  for (int64_t i = 0; i < n; ++i) { /* :124-132 */
+    const int32_t node = idx_next[i];
+    const uint32_t bit = 1u << (node & 31);
+    if (!(bm[node >> 5] & bit)) {
+      idx_next_new[w++] = node;
+      bm[node >> 5] |= bit;
+    }
+  }
+  *n_out = w;
+  return ORACLE_OK;
+}
+
+typedef struct { const float* v; int asc; } rt_cmp_t;
+static int rt_cmp(const void* pa, const void* pb, void* ctx) {
+  const rt_cmp_t* c = (const rt_cmp_t*)ctx;
+  const int64_t a = *(const int64_t*)pa, b = *(const int64_t*)pb;
+  const float va = c->v[a], vb = c->v[b];
+  if (c->asc ? va < vb : va > vb) return -1;
+  if (c->asc ? va > vb : va < vb) return 1;
+  return a < b ? -1 : (a > b ? 1 : 0); /* ties: lower position (unspecified in the reference) */
+}
+
+int oracle_batch_topk_on_rt_f32(const float* values, int64_t n_values, const int64_t* row_splits,
+                                int64_t n_splits, const int64_t* k, int k_is_scalar, int ascending,
+                                float* values_out, int64_t* idx_out, int64_t* row_splits_out,
+                                int64_t* n_out, int64_t* n_out_splits, int* ragged_code) {
+  const int code = oracle_validate_ragged(n_values, row_splits, n_splits);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_INPUT; /* BatchTopKOnRT_kernel.cc:73-75 */
+  const int64_t groups = n_splits - 1;
+  row_splits_out[0] = 0;
+  if (groups == 0) { /* void input :84-92 */
+    *n_out = 0; *n_out_splits = 1;
+    return ORACLE_OK;
+  }
+  int64_t* tmp = (int64_t*)malloc((size_t)(n_values ? n_values : 1) * 8);
+  if (!tmp) return ORACLE_ERR_BAD_ARGUMENT;
+  rt_cmp_t ctx = {values, ascending};
+  int64_t w = 0;
+  for (int64_t g = 0; g < groups; ++g) {
+    const int64_t s = row_splits[g], e = row_splits[g + 1], len = e - s;
+    int64_t kk = k_is_scalar ? k[0] : k[g];
+    if (kk < 0) kk = 0;
+    if (kk > len) kk = len; /* min(len, k) :113-117 */
+    for (int64_t i = 0; i < len; ++i) tmp[i] = s + i;
+    qsort_r(tmp, (size_t)len, 8, rt_cmp, &ctx);
+    for (int64_t i = 0; i < kk; ++i) {
+      values_out[w] = values[tmp[i]];
+      idx_out[w] = tmp[i] - s; /* row-local :145-146 */
+      ++w;
+    }
+    row_splits_out[g + 1] = w;
+  }
+  free(tmp);
+  *n_out = w;
+  *n_out_splits = n_splits;
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* GatherV2, axis 0: gather_functor.h:38-116 (memcpy per row :96-103)        */
 int oracle_gather_rows(const void* params, int64_t n_rows, int64_t row_bytes,
                        const int32_t* idx, int64_t n_idx, void* out, int64_t* bad_i) {

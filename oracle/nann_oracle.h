@@ -79,6 +79,31 @@ int oracle_bitmap_ref_difference_i32(const int32_t* values, int64_t n_values,
                                      int64_t* n_out, int64_t* n_out_splits,
                                      int* ragged_code);
 
+/* ---- sibling ops of SURVEY.md 8(a8): registered by the reference but not wired into the
+ * serving graph.  Covered: BitmapInit, BitmapDifference, BatchTopKOnRT.  Not covered:
+ * BloomFilterDifference (needs FarmHash Fingerprint64, absent from the tree), BlazeTopK
+ * (unstable ties and an out-of-bounds loop). */
+
+/* BitmapInit<int32> (bitmap_ops.cc:28-75): length-word bitmap with the bits of idx set.
+ * Requires 0 <= length and n_idx <= length (:56-57, the reference's own odd check). */
+int oracle_bitmap_init_i32(const int32_t* idx, int64_t n_idx, int32_t length, int32_t* bitmap);
+
+/* BitmapDifference<int32> (bitmap_ops.cc:83-143): value-semantics variant -- copies the
+ * bitmap, then the same first-occurrence filter over ONE flat list. */
+int oracle_bitmap_difference_i32(const int32_t* idx_next, int64_t n, const int32_t* idx_flag,
+                                 int64_t n_words, int32_t* idx_next_new, int64_t* n_out,
+                                 int32_t* idx_flag_new);
+
+/* BatchTopKOnRT<float> (UO/topk_op/BatchTopKOnRT_kernel.cc:62-155): per ragged row the
+ * min(k[i], len) best values (descending, or ascending), row-local indices.  The reference
+ * uses std::partial_sort_copy, whose order among EQUAL values is unspecified; this
+ * restatement breaks ties by lower position (one of the valid outcomes).
+ * k_is_scalar: k[0] applies to every row (:99-101). */
+int oracle_batch_topk_on_rt_f32(const float* values, int64_t n_values, const int64_t* row_splits,
+                                int64_t n_splits, const int64_t* k, int k_is_scalar, int ascending,
+                                float* values_out, int64_t* idx_out, int64_t* row_splits_out,
+                                int64_t* n_out, int64_t* n_out_splits, int* ragged_code);
+
 /* GatherV2 axis 0 (gather_functor.h:38-116): out[i,:] = params[idx[i],:].
  * row_bytes = slice bytes.  bad index -> ORACLE_ERR_INDEX_OUT_OF_RANGE and
  * *bad_i = first bad position (gather_op.cc:170-175). */

@@ -127,6 +127,36 @@ def bitmap_ref_difference(values, row_splits, bitmap):
     return rc, code.value, out[:n_out.value].copy(), ors[:n_os.value].copy()
 
 
+def bitmap_init(idx, length):
+    idx = _c(idx, np.int32)
+    bm = np.zeros(max(length, 1), np.int32)
+    rc = lib().oracle_bitmap_init_i32(_p(idx), C.c_int64(len(idx)), C.c_int32(length), _p(bm))
+    return rc, bm[:max(length, 0)]
+
+
+def bitmap_difference(idx_next, idx_flag):
+    v = _c(idx_next, np.int32); f = _c(idx_flag, np.int32)
+    out = np.zeros(max(len(v), 1), np.int32); fnew = np.zeros(max(len(f), 1), np.int32)
+    n_out = C.c_int64(0)
+    rc = lib().oracle_bitmap_difference_i32(_p(v), C.c_int64(len(v)), _p(f), C.c_int64(len(f)), _p(out),
+                                            C.byref(n_out), _p(fnew))
+    return rc, out[:n_out.value].copy(), fnew[:len(f)]
+
+
+def batch_topk_on_rt(values, row_splits, k, ascending=False):
+    v = _c(values, np.float32); rs = _c(row_splits, np.int64)
+    scalar = np.ndim(k) == 0
+    kk = _c(np.atleast_1d(k), np.int64)
+    ov = np.zeros(max(len(v), 1), np.float32); oi = np.zeros(max(len(v), 1), np.int64)
+    ors = np.zeros(max(len(rs), 1), np.int64)
+    n_out = C.c_int64(0); n_os = C.c_int64(0); code = C.c_int(0)
+    rc = lib().oracle_batch_topk_on_rt_f32(_p(v), C.c_int64(len(v)), _p(rs), C.c_int64(len(rs)), _p(kk),
+                                           C.c_int(1 if scalar else 0), C.c_int(1 if ascending else 0),
+                                           _p(ov), _p(oi), _p(ors), C.byref(n_out), C.byref(n_os),
+                                           C.byref(code))
+    return rc, ov[:n_out.value].copy(), oi[:n_out.value].copy(), ors[:n_os.value].copy()
+
+
 def gather_rows(params, idx):
     params = np.ascontiguousarray(params)
     idx = _c(idx, np.int32)

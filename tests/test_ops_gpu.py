@@ -299,3 +299,25 @@ def test_mlp_score(oracle, d, dtype):
     assert (bits(got3) == bits(exp[:37])).all()
     with pytest.raises(ops.InvalidArgumentError):
         ops.blaze_score(sc, cuda(q), table=dev, indices=[0, n_table])
+
+
+# ---------------------------------------------------------------- sibling ops (8 a8)
+def test_sibling_ops(oracle, ref_ops):
+    from nann_amd import ops
+    for case in ref_ops["batch_topk_on_rt"]:
+        v, i, rs = ops.batch_top_k_on_rt(case["values"], case["row_splits"], case["k"], case["ascending"])
+        assert v.cpu().tolist() == case["values_out"] and i.cpu().tolist() == case["idx_out"], case["name"]
+        assert rs.tolist() == case["row_splits_out"], case["name"]
+    rng = np.random.default_rng(16)
+    idx = rng.integers(0, 5000, size=2000).astype(np.int32)
+    rc, bm = oracle.bitmap_init(idx, 2000)
+    assert (ops.bitmap_init(idx, 2000).cpu().numpy() == bm).all()
+    flags = rng.integers(-2**31, 2**31, size=200, dtype=np.int64).astype(np.int32)
+    nxt = rng.integers(0, 6400, size=3000).astype(np.int32)
+    rc, out, fnew = oracle.bitmap_difference(nxt, flags)
+    dflags = cuda(flags)
+    got, gflags = ops.bitmap_difference(nxt, dflags)
+    assert (got.cpu().numpy() == out).all() and (gflags.cpu().numpy() == fnew).all()
+    assert (dflags.cpu().numpy() == flags).all()  # value semantics: input untouched
+    with pytest.raises(ops.InvalidArgumentError):
+        ops.bitmap_init([1, 2, 3], 2)

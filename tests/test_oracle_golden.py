@@ -152,3 +152,21 @@ def test_regression_vectors(oracle, golden_dir, name):
     # single-query entry point agrees with the batch one
     rc, ids0, sc0, idx0, c0 = oracle.search(ix, sc, q[0], z["level_topn"])
     assert rc == 0 and (ids0 == ids[0]).all()
+
+
+def test_sibling_ops(oracle, ref_ops):
+    """BatchTopKOnRT against the reference test's known answers; BitmapInit /
+    BitmapDifference against the Ref variant they are defined by."""
+    for case in ref_ops["batch_topk_on_rt"]:
+        rc, v, i, rs = oracle.batch_topk_on_rt(case["values"], case["row_splits"], case["k"], case["ascending"])
+        assert rc == 0, case["name"]
+        assert v.tolist() == case["values_out"] and i.tolist() == case["idx_out"], case["name"]
+        assert rs.tolist() == case["row_splits_out"], case["name"]
+    rc, bm = oracle.bitmap_init([1, 1, 2, 33, 63], 5)
+    assert rc == 0 and bm.tolist() == [6, -2147483646, 0, 0, 0]
+    rc, _ = oracle.bitmap_init([1, 2, 3], 2)  # n_idx > length (bitmap_ops.cc:56-57)
+    assert rc == oracle.ERR_BAD_ARGUMENT
+    flags = np.array([32254, 0, 0, 0], np.int32)
+    rc, out, fnew = oracle.bitmap_difference([4, 40, 40, 6, 41], flags)
+    assert rc == 0 and out.tolist() == [40, 41] and flags.tolist() == [32254, 0, 0, 0]
+    assert fnew.tolist() == [32254, 768, 0, 0]

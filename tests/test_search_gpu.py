@@ -173,3 +173,23 @@ def test_long_rows_with_repeated_ids(oracle):
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
     assert (exp[0] == 0).mean() > 0.5
     _assert_same(_run(dix, q, topn), exp)
+
+
+def test_index_from_reference_files(oracle, tmp_path):
+    """The index as build_hnsw_index.py leaves it on disk (f32 embeddings, int64 neighbour
+    values and enter points) -> HugeConst loads with build_model()'s casts -> same results as
+    the oracle on the cast arrays."""
+    from nann_amd import retrieval, synth
+    g, _, _ = synth_index(20000, 64, 32)
+    d = str(tmp_path)
+    disk = dict(g)
+    disk["item_embs"] = g["item_embs"].astype(np.float32)      # extract_feature writes f32
+    disk["nb_values"] = [v.astype(np.int64) for v in g["nb_values"]]  # build_hnsw_index.py:66
+    synth.save_index(disk, d)
+    dix = retrieval.Index.from_files(d, d)
+    assert dix.item_embs.dtype == torch.float16 and dix.nb_values[0].dtype == torch.int32
+    oix = oracle.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 32, seed=4)])
+    topn = [32] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
+    _assert_same(_run(dix, q, topn), exp)
