@@ -764,6 +764,105 @@ int oracle_search_batch(const oracle_index_t* ix, const oracle_scorer_t* sc, con
   return ORACLE_OK;
 }
 
+/* ------------------------------------------------------------------------ */
+/* eval-graph variant: model.py:299-362                                      */
+static int cmp_i32(const void* a, const void* b) {
+  const int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int oracle_search_eval(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                       const int32_t num_scoring[3], const int32_t top_k_per_level[3],
+                       int32_t topk_eval, int64_t* out_item_ids, float* out_scores,
+                       int32_t* out_index, int32_t* n_out) {
+  if (!scorer_ok(sc) || sc->d != ix->d || sc->emb_dtype != ix->emb_dtype) return ORACLE_ERR_BAD_ARGUMENT;
+  if (num_scoring[2] != 1) return ORACLE_ERR_BAD_ARGUMENT; /* model.py:347 */
+  const int64_t N = ix->n_items;
+  int rc = ORACLE_OK;
+  char* tmp = NULL; int64_t tmp_cap = 0;
+  uint8_t* visited = (uint8_t*)calloc((size_t)N, 1);
+  uint8_t* seen = (uint8_t*)calloc((size_t)N, 1);
+  int64_t cap = ix->n_enter + 1;
+  for (int l = 0; l < 2; ++l) if (ix->nb_nnz[l] + 1 > cap) cap = ix->nb_nnz[l] + 1;
+  if (cap < N + 1) cap = N + 1;
+  int32_t* res_ids = (int32_t*)malloc((size_t)cap * 4);
+  float* res_sc = (float*)malloc((size_t)cap * 4);
+  int32_t* cat_ids = (int32_t*)malloc((size_t)cap * 2 * 4);
+  float* cat_sc = (float*)malloc((size_t)cap * 2 * 4);
+  int32_t* nxt = (int32_t*)malloc((size_t)cap * 4);
+  float* nxt_sc = (float*)malloc((size_t)cap * 4);
+  int32_t* cand = (int32_t*)malloc((size_t)cap * 4);
+  int32_t* tidx = (int32_t*)malloc((size_t)cap * 2 * 4);
+  if (!visited || !seen || !res_ids || !res_sc || !cat_ids || !cat_sc || !nxt || !nxt_sc || !cand || !tidx) {
+    rc = ORACLE_ERR_BAD_ARGUMENT;
+    goto done;
+  }
+  /* start level: score all enter points, keep min(k, n) (:349-352, :268) */
+  int64_t n_res = ix->n_enter;
+  if (n_res <= 0) { rc = ORACLE_ERR_EMPTY_SCORE_BATCH; goto done; }
+  rc = forward(ix, sc, q, ix->enter_points, n_res, cat_sc, &tmp, &tmp_cap);
+  if (rc == ORACLE_ERR_TOPK_SCALAR_INPUT) rc = ORACLE_OK; /* a single candidate is fine here: k = min(k, n) */
+  if (rc) goto done;
+  {
+    int32_t k = top_k_per_level[2] < n_res ? top_k_per_level[2] : (int32_t)n_res;
+    rc = topk_ids(ix->enter_points, cat_sc, n_res, k, res_ids, res_sc, tidx);
+    if (rc) goto done;
+    n_res = k;
+  }
+  for (int level = 1; level >= 0; --level) { /* search_level, :299-337 */
+    memset(visited, 0, (size_t)N);
+    for (int64_t i = 0; i < n_res; ++i) visited[res_ids[i]] = 1; /* visited_idx = idx_ep */
+    int64_t n_cand = n_res;
+    memcpy(cand, res_ids, (size_t)n_res * 4);
+    for (int it = 0; it < num_scoring[level]; ++it) {
+      /* neighbours of the candidates, unique, minus visited, ascending (:316-319) */
+      int64_t n_next = 0;
+      for (int64_t i = 0; i < n_cand; ++i) {
+        const int64_t s = ix->nb_row_splits[level][cand[i]], e = ix->nb_row_splits[level][cand[i] + 1];
+        for (int64_t j = s; j < e; ++j) {
+          const int32_t v = ix->nb_values[level][j];
+          if (v < 0 || v >= N) { rc = ORACLE_ERR_INDEX_OUT_OF_RANGE; goto done; }
+          if (!visited[v] && !seen[v]) { seen[v] = 1; nxt[n_next++] = v; }
+        }
+      }
+      qsort(nxt, (size_t)n_next, 4, cmp_i32);
+      for (int64_t i = 0; i < n_next; ++i) { seen[nxt[i]] = 0; visited[nxt[i]] = 1; } /* :321 */
+      if (n_next == 0) { rc = ORACLE_ERR_EMPTY_SCORE_BATCH; goto done; }
+      rc = forward(ix, sc, q, nxt, n_next, nxt_sc, &tmp, &tmp_cap); /* :323 */
+      if (rc == ORACLE_ERR_TOPK_SCALAR_INPUT) rc = ORACLE_OK;
+      if (rc) goto done;
+      /* top-k of result || next (:326-328) */
+      memcpy(cat_ids, res_ids, (size_t)n_res * 4);
+      memcpy(cat_sc, res_sc, (size_t)n_res * 4);
+      memcpy(cat_ids + n_res, nxt, (size_t)n_next * 4);
+      memcpy(cat_sc + n_res, nxt_sc, (size_t)n_next * 4);
+      const int64_t n_cat = n_res + n_next;
+      const int32_t k = top_k_per_level[level] < n_cat ? top_k_per_level[level] : (int32_t)n_cat;
+      rc = topk_ids(cat_ids, cat_sc, n_cat, k, res_ids, res_sc, tidx);
+      if (rc) goto done;
+      n_res = k;
+      /* next frontier: new nodes scoring at least the worst kept result (:333-334) */
+      const float worst = res_sc[n_res - 1];
+      n_cand = 0;
+      for (int64_t i = 0; i < n_next; ++i)
+        if (nxt_sc[i] >= worst) cand[n_cand++] = nxt[i];
+    }
+  }
+  {
+    const int32_t k = topk_eval < n_res ? topk_eval : (int32_t)n_res; /* results[:topk_eval] :358 */
+    for (int32_t i = 0; i < k; ++i) {
+      if (out_index) out_index[i] = res_ids[i];
+      out_scores[i] = res_sc[i];
+      out_item_ids[i] = ix->item_ids[res_ids[i]];
+    }
+    *n_out = k;
+  }
+done:
+  free(tmp); free(visited); free(seen); free(res_ids); free(res_sc); free(cat_ids); free(cat_sc);
+  free(nxt); free(nxt_sc); free(cand); free(tidx);
+  return rc;
+}
+
 int oracle_brute_force(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
                        int32_t k, int32_t* out_index, float* out_scores) {
   if (!scorer_ok(sc)) return ORACLE_ERR_BAD_ARGUMENT;

@@ -182,6 +182,22 @@ int oracle_search(const oracle_index_t* ix, const oracle_scorer_t* sc,
                   int64_t* out_item_ids, float* out_scores, int32_t* out_index,
                   oracle_counters_t* ctr);
 
+/* SURVEY.md 8(f3), oracle side only so far: the EVAL-graph search `Model.retrieval` /
+ * `search_level` (NANN_impls/nann/model/model.py:299-362), a different schedule from
+ * build_model(): per level `num_scoring[level]` rounds; candidates of a round =
+ * sorted(unique(neighbours) - visited) (tf.unique + tf.sets.set_difference: ascending id
+ * order); the result set is re-top-k'ed every round to `top_k_per_level[level]` with
+ * k = min(k, n) (:268); next frontier = new nodes with score >= the worst kept score
+ * (:333-334); one visited set per level seeded with the level's entry set; results
+ * truncated to topk_eval (:358).  Defaults of the reference: start level 2,
+ * num_scoring = [3,1,1], top_k_per_level = [400,200,100], topk_eval = 200 (config.py:50-58).
+ * Arrays are indexed by level (0,1,2); num_scoring[2] must be 1 (:347).
+ * out_* have topk_eval entries; *n_out = entries actually produced. */
+int oracle_search_eval(const oracle_index_t* ix, const oracle_scorer_t* sc, const float* q,
+                       const int32_t num_scoring[3], const int32_t top_k_per_level[3],
+                       int32_t topk_eval, int64_t* out_item_ids, float* out_scores,
+                       int32_t* out_index, int32_t* n_out);
+
 /* n_queries independent searches, one query per thread (mirrors the
  * reference's sessions x threads concurrency, gen_benchmark_conf.py:22-30).
  * status[i] per query.  Returns ORACLE_OK if the batch ran. */

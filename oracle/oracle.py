@@ -260,6 +260,18 @@ def search(index, scorer, q, level_topn):
     return rc, ids[:k], sc[:k], ix[:k], counters
 
 
+def search_eval(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 200, 100), topk_eval=200):
+    """Eval-graph variant (model.py:299-362). -> (status, item_ids, scores, idx)"""
+    q = _c(q, np.float32)
+    ns = _c(num_scoring, np.int32); tk = _c(top_k_per_level, np.int32)
+    ids = np.zeros(max(topk_eval, 1), np.int64); sc = np.zeros(max(topk_eval, 1), np.float32)
+    ix = np.zeros(max(topk_eval, 1), np.int32)
+    n = C.c_int32(0)
+    rc = lib().oracle_search_eval(C.byref(index.s), C.byref(scorer.s), _p(q), _p(ns), _p(tk),
+                                  C.c_int32(topk_eval), _p(ids), _p(sc), _p(ix), C.byref(n))
+    return rc, ids[:n.value], sc[:n.value], ix[:n.value]
+
+
 def search_batch(index, scorer, q, level_topn, n_threads=1):
     """-> (status[nq], item_ids[nq,k], scores[nq,k], idx[nq,k], counters[nq,3,5] int64)"""
     q = _c(q, np.float32)

@@ -93,3 +93,45 @@ def test_merge_topk(oracle):
     flat_s, flat_i = s.reshape(-1), ids.reshape(-1)
     order = sorted(range(40), key=lambda i: (-flat_s[i], i))[:10]
     assert rc == 0 and mi.tolist() == flat_i[order].tolist() and ms.tolist() == flat_s[order].tolist()
+
+
+def test_eval_graph_variant_matches_python_restatement(oracle, golden_dir):
+    """SURVEY.md 8(f3), oracle side: Model.retrieval / search_level (model.py:299-362) written
+    with Python sets exactly as the TF graph does (tf.unique -> tf.sets.set_difference ->
+    tf.sets.set_union -> top_k(min(k, n)) -> score >= worst frontier rule)."""
+    z = dict(np.load(os.path.join(golden_dir, "small_l2_d64.npz")))
+    ix = oracle.Index(z["item_embs"], z["item_ids"], [z["nb_values_0"], z["nb_values_1"]],
+                      [z["nb_row_splits_0"], z["nb_row_splits_1"]], z["enter_points"])
+    sc = oracle.Scorer("l2", 64, oracle.EMB_F16)
+    num_scoring, tk, topk_eval = [3, 1, 1], [40, 20, 10], 25
+
+    def score(q, ids):
+        rc, s = oracle.score_rows(sc, q, z["item_embs"][np.asarray(ids, np.int64)])
+        assert rc == 0
+        return s.tolist()
+
+    def py_eval(q):
+        ep = z["enter_points"].tolist()
+        res, sres = py_topk(ep, score(q, ep), min(tk[2], len(ep)))
+        for level in (1, 0):
+            v, rs = z[f"nb_values_{level}"], z[f"nb_row_splits_{level}"]
+            visited = set(res)
+            cand = list(res)
+            for _ in range(num_scoring[level]):
+                nxt = []
+                for c in cand:
+                    nxt.extend(v[rs[c]:rs[c + 1]].tolist())
+                nxt = sorted(set(nxt) - visited)           # tf.unique + tf.sets.set_difference
+                visited |= set(nxt)                        # tf.sets.set_union
+                snxt = score(q, nxt)
+                res, sres = py_topk(res + nxt, sres + snxt, min(tk[level], len(res) + len(nxt)))
+                cand = [i for i, s in zip(nxt, snxt) if s >= sres[-1]]
+        return res[:topk_eval], sres[:topk_eval]
+
+    for b in range(len(z["q"])):
+        rc, ids, scores, idx = oracle.search_eval(ix, sc, z["q"][b], num_scoring, tk, topk_eval)
+        assert rc == 0
+        pres, psc = py_eval(z["q"][b])
+        assert idx.tolist() == pres
+        assert (scores.view(np.uint32) == np.asarray(psc, np.float32).view(np.uint32)).all()
+        assert (ids == z["item_ids"][np.asarray(pres)]).all()
