@@ -1,0 +1,96 @@
+"""HNSW index construction + export in the reference's on-disk layout.
+
+Mirrors NANN_impls/nann/delivery/build_hnsw_index.py: `build_and_save_index(embeddings,
+start_level, num_neighbors, output_dir)` writes `enter_points.npy`,
+`neighbors_level_{l}_values.npy` (int64, -1 slots dropped) and
+`neighbors_level_{l}_row_splits.npy` (int64[N+1], a row for every item, empty when the node is
+absent at that level).  The graph itself comes from nann_amd/csrc/host/hnsw_build.cpp (C++,
+multi-threaded) instead of Faiss, which is not available; its raw arrays have Faiss' shapes
+(`levels`, `offsets`, `neighbors`, `cum_nneighbor_per_level`) so the export code below is the
+reference's, vectorised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "csrc", "host", "hnsw_build.cpp")
+_LIB_PATH = os.path.join(_HERE, "_build", "libnann_host.so")
+_LIB = None
+
+
+def build_host_lib(force=False):
+    """g++ -O3 the host-side builder into nann_amd/_build/libnann_host.so."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_SRC) > os.path.getmtime(_LIB_PATH):
+        os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-mavx2", "-mfma",
+                               "-o", _LIB_PATH, _SRC])
+    return _LIB_PATH
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build_host_lib())
+    return _LIB
+
+
+def build_hnsw(embeddings, num_neighbors=32, ef_construction=40, seed=0, n_threads=None):
+    """-> dict(levels i32[N], offsets i64[N+1], neighbors i32[slots], cum_nneighbor_per_level),
+    the arrays build_hnsw_index.py:36-39 reads from faiss' `index.hnsw`."""
+    x = np.ascontiguousarray(embeddings, dtype=np.float32)
+    n, d = x.shape
+    if n_threads is None:
+        n_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1
+    levels = np.zeros(n, np.int32)
+    offsets = np.zeros(n + 1, np.int64)
+    cum = np.zeros(64, np.int32)
+    n_slots, max_levels = C.c_int64(0), C.c_int32(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    args = [p(x), C.c_int64(n), C.c_int32(d), C.c_int32(num_neighbors), C.c_int32(ef_construction),
+            C.c_uint64(seed), C.c_int32(n_threads), p(levels), p(offsets)]
+    rc = _lib().nann_hnsw_build(*args, None, C.byref(n_slots), p(cum), C.byref(max_levels))
+    if rc:
+        raise ValueError(f"nann_hnsw_build: bad argument ({rc})")
+    neighbors = np.empty(n_slots.value, np.int32)
+    rc = _lib().nann_hnsw_build(*args, p(neighbors), C.byref(n_slots), p(cum), C.byref(max_levels))
+    if rc:
+        raise ValueError(f"nann_hnsw_build: bad argument ({rc})")
+    return {"levels": levels, "offsets": offsets, "neighbors": neighbors,
+            "cum_nneighbor_per_level": cum[: max_levels.value + 1].copy()}
+
+
+def export_levels(raw, start_level=2):
+    """build_hnsw_index.py:41-66 on the raw arrays: enter points = nodes with
+    `levels > start_level`; per level below it a CSR over ALL items."""
+    levels, offsets, neighbors, cum = (raw["levels"], raw["offsets"], raw["neighbors"],
+                                       raw["cum_nneighbor_per_level"])
+    n = len(levels)
+    enter_points = np.nonzero(levels > start_level)[0]                      # :45
+    nb_values, nb_row_splits = [], []
+    for level in range(start_level):                                         # :49
+        width = int(cum[level + 1] - cum[level])
+        present = levels > level                                             # :53 `level >= levels[idx]` -> empty
+        slots = offsets[:-1, None] + int(cum[level]) + np.arange(width)[None, :]
+        vals = neighbors[np.minimum(slots, len(neighbors) - 1)]
+        keep = present[:, None] & (vals >= 0)                                # :59 drop -1 slots
+        row_len = keep.sum(1)
+        rs = np.zeros(n + 1, np.int64)
+        np.cumsum(row_len, out=rs[1:])
+        nb_values.append(vals[keep].astype(np.int64))                        # :66 int64 on disk
+        nb_row_splits.append(rs)
+    return {"enter_points": enter_points, "nb_values": nb_values, "nb_row_splits": nb_row_splits}
+
+
+def build_and_save_index(embeddings, start_level, num_neighbors, output_dir, seed=0, n_threads=None):
+    """Same name and arguments as the reference's function (build_hnsw_index.py:33)."""
+    raw = build_hnsw(embeddings, num_neighbors=num_neighbors, seed=seed, n_threads=n_threads)
+    ex = export_levels(raw, start_level)
+    os.makedirs(output_dir, exist_ok=True)
+    np.save(os.path.join(output_dir, "enter_points.npy"), ex["enter_points"])
+    for level in range(start_level):
+        np.save(os.path.join(output_dir, f"neighbors_level_{level}_values.npy"), ex["nb_values"][level])
+        np.save(os.path.join(output_dir, f"neighbors_level_{level}_row_splits.npy"), ex["nb_row_splits"][level])
+    return raw, ex
