@@ -1,0 +1,144 @@
+"""Request batching in front of the fused traversal.
+
+The reference serves ONE query per `Session::Run` and gets concurrency from
+sessions x virtual GPUs x MPS (blaze-benchmark model.cc:192-235, README.md:175-177).  On the
+MI355X a launch wants hundreds of queries (one workgroup per CU), so the front end keeps the
+reference's request signature --
+
+    comm_seq  f16[1, seq_len * emb_dim]     (build_opt_graph.py:75-79)
+    level_topn i32[6]
+    -> top_k  i64[1, level_topn[5]]         (:151-159)
+
+-- and aggregates concurrent requests into one `nann_search` launch: a dispatcher thread drains
+the queue up to `max_batch` requests or `max_wait_us` after the first one, whichever comes
+first, runs the batch, and completes each caller's future.  A request the reference would have
+failed (TopKV2 with n < k, ...) raises the same InvalidArgument in its caller only.
+
+The backend is any callable `(comm_seq f16[B, seq_len, d], level_topn) -> (top_k i64[B, k],
+status i32[B])`; `device_backend()` builds the real one.
+"""
+import queue
+import threading
+import time
+from concurrent.futures import Future
+
+import numpy as np
+
+
+class RequestFailed(RuntimeError):
+    def __init__(self, status):
+        super().__init__(f"request failed with nann_status {status}")
+        self.status = status
+
+
+class BatchingServer:
+    def __init__(self, backend, seq_len, emb_dim, level_topn, max_batch=1024, max_wait_us=200):
+        self.backend, self.seq_len, self.emb_dim = backend, seq_len, emb_dim
+        self.level_topn = [int(x) for x in level_topn]
+        self.max_batch, self.max_wait = int(max_batch), max_wait_us * 1e-6
+        self._q = queue.Queue()
+        self._stop = threading.Event()
+        self.batches = 0
+        self.requests = 0
+        self._thread = threading.Thread(target=self._run, name="nann-dispatch", daemon=True)
+        self._thread.start()
+
+    def submit(self, comm_seq):
+        """comm_seq: f16 array of seq_len*emb_dim elements (any shape).  -> Future of i64[1, k]."""
+        a = np.asarray(comm_seq, dtype=np.float16).reshape(-1)
+        if a.size != self.seq_len * self.emb_dim:
+            raise ValueError(f"comm_seq must hold {self.seq_len}x{self.emb_dim} values, got {a.size}")
+        f = Future()
+        self._q.put((a, f))
+        return f
+
+    def predict(self, comm_seq, timeout=None):
+        """Blocking call with the reference's request/response shapes."""
+        return self.submit(comm_seq).result(timeout)
+
+    def close(self):
+        self._stop.set()
+        self._q.put(None)
+        self._thread.join()
+
+    def _run(self):
+        while not self._stop.is_set():
+            first = self._q.get()
+            if first is None:
+                break
+            batch = [first]
+            deadline = time.perf_counter() + self.max_wait
+            while len(batch) < self.max_batch:
+                left = deadline - time.perf_counter()
+                try:
+                    item = self._q.get(timeout=max(left, 0)) if left > 0 else self._q.get_nowait()
+                except queue.Empty:
+                    break
+                if item is None:
+                    self._stop.set()
+                    break
+                batch.append(item)
+            seqs = np.stack([b[0] for b in batch]).reshape(len(batch), self.seq_len, self.emb_dim)
+            try:
+                ids, status = self.backend(seqs, self.level_topn)
+                ids, status = np.asarray(ids), np.asarray(status)
+                for i, (_, fut) in enumerate(batch):
+                    if status[i]:
+                        fut.set_exception(RequestFailed(int(status[i])))
+                    else:
+                        fut.set_result(ids[i:i + 1].copy())
+            except Exception as e:  # a failed launch fails every request of the batch
+                for _, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(e)
+            self.batches += 1
+            self.requests += len(batch)
+
+
+def device_backend(index, scorer):
+    """The real backend: user_seq_mean + fused traversal on the current GPU."""
+    import torch
+    from . import ops, retrieval
+
+    def run(seqs, level_topn):
+        q = ops.user_seq_mean(torch.as_tensor(seqs).to(index.device))
+        r = retrieval.search(index, scorer, q, level_topn, want_counters=False)
+        torch.cuda.synchronize()
+        return r.item_ids.cpu().numpy(), r.status.cpu().numpy()
+
+    return run
+
+
+def closed_loop(server, make_request, n_clients, duration_s):
+    """Closed-loop load (blaze-benchmark's consumer threads, predict_request_consumer.cc:17-53):
+    every client issues its next request when the previous one returns.  Returns throughput and
+    latency percentiles in microseconds."""
+    lat, failures = [], [0]
+    lock = threading.Lock()
+    stop = time.perf_counter() + duration_s
+
+    def client(cid):
+        my = []
+        while time.perf_counter() < stop:
+            t0 = time.perf_counter()
+            try:
+                server.predict(make_request(cid))
+            except RequestFailed:
+                with lock:
+                    failures[0] += 1
+            my.append((time.perf_counter() - t0) * 1e6)
+        with lock:
+            lat.extend(my)
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(n_clients)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    wall = time.perf_counter() - t0
+    a = np.sort(np.asarray(lat)) if lat else np.zeros(1)
+    pct = lambda p: float(a[min(len(a) - 1, int(p * len(a)))])
+    return {"requests": len(lat), "failures": failures[0], "throughput_qps": len(lat) / wall,
+            "latency_us": {"p50": pct(0.5), "p90": pct(0.9), "p99": pct(0.99), "max": float(a[-1])},
+            "mean_batch": server.requests / max(server.batches, 1)}
