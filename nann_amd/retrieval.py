@@ -102,9 +102,9 @@ class Index:
         t = (C.c_int32 * 6)(*[int(x) for x in level_topn])
         nbytes = C.c_int64(0)
         _check(lib().nann_search_workspace_bytes(self.handle, t, C.c_int64(n_queries), C.byref(nbytes)))
-        if self._ws is None or self._ws.numel() < nbytes.value:
-            self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
-        return self._ws
+        # a fresh buffer per call (torch's caching allocator makes it cheap and stream-ordered):
+        # concurrent searches on one Index from several threads/streams must not share scratch
+        return torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
 
 
 class SearchResult:
