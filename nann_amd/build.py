@@ -42,15 +42,31 @@ def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     procs = []
     for src, extra, obj in UNITS:
-        cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(SRC_DIR, src), "-o", os.path.join(OUT_DIR, obj)]
+        # one directory per object: --save-temps keeps the device assembly for the audit below
+        odir = os.path.join(OUT_DIR, obj[:-2] + ".d")
+        os.makedirs(odir, exist_ok=True)
+        cmd = [_hipcc()] + FLAGS + extra + ["--save-temps=obj", "-c", os.path.join(SRC_DIR, src),
+                                            "-o", os.path.join(odir, obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((cmd, odir, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)))
+    for cmd, odir, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    # hipcc (ROCm 7.2) can place VGPR spill code ahead of the exec restore of a join block; the
+    # lanes that were masked off then reload garbage (seen: top-k positions all -1).  Refuse
+    # to ship an object with that pattern.
+    from . import isa_audit
+    for cmd, odir, _ in procs:
+        for f in os.listdir(odir):
+            if f.endswith(".s") and "amdgcn" in f:
+                hits = isa_audit.flow_hits(os.path.join(odir, f))
+                if hits:
+                    raise RuntimeError("miscompiled spill placement in %s: %s" % (f, hits[:3]))
+            if not f.endswith(".o") and not os.environ.get("NANN_KEEP_TEMPS"):
+                os.remove(os.path.join(odir, f))  # preprocessed sources, bitcode, assembly: ~15 MB per object
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + \
-           [os.path.join(OUT_DIR, obj) for _, _, obj in UNITS]
+           [os.path.join(OUT_DIR, obj[:-2] + ".d", obj) for _, _, obj in UNITS]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)

@@ -28,9 +28,19 @@ constexpr int kLdsScores = 4096;
 
 enum : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// threadIdx.x behind an opaque asm.  Every building block of the fused kernel starts from
+// its own copy: what it derives from the thread id (lane masks, LDS addresses, ~tid, ...) is
+// then recomputed inside the block instead of being hoisted out of the round / query loops
+// and kept live -- and spilled -- across all the other blocks.
+__device__ __forceinline__ int local_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  __builtin_assume(t >= 0 && t < 1024);
+  return t;
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }  // per-op kernels
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
-__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 
 // ---------------------------------------------------------------------------
@@ -131,7 +141,7 @@ __device__ __forceinline__ void wg_zero_words(uint32_t* p, uint32_t n_words) {
   // n_words is padded to a multiple of 4 by the caller (16-byte stores)
   uint4* p4 = reinterpret_cast<uint4*>(p);
   const uint32_t n4 = n_words >> 2;
-  for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) p4[i] = make_uint4(0, 0, 0, 0);
+  for (uint32_t i = (uint32_t)local_tid(); i < n4; i += blockDim.x) p4[i] = make_uint4(0, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -161,8 +171,8 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
                                               uint32_t n_items, int32_t* out, int base, int* err) {
   constexpr int U = kLdsBm ? 8 : 1;  // steps per batch
   if (n <= 0) return base;
-  const int lane = lane_id();
-  const uint64_t lt = lanemask_lt();
+  const int lane = local_tid() & 63;
+  const uint64_t lt = lanemask_lt(lane);
   bool bad = false;
   for (int c0 = 0; c0 < n; c0 += 64 * U) {
     int32_t x[U];
@@ -270,7 +280,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
                                               PhaseTimer* pt = nullptr, Consume consume = Consume()) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
   long long tsub = pt ? pt->now() : 0;
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
   if (tid == 0) { S->bad = 0; S->kept = 0; S->kept_pub[0] = 0; S->kept_pub[1] = 0; }
@@ -484,7 +494,7 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
   constexpr int GPW = 64 / LPR;      // rows per wavefront per load
   constexpr int RPI = NWAVES * GPW;  // rows per iteration of the participating wavefronts
   if (end <= begin) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = local_tid() & 63;
   const int sub = lane % LPR, grp = lane / LPR;
   const int slot = wave_rel * GPW + grp;
   float q[8];
@@ -516,7 +526,7 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
 template <int LPR, int DT, int NTHREADS>
 __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int d, const int32_t* ids,
                                             int n, const float* qv, float* scores) {
-  wg_score_l2_part<LPR, DT, NTHREADS / 64>(table, d, ids, 0, n, qv, scores, threadIdx.x >> 6);
+  wg_score_l2_part<LPR, DT, NTHREADS / 64>(table, d, ids, 0, n, qv, scores, local_tid() >> 6);
 }
 
 // ---------------------------------------------------------------------------
@@ -556,8 +566,8 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
                                             int64_t* out_mapped, unsigned char* scratch, PhaseTimer* pt) {
   TopkScratch* S = reinterpret_cast<TopkScratch*>(scratch);
   long long tsub = pt ? pt->now() : 0;
-  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const uint64_t lt = lanemask_lt();
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt = lanemask_lt(lane);
   constexpr bool REG = NS > 0;
   uint32_t key[REG ? NS : 1];
   if constexpr (REG) {

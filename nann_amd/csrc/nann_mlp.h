@@ -19,8 +19,9 @@
 //       holds, for candidate l&31, exactly the hidden units its k-slot needs, so h1 never
 //       leaves the register file (no LDS transpose, no HBM round trip)
 //   output: per-lane fma chain over its 64 outputs with w3, then the two k-slots are added.
-// Weights are staged per 16 KB slice (128 k-rows x 32 columns) into LDS by all waves,
-// register-double-buffered so the L2 fetch of slice s+1 hides under the MFMAs of slice s.
+// Weights are staged per 16 KB slice (layer 1: 128 k-rows x 32 columns; layer 2: 32 k-rows x
+// 128 columns) into LDS by all waves, register-double-buffered so the L2 fetch of slice s+1
+// hides under the MFMAs of slice s.
 #pragma once
 #include "nann_device.h"
 
@@ -62,13 +63,14 @@ __device__ __forceinline__ float prelu(float x, float a) {
 // into LDS.  All NT threads; ends with a barrier.
 template <int NT>
 __device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpScratch* S) {
-  for (int j = threadIdx.x; j < P.h1; j += NT) {
+  const int tid = local_tid();
+  for (int j = tid; j < P.h1; j += NT) {
     float acc = P.b1[j];
     for (int k = 0; k < P.d; ++k) acc = __fmaf_rn(qv[k], P.w1[(size_t)k * P.h1 + j], acc);
     S->u[j] = acc;
     S->alpha1[j] = P.alpha1[j];
   }
-  for (int m = threadIdx.x; m < P.h2; m += NT) {
+  for (int m = tid; m < P.h2; m += NT) {
     S->b2[m] = P.b2[m];
     S->alpha2[m] = P.alpha2[m];
     S->w3[m] = P.w3[m];
@@ -96,6 +98,12 @@ __device__ __forceinline__ float packed_elem(const uint4* r, int k) {  // k is a
 // registers).  All NT threads (NT/64 wavefronts x 32 candidates per pass).
 // wg_mlp_query_setup must have run for this query.
 // Rows outside [0, n_table_rows) are read as row 0 (the caller reports them).
+//
+// Schedule: hidden tile t of layer 1 is finished (KS1 weight slices), PReLU'd, and at once
+// contracted into ALL layer-2 tiles (one more slice: rows 32t..32t+31 of W2, contiguous)
+// before tile t+1 starts, so only one layer-1 tile (16 registers) is live next to the H2T
+// layer-2 accumulators.  Every layer-2 output still sees its k rows in ascending tile / row
+// order, i.e. the same fmaf chain as contracting after all of layer 1 (ORDER_H).
 template <int D, int H1T, int H2T, int DT, int NT>
 __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __restrict__ table,
                                              uint32_t n_table_rows, const int32_t* ids, int n,
@@ -107,27 +115,25 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
   constexpr int NV = HALF * EB / 16;                  // uint4 per lane for its half row
   constexpr int KS1 = (HALF + 63) / 64;               // layer-1 slices per tile (64 kk each)
   constexpr int KK1 = HALF < 64 ? HALF : 64;          // kk per layer-1 slice
-  constexpr int KS2 = H1T / 4;                        // layer-2 slices per tile (128 k each)
-  constexpr int NSLICE = H1T * KS1 + H2T * KS2;
-  static_assert(H1T % 4 == 0, "h1 must be a multiple of 128");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int SPT = KS1 + 1;                        // slices per hidden tile: layer 1, then its layer-2 rows
+  constexpr int NSLICE = H1T * SPT;
+  static_assert(H2T * 32 * 32 == kMlpSlice, "a layer-2 slice is 32 rows of W2 (h2 = 128)");
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, slot = lane >> 5;
   const int h1 = H1T * 32, h2 = H2T * 32;
 
-  // slice s -> global source of float4 number f (0..1023): 128 rows x 8 float4
+  // slice s -> global source of float4 number f (0..1023)
   auto slice_src = [&](int s, int f) -> const float4* {
-    const int row = f >> 3, c4 = f & 7;
-    if (s < H1T * KS1) {  // layer 1: rows {kk0+kkl} of slot 0 then of slot 1, columns of tile t
-      const int t = s / KS1, ks = s % KS1;
+    const int t = s / SPT, ks = s % SPT;
+    if (ks < KS1) {  // layer 1: 128 rows x 8 float4 = rows {kk0+kkl} of slot 0 then of slot 1, columns of tile t
+      const int row = f >> 3, c4 = f & 7;
       const int sl = row >> 6, kkl = row & 63;  // LDS row = slot*64 + kk_local
       const int kk = min(ks * 64 + kkl, HALF - 1);
       const size_t grow = (size_t)D + (size_t)sl * HALF + kk;
       return reinterpret_cast<const float4*>(P.w1 + grow * h1 + t * 32) + c4;
     }
-    const int s2 = s - H1T * KS1;  // layer 2: k rows [128*th, 128*th+128), columns of tile mt
-    const int mt = s2 / KS2, th = s2 % KS2;
-    const size_t grow = (size_t)th * 128 + row;
-    return reinterpret_cast<const float4*>(P.w2 + grow * h2 + mt * 32) + c4;
+    // layer 2: rows [32t, 32t+32) of W2, all h2 columns: one contiguous 16 KB block
+    return reinterpret_cast<const float4*>(P.w2 + (size_t)t * 32 * h2) + f;
   };
 
   for (int i0 = 0; i0 < n; i0 += CPP) {
@@ -143,16 +149,16 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
 #pragma unroll
       for (int v = 0; v < NV; ++v) ev[v] = src[v];
     }
-    f32x16 acc1[H1T];
+    f32x16 acc1;
+    f32x16 acc2[H2T];
 #pragma unroll
-    for (int t = 0; t < H1T; ++t)
+    for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[t][r] = S->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot];
-    f32x16 acc2;
-    float part = 0.0f;
+      for (int r = 0; r < 16; ++r) acc2[mt][r] = S->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot];
     float4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
 #pragma unroll
     for (int s = 0; s < NSLICE; ++s) {
+      const int t = s / SPT, ks = s % SPT;
       __syncthreads();  // every wave is done with the previous slice
       reinterpret_cast<float4*>(S->slice)[tid] = pre0;
       reinterpret_cast<float4*>(S->slice)[tid + NT] = pre1;
@@ -161,45 +167,45 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
         pre0 = *slice_src(s + 1, tid);
         pre1 = *slice_src(s + 1, tid + NT);
       }
-      if (s < H1T * KS1) {
-        const int t = s / KS1, ks = s % KS1;
+      if (ks == 0) {  // the per-query part seeds the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = S->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot];
+      }
+      if (ks < KS1) {
 #pragma unroll
         for (int kkl = 0; kkl < KK1; ++kkl) {
           const float a = S->slice[slot * 2048 + kkl * 32 + cand];
           const float b = packed_elem<DT>(ev, ks * 64 + kkl);
-          acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1[t], 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
         }
-        if (s == H1T * KS1 - 1) {  // layer 1 complete: PReLU in place
+        if (ks == KS1 - 1) {  // tile complete: PReLU in place
 #pragma unroll
-          for (int t2 = 0; t2 < H1T; ++t2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              acc1[t2][r] = prelu(acc1[t2][r], S->alpha1[32 * t2 + (r & 3) + 8 * (r >> 2) + 4 * slot]);
+          for (int r = 0; r < 16; ++r)
+            acc1[r] = prelu(acc1[r], S->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot]);
         }
       } else {
-        const int s2 = s - H1T * KS1;
-        const int mt = s2 / KS2, th = s2 % KS2;
-        if (th == 0) {
+        // the accumulators of tile t ARE the B operand: lane (cand, slot) holds hidden units
+        // 32t + (r&3) + 8(r>>2) + 4 slot, exactly the k rows its k-slot contributes
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc2[r] = S->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot];
-        }
+        for (int r = 0; r < 16; ++r) {
+          const int krow = (r & 3) + 8 * (r >> 2) + 4 * slot;  // row of this slice
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int krow = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * slot;
-            const float a = S->slice[krow * 32 + cand];
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[4 * th + tl][r], acc2, 0, 0, 0);
-          }
-        if (th == KS2 - 1) {  // tile mt complete: PReLU, then its share of the final dot
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot;
-            part = __fmaf_rn(prelu(acc2[r], S->alpha2[m]), S->w3[m], part);
+          for (int mt = 0; mt < H2T; ++mt) {
+            const float a = S->slice[krow * (H2T * 32) + 32 * mt + cand];
+            acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[r], acc2[mt], 0, 0, 0);
           }
         }
       }
     }
+    // PReLU of layer 2 and the bias-free output layer: per-lane chain over its 64 outputs
+    float part = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot;
+        part = __fmaf_rn(prelu(acc2[mt][r], S->alpha2[m]), S->w3[m], part);
+      }
     const float other = __shfl_xor(part, 32);
     const float p0 = slot == 0 ? part : other, p1 = slot == 0 ? other : part;
     if (slot == 0 && i < n) scores[i] = p0 + p1;

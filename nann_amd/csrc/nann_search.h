@@ -116,7 +116,7 @@ template <int LPR, int DT, bool LDSBM, int SC, int NT>
 __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
                                           unsigned char* scratch, float* qv, int32_t* ctr,
                                           long long* ticks) {
-  const int tid = threadIdx.x;
+  const int tid = local_tid();
   const int k5 = a.t[5];
   // L2: candidate scores are mirrored in LDS for the selection; the MLP uses that space
   // for its weight slices (and its selection time is negligible next to the MFMAs)
