@@ -58,6 +58,35 @@ def parse():
     return ap.parse_args()
 
 
+def algorithmic_bytes(counters, d, emb_bytes, n_enter, k_out=200):
+    """bytes one query must move, from the per-round counters the kernel
+    emits (frontier F, gathered G, scored S): S*d*sizeof(emb) + G*4 (adjacency) + F*16 (two
+    row_splits) + G*8 (visited word read+write), + entry ids + the result."""
+    c = np.asarray(counters, dtype=np.int64)
+    F, G, S = c[..., 0, :], c[..., 1, :], c[..., 2, :]
+    return (S * d * emb_bytes + G * 12 + F * 16).sum(axis=-1) + n_enter * 4 + k_out * 12
+
+
+def load_pmc_traffic(args):
+    """HBM bytes per k_search launch from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json, written from tools/gpu_final.sh output): PMC counters cannot
+    be read from inside the timed process.  Only reported when the workload matches."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            p = json.load(f)
+    except (OSError, ValueError):
+        return None
+    w = p.get("workload", {})
+    same = (w.get("items") == args.items and w.get("dim") == args.dim and w.get("ef") == args.ef and
+            w.get("batch") == args.batch and w.get("scorer") == args.scorer and w.get("topk") == args.topk)
+    if not same:
+        return None
+    # MI355X_MICROARCH.md (HBM / rocprofv3): KiB units; gfx950 FETCH_SIZE counts wide reads at half size
+    b = (p["FETCH_SIZE_KiB"] * p.get("fetch_correction", 2.0) + p["WRITE_SIZE_KiB"]) * 1024.0
+    return {"bytes_per_launch": b, "source": "profiles/pmc_latest.json (%s)" % p.get("kernel_version", "?")}
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -151,27 +180,38 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- roofline of the traversal kernel (rank-local launch, HIP events on its stream)
-    from oracle import oracle as O  # checker / baseline only
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     status = r.status.cpu().numpy()
     counters = r.counters.cpu().numpy().astype(np.int64)
     n_valid = int((status == 0).sum())
-    bytes_per_launch = float(O.algorithmic_bytes(counters, args.dim, 2, len(g["enter_points"]),
-                                                 args.topk).sum())
+    bytes_per_launch = float(algorithmic_bytes(counters, args.dim, 2, len(g["enter_points"]),
+                                               args.topk).sum())
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "kernel_ms": round(kern_ms, 4),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_query": round(bytes_per_launch / args.batch, 1),
                 "rows_scored_per_query": round(float(counters[:, 2, :].sum(1).mean()), 1)}
+    pmc = load_pmc_traffic(args)
+    if pmc is not None:
+        roofline["traffic"] = pmc["bytes_per_launch"]
+        roofline["traffic_source"] = pmc["source"]
     if args.scorer == "mlp":
         # 2*(256*256 + 256*128 + 128) flop per scored row; f32-input MFMA dense
         # peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The HBM figure is kept alongside.
-        flops = float(counters[:, 2, :].sum()) * 2.0 * (2 * args.dim * 256 + 256 * 128 + 128)
+        # The kernel computes the query half of layer 1 (W1q.q) once per query instead of once
+        # per row, so the MFMA work it issues is d*256 + 256*128 MACs per row: `issued` below.
+        rows = float(counters[:, 2, :].sum())
+        flops = rows * 2.0 * (2 * args.dim * 256 + 256 * 128 + 128)
+        issued = rows * 2.0 * (args.dim * 256 + 256 * 128)
         tf = flops / (kern_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer)", "achieved": round(tf, 2), "peak": 157.3,
                     "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
-                    "kernel_ms": round(kern_ms, 4), "hbm_algorithmic_GBps": round(achieved, 1),
+                    "kernel_ms": round(kern_ms, 4),
+                    "mfma_issued_TFLOPs": round(issued / (kern_ms * 1e-3) / 1e12, 2),
+                    "mfma_issued_frac": round(issued / (kern_ms * 1e-3) / 1e12 / 157.3, 4),
+                    "hbm_algorithmic_GBps": round(achieved, 1),
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
 
     # ---- whole-job throughput: every rank searched every query on its 1M-item shard
@@ -207,6 +247,7 @@ def main():
             "fraction": {n: round(float(tk[:, i].sum() / tot), 4) for i, n in enumerate(_lib.PHASE_NAMES)}}
 
     if rank == 0 and world == 1:
+        from oracle import oracle as O  # checker / CPU baseline only
         oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
         osc = O.Scorer(args.scorer, args.dim, O.EMB_F16, mlp_w)
         qh = ops.user_seq_mean(comm_seq).cpu().numpy()
