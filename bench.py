@@ -269,15 +269,18 @@ def main():
                                       "kind": "port",
                                       "sample": f"{n_done} queries of the same batch, one query per thread, "
                                                 f"{t_cpu:.1f} s"}
-            # parity on the first CPU chunk: identical ids/scores => identical recall
-            sel, (st, ids, scores, idx, ctr) = first
-            gi = out[0].cpu().numpy()[sel]
-            gs = out[1].cpu().numpy()[sel]
-            ok = st == 0
-            result["parity"] = {"queries_checked": int(len(sel)),
-                                "status_equal": bool((status[sel] == st).all()),
-                                "ids_equal": bool((gi[ok] == ids[ok]).all()),
-                                "scores_bitwise_equal": bool((gs[ok].view(np.uint32) == scores[ok].view(np.uint32)).all())}
+        else:
+            sel = np.arange(min(args.batch, 4 * cores))
+            first = (sel, O.search_batch(oix, osc, qh[sel], topn, n_threads=cores))
+        # parity on the first CPU chunk: identical ids/scores => identical recall
+        sel, (st, ids, scores, idx, ctr) = first
+        gi = out[0].cpu().numpy()[sel]
+        gs = out[1].cpu().numpy()[sel]
+        ok = st == 0
+        result["parity"] = {"queries_checked": int(len(sel)),
+                            "status_equal": bool((status[sel] == st).all()),
+                            "ids_equal": bool((gi[ok] == ids[ok]).all()),
+                            "scores_bitwise_equal": bool((gs[ok].view(np.uint32) == scores[ok].view(np.uint32)).all())}
     if rank == 0 and world == 1:
         # recall@k of the traversal vs brute force under the same scorer (test_all,
         # main.py:194-237).  Brute force = score ALL items with the device scorer (parity-tested

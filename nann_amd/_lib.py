@@ -53,7 +53,8 @@ class IndexDesc(C.Structure):
 
 
 def lib_path():
-    return _build.LIB
+    # NANN_HIP_LIB: load another build of the same ABI (kernel-variant experiments, tools/)
+    return os.environ.get("NANN_HIP_LIB") or _build.LIB
 
 
 def lib():

@@ -34,18 +34,27 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(SRC_DIR, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, extra_flags=()):
     """Compile every HIP source for gfx950 into nann_amd/_build/libnann_hip.so (objects in
-    parallel, then one link).  Returns the library path."""
-    if not force and not is_stale():
-        return LIB
+    parallel, then one link).  Returns the library path.  `variant`: build into
+    nann_amd/_build/var_<variant>/ with `extra_flags` instead (kernel experiments; load it
+    with NANN_HIP_LIB)."""
+    if variant is None:
+        if not force and not is_stale():
+            return LIB
+        return _build_into(OUT_DIR, LIB, (), verbose)
+    out = os.path.join(OUT_DIR, "var_" + variant)
+    return _build_into(out, os.path.join(out, "libnann_hip.so"), tuple(extra_flags), verbose)
+
+
+def _build_into(OUT_DIR, LIB, extra_flags, verbose):
     os.makedirs(OUT_DIR, exist_ok=True)
     procs = []
     for src, extra, obj in UNITS:
         # one directory per object: --save-temps keeps the device assembly for the audit below
         odir = os.path.join(OUT_DIR, obj[:-2] + ".d")
         os.makedirs(odir, exist_ok=True)
-        cmd = [_hipcc()] + FLAGS + extra + ["--save-temps=obj", "-c", os.path.join(SRC_DIR, src),
+        cmd = [_hipcc()] + FLAGS + list(extra_flags) + extra + ["--save-temps=obj", "-c", os.path.join(SRC_DIR, src),
                                             "-o", os.path.join(odir, obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -239,51 +239,196 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
 //
 // The concatenation is never materialised in HBM.  Pass 1 (count, :137-145):
 // one thread per frontier node reads its two row_splits; a block-wide
-// exclusive scan gives every row its offset in the virtual list.  Pass 2 is a
-// two-stage pipeline over kChunk-id pieces of that list: wavefronts 1..15 copy
-// piece c from the CSR into one of two LDS buffers (one wavefront per row, one
-// coalesced <=256-byte load per row, 8 rows in flight per wavefront) while
-// wavefront 0 walks piece c-1 out of the other buffer; one barrier per piece.
+// exclusive scan gives every row its offset in the virtual list.  Pass 2 walks
+// the list in pieces of kChunk ids: the rows of piece c+1 are fetched from the
+// CSR into registers (one wavefront per row, one coalesced <=256-byte load per
+// row) while piece c, already staged in LDS, goes through wg_filter_chunk.
+//
+// wg_filter_chunk is the reference's serial scan (keep an id iff its bit is
+// clear, then set it) done by the whole workgroup, kChunk ids at a time:
+//   1. every thread reads the bitmap words of its ids       -> visited before the piece
+//   2. barrier; the unvisited ones OR their bit in           -> exactly one "winner" per id
+//   3. the losers of step 2 are later/earlier copies of an id that is new in this piece:
+//      they record min(position) per id in a small LDS hash table (slot -> position, ids
+//      compared through the staged list); winners that find their id there join the min
+//   4. an id is kept at the smallest position it occurs at -- the serial scan's choice
+//   5. kept ids are compacted in position order (threads own consecutive positions:
+//      DPP wave scan + one LDS exchange of wave totals), so the output is the serial order.
+// Five barriers per kChunk ids instead of kChunk/64 dependent steps of one wavefront.
 //
 // List mode (row_splits == nullptr): `values[0..n_frontier)` is itself the
 // list to filter (the "mark" calls, build_opt_graph.py:119-120,132-133).
 //
-// All kNT threads.  n_frontier <= kMaxK in CSR mode.  Outputs (uniform):
+// All NT threads.  n_frontier <= kMaxK in CSR mode.  Outputs (uniform):
 // *gathered = length of the virtual list, return value = ids kept (appended
 // to out[0..)); -1 on an out-of-range frontier id or neighbour id.
 constexpr int kChunk = 2048;
+constexpr uint32_t kHashEmpty = 0xffffffffu;
+constexpr int kChunkTab = 64;
 struct ExpandWalkScratch {
   uint32_t off[kMaxK + 1];
   uint32_t rowstart[kMaxK];
   uint32_t wave_tot[kNW];
   int bad;
-  int kept;
-  int kept_pub[2];  // ids the walker had produced at the end of the previous pipeline step
-  int32_t stage[2][kChunk];
+  int any_contested;
+  int pad[2];
+  int chunk_first[kChunkTab];  // first row of piece c (c < kChunkTab), filled by pass 1
+  int32_t stage[kChunk];   // the piece being filtered
+  uint32_t hash[kChunk];   // slot -> smallest position (in the piece) of the id hashed there
 };
 
-// `consume(begin, end, wave_rel, n_waves)` (optional): called by the n_waves = NT/64 - 1
-// copying wavefronts of every pipeline step for the ids out[begin..end) the walker has
-// published so far, and by all wavefronts (n_waves = NT/64) for the tail after the last
-// piece -- the scorer runs underneath the serial walk instead of after it.  Must not
-// contain workgroup barriers.
-struct NoConsume {
-  __device__ __forceinline__ void operator()(int, int, int, int) const {}
+__device__ __forceinline__ uint32_t chunk_hash(int32_t x) {
+  return ((uint32_t)x * 2654435761u) >> 21;  // 11 bits: kChunk slots
+}
+static_assert(kChunk == 2048, "chunk_hash yields 11 bits");
+
+template <bool kLdsBm, int NT>
+__device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, uint32_t* bm,
+                                               uint32_t n_items, int32_t* out, int base) {
+  constexpr int PER = kChunk / NT;  // consecutive positions per thread
+  constexpr int NWV = NT / 64;
+  static_assert(PER == 2 || PER == 4, "NT must be 1024 or 512");
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  int32_t x[PER];
+  if constexpr (PER == 2) {
+    const int2 v = reinterpret_cast<const int2*>(S->stage)[tid];
+    x[0] = v.x; x[1] = v.y;
+  } else {
+    const int4 v = reinterpret_cast<const int4*>(S->stage)[tid];
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  }
+  // ---- 1. visited before this piece?
+  uint32_t* w[PER];
+  uint32_t bit[PER];
+  bool fresh[PER];
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const bool valid = tid * PER + e < n_c;
+    const bool inr = valid && (uint32_t)x[e] < n_items;
+    bad |= valid && !inr;
+    w[e] = bm + (inr ? ((uint32_t)x[e] >> 5) : 0u);
+    bit[e] = inr ? (1u << (x[e] & 31)) : 0u;
+    const uint32_t pre = kLdsBm ? *w[e] : atomicOr(w[e], 0u);  // global bitmap: served by L2 like the update
+    fresh[e] = inr && !(pre & bit[e]);
+  }
+#pragma unroll
+  for (int e = 1; e < PER; ++e)  // the same new id twice inside one thread: the later one is a copy
+#pragma unroll
+    for (int e2 = 0; e2 < e; ++e2)
+      if (fresh[e] && fresh[e2] && x[e] == x[e2]) fresh[e] = false;
+  if (bad) S->bad = 1;
+  __syncthreads();
+  // ---- 2. set the bits; one winner per new id
+  bool won[PER], cont[PER], keep[PER];
+  uint32_t slot[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    won[e] = false;
+    if (fresh[e]) won[e] = !(atomicOr(w[e], bit[e]) & bit[e]);
+    cont[e] = fresh[e] && !won[e];
+    slot[e] = kHashEmpty;
+  }
+  // ---- 3. the other copies of a new id record the smallest position
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    if (cont[e]) {
+      const uint32_t pos = (uint32_t)(tid * PER + e);
+      S->any_contested = 1;
+      uint32_t h = chunk_hash(x[e]);
+      for (;;) {
+        uint32_t cur = S->hash[h];
+        if (cur == kHashEmpty) {
+          cur = atomicCAS(&S->hash[h], kHashEmpty, pos);
+          if (cur == kHashEmpty) break;
+        }
+        if (S->stage[cur] == x[e]) { atomicMin(&S->hash[h], pos); break; }
+        h = (h + 1) & (kChunk - 1);
+      }
+      slot[e] = h;
+    }
+  }
+  __syncthreads();
+  const bool anyc = S->any_contested != 0;
+  if (anyc) {
+    // ---- 4. winners whose id has other copies join the minimum
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      if (won[e]) {
+        const uint32_t pos = (uint32_t)(tid * PER + e);
+        uint32_t h = chunk_hash(x[e]);
+        for (;;) {
+          const uint32_t cur = S->hash[h];
+          if (cur == kHashEmpty) break;  // no other copy
+          if (S->stage[cur] == x[e]) { atomicMin(&S->hash[h], pos); slot[e] = h; break; }
+          h = (h + 1) & (kChunk - 1);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const uint32_t pos = (uint32_t)(tid * PER + e);
+      keep[e] = (won[e] && slot[e] == kHashEmpty) || ((won[e] || cont[e]) && slot[e] != kHashEmpty && S->hash[slot[e]] == pos);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) keep[e] = won[e];
+  }
+  // ---- 5. ordered compaction
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) cnt += keep[e] ? 1u : 0u;
+  const uint32_t inc = wave_scan_add(cnt);
+  if (lane == 63) S->wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int wv = 0; wv < NWV; ++wv) {
+    const uint32_t v = S->wave_tot[wv];
+    if (wv < wave) wbase += v;
+    tot += v;
+  }
+  int o = base + (int)(wbase + inc - cnt);
+#pragma unroll
+  for (int e = 0; e < PER; ++e)
+    if (keep[e]) out[o++] = x[e];
+  if (anyc) {  // leave the table empty for the next piece (read again only after two barriers)
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+      if (cont[e]) S->hash[slot[e]] = kHashEmpty;
+    if (tid == 0) S->any_contested = 0;
+  }
+  return base + (int)tot;
+}
+
+// `stream` (optional): a scorer whose row loads fly underneath the filter.  Before piece c is
+// filtered, stream.issue_ids(b, e) / issue_rows() start the loads for the ids out[b..e) that earlier
+// pieces released (e - b <= Stream::kRows); after the filter, stream.finish() reduces them and
+// writes the scores.  *streamed = number of leading ids of out[] handled that way; the
+// caller scores the rest.  Both calls are made by all threads and contain no barrier.
+struct NoStream {
+  static constexpr int kRows = 0;
+  __device__ __forceinline__ void issue_ids(int, int) {}
+  __device__ __forceinline__ void issue_rows() {}
+  __device__ __forceinline__ void finish() {}
 };
 
-template <bool kLdsBm, int NT = kNT, typename Consume = NoConsume>
+template <bool kLdsBm, int NT, typename Stream>
 __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
-                                              PhaseTimer* pt = nullptr, Consume consume = Consume()) {
+                                              PhaseTimer* pt, Stream& stream, bool stream_on,
+                                              int* streamed) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
   long long tsub = pt ? pt->now() : 0;
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
-  if (tid == 0) { S->bad = 0; S->kept = 0; S->kept_pub[0] = 0; S->kept_pub[1] = 0; }
+  if (tid == 0) { S->bad = 0; S->any_contested = 0; }
+  for (int i = tid; i < kChunk; i += NT) S->hash[i] = kHashEmpty;
   __syncthreads();
   // ---- pass 1: row lengths -> offsets --------------------------------------
   constexpr int NWV = NT / 64;
@@ -314,8 +459,12 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
       tot += v;
     }
     if (t < n_rows) {
-      S->off[t] = total + wbase + inc - len;
+      const uint32_t my_off = total + wbase + inc - len;
+      S->off[t] = my_off;
       S->rowstart[t] = start;
+      // pieces that begin inside this row
+      for (uint32_t c = (my_off + kChunk - 1) / kChunk; c < (uint32_t)kChunkTab && c * kChunk < my_off + len; ++c)
+        S->chunk_first[c] = t;
     }
     total += tot;
     __syncthreads();
@@ -325,87 +474,124 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   *gathered = (int)total;
   if (pt) pt->sub(PH_EX_PASS1, tsub);
   if (S->bad) return -1;
-  // ---- pass 2: fill || walk pipeline ------------------------------------------
+  // ---- pass 2: fetch piece c+1 || filter piece c -------------------------------
   const int G = (int)total;
   const int n_chunks = (G + kChunk - 1) / kChunk;
-  int base = 0;
-  int err = 0;
-  int consumed = 0;  // ids already handed to `consume` (same value in every wavefront)
-  for (int it = 0; it <= n_chunks; ++it) {
-    const int pub = S->kept_pub[(it + 1) & 1];  // walker's output count after step it-1
-    if (wave > 0) {
-      if (it < n_chunks) {  // producers: piece `it` -> stage[it & 1]
-        const uint32_t lo = (uint32_t)it * kChunk;
-        const uint32_t hi = min((uint32_t)G, lo + kChunk);
-        int32_t* dst = S->stage[it & 1];
-        // first row whose end lies beyond lo: upper_bound over off[1..n_rows]
-        int a = 0, b = n_rows;
-        while (a < b) {
-          const int m = (a + b) >> 1;
-          if (S->off[m + 1] > lo) b = m; else a = m + 1;
+  constexpr int RB = 64 / NWV;  // rows per wavefront in the register-staged batch: 64 rows per piece
+  struct RowBatch {
+    int dst_off[RB];  // index into the staging buffer, -1 = nothing
+    int32_t v[RB];
+    uint32_t long_rows;
+    int r0;
+  };
+  // rows r0, r0 + NWV, ... of piece c: one coalesced load per row into registers
+  auto issue = [&](int c, int r0, RowBatch& B) {
+    const uint32_t lo = (uint32_t)c * kChunk;
+    const uint32_t hi = min((uint32_t)G, lo + kChunk);
+    uint32_t src_off[RB];  // index into values[] (0 when the lane has nothing to copy)
+    B.long_rows = 0;
+    B.r0 = r0;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {  // row descriptors (LDS)
+      const int r = r0 + j * NWV;
+      src_off[j] = 0; B.dst_off[j] = -1;
+      if (r < n_rows) {
+        const uint32_t o = S->off[r];
+        const uint32_t l = S->off[r + 1] - o;
+        const uint32_t p = o + lane;
+        if (lane < l && p >= lo && p < hi) {
+          src_off[j] = S->rowstart[r] + lane;
+          B.dst_off[j] = (int)(p - lo);
         }
-        constexpr int RB = 16;  // rows in flight per wavefront: a 2048-id piece is one batch
-        for (int r0 = a + (wave - 1); r0 < n_rows; r0 += (NWV - 1) * RB) {
-          if (S->off[r0] >= hi) break;
-          uint32_t src_off[RB];  // index into values[] (0 when the lane has nothing to copy)
-          int dst_off[RB];       // index into the staging buffer, -1 = nothing
-          int32_t v[RB];
-          uint32_t long_rows = 0;
+        if (l > 64 && o < hi) B.long_rows |= 1u << j;
+      }
+    }
 #pragma unroll
-          for (int j = 0; j < RB; ++j) {  // row descriptors (LDS)
-            const int r = r0 + j * (NWV - 1);
-            src_off[j] = 0; dst_off[j] = -1;
-            if (r < n_rows) {
-              const uint32_t o = S->off[r];
-              const uint32_t l = S->off[r + 1] - o;
-              const uint32_t p = o + lane;
-              if (lane < l && p >= lo && p < hi) {
-                src_off[j] = S->rowstart[r] + lane;
-                dst_off[j] = (int)(p - lo);
-              }
-              if (l > 64) long_rows |= 1u << j;
-            }
-          }
+    for (int j = 0; j < RB; ++j) B.v[j] = values[src_off[j]];
+  };
+  auto commit = [&](int c, const RowBatch& B) {
+    const uint32_t lo = (uint32_t)c * kChunk;
+    const uint32_t hi = min((uint32_t)G, lo + kChunk);
 #pragma unroll
-          for (int j = 0; j < RB; ++j) v[j] = values[src_off[j]];  // RB coalesced row loads in flight
-#pragma unroll
-          for (int j = 0; j < RB; ++j)
-            if (dst_off[j] >= 0) dst[dst_off[j]] = v[j];
-          if (long_rows) {  // rows longer than 64 (not produced by HNSW with M <= 32): remaining pieces
-            for (int j = 0; j < RB; ++j) {
-              if (!((long_rows >> j) & 1u)) continue;
-              const int r = r0 + j * (NWV - 1);
-              const uint32_t o = S->off[r], l = S->off[r + 1] - o, st = S->rowstart[r];
-              for (uint32_t c = 64 + lane; c < l; c += 64) {
-                const uint32_t pp = o + c;
-                if (pp >= lo && pp < hi) dst[pp - lo] = values[(size_t)st + c];
-              }
-            }
-          }
+    for (int j = 0; j < RB; ++j)
+      if (B.dst_off[j] >= 0) S->stage[B.dst_off[j]] = B.v[j];
+    if (B.long_rows) {  // rows longer than 64 (not produced by HNSW with M <= 32): remaining pieces
+      for (int j = 0; j < RB; ++j) {
+        if (!((B.long_rows >> j) & 1u)) continue;
+        const int r = B.r0 + j * NWV;
+        const uint32_t o = S->off[r], l = S->off[r + 1] - o, st = S->rowstart[r];
+        for (uint32_t cc = 64 + lane; cc < l; cc += 64) {
+          const uint32_t pp = o + cc;
+          if (pp >= lo && pp < hi) S->stage[pp - lo] = values[(size_t)st + cc];
         }
       }
-      consume(consumed, pub, wave - 1, NWV - 1);  // score what the walker has released so far
-    } else if (it >= 1) {  // walker: piece it-1
-      const int c = it - 1;
-      const int n_c = min(kChunk, G - c * kChunk);
-      long long tw = pt ? pt->now() : 0;
-      __builtin_amdgcn_s_setprio(3);  // the serial wavefront: issue ahead of the copying ones
-      base = wave_walk_span<kLdsBm>(S->stage[c & 1], n_c, bm, n_items, out, base, &err);
-      __builtin_amdgcn_s_setprio(0);
-      if (pt) pt->sub(PH_EX_WALKBUSY, tw);
-      if (lane == 0) S->kept_pub[it & 1] = base;
     }
-    consumed = pub;
+  };
+  // first row whose end lies beyond the start of piece c: upper_bound over off[1..n_rows]
+  auto first_row = [&](int c) {
+    if (c < kChunkTab) return S->chunk_first[c];
+    const uint32_t lo = (uint32_t)c * kChunk;
+    int a = 0, b = n_rows;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (S->off[m + 1] > lo) b = m; else a = m + 1;
+    }
+    return a;
+  };
+  // rows of piece c beyond the register-staged batch (pieces made of many short rows)
+  auto rest = [&](int c, int r_first) {
+    const uint32_t hi = min((uint32_t)G, (uint32_t)c * kChunk + kChunk);
+    for (int r0 = r_first + NWV * RB; r0 < n_rows && S->off[r0] < hi; r0 += NWV * RB) {
+      RowBatch B2;
+      issue(c, r0, B2);
+      commit(c, B2);
+    }
+  };
+  RowBatch B;
+  if (n_chunks > 0) {
+    issue(0, first_row(0) + wave, B);
+    commit(0, B);
+    rest(0, B.r0);
+  }
+  __syncthreads();
+  int base = 0;
+  int scored = 0;  // leading ids of out[] whose scores the stream has produced (uniform)
+  for (int c = 0; c < n_chunks; ++c) {
+    const bool more = c + 1 < n_chunks;
+    const int s_end = min(base, scored + Stream::kRows);
+    if (Stream::kRows > 0 && stream_on) stream.issue_ids(scored, s_end);  // ids released so far
+    if (more) issue(c + 1, first_row(c + 1) + wave, B);  // adjacency loads in flight underneath the filter
+    if (Stream::kRows > 0 && stream_on) stream.issue_rows();
+    const int n_c = min(kChunk, G - c * kChunk);
+    long long tw = pt ? pt->now() : 0;
+    base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
+    if (pt) pt->sub(PH_EX_WALKBUSY, tw);
+    if (Stream::kRows > 0 && stream_on) { stream.finish(); scored = s_end; }
+    if (more) {
+      commit(c + 1, B);
+      rest(c + 1, B.r0);
+    }
     __syncthreads();
   }
   if (pt) pt->sub(PH_EX_LOOP, tsub);
-  if (wave == 0 && lane == 0) { S->kept = base; if (err) S->bad = 1; }
-  __syncthreads();
-  const int kept = S->kept;
   const int bad = S->bad;
   __syncthreads();
-  if (!bad) consume(consumed, kept, wave, NWV);  // the tail, by every wavefront
-  return bad ? -1 : kept;
+  *streamed = scored;
+  return bad ? -1 : base;
+}
+
+// without a stream
+template <bool kLdsBm, int NT = kNT>
+__device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
+                                              const int32_t* __restrict__ values,
+                                              const int64_t* __restrict__ row_splits,
+                                              uint32_t n_items, uint32_t* bm, int32_t* out,
+                                              unsigned char* scratch, int* gathered,
+                                              PhaseTimer* pt = nullptr) {
+  NoStream none;
+  int streamed = 0;
+  return wg_expand_walk<kLdsBm, NT, NoStream>(frontier, n_frontier, values, row_splits, n_items, bm, out,
+                                              scratch, gathered, pt, none, false, &streamed);
 }
 
 // ---------------------------------------------------------------------------
@@ -521,6 +707,57 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
     }
   }
 }
+
+#ifndef NANN_STREAM_U
+#define NANN_STREAM_U 6  // build-time knob: 16-byte row loads a lane keeps in flight across the filter
+#endif
+// L2Stream: the same scorer split into "start the row loads" / "reduce and store", so that a
+// batch of U row loads per lane stays in flight across other work (wg_expand_walk's filter).
+template <int LPR, int DT, int NT>
+struct L2Stream {
+  static constexpr int U = (DT == DT_F32) ? NANN_STREAM_U / 2 : NANN_STREAM_U;  // rows in flight per lane across the filter
+  static constexpr int GPW = 64 / LPR;
+  static constexpr int RPI = (NT / 64) * GPW;
+  static constexpr int kRows = U * RPI;
+  const void* table;
+  int d;
+  const int32_t* ids;
+  const float* qv;
+  float* scores;
+  RowChunk<DT> r[U];
+  int32_t id[U];
+  int begin, end;
+  __device__ __forceinline__ void issue_ids(int b, int e) {  // the ids first (an L2 round trip) ...
+    begin = b; end = e;
+    if (e <= b) return;
+    const int tid = local_tid(), lane = tid & 63;
+    const int slot = (tid >> 6) * GPW + lane / LPR;
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = ids[min(b + u * RPI + slot, e - 1)];
+  }
+  __device__ __forceinline__ void issue_rows() {  // ... then their rows
+    if (end <= begin) return;
+    const int sub = (local_tid() & 63) % LPR;
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = load_chunk<DT>(table, (size_t)id[u], d, sub);
+  }
+  __device__ __forceinline__ void finish() {
+    if (end <= begin) return;
+    const int tid = local_tid(), lane = tid & 63;
+    const int sub = lane % LPR, slot = (tid >> 6) * GPW + lane / LPR;
+    float q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float x[8];
+      chunk_to_float<DT>(r[u], x);
+      const float sc = l2_finish<LPR>(q, x);
+      const int i = begin + u * RPI + slot;
+      if (sub == 0 && i < end) scores[i] = sc;
+    }
+  }
+};
 
 // whole workgroup, i < n
 template <int LPR, int DT, int NTHREADS>

@@ -929,10 +929,20 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   const size_t fixed = kPhaseScratch + kMaxD * 4 + 256;
   const size_t bm_bytes = (size_t)ix->bm_words * 4;
   p->lds_bitmap = bm_bytes + fixed <= di.lds_max;
+  p->nt = kNT;
+  int per_cu = p->lds_bitmap ? 1 : 2;  // LDS-resident bitmap: one workgroup per CU
+  // tuning knob: NANN_L2_VARIANT=glb512[:wgs] keeps the visited bitmap in HBM/L2 and
+  // runs half-size workgroups, `wgs` of them per CU (default 2), so that the phases of
+  // different queries overlap on one CU
+  static const std::string variant = [] { const char* e = std::getenv("NANN_L2_VARIANT"); return std::string(e ? e : ""); }();
+  if (variant.rfind("glb512", 0) == 0) {
+    p->lds_bitmap = false;
+    p->nt = 512;
+    per_cu = variant.size() > 7 ? std::max(1, std::atoi(variant.c_str() + 7)) : 2;
+  }
   p->lds_bytes = fixed + (p->lds_bitmap ? bm_bytes : 0);
   unsigned long long off[8];
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, p->lds_bitmap ? 0u : ix->bm_words, off);
-  const int per_cu = p->lds_bitmap ? 1 : 2;  // LDS-resident bitmap: one workgroup per CU
   p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
   return NANN_OK;
 }

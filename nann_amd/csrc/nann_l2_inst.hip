@@ -12,6 +12,14 @@
 namespace nann {
 
 int NANN_CAT(launch_search_l2_, NANN_L2_NAME)(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  if (p.nt == 512) {  // global-bitmap variant: two half-size workgroups per CU
+    switch (lpr) {
+      case 8: return launch_search_global<8, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+      case 16: return launch_search_global<16, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+      case 32: return launch_search_global<32, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+      default: return launch_search_global<64, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+    }
+  }
   switch (lpr) {
     case 8: return launch_search<8, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
     case 16: return launch_search<16, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);

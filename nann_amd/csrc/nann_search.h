@@ -141,12 +141,15 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     const int32_t* sc_ids = nullptr;  // what this stage scores
     float* sc_out = nullptr;
     int sc_n = 0, base_off = 0;
+    int sc_done = 0;   // leading candidates already scored underneath the expand
+    int streamed = 0;
     if (r == 0) {
       sc_ids = a.enter; sc_out = sv.cand_scores; sc_n = E;
       if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
     } else if (r < NANN_NUM_ROUNDS) {
       const int level = (r == 1) ? 1 : 0;
       int nC = 0, G = 0;
+      sc_done = 0;
       // sub-step 0 ("mark", only when a level starts): fresh bitmap, then the current
       // result set goes through BitmapRefDifference (:115-120, :131-133).
       // sub-step 1: neighbours of the frontier, filtered (:116,121-122 / :136-137).
@@ -169,6 +172,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         }
         int gathered = 0;
         int kept = -2;
+        streamed = 0;
         if (ss == 0) {
           // The list to mark is a TopKV2 output over distinct nodes, hence duplicate-free, and
           // the bitmap is empty: BitmapRefDifference returns the list unchanged and the order
@@ -200,18 +204,14 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         }
         if (kept == -2) {
           if constexpr (SC == NANN_SCORER_L2) {
-            // the L2 scorer runs underneath the walk: the copying wavefronts score every id the
-            // walker has released (GatherV2 + scorer of forward(), :91-107 / :124,138)
-            float* sc_dst = sv.cand_scores + base_off;
-            auto stream_score = [&](int begin, int end, int wave_rel, int n_waves) {
-              if (ss == 0) return;
-              if (n_waves == NT / 64)
-                wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, dst, begin, end, qv, sc_dst, wave_rel);
-              else
-                wg_score_l2_part<LPR, DT, NT / 64 - 1>(a.emb, a.d, dst, begin, end, qv, sc_dst, wave_rel);
-            };
-            kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
-                                             scratch, &gathered, ss == 0 ? nullptr : pt, stream_score);
+            // GatherV2 + scorer of forward() (:91-107 / :124,138) ride along: the rows of the ids
+            // one piece releases are fetched while the next piece is filtered
+            L2Stream<LPR, DT, NT> stream;
+            stream.table = a.emb; stream.d = a.d; stream.ids = dst; stream.qv = qv;
+            stream.scores = sv.cand_scores + base_off;
+            kept = wg_expand_walk<LDSBM, NT, L2Stream<LPR, DT, NT>>(
+                ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst, scratch, &gathered,
+                ss == 0 ? nullptr : pt, stream, ss != 0, &streamed);
           } else {
             kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
                                              scratch, &gathered, ss == 0 ? nullptr : pt);
@@ -227,7 +227,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
           nB = kept;
         } else {
-          nC = kept; G = gathered;
+          nC = kept; G = gathered; sc_done = streamed;
         }
       }
       if (r == 1) {  // sR in front of sC (:125-126); after the walk, whose staging shares this LDS
@@ -244,8 +244,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
       mark(PH_OTHER);
       if constexpr (SC == NANN_SCORER_L2) {
-        // stage 0 scores the entry points here; later stages were scored underneath the walk
-        if (r == 0) wg_score_l2<LPR, DT, NT>(a.emb, a.d, sc_ids, sc_n, qv, sc_out);
+        wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, sc_done, sc_n, qv, sc_out, tid >> 6);
         __syncthreads();
         for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
           lds_scores[base_off + i] = sc_out[i];
@@ -352,6 +351,7 @@ struct SearchPlan {
   size_t lds_bytes;
   unsigned long long slot_bytes;
   int slots;
+  int nt;  // threads per workgroup of the L2 traversal: kNT, or 512 for the global-bitmap variant
 };
 
 template <int LPR, int DT, int SC, int NT>
@@ -369,6 +369,15 @@ inline int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t s
   return NANN_OK;
 }
 
+
+// bitmap in HBM/L2 only (several workgroups per CU)
+template <int LPR, int DT, int SC, int NT>
+inline int launch_search_global(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  auto kern = k_search<LPR, DT, false, SC, NT>;
+  hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
 
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype)
 int launch_search_l2_f16(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);

@@ -1,0 +1,82 @@
+#!/bin/bash
+# One call on the MI355X box, most important first, each step skipped once DEADLINE seconds
+# have passed: GPU tests, smoke, bench.py line (+CPU baseline), rocprofv3 kernel stats, HBM
+# PMC passes, kernel-variant A/B runs (prebuilt libs under nann_amd/_build/var_*), MLP bench.
+# usage: tools/gpu_final2.sh <tag> [deadline_s]
+set -u
+TAG=${1:-final}
+DEADLINE=${2:-320}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+T0=$(date +%s)
+left() { echo $(( DEADLINE - ($(date +%s) - T0) )); }
+mkdir -p $OUT /tmp/idx /tmp/prof
+cd $R
+timeout 200 python -m pytest tests -m gpu -q --timeout 120 -x > $OUT/pytest_$TAG.log 2>&1
+RC=$?; tail -3 $OUT/pytest_$TAG.log
+if [ $RC -ne 0 ]; then echo "GPU TESTS FAILED"; grep -E "^(E  |FAILED)" $OUT/pytest_$TAG.log | head -20; exit 1; fi
+timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -1 $OUT/smoke_$TAG.log
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --index-cache /tmp/idx"
+timeout 260 $BENCH --phase-ticks --cpu-seconds 8 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$? left=$(left)"
+python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench_$TAG.json').read().strip().splitlines()[-1])
+    print('DEFAULT', d['value'], d['roofline']['kernel_ms'], d['roofline']['frac'], d.get('cpu_baseline', {}).get('value'), d.get('parity'))
+    print({k: round(v) for k, v in d['phase_breakdown']['ticks_per_query'].items()})
+except Exception as e:
+    print('bench parse failed', e)
+PY
+if [ $(left) -gt 45 ]; then
+  rm -rf /tmp/prof/kt
+  timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- \
+      $BENCH --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_kt_$TAG.log 2>&1
+  find /tmp/prof/kt -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_$TAG.csv \;
+  grep -E "k_search" $OUT/kernel_stats_$TAG.csv | head -2
+fi
+: > $OUT/pmc_$TAG.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  if [ $(left) -gt 40 ]; then
+    rm -rf /tmp/prof/pmc_$C
+    timeout 100 rocprofv3 --pmc $C --output-format csv -d /tmp/prof/pmc_$C -o pmc -- \
+        $BENCH --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_pmc_${C}_$TAG.log 2>&1
+    python - <<PY >> $OUT/pmc_$TAG.txt 2>&1
+import csv, glob
+for f in glob.glob('/tmp/prof/pmc_$C/**/*counter_collection.csv', recursive=True):
+    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
+            if 'k_search' in r.get('Kernel_Name', '') and r.get('Counter_Name') == '$C']
+    if vals:
+        print('$C k_search dispatches', len(vals), 'mean', sum(vals) / len(vals), 'min', min(vals), 'max', max(vals))
+PY
+  fi
+done
+cat $OUT/pmc_$TAG.txt
+# ---- kernel variants (same index, no CPU baseline)
+run_variant() {  # name, env assignments...
+  local name=$1; shift
+  if [ $(left) -gt 30 ]; then
+    env "$@" timeout 90 $BENCH --phase-ticks --no-cpu-baseline --steps 10 > $OUT/bench_${TAG}_$name.json 2> $OUT/bench_${TAG}_$name.err
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench_${TAG}_$name.json').read().strip().splitlines()[-1])
+    t = d['phase_breakdown']['ticks_per_query']
+    print('VARIANT $name', d['value'], d['roofline']['kernel_ms'], d.get('parity', {}).get('ids_equal'), 'expand', round(t['expand']), 'score', round(t['score']), 'topk', round(t['topk']), 'filter', round(t['ex_walkbusy']))
+except Exception as e:
+    print('variant $name failed', e)
+PY
+  fi
+}
+run_variant u8 NANN_HIP_LIB=$R/nann_amd/_build/var_u8/libnann_hip.so
+run_variant u4 NANN_HIP_LIB=$R/nann_amd/_build/var_u4/libnann_hip.so
+# ---- MLP scorer (BASELINE configs[2])
+if [ $(left) -gt 35 ]; then
+  MB="$BENCH --scorer mlp --batch 512 --steps 3 --warmup 1 --no-cpu-baseline"
+  timeout 100 $MB > $OUT/bench_${TAG}_mlp.json 2> $OUT/bench_${TAG}_mlp.err; echo "mlp bench rc=$?"
+  tail -c 900 $OUT/bench_${TAG}_mlp.json
+fi
+run_variant glb512 NANN_L2_VARIANT=glb512
+run_variant glb512x3 NANN_L2_VARIANT=glb512:3
+run_variant u2 NANN_HIP_LIB=$R/nann_amd/_build/var_u2/libnann_hip.so
+echo "done left=$(left)"
