@@ -708,14 +708,19 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
   }
 }
 
+// Build-time knob: 16-byte row loads a lane keeps in flight across the filter; 0 = score after
+// the expand.  Measured on MI355X (1M x 128-d f16, ef=128, batch 4096, k_search ms): 0: 2.715,
+// 2: 2.755, 4: 2.812, 6: 2.943, 8: 3.175 -- the random 256-byte row reads are already limited by
+// the memory system (tools/ubench_gather.hip), so moving them under the filter only makes
+// both slower.  Kept for shards / row sizes where that balance differs.
 #ifndef NANN_STREAM_U
-#define NANN_STREAM_U 6  // build-time knob: 16-byte row loads a lane keeps in flight across the filter
+#define NANN_STREAM_U 0
 #endif
 // L2Stream: the same scorer split into "start the row loads" / "reduce and store", so that a
 // batch of U row loads per lane stays in flight across other work (wg_expand_walk's filter).
 template <int LPR, int DT, int NT>
 struct L2Stream {
-  static constexpr int U = (DT == DT_F32) ? NANN_STREAM_U / 2 : NANN_STREAM_U;  // rows in flight per lane across the filter
+  static constexpr int U = NANN_STREAM_U > 0 ? ((DT == DT_F32) ? (NANN_STREAM_U + 1) / 2 : NANN_STREAM_U) : 1;  // rows in flight per lane across the filter
   static constexpr int GPW = 64 / LPR;
   static constexpr int RPI = (NT / 64) * GPW;
   static constexpr int kRows = U * RPI;

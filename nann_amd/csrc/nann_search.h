@@ -203,7 +203,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           }
         }
         if (kept == -2) {
-          if constexpr (SC == NANN_SCORER_L2) {
+          if constexpr (SC == NANN_SCORER_L2 && NANN_STREAM_U > 0) {
             // GatherV2 + scorer of forward() (:91-107 / :124,138) ride along: the rows of the ids
             // one piece releases are fetched while the next piece is filtered
             L2Stream<LPR, DT, NT> stream;

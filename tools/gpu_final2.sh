@@ -2,7 +2,7 @@
 # One call on the MI355X box, most important first, each step skipped once DEADLINE seconds
 # have passed: GPU tests, smoke, bench.py line (+CPU baseline), rocprofv3 kernel stats, HBM
 # PMC passes, kernel-variant A/B runs (prebuilt libs under nann_amd/_build/var_*), MLP bench.
-# usage: tools/gpu_final2.sh <tag> [deadline_s]
+# usage: tools/gpu_final2.sh <tag> [deadline_s] [variants: yes|no]
 set -u
 TAG=${1:-final}
 DEADLINE=${2:-320}
@@ -52,9 +52,18 @@ PY
   fi
 done
 cat $OUT/pmc_$TAG.txt
+# ---- what the memory system delivers for the scoring phase's access pattern
+if [ -x $R/tools/_build/ubench_gather ] && [ $(left) -gt 20 ]; then
+  timeout 60 $R/tools/_build/ubench_gather > $OUT/ubench_gather_$TAG.txt 2>&1; cat $OUT/ubench_gather_$TAG.txt
+fi
 # ---- kernel variants (same index, no CPU baseline)
+VARIANTS=${3:-yes}
 run_variant() {  # name, env assignments...
   local name=$1; shift
+  for kv in "$@"; do  # a variant whose prebuilt library is not there is skipped
+    case $kv in NANN_HIP_LIB=*) [ -f "${kv#NANN_HIP_LIB=}" ] || return 0;; esac
+  done
+  [ "$VARIANTS" = yes ] || return 0
   if [ $(left) -gt 30 ]; then
     env "$@" timeout 90 $BENCH --phase-ticks --no-cpu-baseline --steps 10 > $OUT/bench_${TAG}_$name.json 2> $OUT/bench_${TAG}_$name.err
     python - <<PY
