@@ -931,14 +931,18 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->lds_bitmap = bm_bytes + fixed <= di.lds_max;
   p->nt = kNT;
   int per_cu = p->lds_bitmap ? 1 : 2;  // LDS-resident bitmap: one workgroup per CU
-  // tuning knob: NANN_L2_VARIANT=glb512[:wgs] keeps the visited bitmap in HBM/L2 and
+  // tuning / test knob: NANN_L2_VARIANT=glb512[:wgs] keeps the visited bitmap in HBM/L2 and
   // runs half-size workgroups, `wgs` of them per CU (default 2), so that the phases of
-  // different queries overlap on one CU
+  // different queries overlap on one CU (measured slower: 4.14 ms vs 2.67 ms at 1M x 128-d);
+  // glb1024 forces the HBM bitmap with full-size workgroups (what > 1.05M-item shards use)
   static const std::string variant = [] { const char* e = std::getenv("NANN_L2_VARIANT"); return std::string(e ? e : ""); }();
   if (variant.rfind("glb512", 0) == 0) {
     p->lds_bitmap = false;
     p->nt = 512;
     per_cu = variant.size() > 7 ? std::max(1, std::atoi(variant.c_str() + 7)) : 2;
+  } else if (variant == "glb1024") {  // the path shards beyond the LDS bitmap's capacity take
+    p->lds_bitmap = false;
+    per_cu = 2;
   }
   p->lds_bytes = fixed + (p->lds_bitmap ? bm_bytes : 0);
   unsigned long long off[8];

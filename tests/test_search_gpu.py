@@ -193,3 +193,41 @@ def test_index_from_reference_files(oracle, tmp_path):
     topn = [32] * 5 + [20]
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
     _assert_same(_run(dix, q, topn), exp)
+
+
+@pytest.mark.parametrize("d,dtype,ef,k", [(256, "bf16", 64, 40), (64, "f32", 32, 20), (256, "f16", 48, 30),
+                                          (128, "bf16", 256, 200)])
+def test_search_row_dtypes_and_dims(oracle, d, dtype, ef, k):
+    """bf16 / f32 rows and 256-d (BASELINE configs[4] shape: 256-d bf16, ef_search=256) through the
+    fused traversal."""
+    from nann_amd import retrieval
+    g, _, _ = synth_index(20000, d, min(ef, 64))
+    x = g["item_embs"].astype(np.float32)
+    if dtype == "bf16":
+        dev = cuda(x).to(torch.bfloat16)
+        host = dev.view(torch.int16).cpu().numpy().view(np.uint16)
+        code = oracle.EMB_BF16
+    elif dtype == "f32":
+        host, dev, code = x, cuda(x), oracle.EMB_F32
+    else:
+        host, dev, code = g["item_embs"], cuda(g["item_embs"]), oracle.EMB_F16
+    oix = oracle.Index(host, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    dix = retrieval.Index(dev, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 40, seed=5)])
+    topn = [min(ef, len(g["enter_points"]))] + [ef] * 4 + [k]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", d, code), q, topn, n_threads=8)
+    assert (exp[0] == 0).mean() > 0.5
+    _assert_same(_run(dix, q, topn), exp)
+
+
+@pytest.mark.parametrize("variant", ["glb1024", "glb512"])
+def test_global_bitmap_variants(variant):
+    """The visited bitmap in HBM/L2 instead of LDS (what shards beyond ~1.05M items use, and the
+    half-size-workgroup tuning variant): same results.  Fresh process: the knob is read once."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NANN_L2_VARIANT=variant)
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "gpu_variant_check.py")], env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
