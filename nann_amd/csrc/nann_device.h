@@ -5,7 +5,8 @@
 // Each block below states which reference loop it replaces (paths relative to
 // /root/reference/, UO/ = tensorflow/tensorflow/core/user_ops/).
 //
-//   wave_walk_span  BitmapRefDifference::Differ  UO/bitmap_op/bitmap_ops.cc:221-234
+//   wave_walk_span  BitmapRefDifference::Differ  UO/bitmap_op/bitmap_ops.cc:221-234 (one wavefront)
+//   wg_filter_chunk the same scan by the whole workgroup, 2048 ids per step
 //   wg_expand_walk  GroupGather::Fill + Differ   UO/beam_search_op/GroupGather_kernel.cc:137-168
 //   wg_score     GatherV2 + scorer             core/kernels/gather_functor.h:96-103 + BlazeXlaOp
 //   wg_topk      TopKV2 (+ Gather of ids)      core/kernels/topk_op.cc:104-205
@@ -668,8 +669,8 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
-// inside, so a subset of the workgroup can run it while the walker wavefront keeps walking.
-// ids must be in range (the walker and index validation guarantee it on the fused path).
+// inside, so a subset of the workgroup can run it.
+// ids must be in range (the visited filter and index validation guarantee it on the fused path).
 // qv: f32[d] (LDS or global).  U row loads per lane are in flight at once (U * 16 KB per
 // workgroup), and the candidate ids of the next batch are fetched underneath them.
 template <int LPR, int DT, int NWAVES>

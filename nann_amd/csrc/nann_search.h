@@ -177,7 +177,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           // The list to mark is a TopKV2 output over distinct nodes, hence duplicate-free, and
           // the bitmap is empty: BitmapRefDifference returns the list unchanged and the order
           // in which bits are set does not matter -> every thread ORs its bit.  The returned
-          // words prove the premise; if it ever failed, redo the step with the serial walker.
+          // words prove the premise; if it ever failed, redo the step with the ordered filter.
           int* flags = reinterpret_cast<int*>(scratch);  // [0] duplicate seen, [1] id out of range
           if (tid < 2) flags[tid] = 0;
           __syncthreads();
