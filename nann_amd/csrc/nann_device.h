@@ -667,6 +667,11 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
   return 0.0f - acc;
 }
 
+// Build-time knob: 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per CU).
+// The phase is latency-bound per CU; 12 / 16 are the next things to measure.
+#ifndef NANN_SCORE_U
+#define NANN_SCORE_U 8
+#endif
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
 // inside, so a subset of the workgroup can run it.
@@ -677,7 +682,7 @@ template <int LPR, int DT, int NWAVES>
 __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table, int d, const int32_t* ids,
                                                  int begin, int end, const float* qv, float* scores,
                                                  int wave_rel) {
-  constexpr int U = (DT == DT_F32) ? 4 : 8;
+  constexpr int U = (DT == DT_F32) ? NANN_SCORE_U / 2 : NANN_SCORE_U;
   constexpr int GPW = 64 / LPR;      // rows per wavefront per load
   constexpr int RPI = NWAVES * GPW;  // rows per iteration of the participating wavefronts
   if (end <= begin) return;

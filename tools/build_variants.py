@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Build kernel-experiment variants of libnann_hip.so side by side (nann_amd/_build/var_<name>/),
+for A/B runs on the GPU box in ONE call: tools/gpu_final2.sh benches every var_* it finds
+against the same cached index (NANN_HIP_LIB selects the library).
+usage: tools/build_variants.py [name=flag,flag ...]   (no arguments: the default set)"""
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nann_amd import build  # noqa: E402
+
+DEFAULT = {
+    "su12": ["-DNANN_SCORE_U=12"],   # scoring phase: 12 row loads per lane in flight
+    "su16": ["-DNANN_SCORE_U=16"],   # ... 16 (256 KB per CU)
+}
+
+
+def main():
+    todo = dict(DEFAULT)
+    if len(sys.argv) > 1:
+        todo = {}
+        for a in sys.argv[1:]:
+            name, _, flags = a.partition("=")
+            todo[name] = [f for f in flags.split(",") if f]
+    with ThreadPoolExecutor(max(1, min(3, len(todo)))) as ex:
+        for path in ex.map(lambda kv: build.build(variant=kv[0], extra_flags=kv[1]), todo.items()):
+            print(path)
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 # One call on the MI355X box, most important first, each step skipped once DEADLINE seconds
 # have passed: GPU tests, smoke, bench.py line (+CPU baseline), rocprofv3 kernel stats, HBM
 # PMC passes, kernel-variant A/B runs (prebuilt libs under nann_amd/_build/var_*), MLP bench.
-# usage: tools/gpu_final2.sh <tag> [deadline_s] [variants: yes|no]
+# usage: tools/gpu_final2.sh <tag> [deadline_s] [variants: yes|no] [glb]
 set -u
 TAG=${1:-final}
 DEADLINE=${2:-320}
@@ -77,15 +77,14 @@ except Exception as e:
 PY
   fi
 }
-run_variant u8 NANN_HIP_LIB=$R/nann_amd/_build/var_u8/libnann_hip.so
-run_variant u4 NANN_HIP_LIB=$R/nann_amd/_build/var_u4/libnann_hip.so
+for d in $R/nann_amd/_build/var_*; do  # tools/build_variants.py
+  [ -d "$d" ] && run_variant $(basename $d | sed 's/^var_//') NANN_HIP_LIB=$d/libnann_hip.so
+done
 # ---- MLP scorer (BASELINE configs[2])
 if [ $(left) -gt 35 ]; then
   MB="$BENCH --scorer mlp --batch 512 --steps 3 --warmup 1 --no-cpu-baseline"
   timeout 100 $MB > $OUT/bench_${TAG}_mlp.json 2> $OUT/bench_${TAG}_mlp.err; echo "mlp bench rc=$?"
   tail -c 900 $OUT/bench_${TAG}_mlp.json
 fi
-run_variant glb512 NANN_L2_VARIANT=glb512
-run_variant glb512x3 NANN_L2_VARIANT=glb512:3
-run_variant u2 NANN_HIP_LIB=$R/nann_amd/_build/var_u2/libnann_hip.so
+[ "${4:-}" = glb ] && run_variant glb512 NANN_L2_VARIANT=glb512
 echo "done left=$(left)"
