@@ -84,6 +84,24 @@ __device__ __forceinline__ uint32_t wave_and(uint32_t v) {
   v &= dpp_u32<0x143, 0xC>(0xffffffffu, v);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+  v = min(v, dpp_u32<0x111>(0xffffffffu, v));
+  v = min(v, dpp_u32<0x112>(0xffffffffu, v));
+  v = min(v, dpp_u32<0x114>(0xffffffffu, v));
+  v = min(v, dpp_u32<0x118>(0xffffffffu, v));
+  v = min(v, dpp_u32<0x142, 0xA>(0xffffffffu, v));
+  v = min(v, dpp_u32<0x143, 0xC>(0xffffffffu, v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+  v = max(v, dpp_u32<0x111>(0, v));
+  v = max(v, dpp_u32<0x112>(0, v));
+  v = max(v, dpp_u32<0x114>(0, v));
+  v = max(v, dpp_u32<0x118>(0, v));
+  v = max(v, dpp_u32<0x142, 0xA>(0, v));
+  v = max(v, dpp_u32<0x143, 0xC>(0, v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -805,6 +823,10 @@ static_assert(sizeof(TopkScratch) <= kLdsScoresOff, "top-k scratch overlaps the 
 static_assert(kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
 static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too small");
 
+// Build-time knob: 1 = radix search on key - min(key) instead of skipping the common prefix.
+#ifndef NANN_TOPK_MINSUB
+#define NANN_TOPK_MINSUB 0
+#endif
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
 // SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
 template <int NS, bool SCL, int NT>
@@ -853,6 +875,21 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     }                                                                         \
   }
 
+#if NANN_TOPK_MINSUB
+  // ---- 2a. range of the keys: the search runs on key - min(key), whose leading digit is spread
+  //          over the bins (the raw keys of scores within a few binades share all but 2-3 values of
+  //          their top 8 undecided bits, and same-bin LDS atomics serialise)
+  {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    NANN_FOR_KEYS({ if (valid) { lo = min(lo, kj); hi = max(hi, kj); } })
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0) { atomicMin(&S->andv, lo); atomicMax(&S->orv, hi); }
+  }
+  __syncthreads();
+  const uint32_t kbase = S->andv;          // smallest key
+  const uint32_t diff = S->orv - kbase;    // largest key - smallest key
+#else
   // ---- 2a. common prefix of all keys: the search only has to resolve the bits
   //          below the highest bit in which any two keys differ
   {
@@ -863,14 +900,20 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     if (lane == 0) { atomicOr(&S->orv, lo); atomicAnd(&S->andv, la); }
   }
   __syncthreads();
+  const uint32_t kbase = 0u;
   const uint32_t diff = S->orv ^ S->andv;
+#endif
   // ---- 2b. k-th largest key: radix select over the undecided bits, 8 bits per pass
   //          (LDS histogram -> 256-bin suffix scan).  A pass ends the search early when the
-  //          bin holding the k-th key is needed in full.
+  //          bin holding the k-th key is needed in full.  T is relative to kbase until the end.
   uint32_t T = 0, c_ge = (uint32_t)n, c_gt = 0;
   if (diff != 0u) {
     const int hb = 31 - __clz((int)diff);  // highest differing bit
+#if NANN_TOPK_MINSUB
+    T = 0u;
+#else
     T = S->andv & ~((hb == 31) ? 0xffffffffu : ((2u << hb) - 1u));
+#endif
     int top = hb + 1;          // undecided low bits
     uint32_t kk = (uint32_t)k;  // still to find among keys that match T above `top`
     bool exact = false;
@@ -880,7 +923,8 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       const uint32_t dmask = (1u << nb) - 1u;
       uint32_t* h = hist + pass * 256;
       NANN_FOR_KEYS({
-        if (valid && (top >= 32 || (kj >> top) == (T >> top))) atomicAdd(&h[(kj >> shift) & dmask], 1u);
+        const uint32_t kq = kj - kbase;
+        if (valid && (top >= 32 || (kq >> top) == (T >> top))) atomicAdd(&h[(kq >> shift) & dmask], 1u);
       })
       __syncthreads();
       // every wavefront scans the 256 bins on its own (no further barrier): lane l owns bins
@@ -912,6 +956,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       exact = (inbin == kk);
       top = shift;
     }
+    T += kbase;
   } else {
     T = S->andv;  // all keys equal
   }

@@ -13,6 +13,8 @@ from nann_amd import build  # noqa: E402
 DEFAULT = {
     "su12": ["-DNANN_SCORE_U=12"],   # scoring phase: 12 row loads per lane in flight
     "su16": ["-DNANN_SCORE_U=16"],   # ... 16 (256 KB per CU)
+    "tkms": ["-DNANN_TOPK_MINSUB=1"],  # top-k: radix search on key - min(key)
+    "su16_tkms": ["-DNANN_SCORE_U=16", "-DNANN_TOPK_MINSUB=1"],
 }
 
 
