@@ -208,3 +208,55 @@ def search_per_op(index, scorer, q, level_topn):
     idx_result, scores_result = _top_k(idx_result, scores_result, t[5])     # :143
     item_ids = ops.gather(index.item_ids.view(torch.int32).reshape(-1, 2), idx_result)   # :144
     return item_ids.reshape(-1).view(torch.int64), scores_result, idx_result
+
+
+# -----------------------------------------------------------------------------
+# f3: the eval-graph traversal (Model.retrieval / search_level, model.py:299-362) spelled with
+# the same drop-in ops.  It differs from the serving schedule in its frontier rule (new nodes
+# that score at least the worst kept result), in the min(k, n) guard of its top_k (model.py:268)
+# and in visiting neighbours as an ascending set (tf.unique + tf.sets, :316-321).
+def search_eval_per_op(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 200, 100),
+                       topk_eval=200, backend=None):
+    """One query through Model.retrieval().  num_scoring / top_k_per_level are indexed by level
+    (0, 1, start level 2), as config.py:50-58 lists them.  Returns
+    (item_ids i64[<=topk_eval], scores f32, internal index i32).  `backend`: the module providing
+    group_gather / bitmap_ref_difference / blaze_score / top_k / gather (default: nann_amd.ops, the
+    HIP kernels; the CPU tests pass a stand-in to check this host logic against the oracle)."""
+    B = ops if backend is None else backend
+    assert int(num_scoring[2]) == 1                                          # model.py:347
+    q = q.reshape(-1)
+
+    def get_scores(idx):                                                     # :240-262
+        if idx.numel() == 0:
+            raise ops.InternalError(6, "Error when getting input address or size")
+        return B.blaze_score(scorer, q, table=index.item_embs, indices=idx)
+
+    def top_k(ids, scores, k):                                               # :264-283, k = min(k, n)
+        k = min(int(k), int(ids.numel()))
+        scores, indices = B.top_k(scores, k)
+        return B.gather(ids, indices), scores
+
+    results = index.enter_points
+    scores = get_scores(results)                                             # :350-351
+    results, scores = top_k(results, scores, top_k_per_level[2])             # :353
+    for level in (1, 0):                                                     # :355-356
+        flags = torch.zeros(index.bitmap_words, dtype=torch.int32, device=index.enter_points.device)
+        idx_result, scores_result = results, scores
+        _, _, flags = B.bitmap_ref_difference(results, _fake_row_splits(results), flags)   # visited = idx_ep (:311)
+        idx_candidate = results
+        for _ in range(int(num_scoring[level])):
+            nxt, _ = B.group_gather(index.nb_values[level], index.nb_row_splits[level],
+                                    idx_candidate.to(torch.int64), _fake_row_splits(idx_candidate),
+                                    unique=False)                            # :316
+            nxt, _, flags = B.bitmap_ref_difference(nxt, _fake_row_splits(nxt), flags)   # unique, minus visited, visited |= (:317-321)
+            idx_next = torch.sort(nxt).values                                # tf.sets results are ascending
+            scores_next = get_scores(idx_next)                               # :323
+            idx_result, scores_result = top_k(torch.cat([idx_result, idx_next]),
+                                              torch.cat([scores_result, scores_next]),
+                                              top_k_per_level[level])        # :326-328
+            mask = scores_next >= scores_result[-1]                          # :330
+            idx_candidate = idx_next[mask]                                   # :331
+        results, scores = idx_result, scores_result
+    results, scores = results[:topk_eval], scores[:topk_eval]                # :358
+    item_ids = B.gather(index.item_ids.view(torch.int32).reshape(-1, 2), results)   # :360
+    return item_ids.reshape(-1).view(torch.int64), scores, results

@@ -231,3 +231,26 @@ def test_global_bitmap_variants(variant):
     p = subprocess.run([sys.executable, os.path.join(here, "gpu_variant_check.py")], env=env,
                        capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kind", ["l2", "mlp"])
+def test_eval_graph_matches_oracle(oracle, kind):
+    """f3: Model.retrieval / search_level (model.py:299-362) on the HIP ops vs the oracle's
+    restatement: threshold frontier rule, min(k, n) guard, ascending neighbour sets."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 64, 32)
+    w = synth.make_mlp_weights(64) if kind == "mlp" else None
+    osc = oracle.Scorer(kind, 64, oracle.EMB_F16, w)
+    sc = ops.Scorer(kind, 64, torch.float16, w)
+    qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 6, seed=9)])
+    n_ok = 0
+    for cfg in [((3, 1, 1), (400, 200, 100), 200), ((2, 2, 1), (60, 40, 16), 30)]:
+        for q in qs:
+            rc, eids, esc, eidx = oracle.search_eval(oix, osc, q, *cfg)
+            if rc:
+                continue
+            ids, s, idx = retrieval.search_eval_per_op(dix, sc, cuda(q), *cfg)
+            assert (idx.cpu().numpy() == eidx).all() and (ids.cpu().numpy() == eids).all()
+            assert (bits(s.cpu().numpy()) == bits(esc)).all()
+            n_ok += 1
+    assert n_ok >= 6
