@@ -21,7 +21,12 @@ constexpr int kNT = 1024;            // threads per traversal workgroup
 constexpr int kNW = kNT / 64;        // 16 wavefronts
 constexpr int kTopkEPT = 16;         // top-k keys held in registers per thread (n <= 16384)
 constexpr int kMaxK = 1024;          // largest k / frontier a workgroup handles
-constexpr int kPhaseScratch = 27648; // LDS bytes shared by the phases below
+// Build-time knob: 1 = the LDS-bitmap filter without the pre-read (wg_filter_chunk_packed); needs a
+// 4096-slot hash table, i.e. 5.5 KB more phase scratch (LDS bitmap capacity 1.026 M instead of 1.07 M items)
+#ifndef NANN_FILTER_PACKED
+#define NANN_FILTER_PACKED 0
+#endif
+constexpr int kPhaseScratch = NANN_FILTER_PACKED ? 33280 : 27648; // LDS bytes shared by the phases below
 constexpr int kMaxD = 512;
 // candidate scores of a round are mirrored in LDS behind the top-k scratch
 constexpr int kLdsScoresOff = 10752;
@@ -284,6 +289,7 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
 constexpr int kChunk = 2048;
 constexpr uint32_t kHashEmpty = 0xffffffffu;
 constexpr int kChunkTab = 64;
+constexpr int kHashSlots = NANN_FILTER_PACKED ? 2 * kChunk : kChunk;
 struct ExpandWalkScratch {
   uint32_t off[kMaxK + 1];
   uint32_t rowstart[kMaxK];
@@ -293,7 +299,7 @@ struct ExpandWalkScratch {
   int pad[2];
   int chunk_first[kChunkTab];  // first row of piece c (c < kChunkTab), filled by pass 1
   int32_t stage[kChunk];   // the piece being filtered
-  uint32_t hash[kChunk];   // slot -> smallest position (in the piece) of the id hashed there
+  uint32_t hash[kHashSlots];  // slot -> smallest position (in the piece) of the id hashed there
 };
 
 __device__ __forceinline__ uint32_t chunk_hash(int32_t x) {
@@ -421,6 +427,98 @@ __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, ui
   return base + (int)tot;
 }
 
+#if NANN_FILTER_PACKED
+// wg_filter_chunk_packed: the same result with one bitmap access per id and three barriers (LDS
+// bitmap only; ids < 2^21).  Every id ORs its bit in straight away: the lane that finds it clear
+// is the winner and publishes (id << 11 | position) in a 4096-slot table; after a barrier the
+// lanes that found the bit set look their id up -- present means "new in this piece, another copy
+// won", and they join the minimum; absent means "visited before this piece".  An id is kept at
+// the position that survives in its slot.
+__device__ __forceinline__ uint32_t chunk_hash12(int32_t x) { return ((uint32_t)x * 2654435761u) >> 20; }
+
+template <int NT>
+__device__ __forceinline__ int wg_filter_chunk_packed(ExpandWalkScratch* S, int n_c, uint32_t* bm,
+                                                      uint32_t n_items, int32_t* out, int base) {
+  constexpr int PER = kChunk / NT;
+  constexpr int NWV = NT / 64;
+  constexpr uint32_t HM = kHashSlots - 1;
+  static_assert(kHashSlots == 4096, "chunk_hash12 yields 12 bits");
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  int32_t x[PER];
+  if constexpr (PER == 2) {
+    const int2 v = reinterpret_cast<const int2*>(S->stage)[tid];
+    x[0] = v.x; x[1] = v.y;
+  } else {
+    const int4 v = reinterpret_cast<const int4*>(S->stage)[tid];
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  }
+  bool won[PER], lost[PER], keep[PER];
+  uint32_t entry[PER], slot[PER];
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {  // 1. set the bits (a lane's LDS operations execute in order)
+    const bool valid = tid * PER + e < n_c;
+    const bool inr = valid && (uint32_t)x[e] < n_items;
+    bad |= valid && !inr;
+    const uint32_t bit = 1u << (x[e] & 31);
+    uint32_t old = 0xffffffffu;
+    if (inr) old = atomicOr(bm + ((uint32_t)x[e] >> 5), bit);
+    won[e] = inr && !(old & bit);
+    lost[e] = inr && (old & bit);
+    entry[e] = ((uint32_t)x[e] << 11) | (uint32_t)(tid * PER + e);
+    slot[e] = 0;
+  }
+  if (bad) S->bad = 1;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {  // 2. winners publish
+    if (won[e]) {
+      uint32_t h = chunk_hash12(x[e]);
+      while (atomicCAS(&S->hash[h], kHashEmpty, entry[e]) != kHashEmpty) h = (h + 1) & HM;
+      slot[e] = h;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {  // 3. other copies of an id that is new in this piece join the minimum
+    bool cont = false;
+    if (lost[e]) {
+      uint32_t h = chunk_hash12(x[e]);
+      for (;;) {
+        const uint32_t cur = S->hash[h];
+        if (cur == kHashEmpty) break;  // visited before this piece
+        if ((cur >> 11) == (uint32_t)x[e]) { atomicMin(&S->hash[h], entry[e]); slot[e] = h; cont = true; break; }
+        h = (h + 1) & HM;
+      }
+    }
+    lost[e] = cont;
+  }
+  __syncthreads();
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {  // 4. the surviving position keeps the id
+    keep[e] = (won[e] || lost[e]) && S->hash[slot[e]] == entry[e];
+    cnt += keep[e] ? 1u : 0u;
+  }
+  const uint32_t inc = wave_scan_add(cnt);  // 5. ordered compaction
+  if (lane == 63) S->wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int wv = 0; wv < NWV; ++wv) {
+    const uint32_t v = S->wave_tot[wv];
+    if (wv < wave) wbase += v;
+    tot += v;
+  }
+  int o = base + (int)(wbase + inc - cnt);
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    if (keep[e]) out[o++] = x[e];
+    if (won[e]) S->hash[slot[e]] = kHashEmpty;  // every used slot belongs to exactly one winner
+  }
+  return base + (int)tot;
+}
+#endif
+
 // `stream` (optional): a scorer whose row loads fly underneath the filter.  Before piece c is
 // filtered, stream.issue_ids(b, e) / issue_rows() start the loads for the ids out[b..e) that earlier
 // pieces released (e - b <= Stream::kRows); after the filter, stream.finish() reduces them and
@@ -447,7 +545,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
   if (tid == 0) { S->bad = 0; S->any_contested = 0; }
-  for (int i = tid; i < kChunk; i += NT) S->hash[i] = kHashEmpty;
+  for (int i = tid; i < kHashSlots; i += NT) S->hash[i] = kHashEmpty;
   __syncthreads();
   // ---- pass 1: row lengths -> offsets --------------------------------------
   constexpr int NWV = NT / 64;
@@ -583,7 +681,12 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
     if (Stream::kRows > 0 && stream_on) stream.issue_rows();
     const int n_c = min(kChunk, G - c * kChunk);
     long long tw = pt ? pt->now() : 0;
+#if NANN_FILTER_PACKED
+    if constexpr (kLdsBm) base = wg_filter_chunk_packed<NT>(S, n_c, bm, n_items, out, base);
+    else base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
+#else
     base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
+#endif
     if (pt) pt->sub(PH_EX_WALKBUSY, tw);
     if (Stream::kRows > 0 && stream_on) { stream.finish(); scored = s_end; }
     if (more) {
