@@ -248,6 +248,41 @@ def make_mlp_weights(d, h1=256, h2=128, seed=777):
     }
 
 
+def make_attn_weights(d, E=64, h=(128, 64, 32), seed=778):
+    """Seeded weights of the reference's scorer model (model.py:189-233, model_util.py:70-97) with
+    the reference's initialisers' scales: attention dense layers glorot-uniform with zero bias
+    (tf.layers.dense defaults), DNN layers variance-scaling(fan_in) normal with bias 0.1
+    (model_util.py:47-48), PReLU slopes around 0.25 (:10), and non-trivial batch-norm statistics,
+    folded (scale = gamma / sqrt(var + 1e-3), shift = beta - mean * scale)."""
+    rng = np.random.default_rng(seed)
+
+    def glorot(n_in, n_out):
+        lim = math.sqrt(6.0 / (n_in + n_out))
+        return rng.uniform(-lim, lim, size=(n_in, n_out)).astype(np.float32)
+
+    def small(n, centre=0.0, spread=0.05):
+        return (centre + spread * rng.standard_normal(n)).astype(np.float32)
+
+    w = {"wq1": glorot(d, 2 * E), "bq1": small(2 * E), "aq": small(2 * E, 0.25),
+         "wq2": glorot(2 * E, 4 * E), "bq2": small(4 * E),
+         "wk1": glorot(E, 2 * E), "bk1": small(2 * E), "ak": small(2 * E, 0.25),
+         "wk2": glorot(2 * E, 4 * E), "bk2": small(4 * E),
+         "w": [], "b": [], "bn_scale": [], "bn_shift": [], "alpha": []}
+    n_in = E + d
+    for n_out in h:
+        w["w"].append((rng.standard_normal((n_in, n_out)) / math.sqrt(n_in)).astype(np.float32))
+        w["b"].append(small(n_out, 0.1, 0.02))
+        gamma, beta = small(n_out, 1.0, 0.1), small(n_out, 0.0, 0.1)
+        mean, var = small(n_out, 0.0, 0.3), (0.5 + rng.random(n_out)).astype(np.float32)
+        scale = (gamma / np.sqrt(var + np.float32(1e-3))).astype(np.float32)
+        w["bn_scale"].append(scale)
+        w["bn_shift"].append((beta - mean * scale).astype(np.float32))
+        w["alpha"].append(small(n_out, 0.25))
+        n_in = n_out
+    w["w"].append((rng.standard_normal(n_in) / math.sqrt(n_in)).astype(np.float32))
+    return w
+
+
 def make_index(n_items, d, ef, m=M_DEFAULT, device=None, mode="hnsw", seed=1234,
                n_clusters=256, noise=0.5, shard=0):
     """One call: corpus + ids + graph.  Guarantees E >= ef."""

@@ -885,3 +885,72 @@ int oracle_merge_topk(const float* scores, const int64_t* ids, int n_shards, int
   free(idx);
   return rc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* the reference's scorer model (see nann_oracle.h)         */
+static void dense(const float* x, int n_in, const float* w, const float* b, int n_out, float* y) {
+  for (int j = 0; j < n_out; ++j) {
+    float acc = b ? b[j] : 0.0f;
+    for (int k = 0; k < n_in; ++k) acc = fmaf(x[k], w[(int64_t)k * n_out + j], acc);
+    y[j] = acc;
+  }
+}
+
+static int attn_ok(const oracle_attn_model_t* m) {
+  return m && m->d > 0 && m->d <= 512 && m->E > 0 && m->E <= 256 && m->L > 0 && m->L <= 1024 &&
+         m->h[0] > 0 && m->h[0] <= 1024 && m->h[1] > 0 && m->h[1] <= 1024 && m->h[2] > 0 && m->h[2] <= 1024;
+}
+
+int oracle_attn_prepare(const oracle_attn_model_t* m, const float* user_seq, float* kproj) {
+  if (!attn_ok(m)) return ORACLE_ERR_BAD_ARGUMENT;
+  const int E = m->E;
+  float k1[512];
+  for (int l = 0; l < m->L; ++l) { /* model_util.py:84-85 */
+    dense(user_seq + (int64_t)l * E, E, m->wk1, m->bk1, 2 * E, k1);
+    for (int j = 0; j < 2 * E; ++j) k1[j] = prelu(k1[j], m->ak[j]);
+    dense(k1, 2 * E, m->wk2, m->bk2, 4 * E, kproj + (int64_t)l * 4 * E);
+  }
+  return ORACLE_OK;
+}
+
+int oracle_attn_score_rows(const oracle_attn_model_t* m, const float* user_seq, const float* kproj,
+                           const void* rows, int64_t n, float* out_scores) {
+  if (!attn_ok(m)) return ORACLE_ERR_BAD_ARGUMENT;
+  if (n <= 0) return ORACLE_ERR_EMPTY_SCORE_BATCH; /* blaze_xla_predictor.cc:259-263 */
+  const int d = m->d, E = m->E, L = m->L;
+  float e[512], q1[512], q_[1024], att[1024], x[1024], y[1024];
+  const float inv = 1.0f / sqrtf((float)(4 * E)); /* model_util.py:89-91 */
+  for (int64_t i = 0; i < n; ++i) {
+    const char* row = (const char*)rows + i * (int64_t)d * elem_bytes(m->emb_dtype);
+    for (int k = 0; k < d; ++k) e[k] = load_elem(row, m->emb_dtype, k);
+    dense(e, d, m->wq1, m->bq1, 2 * E, q1); /* :81-82 */
+    for (int j = 0; j < 2 * E; ++j) q1[j] = prelu(q1[j], m->aq[j]);
+    dense(q1, 2 * E, m->wq2, m->bq2, 4 * E, q_);
+    float mx = -INFINITY;
+    for (int l = 0; l < L; ++l) { /* einsum knd,kld->knl, / sqrt(d_k) (:90-91) */
+      float acc = 0.0f;
+      for (int k = 0; k < 4 * E; ++k) acc = fmaf(q_[k], kproj[(int64_t)l * 4 * E + k], acc);
+      att[l] = acc * inv;
+      if (att[l] > mx) mx = att[l];
+    }
+    float sum = 0.0f;
+    for (int l = 0; l < L; ++l) { att[l] = expf(att[l] - mx); sum += att[l]; } /* softmax (:93) */
+    for (int k = 0; k < E; ++k) { /* att_out summed over the sequence (:95, model.py:204-206) */
+      float acc = 0.0f;
+      for (int l = 0; l < L; ++l) acc = fmaf(att[l] / sum, user_seq[(int64_t)l * E + k], acc);
+      x[k] = acc;
+    }
+    for (int k = 0; k < d; ++k) x[E + k] = e[k]; /* concat (model.py:211) */
+    int n_in = E + d;
+    for (int layer = 0; layer < 3; ++layer) { /* DNN + bn + prelu (model.py:213-216) */
+      dense(x, n_in, m->w[layer], m->b[layer], m->h[layer], y);
+      for (int j = 0; j < m->h[layer]; ++j)
+        x[j] = prelu(fmaf(y[j], m->bn_scale[layer][j], m->bn_shift[layer][j]), m->alpha[layer][j]);
+      n_in = m->h[layer];
+    }
+    float logit = 0.0f; /* last layer: no bias, no activation (:218-219) */
+    for (int k = 0; k < n_in; ++k) logit = fmaf(x[k], m->w[3][k], logit);
+    out_scores[i] = logit;
+  }
+  return ORACLE_OK;
+}

@@ -220,6 +220,41 @@ int oracle_merge_topk(const float* scores, const int64_t* ids, int n_shards,
                       int32_t k_in, int32_t k_out, float* out_scores,
                       int64_t* out_ids);
 
+/* SURVEY.md 8(f2), oracle side only so far -- PARITY UNPINNED: TensorFlow is not in the image,
+ * so this restatement of the reference's scorer model has not been checked against a run of the
+ * frozen graph; it is cross-checked against an independent float64 numpy restatement
+ * (tests/test_attn_model_cpu.py).
+ *
+ * The model behind BlazeXlaOp in the reference (NANN_impls/nann/model/model.py:189-233,
+ * model_util.py:9-11,32-67,70-97): for one user sequence u [L, E] and a candidate row e [d]
+ *   q1 = prelu(e Wq1 + bq1; aq)      [2E]      k1_l = prelu(u_l Wk1 + bk1; ak)  [2E]
+ *   q_ = q1 Wq2 + bq2                [4E]      k_l  = k1_l Wk2 + bk2            [4E]
+ *   att_l = <q_, k_l> / sqrt(4E);  p = softmax_l(att);  a = sum_l p_l u_l        [E]
+ *   x = [a ; e];  three times x = prelu(bn(x W + b)); logit = x W4 (no bias, model.py:218-219)
+ * Inference-mode batch norm is folded to y = x * bn_scale + bn_shift
+ * (scale = gamma / sqrt(moving_var + 1e-3), shift = beta - moving_mean * scale).
+ * No attention mask: zero-padded sequence positions take part in the softmax, as in
+ * nonlinear_attention().  All dense layers: acc = bias; acc = fmaf(x[k], W[k][j], acc), k ascending. */
+typedef struct {
+  int d, E, L, emb_dtype;
+  const float *wq1, *bq1, *aq; /* [d,2E] [2E] [2E] */
+  const float *wq2, *bq2;      /* [2E,4E] [4E] */
+  const float *wk1, *bk1, *ak; /* [E,2E] [2E] [2E] */
+  const float *wk2, *bk2;      /* [2E,4E] [4E] */
+  int h[3];                    /* DNN widths, 128-64-32 in the reference */
+  const float* w[4];           /* [E+d,h0] [h0,h1] [h1,h2] [h2] */
+  const float* b[3];
+  const float* bn_scale[3];
+  const float* bn_shift[3];
+  const float* alpha[3];
+} oracle_attn_model_t;
+
+/* per-user part: kproj[l] = k_l, f32 [L, 4E] */
+int oracle_attn_prepare(const oracle_attn_model_t* m, const float* user_seq, float* kproj);
+/* logits of n candidate rows ([n, d] in m->emb_dtype) for that user */
+int oracle_attn_score_rows(const oracle_attn_model_t* m, const float* user_seq, const float* kproj,
+                           const void* rows, int64_t n, float* out_scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -312,3 +312,50 @@ def algorithmic_bytes(counters, d, emb_bytes, n_enter, k_out=200):
     F, G, S = c[..., 0, :], c[..., 1, :], c[..., 2, :]
     per_round = S * d * emb_bytes + G * 4 + F * 16 + G * 8
     return per_round.sum(axis=-1) + n_enter * 4 + k_out * 12
+
+
+# ---- f2: the reference's scorer model (attention over the user sequence + DNN); PARITY UNPINNED
+class AttnModelStruct(C.Structure):
+    _fields_ = ([("d", C.c_int), ("E", C.c_int), ("L", C.c_int), ("emb_dtype", C.c_int)] +
+                [(n, C.c_void_p) for n in ("wq1", "bq1", "aq", "wq2", "bq2", "wk1", "bk1", "ak", "wk2", "bk2")] +
+                [("h", C.c_int * 3), ("w", C.c_void_p * 4), ("b", C.c_void_p * 3),
+                 ("bn_scale", C.c_void_p * 3), ("bn_shift", C.c_void_p * 3), ("alpha", C.c_void_p * 3)])
+
+
+class AttnModel:
+    """weights: dict with wq1,bq1,aq,wq2,bq2,wk1,bk1,ak,wk2,bk2 and lists w[4], b[3], bn_scale[3],
+    bn_shift[3], alpha[3] (f32 arrays; nann_amd.synth.make_attn_weights makes a seeded set)."""
+
+    def __init__(self, d, E, L, emb_dtype, weights):
+        s = AttnModelStruct()
+        s.d, s.E, s.L, s.emb_dtype = d, E, L, emb_dtype
+        self._keep = []
+
+        def hold(a):
+            a = _c(a, np.float32)
+            self._keep.append(a)
+            return a.ctypes.data
+
+        for n in ("wq1", "bq1", "aq", "wq2", "bq2", "wk1", "bk1", "ak", "wk2", "bk2"):
+            setattr(s, n, hold(weights[n]))
+        for i in range(3):
+            s.h[i] = int(np.asarray(weights["w"][i]).shape[1])
+            s.b[i], s.bn_scale[i] = hold(weights["b"][i]), hold(weights["bn_scale"][i])
+            s.bn_shift[i], s.alpha[i] = hold(weights["bn_shift"][i]), hold(weights["alpha"][i])
+        for i in range(4):
+            s.w[i] = hold(weights["w"][i])
+        self.s = s
+
+
+def attn_score_rows(model, user_seq, rows):
+    """user_seq f32[L, E]; rows [n, d] in the model's emb dtype -> (status, logits f32[n])"""
+    u = _c(user_seq, np.float32)
+    rows = np.ascontiguousarray(rows)
+    n = rows.shape[0]
+    kproj = np.zeros((model.s.L, 4 * model.s.E), np.float32)
+    rc = lib().oracle_attn_prepare(C.byref(model.s), _p(u), _p(kproj))
+    if rc:
+        return rc, np.zeros(0, np.float32)
+    out = np.zeros(max(n, 1), np.float32)
+    rc = lib().oracle_attn_score_rows(C.byref(model.s), _p(u), _p(kproj), _p(rows), C.c_int64(n), _p(out))
+    return rc, out[:n]
