@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--scorer", default="l2", choices=["l2", "mlp"],
                     help="l2 = BASELINE configs[1] (the headline metric); mlp = configs[2]: 256-128-1 MLP on MFMA")
     ap.add_argument("--index-cache", default=None, help="directory to cache the synthetic index in")
+    ap.add_argument("--batch-sweep", default="", help="comma-separated smaller batch sizes to time as well, e.g. 1,64,1024")
     ap.add_argument("--phase-ticks", action="store_true",
                     help="one extra instrumented launch: per-phase time attribution")
     return ap.parse_args()
@@ -180,7 +181,8 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- roofline of the traversal kernel (rank-local launch, HIP events on its stream)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_all = np.asarray([a.elapsed_time(b) for a, b in ev], np.float64)
+    kern_ms = float(kern_all.mean())
     status = r.status.cpu().numpy()
     counters = r.counters.cpu().numpy().astype(np.int64)
     n_valid = int((status == 0).sum())
@@ -234,7 +236,31 @@ def main():
                    "merge": args.merge if world > 1 else None},
         "qps_end_to_end": round(qps, 1), "valid_queries": n_valid, "setup_s": round(setup_s, 1),
         "roofline": roofline,
+        # per-launch latency of the traversal for one batch (HIP events, this rank)
+        "batch_latency_ms": {"batch": args.batch, "p50": round(float(np.percentile(kern_all, 50)), 4),
+                             "p99": round(float(np.percentile(kern_all, 99)), 4),
+                             "max": round(float(kern_all.max()), 4)},
     }
+    if args.batch_sweep:
+        # smaller request batches (B in {1, 64, 1024}): latency and QPS of one launch
+        sweep = []
+        for bsz in [int(x) for x in args.batch_sweep.split(",") if x]:
+            bsz = max(1, min(bsz, args.batch))
+            qb = ops.user_seq_mean(comm_seq[:bsz])
+            ts = []
+            for it in range(3 + 10):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                retrieval.search(index, scorer, qb, topn, want_counters=False)
+                e1.record()
+                torch.cuda.synchronize()
+                if it >= 3:
+                    ts.append(e0.elapsed_time(e1))
+            ts = np.asarray(ts)
+            sweep.append({"batch": bsz, "ms_p50": round(float(np.percentile(ts, 50)), 4),
+                          "ms_max": round(float(ts.max()), 4),
+                          "qps": round(bsz / (float(np.percentile(ts, 50)) * 1e-3), 1)})
+        result["batch_sweep"] = sweep
 
     if args.phase_ticks:
         from nann_amd import _lib

@@ -18,7 +18,7 @@ if [ $RC -ne 0 ]; then echo "GPU TESTS FAILED"; grep -E "^(E  |FAILED)" $OUT/pyt
 timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -1 $OUT/smoke_$TAG.log
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --index-cache /tmp/idx"
-timeout 260 $BENCH --phase-ticks --cpu-seconds 8 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$? left=$(left)"
+timeout 260 $BENCH --phase-ticks --cpu-seconds 8 --batch-sweep 1,64,1024 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$? left=$(left)"
 python - <<PY
 import json
 try:
