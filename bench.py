@@ -70,7 +70,7 @@ def algorithmic_bytes(counters, d, emb_bytes, n_enter, k_out=200):
 
 def load_pmc_traffic(args):
     """HBM bytes per k_search launch from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json, written from tools/gpu_final.sh output): PMC counters cannot
+    (profiles/pmc_latest.json, written from tools/gpu_round.sh output): PMC counters cannot
     be read from inside the timed process.  Only reported when the workload matches."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
     try:

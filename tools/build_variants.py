@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build kernel-experiment variants of libnann_hip.so side by side (nann_amd/_build/var_<name>/),
-for A/B runs on the GPU box in ONE call: tools/gpu_final2.sh benches every var_* it finds
+for A/B runs on the GPU box in ONE call: tools/gpu_round.sh benches every var_* it finds
 against the same cached index (NANN_HIP_LIB selects the library).
 usage: tools/build_variants.py [name=flag,flag ...]   (no arguments: the default set)"""
 import os

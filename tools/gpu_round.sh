@@ -2,7 +2,7 @@
 # One call on the MI355X box, most important first, each step skipped once DEADLINE seconds
 # have passed: GPU tests, smoke, bench.py line (+CPU baseline), rocprofv3 kernel stats, HBM
 # PMC passes, kernel-variant A/B runs (prebuilt libs under nann_amd/_build/var_*), MLP bench.
-# usage: tools/gpu_final2.sh <tag> [deadline_s] [variants: yes|no] [glb]
+# usage: tools/gpu_round.sh <tag> [deadline_s] [variants: yes|no] [glb]
 set -u
 TAG=${1:-final}
 DEADLINE=${2:-320}
