@@ -142,6 +142,21 @@ struct PhaseTimer {
   }
   __device__ __forceinline__ long long now() const { return on ? (long long)clock64() : 0; }
 };
+// The view of the timer the building blocks take BY VALUE (a pointer to the PhaseTimer object,
+// nullable, kept it in scratch memory: every mark cost a scratch load even with timing off).
+struct SubTimer {
+  long long* ticks;
+  bool on;
+  __device__ __forceinline__ long long now() const { return on ? (long long)clock64() : 0; }
+  __device__ __forceinline__ void sub(int phase, long long& t0) const {
+    if (on && threadIdx.x == 0) {
+      const long long t = (long long)clock64();
+      ticks[phase] += t - t0;
+      t0 = t;
+    }
+  }
+};
+__device__ __forceinline__ SubTimer no_timer() { return SubTimer{nullptr, false}; }
 
 // ---------------------------------------------------------------------------
 // scalar conversions (exact)
@@ -537,10 +552,10 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
-                                              PhaseTimer* pt, Stream& stream, bool stream_on,
+                                              SubTimer pt, Stream& stream, bool stream_on,
                                               int* streamed) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
-  long long tsub = pt ? pt->now() : 0;
+  long long tsub = pt.now();
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
@@ -589,7 +604,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   if (tid == 0) S->off[n_rows] = total;
   __syncthreads();
   *gathered = (int)total;
-  if (pt) pt->sub(PH_EX_PASS1, tsub);
+  pt.sub(PH_EX_PASS1, tsub);
   if (S->bad) return -1;
   // ---- pass 2: fetch piece c+1 || filter piece c -------------------------------
   const int G = (int)total;
@@ -680,14 +695,14 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
     if (more) issue(c + 1, first_row(c + 1) + wave, B);  // adjacency loads in flight underneath the filter
     if (Stream::kRows > 0 && stream_on) stream.issue_rows();
     const int n_c = min(kChunk, G - c * kChunk);
-    long long tw = pt ? pt->now() : 0;
+    long long tw = pt.now();
 #if NANN_FILTER_PACKED
     if constexpr (kLdsBm) base = wg_filter_chunk_packed<NT>(S, n_c, bm, n_items, out, base);
     else base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
 #else
     base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
 #endif
-    if (pt) pt->sub(PH_EX_WALKBUSY, tw);
+    pt.sub(PH_EX_WALKBUSY, tw);
     if (Stream::kRows > 0 && stream_on) { stream.finish(); scored = s_end; }
     if (more) {
       commit(c + 1, B);
@@ -695,7 +710,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
     }
     __syncthreads();
   }
-  if (pt) pt->sub(PH_EX_LOOP, tsub);
+  pt.sub(PH_EX_LOOP, tsub);
   const int bad = S->bad;
   __syncthreads();
   *streamed = scored;
@@ -709,7 +724,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
-                                              PhaseTimer* pt = nullptr) {
+                                              SubTimer pt = no_timer()) {
   NoStream none;
   int streamed = 0;
   return wg_expand_walk<kLdsBm, NT, NoStream>(frontier, n_frontier, values, row_splits, n_items, bm, out,
@@ -936,9 +951,9 @@ template <int NS, bool SCL, int NT>
 __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
                                             const float* lds_scores, int n, int k, int32_t* out_pos,
                                             int32_t* out_ids, float* out_scores, const int64_t* id_map,
-                                            int64_t* out_mapped, unsigned char* scratch, PhaseTimer* pt) {
+                                            int64_t* out_mapped, unsigned char* scratch, SubTimer pt) {
   TopkScratch* S = reinterpret_cast<TopkScratch*>(scratch);
-  long long tsub = pt ? pt->now() : 0;
+  long long tsub = pt.now();
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const uint64_t lt = lanemask_lt(lane);
   constexpr bool REG = NS > 0;
@@ -959,7 +974,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   if (tid < 4) S->misc[tid] = 0;
   if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
   __syncthreads();
-  if (pt) pt->sub(PH_TK_LOAD, tsub);
+  pt.sub(PH_TK_LOAD, tsub);
 
 #define NANN_FOR_KEYS(...)                                                    \
   if constexpr (REG) {                                                        \
@@ -1066,7 +1081,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   // c_ge = #keys >= T >= k; c_gt = #keys > T (when the search ran to the last bit).  If
   // c_ge > k, T is the exact k-th key and only some of the keys equal to T are admitted.
   __syncthreads();  // the histograms alias sel: every wavefront is done scanning them
-  if (pt) pt->sub(PH_TK_SEARCH, tsub);
+  pt.sub(PH_TK_SEARCH, tsub);
   const bool partial_eq = c_ge > (uint32_t)k;
   // ---- 3. collect -----------------------------------------------------------
   if (!partial_eq) {
@@ -1115,7 +1130,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   }
 #undef NANN_FOR_KEYS
   __syncthreads();
-  if (pt) pt->sub(PH_TK_COLLECT, tsub);
+  pt.sub(PH_TK_COLLECT, tsub);
   // ---- 4. rank sort + output --------------------------------------------------
   // rank(e) = #{o : sel[o] > sel[e]} (pairs are distinct).  The k x k comparisons are
   // spread over all threads: element e = tid % K2, comparison segment = tid / K2.
@@ -1154,7 +1169,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     if (out_mapped) out_mapped[rank] = id_map[idv];
   }
   __syncthreads();
-  if (pt) pt->sub(PH_TK_SORT, tsub);
+  pt.sub(PH_TK_SORT, tsub);
   return 0;
 }
 
@@ -1163,7 +1178,7 @@ template <int NT = kNT>
 __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, const float* lds_scores,
                                        int n, int k, int32_t* out_pos, int32_t* out_ids,
                                        float* out_scores, const int64_t* id_map, int64_t* out_mapped,
-                                       unsigned char* scratch, PhaseTimer* pt = nullptr) {
+                                       unsigned char* scratch, SubTimer pt = no_timer()) {
   if (k < 0 || k > kMaxK) return 7;  // NANN_ERR_BAD_ARGUMENT
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;

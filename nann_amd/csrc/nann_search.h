@@ -123,7 +123,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   float* lds_scores = SC == NANN_SCORER_L2 ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
   PhaseTimer timer;
   timer.start(ticks, a.phase_ticks != nullptr);
-  PhaseTimer* pt = a.phase_ticks ? &timer : nullptr;
+  const SubTimer pt{ticks, a.phase_ticks != nullptr};
   auto mark = [&](int phase) { timer.mark(phase); };
 
   for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
@@ -211,10 +211,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
             stream.scores = sv.cand_scores + base_off;
             kept = wg_expand_walk<LDSBM, NT, L2Stream<LPR, DT, NT>>(
                 ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst, scratch, &gathered,
-                ss == 0 ? nullptr : pt, stream, ss != 0, &streamed);
+                ss == 0 ? no_timer() : pt, stream, ss != 0, &streamed);
           } else {
             kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
-                                             scratch, &gathered, ss == 0 ? nullptr : pt);
+                                             scratch, &gathered, ss == 0 ? no_timer() : pt);
           }
         }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
