@@ -129,7 +129,8 @@ def _hnsw_like(x_f16, members, deg, device=None, chunk=4096):
         c = e - s
         dist = sq[s:e, None] - 2.0 * (sub[s:e] @ sub[:e].T) + sq[None, :e]
         rows = torch.arange(s, e, device=dev)
-        dist.masked_fill_(torch.arange(e, device=dev)[None, :] >= rows[:, None], float("inf"))
+        # only earlier nodes are candidates: columns < s are all earlier, the diagonal block needs the mask
+        dist[:, s:e].masked_fill_(rows[None, :] >= rows[:, None], float("inf"))
         kk = min(k, e)
         dv, idx = torch.topk(dist, kk, dim=1, largest=False, sorted=True)
         del dist
@@ -142,8 +143,13 @@ def _hnsw_like(x_f16, members, deg, device=None, chunk=4096):
     src = torch.cat(src_l); dst = torch.cat(dst_l)
     # ---- add back-links, then shrink every row to <= deg ---------------------
     a = torch.cat([src, dst]); b = torch.cat([dst, src])
-    dd = ((sub[a] - sub[b]) ** 2).sum(1)
-    order = torch.argsort(a * (len(dd) + 1) + torch.argsort(torch.argsort(dd)))  # by (row, dist)
+    dd = torch.empty(len(a), dtype=torch.float32, device=dev)
+    for s0 in range(0, len(a), 1 << 22):  # edge distances in pieces: [edges, d] temporaries stay small
+        s1 = min(s0 + (1 << 22), len(a))
+        dd[s0:s1] = ((sub[a[s0:s1]] - sub[b[s0:s1]]) ** 2).sum(1)
+    o1 = torch.argsort(dd, stable=True)                 # by (row, dist): distance first, then a stable sort by row
+    order = o1[torch.argsort(a[o1], stable=True)]
+    del o1
     a, b, dd = a[order], b[order], dd[order]
     counts = torch.bincount(a, minlength=n)
     starts = torch.cumsum(counts, 0) - counts
