@@ -245,6 +245,41 @@ int nann_merge_topk_host(const float* scores, const int64_t* ids, int64_t n_quer
                          int32_t n_shards, int32_t k_in, int32_t k_out, float* out_scores,
                          int64_t* out_ids);
 
+/* ---- 8(f2): the reference's own scorer model behind the BlazeXlaOp contract -------------
+ * NANN_impls/nann/model/model.py:189-233 + model_util.py:70-97: softmax attention of the candidate
+ * over the user's behaviour sequence u f16[L, 64] (comm_seq, build_opt_graph.py:76-79), then a DNN
+ * 128-64-32-1 with batch norm (folded to scale/shift) and PReLU, last layer bias-free.  f32 logits,
+ * rows scored independently.  This build: E = 64, L <= 64, d in {64, 128}, rows f16 or bf16.
+ * STATUS: kernel written against the oracle restatement, not yet run on hardware.
+ * All descriptor pointers are [host] f32; the scorer owns device copies. */
+typedef struct nann_attn_scorer nann_attn_scorer;
+typedef struct {
+  int32_t d;         /* item embedding dim */
+  int32_t emb_dtype; /* NANN_F16 | NANN_BF16 */
+  int32_t seq_len;   /* L */
+  const float *wq1, *bq1, *aq; /* [d,128] [128] [128] */
+  const float *wq2, *bq2;      /* [128,256] [256] */
+  const float *wk1, *bk1, *ak; /* [64,128] [128] [128] */
+  const float *wk2, *bk2;      /* [128,256] [256] */
+  const float* w[4];           /* [64+d,128] [128,64] [64,32] [32] */
+  const float* b[3];
+  const float* bn_scale[3];
+  const float* bn_shift[3];
+  const float* alpha[3];
+} nann_attn_desc;
+int nann_attn_scorer_create(const nann_attn_desc* desc /*[host]*/, nann_attn_scorer** out);
+void nann_attn_scorer_destroy(nann_attn_scorer* s);
+/* Per-user part, once per request: user_seq f16[n_users, L, 64] -> kt f32[n_users, 256, 64]
+ * (the projected keys, transposed, zero beyond L) and upad f32[n_users, 64, 64] (the sequence,
+ * zero-padded); both caller-owned device buffers. */
+int nann_attn_prepare(const nann_attn_scorer* s, const void* user_seq_f16, int64_t n_users, float* kt,
+                      float* upad, nann_stream_t stream);
+/* Logits of n candidate rows for ONE user (kt / upad of that user); table / indices / errors as
+ * nann_score. */
+int nann_attn_score(const nann_attn_scorer* s, const float* kt, const float* upad, const void* table,
+                    int64_t n_table_rows, const int32_t* indices, int64_t n, float* out_scores,
+                    int64_t* bad_i, nann_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ SYMBOLS = [
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
     "nann_search", "nann_search_ex", "nann_merge_topk", "nann_merge_topk_host",
+    "nann_attn_scorer_create", "nann_attn_scorer_destroy", "nann_attn_prepare", "nann_attn_score",
 ]
 
 
@@ -41,6 +42,13 @@ class ScorerDesc(C.Structure):
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("alpha1", C.c_void_p),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("alpha2", C.c_void_p),
                 ("w3", C.c_void_p)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = ([("d", C.c_int32), ("emb_dtype", C.c_int32), ("seq_len", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("wq1", "bq1", "aq", "wq2", "bq2", "wk1", "bk1", "ak", "wk2", "bk2")] +
+                [("w", C.c_void_p * 4), ("b", C.c_void_p * 3), ("bn_scale", C.c_void_p * 3),
+                 ("bn_shift", C.c_void_p * 3), ("alpha", C.c_void_p * 3)])
 
 
 class IndexDesc(C.Structure):
@@ -74,6 +82,7 @@ def lib():
         for name in SYMBOLS:
             getattr(L, name)  # AttributeError if the ABI is incomplete
         L.nann_scorer_destroy.restype = None
+        L.nann_attn_scorer_destroy.restype = None
         L.nann_index_destroy.restype = None
         _LIB = L
     return _LIB

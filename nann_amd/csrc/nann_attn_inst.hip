@@ -1,0 +1,31 @@
+// nann_attn_inst.hip -- kernels of the reference scorer model (nann_attn.h) and their launchers.
+#include "nann_search.h"
+#include "nann_attn_kernels.h"
+
+namespace nann {
+
+int launch_attn_prepare(hipStream_t st, const AttnParams& P, const void* user_seq_f16, long long n_users,
+                        float* kt, float* upad) {
+  hipLaunchKernelGGL(k_attn_prepare, dim3((unsigned)n_users), dim3(256), 0, st, P,
+                     static_cast<const uint16_t*>(user_seq_f16), kt, upad);
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+int launch_score_attn(int dt, unsigned blocks, hipStream_t st, const AttnParams& P, const float* kt,
+                      const float* upad, const void* table, long long n_table_rows, const int32_t* indices,
+                      long long n, float* scores, long long* bad_i) {
+#define NANN_ATTN_CASE(D_, DT_)                                                                      \
+  hipLaunchKernelGGL((k_score_attn<D_, DT_>), dim3(blocks), dim3(kAttnNT), 0, st, P, kt, upad, table, \
+                     n_table_rows, indices, n, scores, bad_i)
+  if (P.d == 64 && dt == NANN_F16) NANN_ATTN_CASE(64, DT_F16);
+  else if (P.d == 64 && dt == NANN_BF16) NANN_ATTN_CASE(64, DT_BF16);
+  else if (P.d == 128 && dt == NANN_F16) NANN_ATTN_CASE(128, DT_F16);
+  else if (P.d == 128 && dt == NANN_BF16) NANN_ATTN_CASE(128, DT_BF16);
+  else return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d in {64, 128}, rows f16 or bf16");
+#undef NANN_ATTN_CASE
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+}  // namespace nann

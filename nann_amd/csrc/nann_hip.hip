@@ -2,6 +2,7 @@
 // The ABI is documented in include/nann_hip.h; the workgroup building blocks
 // in nann_device.h.  Reference citations are relative to /root/reference/.
 #include "nann_search.h"
+#include "nann_attn.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -352,6 +353,12 @@ struct nann_scorer {
   nann_scorer_desc desc;
   float* dev_weights = nullptr;  // MLP weights block in HBM
   MlpParams mlp = {};
+};
+
+struct nann_attn_scorer {
+  AttnParams P = {};
+  int emb_dtype = 0;
+  float* dev_weights = nullptr;
 };
 
 struct nann_index {
@@ -811,6 +818,93 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table, int
     default: launch_score<64>(dt, blocks, st, table, n_table_rows, d, indices, n, q, out_scores, rb->dev); break;
   }
   HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  if (rb->host->bad_i != 0x7fffffffffffffffll) {
+    if (bad_i) *bad_i = rb->host->bad_i;
+    return fail(NANN_ERR_INDEX_OUT_OF_RANGE, "indices[" + std::to_string(rb->host->bad_i) +
+                                                 "] is not in [0, " + std::to_string(n_table_rows) + ")");
+  }
+  return NANN_OK;
+}
+
+// ---- 8(f2): the reference scorer model -------------------------------------------------
+int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) {
+  if (!desc || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_attn_scorer_create: null argument");
+  const int d = desc->d, L = desc->seq_len;
+  if (d != 64 && d != 128) return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d must be 64 or 128");
+  if (L <= 0 || L > kAttnLP) return fail(NANN_ERR_UNSUPPORTED, "attention scorer: seq_len must be in [1, 64]");
+  if (desc->emb_dtype != NANN_F16 && desc->emb_dtype != NANN_BF16)
+    return fail(NANN_ERR_UNSUPPORTED, "attention scorer: item rows must be f16 or bf16");
+  const float* src[] = {desc->wq1, desc->bq1, desc->aq, desc->wq2, desc->bq2, desc->wk1, desc->bk1, desc->ak,
+                        desc->wk2, desc->bk2,
+                        desc->w[0], desc->b[0], desc->bn_scale[0], desc->bn_shift[0], desc->alpha[0],
+                        desc->w[1], desc->b[1], desc->bn_scale[1], desc->bn_shift[1], desc->alpha[1],
+                        desc->w[2], desc->b[2], desc->bn_scale[2], desc->bn_shift[2], desc->alpha[2],
+                        desc->w[3]};
+  const size_t cnt[] = {(size_t)d * 128, 128, 128, 128 * 256, 256, 64 * 128, 128, 128, 128 * 256, 256,
+                        (size_t)(64 + d) * 128, 128, 128, 128, 128,
+                        128 * 64, 64, 64, 64, 64,
+                        64 * 32, 32, 32, 32, 32,
+                        32};
+  constexpr int NV = sizeof(cnt) / sizeof(cnt[0]);
+  size_t off[NV], total = 0;
+  for (int i = 0; i < NV; ++i) {
+    if (!src[i]) return fail(NANN_ERR_BAD_ARGUMENT, "attention scorer: null weight pointer");
+    off[i] = total;
+    total += (cnt[i] + 3) & ~(size_t)3;  // keep every vector 16-byte aligned (float4 staging)
+  }
+  std::vector<float> host(total, 0.0f);
+  for (int i = 0; i < NV; ++i) std::memcpy(host.data() + off[i], src[i], cnt[i] * 4);
+  nann_attn_scorer* s = new nann_attn_scorer();
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->dev_weights), total * 4);
+  if (e == hipSuccess) e = hipMemcpy(s->dev_weights, host.data(), total * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    nann_attn_scorer_destroy(s);
+    return fail(NANN_ERR_HIP, std::string("attention scorer weights: ") + hipGetErrorString(e));
+  }
+  const float* w = s->dev_weights;
+  AttnParams& P = s->P;
+  const float** dst[] = {&P.wq1, &P.bq1, &P.aq, &P.wq2, &P.bq2, &P.wk1, &P.bk1, &P.ak, &P.wk2, &P.bk2,
+                         &P.w1, &P.b1, &P.s1, &P.t1, &P.a1, &P.w2, &P.b2, &P.s2, &P.t2, &P.a2,
+                         &P.w3, &P.b3, &P.s3, &P.t3, &P.a3, &P.w4};
+  for (int i = 0; i < NV; ++i) *dst[i] = w + off[i];
+  P.d = d;
+  P.L = L;
+  s->emb_dtype = desc->emb_dtype;
+  *out = s;
+  return NANN_OK;
+}
+
+void nann_attn_scorer_destroy(nann_attn_scorer* s) {
+  if (!s) return;
+  if (s->dev_weights) (void)hipFree(s->dev_weights);
+  delete s;
+}
+
+int nann_attn_prepare(const nann_attn_scorer* s, const void* user_seq_f16, int64_t n_users, float* kt,
+                      float* upad, nann_stream_t stream) {
+  if (!s || !user_seq_f16 || !kt || !upad) return fail(NANN_ERR_BAD_ARGUMENT, "nann_attn_prepare: null argument");
+  if (n_users <= 0) return NANN_OK;
+  return launch_attn_prepare(as_stream(stream), s->P, user_seq_f16, n_users, kt, upad);
+}
+
+int nann_attn_score(const nann_attn_scorer* s, const float* kt, const float* upad, const void* table,
+                    int64_t n_table_rows, const int32_t* indices, int64_t n, float* out_scores,
+                    int64_t* bad_i, nann_stream_t stream) {
+  if (!s || !kt || !upad || !table) return fail(NANN_ERR_BAD_ARGUMENT, "nann_attn_score: null argument");
+  if (bad_i) *bad_i = -1;
+  if (n <= 0)  // blaze_xla_predictor.cc:259-263
+    return fail(NANN_ERR_EMPTY_SCORE_BATCH, "Error when getting input address or size");
+  ResultBuf* rb;
+  int rc = get_result_buf(&rb);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, st, rb->dev);
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+  rc = launch_score_attn(s->emb_dtype, blocks, st, s->P, kt, upad, table, n_table_rows, indices, n, out_scores,
+                         &rb->dev->bad_i);
+  if (rc) return rc;
   rc = fetch_result(rb, st);
   if (rc) return rc;
   if (rb->host->bad_i != 0x7fffffffffffffffll) {

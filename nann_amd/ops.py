@@ -250,6 +250,63 @@ class Scorer:
             self.handle = C.c_void_p(0)
 
 
+class AttnScorer:
+    """The reference's own scorer model behind the BlazeXlaOp contract (SURVEY.md 8 f2;
+    model.py:189-233, model_util.py:70-97): weights dict as synth.make_attn_weights.  The kernel
+    has not been run on hardware yet."""
+
+    def __init__(self, d, seq_len, emb_dtype=torch.float16, weights=None):
+        self.d, self.seq_len, self.emb_dtype = d, seq_len, emb_dtype
+        desc = _lib.AttnDesc()
+        desc.d, desc.seq_len, desc.emb_dtype = d, seq_len, _DT[emb_dtype]
+        self._keep = []
+
+        def hold(a):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            self._keep.append(a)
+            return a.ctypes.data
+
+        for name in ("wq1", "bq1", "aq", "wq2", "bq2", "wk1", "bk1", "ak", "wk2", "bk2"):
+            setattr(desc, name, hold(weights[name]))
+        for i in range(4):
+            desc.w[i] = hold(weights["w"][i])
+        for i in range(3):
+            desc.b[i], desc.bn_scale[i] = hold(weights["b"][i]), hold(weights["bn_scale"][i])
+            desc.bn_shift[i], desc.alpha[i] = hold(weights["bn_shift"][i]), hold(weights["alpha"][i])
+        self.handle = C.c_void_p(0)
+        _check(lib().nann_attn_scorer_create(C.byref(desc), C.byref(self.handle)), "attention scorer")
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            lib().nann_attn_scorer_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+    def prepare(self, comm_seq):
+        """comm_seq f16[B, L, 64] (the `comm_seq` feed reshaped) -> per-user (kt f32[B,256,64],
+        upad f32[B,64,64]), the user side of forward() computed once per request."""
+        u = _dev(comm_seq, torch.float16).reshape(-1, self.seq_len, 64)
+        kt = torch.empty((u.shape[0], 256, 64), dtype=torch.float32, device=u.device)
+        upad = torch.empty((u.shape[0], 64, 64), dtype=torch.float32, device=u.device)
+        _check(lib().nann_attn_prepare(self.handle, _ptr(u), C.c_int64(u.shape[0]), _ptr(kt), _ptr(upad),
+                                       _stream()), "attention prepare")
+        return kt, upad
+
+    def score(self, kt, upad, item_emb=None, table=None, indices=None):
+        """f32 logits of the candidate rows for ONE user (kt[b], upad[b]); arguments as blaze_score."""
+        bad = C.c_int64(-1)
+        if item_emb is not None:
+            rows, n_table, idx, n = item_emb.contiguous(), item_emb.shape[0], None, item_emb.shape[0]
+        else:
+            rows, n_table = table, table.shape[0]
+            idx = _dev(indices, torch.int32)
+            n = idx.numel()
+        out = torch.empty(max(n, 1), dtype=torch.float32, device=kt.device)
+        st = lib().nann_attn_score(self.handle, _ptr(kt), _ptr(upad), _ptr(rows), C.c_int64(n_table), _ptr(idx),
+                                   C.c_int64(n), _ptr(out), C.byref(bad), _stream())
+        _check(st, "BlazeXlaOp")
+        return out[:n]
+
+
 def user_seq_mean(comm_seq):
     """comm_seq f16[B, L, d] (the `comm_seq` feed reshaped, build_opt_graph.py:76-79)
     -> q f32[B, d]: mean of the non-pad history rows."""

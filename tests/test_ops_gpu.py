@@ -321,3 +321,37 @@ def test_sibling_ops(oracle, ref_ops):
     assert (dflags.cpu().numpy() == flags).all()  # value semantics: input untouched
     with pytest.raises(ops.InvalidArgumentError):
         ops.bitmap_init([1, 2, 3], 2)
+
+
+# ---------------------------------------------------------------- f2: the reference scorer model
+@pytest.mark.skipif(os.environ.get("NANN_RUN_UNVERIFIED") != "1",
+                    reason="k_score_attn has not been run on hardware yet; opt in with NANN_RUN_UNVERIFIED=1")
+@pytest.mark.parametrize("d,dtype", [(64, "f16"), (128, "bf16")])
+def test_attn_scorer_matches_oracle(oracle, d, dtype):
+    """Attention + DNN scorer (model.py:189-233) vs the oracle restatement: the per-user projection is
+    bit-identical (same fmaf order), the logits within 1e-5 (MFMA order, device expf)."""
+    from nann_amd import ops, synth
+    E, L, n_table, n = 64, 50, 3000, 1500
+    w = synth.make_attn_weights(d, E)
+    rng = np.random.default_rng(d)
+    u = (rng.standard_normal((L, E)) / 8).astype(np.float16)
+    u[41:] = 0
+    x = (rng.standard_normal((n_table, d)) / 8).astype(np.float32)
+    idx = rng.integers(0, n_table, size=n).astype(np.int32)
+    if dtype == "f16":
+        host, dev, code, tdt = x.astype(np.float16), cuda(x.astype(np.float16)), oracle.EMB_F16, torch.float16
+    else:
+        dev = cuda(x).to(torch.bfloat16)
+        host, code, tdt = dev.view(torch.int16).cpu().numpy().view(np.uint16), oracle.EMB_BF16, torch.bfloat16
+    m = oracle.AttnModel(d, E, L, code, w)
+    rc, exp = oracle.attn_score_rows(m, u.astype(np.float32), host[idx])
+    sc = ops.AttnScorer(d, L, tdt, w)
+    kt, upad = sc.prepare(cuda(u)[None])
+    got = sc.score(kt[0], upad[0], table=dev, indices=idx).cpu().numpy()
+    assert rc == 0
+    assert np.abs(got - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max())
+    got2 = sc.score(kt[0], upad[0], item_emb=dev[torch.as_tensor(idx).long().cuda()]).cpu().numpy()
+    assert (bits(got2) == bits(got)).all()
+    with pytest.raises(ops.InvalidArgumentError) as e:
+        sc.score(kt[0], upad[0], table=dev, indices=[0, n_table])
+    assert e.value.status == 5
