@@ -25,7 +25,7 @@ def one(unit):
     for f in sorted(os.listdir(d)):
         if f.endswith(".s") and "amdgcn" in f:
             for line in open(os.path.join(d, f), errors="replace"):
-                s = line.split(";")[0].rstrip()
+                s = re.sub(r"__hip_cuid_[0-9a-f]+", "__hip_cuid", line.split(";")[0].rstrip())  # per-compile id
                 if not s or re.match(r"\s*\.(file|ident|section|loc|amdgpu_metadata|end_amdgpu_metadata)\b", s):
                     continue
                 h.update(s.encode() + b"\n")
