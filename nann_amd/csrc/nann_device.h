@@ -17,20 +17,29 @@
 
 namespace nann {
 
+// Build-time knob (experimental library variant, tools/build_variants.py "compact"): the visited
+// set of a query is an exact open-addressing hash set of ids (64 KB) instead of the 1-bit-per-item
+// bitmap (125 KB at 1M items), every phase buffer is cut to what ef <= 256 needs, and the L2
+// traversal runs in 512-thread workgroups -- so that TWO queries fit one CU and their phases
+// overlap.  Not the default: written on the CPU, hardware run pending.
+#ifndef NANN_COMPACT
+#define NANN_COMPACT 0
+#endif
 constexpr int kNT = 1024;            // threads per traversal workgroup
 constexpr int kNW = kNT / 64;        // 16 wavefronts
 constexpr int kTopkEPT = 16;         // top-k keys held in registers per thread (n <= 16384)
-constexpr int kMaxK = 1024;          // largest k / frontier a workgroup handles
+constexpr int kMaxK = NANN_COMPACT ? 256 : 1024;  // largest k / frontier a workgroup handles
 // Build-time knob: 1 = the LDS-bitmap filter without the pre-read (wg_filter_chunk_packed); needs a
 // 4096-slot hash table, i.e. 5.5 KB more phase scratch (LDS bitmap capacity 1.026 M instead of 1.07 M items)
 #ifndef NANN_FILTER_PACKED
 #define NANN_FILTER_PACKED 0
 #endif
-constexpr int kPhaseScratch = NANN_FILTER_PACKED ? 33280 : 27648; // LDS bytes shared by the phases below
+constexpr int kPhaseScratch = NANN_COMPACT ? 11264 : (NANN_FILTER_PACKED ? 33280 : 27648); // LDS bytes shared by the phases below
 constexpr int kMaxD = 512;
-// candidate scores of a round are mirrored in LDS behind the top-k scratch
+// candidate scores of a round are mirrored in LDS behind the top-k scratch (not in the compact variant)
 constexpr int kLdsScoresOff = 10752;
-constexpr int kLdsScores = 4096;
+constexpr int kLdsScores = NANN_COMPACT ? 0 : 4096;
+constexpr int kVisSetSlots = 16384;  // compact variant: slots of the visited hash set (ids are stored +1, 0 = free)
 
 enum : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
 
@@ -301,7 +310,7 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
 // All NT threads.  n_frontier <= kMaxK in CSR mode.  Outputs (uniform):
 // *gathered = length of the virtual list, return value = ids kept (appended
 // to out[0..)); -1 on an out-of-range frontier id or neighbour id.
-constexpr int kChunk = 2048;
+constexpr int kChunk = NANN_COMPACT ? 1024 : 2048;
 constexpr uint32_t kHashEmpty = 0xffffffffu;
 constexpr int kChunkTab = 64;
 constexpr int kHashSlots = NANN_FILTER_PACKED ? 2 * kChunk : kChunk;
@@ -318,9 +327,37 @@ struct ExpandWalkScratch {
 };
 
 __device__ __forceinline__ uint32_t chunk_hash(int32_t x) {
-  return ((uint32_t)x * 2654435761u) >> 21;  // 11 bits: kChunk slots
+  return ((uint32_t)x * 2654435761u) >> (NANN_COMPACT ? 22 : 21);  // 11 (10) bits: kChunk slots
 }
-static_assert(kChunk == 2048, "chunk_hash yields 11 bits");
+static_assert(kChunk == (NANN_COMPACT ? 1024 : 2048), "chunk_hash yields log2(kChunk) bits");
+
+#if NANN_COMPACT
+// exact visited set: open addressing over kVisSetSlots words of LDS, entries = id + 1
+__device__ __forceinline__ uint32_t vis_hash(int32_t x) { return ((uint32_t)x * 2654435761u) >> 18; }
+static_assert(kVisSetSlots == 16384, "vis_hash yields 14 bits");
+__device__ __forceinline__ bool vis_contains(const uint32_t* V, int32_t x) {
+  uint32_t h = vis_hash(x);
+  for (;;) {
+    const uint32_t cur = V[h];
+    if (cur == (uint32_t)x + 1u) return true;
+    if (cur == 0u) return false;
+    h = (h + 1) & (kVisSetSlots - 1);
+  }
+}
+// true iff this call put x in (exactly one caller per id gets true, like a bit flipping 0 -> 1)
+__device__ __forceinline__ bool vis_insert(uint32_t* V, int32_t x) {
+  uint32_t h = vis_hash(x);
+  for (;;) {
+    uint32_t cur = V[h];
+    if (cur == 0u) {
+      cur = atomicCAS(&V[h], 0u, (uint32_t)x + 1u);
+      if (cur == 0u) return true;
+    }
+    if (cur == (uint32_t)x + 1u) return false;
+    h = (h + 1) & (kVisSetSlots - 1);
+  }
+}
+#endif
 
 template <bool kLdsBm, int NT>
 __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, uint32_t* bm,
@@ -347,10 +384,15 @@ __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, ui
     const bool valid = tid * PER + e < n_c;
     const bool inr = valid && (uint32_t)x[e] < n_items;
     bad |= valid && !inr;
+#if NANN_COMPACT
+    w[e] = bm; bit[e] = 0u;
+    fresh[e] = inr && !vis_contains(bm, x[e]);
+#else
     w[e] = bm + (inr ? ((uint32_t)x[e] >> 5) : 0u);
     bit[e] = inr ? (1u << (x[e] & 31)) : 0u;
     const uint32_t pre = kLdsBm ? *w[e] : atomicOr(w[e], 0u);  // global bitmap: served by L2 like the update
     fresh[e] = inr && !(pre & bit[e]);
+#endif
   }
 #pragma unroll
   for (int e = 1; e < PER; ++e)  // the same new id twice inside one thread: the later one is a copy
@@ -365,7 +407,11 @@ __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, ui
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     won[e] = false;
+#if NANN_COMPACT
+    if (fresh[e]) won[e] = vis_insert(bm, x[e]);
+#else
     if (fresh[e]) won[e] = !(atomicOr(w[e], bit[e]) & bit[e]);
+#endif
     cont[e] = fresh[e] && !won[e];
     slot[e] = kHashEmpty;
   }
@@ -553,7 +599,7 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
                                               SubTimer pt, Stream& stream, bool stream_on,
-                                              int* streamed) {
+                                              int* streamed, int vis_count = 0) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
   long long tsub = pt.now();
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
@@ -606,6 +652,10 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   *gathered = (int)total;
   pt.sub(PH_EX_PASS1, tsub);
   if (S->bad) return -1;
+#if NANN_COMPACT
+  // every gathered id may be new: keep the hash set below full so that probing always ends
+  if (vis_count + (int)total > kVisSetSlots - 64) return -2;
+#endif
   // ---- pass 2: fetch piece c+1 || filter piece c -------------------------------
   const int G = (int)total;
   const int n_chunks = (G + kChunk - 1) / kChunk;
@@ -724,11 +774,11 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
-                                              SubTimer pt = no_timer()) {
+                                              SubTimer pt = no_timer(), int vis_count = 0) {
   NoStream none;
   int streamed = 0;
   return wg_expand_walk<kLdsBm, NT, NoStream>(frontier, n_frontier, values, row_splits, n_items, bm, out,
-                                              scratch, gathered, pt, none, false, &streamed);
+                                              scratch, gathered, pt, none, false, &streamed, vis_count);
 }
 
 // ---------------------------------------------------------------------------
@@ -929,7 +979,7 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
 // out_pos / out_ids / out_scores / out_mapped may each be null.  ids == null
 // means "ids are positions".  Returns NANN status (uniform).
 struct TopkScratch {
-  unsigned long long sel[kMaxK];  // first: 16-byte aligned (the radix histograms alias it)
+  unsigned long long sel[kMaxK < 512 ? 512 : kMaxK];  // first: 16-byte aligned (the four 256-bin radix histograms alias it)
   unsigned short prank[kNT];      // partial ranks of the rank sort: [segment][element]
   uint32_t misc[4];               // [0] nsel, [2] unordered append cursor
   uint32_t orv, andv;
@@ -937,8 +987,8 @@ struct TopkScratch {
 };
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
 // the selection does not wait on L2 (positions < kLdsScores only)
-static_assert(sizeof(TopkScratch) <= kLdsScoresOff, "top-k scratch overlaps the LDS scores");
-static_assert(kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
+static_assert(sizeof(TopkScratch) <= (NANN_COMPACT ? kPhaseScratch : kLdsScoresOff), "top-k scratch overlaps the LDS scores");
+static_assert(NANN_COMPACT || kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
 static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too small");
 
 // Build-time knob: 1 = radix search on key - min(key) instead of skipping the common prefix.

@@ -1038,6 +1038,19 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     p->lds_bitmap = false;
     per_cu = 2;
   }
+#if NANN_COMPACT
+  // the visited structure is the 64 KB hash set whatever the shard size: two 512-thread workgroups per CU
+  p->lds_bitmap = true;
+  p->nt = 512;
+  per_cu = 2;
+  p->lds_bytes = fixed + (size_t)kVisSetSlots * 4;
+  {
+    unsigned long long off2[8];
+    p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, 0u, off2);
+    p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
+    return NANN_OK;
+  }
+#endif
   p->lds_bytes = fixed + (p->lds_bitmap ? bm_bytes : 0);
   unsigned long long off[8];
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, p->lds_bitmap ? 0u : ix->bm_words, off);
@@ -1110,7 +1123,11 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   for (int i = 0; i < 6; ++i) a.t[i] = level_topn[i];
   a.ws = static_cast<unsigned char*>(workspace);
   a.slot_bytes = p.slot_bytes;
+#if NANN_COMPACT
+  a.bm_words = kVisSetSlots;  // words of the visited hash set
+#else
   a.bm_words = ix->bm_words;
+#endif
   a.max_cand = p.max_cand; a.max_raw = p.max_raw; a.pool_cap = p.pool_cap;
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index;
   a.status = status; a.counters = counters;

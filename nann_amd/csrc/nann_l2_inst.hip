@@ -12,6 +12,16 @@
 namespace nann {
 
 int NANN_CAT(launch_search_l2_, NANN_L2_NAME)(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+#if NANN_COMPACT
+  // compact library variant: only the 512-thread kernel with the visited set in LDS exists
+  if (!(p.nt == 512 && p.lds_bitmap)) return fail(NANN_ERR_UNSUPPORTED, "compact build: plan not supported");
+  switch (lpr) {
+    case 8: return launch_search_lds<8, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+    case 16: return launch_search_lds<16, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+    case 32: return launch_search_lds<32, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+    default: return launch_search_lds<64, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+  }
+#else
   if (p.nt == 512) {  // global-bitmap variant: two half-size workgroups per CU
     switch (lpr) {
       case 8: return launch_search_global<8, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
@@ -26,6 +36,7 @@ int NANN_CAT(launch_search_l2_, NANN_L2_NAME)(int lpr, const SearchPlan& p, cons
     case 32: return launch_search<32, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
     default: return launch_search<64, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
   }
+#endif
 }
 
 }  // namespace nann

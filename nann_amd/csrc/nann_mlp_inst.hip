@@ -11,6 +11,18 @@
 
 namespace nann {
 
+#if NANN_COMPACT
+// the compact library variant carries the L2 traversal only (its phase scratch is too small for the MLP)
+int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int, const SearchPlan&, const SearchArgs&, hipStream_t) {
+  return fail(NANN_ERR_UNSUPPORTED, "compact build: L2 scorer only");
+}
+int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int, unsigned, hipStream_t, const MlpParams&, const void*, long long,
+                                             const int32_t*, long long, const float*, float*, OpResult*) {
+  return fail(NANN_ERR_UNSUPPORTED, "compact build: L2 scorer only");
+}
+}  // namespace nann
+#else
+
 int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
   constexpr int LPR = NANN_MLP_D / 8;
   if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT>(p, a, st);
@@ -35,3 +47,4 @@ int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int dt, unsigned blocks, hipStream_
 }
 
 }  // namespace nann
+#endif

@@ -120,7 +120,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   const int k5 = a.t[5];
   // L2: candidate scores are mirrored in LDS for the selection; the MLP uses that space
   // for its weight slices (and its selection time is negligible next to the MFMAs)
-  float* lds_scores = SC == NANN_SCORER_L2 ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
+  float* lds_scores = (SC == NANN_SCORER_L2 && !NANN_COMPACT) ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
   PhaseTimer timer;
   timer.start(ticks, a.phase_ticks != nullptr);
   const SubTimer pt{ticks, a.phase_ticks != nullptr};
@@ -133,6 +133,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
   // 2..4 = the three level-0 rounds (:129-141), 5 = final top-k (:143-149).
+#if NANN_COMPACT
+  int vis_count = 0;  // ids in the visited hash set (uniform)
+#define NANN_VIS_ARG , (ss == 0 ? 0 : vis_count)
+#else
+#define NANN_VIS_ARG
+#endif
   const int E = a.n_enter;
   int nP = 0;                         // pool size so far
   const int32_t* frontier = nullptr;  // beam walked by the next stage
@@ -184,8 +190,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           for (int i = tid; i < n_in; i += NT) {
             const int32_t id = src[i];
             if ((uint32_t)id < a.n_items) {
+#if NANN_COMPACT
+              if (!vis_insert(bm, id)) flags[0] = 1;
+#else
               const uint32_t bit = 1u << (id & 31);
               if (atomicOr(&bm[(uint32_t)id >> 5], bit) & bit) flags[0] = 1;
+#endif
               dst[i] = id;
             } else {
               flags[1] = 1;
@@ -211,13 +221,17 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
             stream.scores = sv.cand_scores + base_off;
             kept = wg_expand_walk<LDSBM, NT, L2Stream<LPR, DT, NT>>(
                 ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst, scratch, &gathered,
-                ss == 0 ? no_timer() : pt, stream, ss != 0, &streamed);
+                ss == 0 ? no_timer() : pt, stream, ss != 0, &streamed NANN_VIS_ARG);
           } else {
             kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
-                                             scratch, &gathered, ss == 0 ? no_timer() : pt);
+                                             scratch, &gathered, ss == 0 ? no_timer() : pt NANN_VIS_ARG);
           }
         }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
+#if NANN_COMPACT
+        if (kept == -2) return NANN_ERR_CAPACITY;  // the visited set would overflow: rerun on the bitmap kernel
+        if (kept >= 0) vis_count = (ss == 0 ? 0 : vis_count) + kept;
+#endif
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {
           if (r == 1) {
@@ -290,6 +304,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   }
   mark(PH_OTHER);
   return NANN_OK;
+#undef NANN_VIS_ARG
 }
 
 template <int LPR, int DT, bool LDSBM, int SC, int NT>
@@ -369,6 +384,17 @@ inline int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t s
   return NANN_OK;
 }
 
+
+// visited structure in LDS only
+template <int LPR, int DT, int SC, int NT>
+inline int launch_search_lds(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+  auto kern = k_search<LPR, DT, true, SC, NT>;
+  NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
 
 // bitmap in HBM/L2 only (several workgroups per CU)
 template <int LPR, int DT, int SC, int NT>

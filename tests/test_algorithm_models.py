@@ -192,3 +192,71 @@ def test_min_subtraction_spreads_the_leading_digit():
     _, _, _, passes_raw, big_raw = radix_select(keys, 128, False)
     _, _, _, passes_sub, big_sub = radix_select(keys, 128, True)
     assert big_raw[0] > 10 * big_sub[0] and passes_sub <= passes_raw
+
+
+# ---- NANN_COMPACT: the visited set as an open-addressing table (vis_contains / vis_insert) ----------
+class VisTable:
+    """Each probe step of an insert is one atomic LDS operation; inserts of different lanes are
+    interleaved at that granularity (generator per insert, scheduled in random order)."""
+
+    def __init__(self, slots=64):
+        self.v = [0] * slots
+        self.slots = slots
+
+    def hash(self, x):
+        return ((x * 2654435761) & 0xFFFFFFFF) % self.slots
+
+    def contains(self, x):
+        h = self.hash(x)
+        while True:
+            cur = self.v[h]
+            if cur == x + 1:
+                return True
+            if cur == 0:
+                return False
+            h = (h + 1) % self.slots
+
+    def insert_steps(self, x, result, key):
+        h = self.hash(x)
+        while True:
+            cur = self.v[h]
+            yield
+            if cur == 0:
+                cur = self.v[h]          # atomicCAS(&V[h], 0, x + 1): returns the old value
+                if cur == 0:
+                    self.v[h] = x + 1
+                    result[key] = True
+                    return
+                yield
+            if cur == x + 1:
+                result[key] = False
+                return
+            h = (h + 1) % self.slots
+
+
+def test_visited_hash_set_has_one_winner_per_id():
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        t = VisTable(64)
+        before = set(int(v) for v in rng.integers(0, 40, size=int(rng.integers(0, 20))))
+        for x in before:
+            res = {}
+            for _ in t.insert_steps(x, res, 0):
+                pass
+        xs = [int(v) for v in rng.integers(0, 40, size=int(rng.integers(1, 30)))]
+        if len(before | set(xs)) > 48:
+            continue
+        res = {}
+        gens = [t.insert_steps(x, res, i) for i, x in enumerate(xs)]
+        live = list(range(len(gens)))
+        while live:
+            i = live[rng.integers(len(live))]
+            try:
+                next(gens[i])
+            except StopIteration:
+                live.remove(i)
+        for x in set(xs):
+            winners = [i for i, y in enumerate(xs) if y == x and res[i]]
+            assert len(winners) == (0 if x in before else 1)
+        assert all(t.contains(x) for x in before | set(xs))
+        assert sum(1 for v in t.v if v) == len(before | set(xs))   # no id stored twice

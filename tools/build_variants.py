@@ -16,6 +16,9 @@ DEFAULT = {
     "tkms": ["-DNANN_TOPK_MINSUB=1"],  # top-k: radix search on key - min(key)
     "fp": ["-DNANN_FILTER_PACKED=1"],  # LDS filter without the pre-read (3 barriers per piece)
     "su16_tkms_fp": ["-DNANN_SCORE_U=16", "-DNANN_TOPK_MINSUB=1", "-DNANN_FILTER_PACKED=1"],
+    # L2 only: exact hash set of visited ids (64 KB) + small phase buffers -> two 512-thread workgroups per CU
+    "compact": ["-DNANN_COMPACT=1"],
+    "compact_tkms": ["-DNANN_COMPACT=1", "-DNANN_TOPK_MINSUB=1"],
 }
 
 
