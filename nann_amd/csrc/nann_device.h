@@ -854,9 +854,13 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 }
 
 // Build-time knob: 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per CU).
-// The phase is latency-bound per CU; 12 / 16 are the next things to measure.
+// The phase is latency-bound per CU; 12 / 16 are the next things to measure, and
+// NANN_SCORE_ROLL=1 (refill each slot as soon as it is reduced instead of batch by batch).
 #ifndef NANN_SCORE_U
 #define NANN_SCORE_U 8
+#endif
+#ifndef NANN_SCORE_ROLL
+#define NANN_SCORE_ROLL 0
 #endif
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
@@ -879,6 +883,28 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
 #pragma unroll
   for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
   // branch-free: positions past `end` re-read candidate end-1 and their result is dropped
+#if NANN_SCORE_ROLL
+  // rolling window: the oldest of the U row loads in flight is reduced and its slot refilled at
+  // once, so the number of loads in flight never drains to zero between batches
+  int32_t id1[U];
+  RowChunk<DT> ch[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) ch[u] = load_chunk<DT>(table, (size_t)ids[min(begin + u * RPI + slot, end - 1)], d, sub);
+#pragma unroll
+  for (int u = 0; u < U; ++u) id1[u] = ids[min(begin + (U + u) * RPI + slot, end - 1)];
+  for (int i0 = begin; i0 < end; i0 += RPI * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * RPI + slot;
+      float x[8];
+      chunk_to_float<DT>(ch[u], x);
+      const float s = l2_finish<LPR>(q, x);
+      if (sub == 0 && i < end) scores[i] = s;
+      ch[u] = load_chunk<DT>(table, (size_t)id1[u], d, sub);            // position i + U * RPI
+      id1[u] = ids[min(i0 + (2 * U + u) * RPI + slot, end - 1)];        // position i + 2 U * RPI
+    }
+  }
+#else
   int32_t nxt[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) nxt[u] = ids[min(begin + u * RPI + slot, end - 1)];
@@ -898,13 +924,14 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
       if (sub == 0 && i < end) scores[i] = s;
     }
   }
+#endif
 }
 
 // Build-time knob: 16-byte row loads a lane keeps in flight across the filter; 0 = score after
 // the expand.  Measured on MI355X (1M x 128-d f16, ef=128, batch 4096, k_search ms): 0: 2.715,
-// 2: 2.755, 4: 2.812, 6: 2.943, 8: 3.175 -- the random 256-byte row reads are already limited by
-// the memory system (tools/ubench_gather.hip), so moving them under the filter only makes
-// both slower.  Kept for shards / row sizes where that balance differs.
+// 2: 2.755, 4: 2.812, 6: 2.943, 8: 3.175 -- the id -> row dependency adds an L2 round trip per piece and
+// the registers the rows pin slow the filter down (the memory system itself has headroom:
+// tools/ubench_gather.hip).  Kept for shards / row sizes where that balance differs.
 #ifndef NANN_STREAM_U
 #define NANN_STREAM_U 0
 #endif

@@ -13,6 +13,8 @@ from nann_amd import build  # noqa: E402
 DEFAULT = {
     "su12": ["-DNANN_SCORE_U=12"],   # scoring phase: 12 row loads per lane in flight
     "su16": ["-DNANN_SCORE_U=16"],   # ... 16 (256 KB per CU)
+    "roll": ["-DNANN_SCORE_ROLL=1"],   # scoring phase: rolling window of row loads
+    "roll_su16": ["-DNANN_SCORE_ROLL=1", "-DNANN_SCORE_U=16"],
     "tkms": ["-DNANN_TOPK_MINSUB=1"],  # top-k: radix search on key - min(key)
     "fp": ["-DNANN_FILTER_PACKED=1"],  # LDS filter without the pre-read (3 barriers per piece)
     "su16_tkms_fp": ["-DNANN_SCORE_U=16", "-DNANN_TOPK_MINSUB=1", "-DNANN_FILTER_PACKED=1"],
