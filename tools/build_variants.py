@@ -14,7 +14,8 @@ DEFAULT = {
     "su12": ["-DNANN_SCORE_U=12"],   # scoring phase: 12 row loads per lane in flight
     "su16": ["-DNANN_SCORE_U=16"],   # ... 16 (256 KB per CU)
     "roll": ["-DNANN_SCORE_ROLL=1"],   # scoring phase: rolling window of row loads
-    "roll_su16": ["-DNANN_SCORE_ROLL=1", "-DNANN_SCORE_U=16"],
+    "roll_su12": ["-DNANN_SCORE_ROLL=1", "-DNANN_SCORE_U=12"],
+    "roll_su16": ["-DNANN_SCORE_ROLL=1", "-DNANN_SCORE_U=16"],   # 32 VGPRs spilled at 1024 threads: expect no gain
     "tkms": ["-DNANN_TOPK_MINSUB=1"],  # top-k: radix search on key - min(key)
     "fp": ["-DNANN_FILTER_PACKED=1"],  # LDS filter without the pre-read (3 barriers per piece)
     "su16_tkms_fp": ["-DNANN_SCORE_U=16", "-DNANN_TOPK_MINSUB=1", "-DNANN_FILTER_PACKED=1"],
