@@ -128,7 +128,8 @@ int nann_gather_rows(const void* params, int64_t n_rows, int64_t row_bytes,
 /* ---- a5: TopKV2 sorted=true (core/kernels/topk_op.cc:40-205) ---------------
  * values f32[n_rows, n_cols] -> out_values f32[n_rows,k], out_indices
  * i32[n_rows,k]; descending, ties -> lower index.  n_cols < k ->
- * NANN_ERR_TOPK_K_GT_N (checked on the host, nothing launched). */
+ * NANN_ERR_TOPK_K_GT_N (checked on the host, nothing launched).  k <= 1024: radix select;
+ * larger k (the reference's tests go to k = n = 5000): whole-row sort in LDS, n_cols <= 16384. */
 int nann_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k,
               float* out_values, int32_t* out_indices, nann_stream_t stream);
 
@@ -244,6 +245,33 @@ int nann_merge_topk(const float* scores, const int64_t* ids, int64_t n_queries, 
 int nann_merge_topk_host(const float* scores, const int64_t* ids, int64_t n_queries,
                          int32_t n_shards, int32_t k_in, int32_t k_out, float* out_scores,
                          int64_t* out_ids);
+
+/* ---- 8(e): the exchange step owned by the C++ host (one process per GPU) -----------------
+ * Rank g searches every query on shard g (nann_search), then nann_sharded_topk packs its
+ * [scores | item ids] lists into one record, exchanges the records with ONE ncclAllGather
+ * (RCCL over xGMI, k_in x 12 B per query per shard) and merges them on the device with
+ * nann_merge_topk's order.  The reference has no collective on this path (replicas only,
+ * blaze-benchmark/benchmark/core/model.cc:192-235); BASELINE configs 4-5 define this one.
+ * RCCL is bound at run time (an RCCL already loaded in the process is shared, else
+ * /opt/rocm/lib/librccl.so.1); without it these calls return NANN_ERR_UNSUPPORTED.
+ *   nann_comm_get_unique_id  one rank draws the 128-byte id (ncclGetUniqueId) and the host
+ *                            hands it to the others by its own means (file, socket, MPI ...)
+ *   nann_comm_create         collective over all ranks (ncclCommInitRank) on the calling
+ *                            thread's current HIP device; world == 1 needs no id and no RCCL
+ *   status (may be NULL)     a query with status != 0 on this shard contributes scores -inf /
+ *                            ids 0: it is never selected while another shard holds real
+ *                            candidates, and surfaces as (-inf, 0) entries otherwise
+ *   workspace                device, nann_sharded_topk_workspace_bytes(...) bytes
+ * Asynchronous on `stream`; every rank must make the same sequence of calls. */
+typedef struct nann_comm nann_comm;
+#define NANN_COMM_ID_BYTES 128
+int nann_comm_get_unique_id(void* id /*[host] NANN_COMM_ID_BYTES*/);
+int nann_comm_create(int32_t world, int32_t rank, const void* id /*[host]*/, nann_comm** out);
+void nann_comm_destroy(nann_comm* c);
+int nann_sharded_topk_workspace_bytes(int32_t world, int64_t n_queries, int32_t k_in, int64_t* nbytes);
+int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, const int32_t* status,
+                      int64_t n_queries, int32_t k_in, int32_t k_out, void* workspace,
+                      int64_t workspace_bytes, float* out_scores, int64_t* out_ids, nann_stream_t stream);
 
 /* ---- 8(f2): the reference's own scorer model behind the BlazeXlaOp contract -------------
  * NANN_impls/nann/model/model.py:189-233 + model_util.py:70-97: softmax attention of the candidate

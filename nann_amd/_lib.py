@@ -33,6 +33,8 @@ SYMBOLS = [
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
     "nann_search", "nann_search_ex", "nann_merge_topk", "nann_merge_topk_host",
     "nann_attn_scorer_create", "nann_attn_scorer_destroy", "nann_attn_prepare", "nann_attn_score",
+    "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_sharded_topk_workspace_bytes",
+    "nann_sharded_topk",
 ]
 
 
@@ -70,7 +72,9 @@ def lib():
     global _LIB
     if _LIB is None:
         path = lib_path()
-        if not os.path.exists(path):
+        # the default library is rebuilt when its sources changed since it was linked (content
+        # hash, nann_amd/build.py); a library named by NANN_HIP_LIB is loaded as it is
+        if not os.path.exists(path) or (not os.environ.get("NANN_HIP_LIB") and _build.is_stale()):
             try:
                 _build.build()
             except Exception as e:  # no hipcc and no prebuilt library: fail loudly
@@ -84,6 +88,7 @@ def lib():
         L.nann_scorer_destroy.restype = None
         L.nann_attn_scorer_destroy.restype = None
         L.nann_index_destroy.restype = None
+        L.nann_comm_destroy.restype = None
         _LIB = L
     return _LIB
 

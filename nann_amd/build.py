@@ -15,8 +15,9 @@ UNITS = [("nann_hip.hip", [], "nann_hip.o"),
          ("nann_mlp_inst.hip", ["-DNANN_MLP_D=64"], "nann_mlp_d64.o"),
          ("nann_mlp_inst.hip", ["-DNANN_MLP_D=128"], "nann_mlp_d128.o"),
          ("nann_mlp_inst.hip", ["-DNANN_MLP_D=256"], "nann_mlp_d256.o"),
-         ("nann_attn_inst.hip", [], "nann_attn.o")]
-DEPS = ["nann_hip.hip", "nann_mlp_inst.hip", "nann_l2_inst.hip", "nann_attn_inst.hip", "nann_device.h", "nann_mlp.h",
+         ("nann_attn_inst.hip", [], "nann_attn.o"),
+         ("nann_comm.hip", [], "nann_comm.o")]
+DEPS = ["nann_hip.hip", "nann_mlp_inst.hip", "nann_l2_inst.hip", "nann_attn_inst.hip", "nann_comm.hip", "nann_device.h", "nann_mlp.h",
         "nann_attn.h", "nann_attn_kernels.h", "nann_search.h",
         os.path.join("..", "..", "include", "nann_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-fast-math", "-ffp-contract=off"]
@@ -29,11 +30,27 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """Content hash of every source the library is built from (mtimes do not survive the copy to
+    the GPU box; contents do)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        with open(os.path.join(SRC_DIR, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale():
+    """True when there is no library or it was built from other sources (hash recorded next to it)."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(SRC_DIR, d)) > t for d in DEPS)
+    try:
+        with open(LIB + ".srchash") as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, variant=None, extra_flags=()):
@@ -77,10 +94,12 @@ def _build_into(OUT_DIR, LIB, extra_flags, verbose):
             if not f.endswith(".o") and not os.environ.get("NANN_KEEP_TEMPS"):
                 os.remove(os.path.join(odir, f))  # preprocessed sources, bitcode, assembly: ~15 MB per object
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + \
-           [os.path.join(OUT_DIR, obj[:-2] + ".d", obj) for _, _, obj in UNITS]
+           [os.path.join(OUT_DIR, obj[:-2] + ".d", obj) for _, _, obj in UNITS] + ["-ldl"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)
+    with open(LIB + ".srchash", "w") as f:
+        f.write(source_hash())
     return LIB
 
 

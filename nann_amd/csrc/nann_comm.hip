@@ -1,0 +1,197 @@
+// nann_comm.hip -- the exchange step of the item-id-sharded search (BASELINE
+// configs 4-5), owned by the C++ host: one process per GPU, every rank searches every query on
+// its shard, then ONE ncclAllGather (RCCL over xGMI) of a packed per-rank record
+// [scores f32[B,k] | item ids i64[B,k]] and a merge with TopKV2's order over the shard-major
+// concatenation (score descending, ties -> lower shard, then lower local rank).
+//
+// RCCL is bound at run time (dlopen): a process that already carries an RCCL (torch ships its
+// own copy) shares that one, a plain C++ host gets /opt/rocm's; libnann_hip.so itself keeps
+// loading on boxes without RCCL.  The reference has no collective on this path (its only
+// multi-GPU mode is replicas, blaze-benchmark/benchmark/core/model.cc:192-235).
+#include "nann_search.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+using namespace nann;
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string where;
+};
+
+int load_rccl(Rccl** out) {
+  static std::mutex mu;
+  static Rccl R;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!R.handle) {
+    // an RCCL that is already in the process first (RTLD_NOLOAD), then the system one
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !R.handle; ++pass)
+      for (const char* n : names) {
+        R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if (R.handle) { R.where = n; break; }
+      }
+    if (!R.handle) return fail(NANN_ERR_UNSUPPORTED, std::string("RCCL not found: ") + dlerror());
+    R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(dlsym(R.handle, "ncclGetUniqueId"));
+    R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.handle, "ncclCommInitRank"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.handle, "ncclCommDestroy"));
+    R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.handle, "ncclAllGather"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.handle, "ncclGetErrorString"));
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) {
+      R.handle = nullptr;
+      return fail(NANN_ERR_UNSUPPORTED, "RCCL library lacks the ncclAllGather entry points");
+    }
+  }
+  *out = &R;
+  return NANN_OK;
+}
+
+#define RCCL_TRY(R, expr)                                                                       \
+  do {                                                                                          \
+    ncclResult_t _r = (expr);                                                                   \
+    if (_r != ncclSuccess)                                                                      \
+      return fail(NANN_ERR_HIP, std::string(#expr) + ": " +                                     \
+                                    ((R)->GetErrorString ? (R)->GetErrorString(_r) : "rccl error")); \
+  } while (0)
+
+inline size_t rec_bytes(long long B, int k) { return ((size_t)B * k * 12 + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// per-rank record: scores (a query that failed on this shard contributes -inf and id 0: its
+// slots are never selected while another shard holds real candidates) followed by the ids
+__global__ void k_pack_record(const float* scores, const int64_t* ids, const int32_t* status, long long B, int k,
+                              unsigned char* rec) {
+  float* rs = reinterpret_cast<float*>(rec);
+  int64_t* ri = reinterpret_cast<int64_t*>(rec + (size_t)B * k * 4);
+  const long long n = B * k;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const bool bad = status != nullptr && status[i / k] != 0;
+    rs[i] = bad ? -__builtin_inff() : scores[i];
+    ri[i] = bad ? 0 : ids[i];
+  }
+}
+
+// merge straight from the all-gathered records (rank-major, no transposition): one workgroup
+// per query stages its world x k_in scores in LDS in shard-major order and runs TopKV2 on them
+__global__ __launch_bounds__(kNT) void k_merge_records(const unsigned char* recv, unsigned long long stride, int world,
+                                                       long long B, int k_in, int k_out, float* out_scores,
+                                                       int64_t* out_ids) {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(TopkScratch)];
+  __shared__ int32_t s_pos[kMaxK];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  float* s_sc = reinterpret_cast<float*>(dyn);  // [world * k_in]
+  const long long qi = blockIdx.x;
+  const int n_in = world * k_in;
+  for (int i = threadIdx.x; i < n_in; i += kNT) {
+    const int s = i / k_in, j = i - s * k_in;
+    s_sc[i] = reinterpret_cast<const float*>(recv + (size_t)s * stride)[qi * k_in + j];
+  }
+  __syncthreads();
+  wg_topk(nullptr, s_sc, nullptr, n_in, k_out, s_pos, nullptr, nullptr, nullptr, nullptr, scratch);
+  __syncthreads();
+  for (int r = threadIdx.x; r < k_out; r += kNT) {
+    const int pos = s_pos[r], s = pos / k_in, j = pos - s * k_in;
+    out_scores[qi * k_out + r] = s_sc[pos];
+    out_ids[qi * k_out + r] =
+        reinterpret_cast<const int64_t*>(recv + (size_t)s * stride + (size_t)B * k_in * 4)[qi * k_in + j];
+  }
+}
+
+struct nann_comm {
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+  Rccl* R = nullptr;
+};
+
+extern "C" {
+
+int nann_comm_get_unique_id(void* id) {
+  if (!id) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_get_unique_id: null argument");
+  Rccl* R;
+  int rc = load_rccl(&R);
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == NANN_COMM_ID_BYTES, "NANN_COMM_ID_BYTES out of sync with rccl.h");
+  RCCL_TRY(R, R->GetUniqueId(static_cast<ncclUniqueId*>(id)));
+  return NANN_OK;
+}
+
+int nann_comm_create(int32_t world, int32_t rank, const void* id, nann_comm** out) {
+  if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id))
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_create: bad argument");
+  nann_comm* c = new nann_comm();
+  c->world = world;
+  c->rank = rank;
+  if (world > 1) {
+    int rc = load_rccl(&c->R);
+    if (rc) { delete c; return rc; }
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = c->R->CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+      const std::string msg = c->R->GetErrorString ? c->R->GetErrorString(r) : "rccl error";
+      delete c;
+      return fail(NANN_ERR_HIP, "ncclCommInitRank: " + msg);
+    }
+  }
+  *out = c;
+  return NANN_OK;
+}
+
+void nann_comm_destroy(nann_comm* c) {
+  if (!c) return;
+  if (c->comm) (void)c->R->CommDestroy(c->comm);
+  delete c;
+}
+
+int nann_sharded_topk_workspace_bytes(int32_t world, int64_t n_queries, int32_t k_in, int64_t* nbytes) {
+  if (!nbytes || world < 1 || n_queries < 0 || k_in < 0) return fail(NANN_ERR_BAD_ARGUMENT, "bad argument");
+  *nbytes = (int64_t)(rec_bytes(n_queries, k_in) * (size_t)(world + 1));
+  return NANN_OK;
+}
+
+int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, const int32_t* status,
+                      int64_t n_queries, int32_t k_in, int32_t k_out, void* workspace, int64_t workspace_bytes,
+                      float* out_scores, int64_t* out_ids, nann_stream_t stream) {
+  if (!c || !scores || !ids || !out_scores || !out_ids) return fail(NANN_ERR_BAD_ARGUMENT, "nann_sharded_topk: null argument");
+  const int world = c->world;
+  const long long n_in = (long long)world * k_in;
+  if (k_out < 0 || k_out > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "k_out must be in [0, 1024]");
+  if (n_in < k_out) return fail(NANN_ERR_TOPK_K_GT_N, "fewer candidates than k_out");
+  if (n_in > kTopkEPT * kNT) return fail(NANN_ERR_UNSUPPORTED, "world * k_in > 16384");
+  if (n_queries <= 0 || k_out == 0) return NANN_OK;
+  const size_t rb = rec_bytes(n_queries, k_in);
+  if (!workspace || workspace_bytes < (int64_t)(rb * (size_t)(world + 1)))
+    return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_sharded_topk_workspace_bytes()");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  unsigned char* send = static_cast<unsigned char*>(workspace);
+  unsigned char* recv = send + rb;
+  const long long n = n_queries * k_in;
+  hipLaunchKernelGGL(k_pack_record, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st,
+                     scores, ids, status, (long long)n_queries, (int)k_in, world > 1 ? send : recv);
+  NANN_HIP_TRY(hipGetLastError());
+  if (world > 1) RCCL_TRY(c->R, c->R->AllGather(send, recv, rb, ncclChar, c->comm, st));
+  const size_t lds = (size_t)n_in * 4;
+  if (lds > 48 * 1024)
+    NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_records),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_merge_records, dim3((unsigned)n_queries), dim3(kNT), lds, st, recv, (unsigned long long)rb,
+                     world, (long long)n_queries, (int)k_in, (int)k_out, out_scores, out_ids);
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+}  // extern "C"

@@ -277,6 +277,36 @@ __global__ __launch_bounds__(kNT) void k_topk(const float* values, long long n_c
           out_values + row * k, nullptr, nullptr, scratch);
 }
 
+// TopKV2 with k beyond the radix-select kernel's 1024 (topk_op.cc:154-173 sorts the whole row
+// when k == n; the reference's own tests go to k = n = 5000): one workgroup per row, the row's
+// (key, ~position) pairs bitonic-sorted in LDS (n <= 16384 -> 128 KB), first k written out.
+__global__ __launch_bounds__(kNT) void k_topk_sort(const float* values, long long n_cols, int k, int n_pow2,
+                                                   float* out_values, int32_t* out_indices) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* e = reinterpret_cast<unsigned long long*>(smem);
+  const long long row = blockIdx.x;
+  const float* v = values + row * n_cols;
+  for (int i = threadIdx.x; i < n_pow2; i += kNT)  // pads sort behind every real pair (key 0 is below any score key)
+    e[i] = i < n_cols ? (((unsigned long long)score_key(v[i]) << 32) | (uint32_t)(~(uint32_t)i)) : 0ull;
+  __syncthreads();
+  for (int size = 2; size <= n_pow2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (n_pow2 >> 1); t += kNT) {
+        const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);  // descending overall
+        const unsigned long long a = e[lo], b = e[hi];
+        if ((a < b) == desc) { e[lo] = b; e[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += kNT) {
+    const int pos = (int)(~(uint32_t)(e[i] & 0xffffffffull));
+    out_indices[row * k + i] = pos;
+    out_values[row * k + i] = v[pos];
+  }
+}
+
 // merge of per-shard top-k lists: TopKV2 over the shard-major
 // concatenation, ids carried along.
 __global__ __launch_bounds__(kNT) void k_merge_topk(const float* scores, const int64_t* ids,
@@ -687,9 +717,20 @@ int nann_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k, fl
   if (n_cols < k)
     return fail(NANN_ERR_TOPK_K_GT_N, "input must have at least k columns. Had " +
                                           std::to_string(n_cols) + ", needed " + std::to_string(k));
-  if (k > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "k > 1024 not supported");
   if (n_cols > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "n_cols too large");
   if (k == 0 || n_rows == 0) return NANN_OK;  // :84-85
+  if (k > kMaxK) {  // whole-row sort in LDS
+    if (n_cols > 16384) return fail(NANN_ERR_UNSUPPORTED, "k > 1024 needs n_cols <= 16384");
+    int p2 = 2;
+    while (p2 < n_cols) p2 <<= 1;
+    auto kern = k_topk_sort;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                p2 * 8));
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_rows), dim3(kNT), (size_t)p2 * 8, as_stream(stream), values,
+                       (long long)n_cols, (int)k, p2, out_values, out_indices);
+    HIP_TRY(hipGetLastError());
+    return NANN_OK;
+  }
   hipLaunchKernelGGL(k_topk, dim3((unsigned)n_rows), dim3(kNT), 0, as_stream(stream), values,
                      (long long)n_cols, (int)k, out_values, out_indices);
   HIP_TRY(hipGetLastError());
