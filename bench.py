@@ -2,27 +2,35 @@
 """bench.py -- retrieval QPS of the fused HNSW-with-model-scoring traversal on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 ...            (spawns one rank per GPU itself), or
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic UserBehavior-shaped
-queries: comm_seq -> query vectors -> layered traversal (neighbour gather, visited-bitmap
-dedup, embedding gather + L2 scoring, top-k) -> top-200 item ids.  Inputs are resident
-in HBM when the timed region starts.
+queries: comm_seq -> query vectors -> layered traversal (neighbour gather, visited-set
+dedup, embedding gather + scoring, top-k) -> top-200 item ids.  Inputs are resident in HBM
+when the timed region starts; every step sees a DIFFERENT batch of queries.
 
-Workload (BASELINE.json configs[1]): 1M items x 128-d f16, M=32, ef_search=128
-(level_topn = [128]*5 + [200]), L2 scoring, on each GPU.  With N > 1 ranks the corpus
-is N shards of 1M items (configs[3] shape: item-id sharding); every rank searches every
-query on its shard, per-shard top-200 lists are all-gathered over RCCL and merged.
+Primary workload (BASELINE.json configs[1]): 1M items x 128-d f16, M=32, ef_search=128
+(level_topn = [128]*5 + [200]), L2 scoring, on each GPU; the graph comes from the shipped
+index builder (nann_amd/csrc/host/hnsw_build.cpp: HNSW M=32, efConstruction=40 -- what the
+reference gets from faiss.IndexHNSWFlat, build_hnsw_index.py:33-35).  With N > 1 ranks the
+corpus is N shards of 1M items (configs[3] shape: item-id sharding); every rank searches
+every query on its shard, the per-shard top-200 lists are exchanged with one ncclAllGather
+issued by the C ABI (nann_sharded_topk) and merged on the device.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the traversal kernel's ALGORITHMIC
-bytes (BASELINE.md section 4 formula over the kernel's own per-round counters, which the
-parity tests pin to the oracle's) against 8 TB/s HBM; `cpu_baseline` is the oracle
-(oracle/nann_oracle.c, a port of the reference's CPU op loops) timed on this box's cores.
+Prints ONE JSON line (rank 0).  `roofline` prices the traversal kernel's ALGORITHMIC bytes
+(SURVEY.md 8d formula over the kernel's own per-round counters, which the parity tests pin
+to the oracle's) against 8 TB/s HBM; `cpu_baseline` is the oracle (oracle/nann_oracle.c, a
+port of the reference's CPU op loops) timed on this box's cores.  At N = 1 the line also
+carries `secondary`: configs[2] (MLP scorer), an HBM-honest stress run (2M x 256-d bf16,
+ef=256: config 5's shard shape at half its size, table >> Infinity Cache) and the
+B in {1, 64, 1024} latency sweep.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,7 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3  # f32-input MFMA dense peak
 
 
 def parse():
@@ -42,18 +51,25 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--items", type=int, default=1_000_000, help="items per GPU")
     ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="row dtype of item_embs")
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
-    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "knn"])
+    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "synth", "knn"],
+                    help="hnsw = the shipped C++ HNSW builder (default); synth = exact-search insertion graph "
+                         "built with torch (round-1 default, ~2 min at 1M); knn = full-degree exact k-NN rows")
     ap.add_argument("--noise", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="primary workload only")
     ap.add_argument("--merge", default="device", choices=["device", "host"])
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: rccl = ncclAllGather issued by the C ABI; torch = torch.distributed collectives")
     ap.add_argument("--scorer", default="l2", choices=["l2", "mlp"],
                     help="l2 = BASELINE configs[1] (the headline metric); mlp = configs[2]: 256-128-1 MLP on MFMA")
-    ap.add_argument("--index-cache", default=None, help="directory to cache the synthetic index in")
-    ap.add_argument("--batch-sweep", default="", help="comma-separated smaller batch sizes to time as well, e.g. 1,64,1024")
+    ap.add_argument("--traversal", default="auto", choices=["auto", "lds_bitmap", "hbm_bitmap", "lds_hash", "lds_hash32"])
+    ap.add_argument("--index-cache", default=None, help="directory to cache built indices in")
+    ap.add_argument("--stress-items", type=int, default=2_000_000)
     ap.add_argument("--phase-ticks", action="store_true",
                     help="one extra instrumented launch: per-phase time attribution")
     return ap.parse_args()
@@ -62,26 +78,26 @@ def parse():
 def algorithmic_bytes(counters, d, emb_bytes, n_enter, k_out=200):
     """bytes one query must move, from the per-round counters the kernel
     emits (frontier F, gathered G, scored S): S*d*sizeof(emb) + G*4 (adjacency) + F*16 (two
-    row_splits) + G*8 (visited word read+write), + entry ids + the result."""
+    row_splits) + G*8 (visited word read+write), + entry ids + the result.  Returns
+    (total, hbm_only): the visited-set term never leaves LDS in the LDS modes, so `hbm_only`
+    drops it."""
     c = np.asarray(counters, dtype=np.int64)
     F, G, S = c[..., 0, :], c[..., 1, :], c[..., 2, :]
-    return (S * d * emb_bytes + G * 12 + F * 16).sum(axis=-1) + n_enter * 4 + k_out * 12
+    base = (S * d * emb_bytes + G * 4 + F * 16).sum(axis=-1) + n_enter * 4 + k_out * 12
+    return base + (G * 8).sum(axis=-1), base
 
 
-def load_pmc_traffic(args):
-    """HBM bytes per k_search launch from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json, written from tools/gpu_round.sh output): PMC counters cannot
-    be read from inside the timed process.  Only reported when the workload matches."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")
+def load_pmc_traffic(tag):
+    """HBM bytes per k_search launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json,
+    written from the same bench command under rocprofv3): PMC counters cannot be read from inside the
+    timed process.  Only reported for the workload they were collected on."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             p = json.load(f)
     except (OSError, ValueError):
         return None
-    w = p.get("workload", {})
-    same = (w.get("items") == args.items and w.get("dim") == args.dim and w.get("ef") == args.ef and
-            w.get("batch") == args.batch and w.get("scorer") == args.scorer and w.get("topk") == args.topk)
-    if not same:
+    if p.get("workload_tag") != tag:
         return None
     # MI355X_MICROARCH.md (HBM / rocprofv3): KiB units; gfx950 FETCH_SIZE counts wide reads at half size
     b = (p["FETCH_SIZE_KiB"] * p.get("fetch_correction", 2.0) + p["WRITE_SIZE_KiB"]) * 1024.0
@@ -100,76 +116,115 @@ def usable_cores():
     return n
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    from nann_amd import ops, retrieval, shard, synth
+def to_bf16_bits(x_f32):
+    """f32 -> bf16 bit patterns (uint16), round to nearest even (numpy has no bfloat16)."""
+    u = np.ascontiguousarray(x_f32, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    topn = [args.ef] * 5 + [args.topk]
-    t0 = time.time()
-    g = None
+def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_dir=None):
+    """Seeded synthetic corpus + graph in the reference's array layout."""
+    from nann_amd import index_build, synth
     cache = None
-    if args.index_cache:
-        os.makedirs(args.index_cache, exist_ok=True)
-        cache = os.path.join(args.index_cache,
-                             f"idx_{args.items}_{args.dim}_{args.ef}_{args.graph}_{args.noise}_{rank}.npz")
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        cache = os.path.join(cache_dir, f"idx_{items}_{dim}_{dtype}_{ef}_{graph}_{noise}_{rank}.npz")
         if os.path.exists(cache):
             z = np.load(cache)
-            g = {"item_embs": z["item_embs"], "item_ids": z["item_ids"],
-                 "nb_values": [z["nb_values_0"], z["nb_values_1"]],
-                 "nb_row_splits": [z["nb_row_splits_0"], z["nb_row_splits_1"]],
-                 "enter_points": z["enter_points"]}
-    if g is None:
-        g = synth.make_index(args.items, args.dim, ef=args.ef, mode=args.graph, noise=args.noise,
+            return {"item_embs": z["item_embs"], "item_ids": z["item_ids"],
+                    "nb_values": [z["nb_values_0"], z["nb_values_1"]],
+                    "nb_row_splits": [z["nb_row_splits_0"], z["nb_row_splits_1"]],
+                    "enter_points": z["enter_points"]}
+    if graph == "hnsw":
+        embs, _ = synth.make_corpus(items, dim, noise=noise, seed=1234, item_seed=1234 + 100 + 1000 * rank)
+        x32 = embs.astype(np.float32)  # the builder sees exactly the values the index stores (f16-exact)
+        if dtype == "bf16":
+            bits = to_bf16_bits(x32)
+            x32 = (bits.astype(np.uint32) << 16).view(np.float32)
+        raw = index_build.build_hnsw(x32, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank,
+                                     n_threads=n_threads)
+        ex = index_build.export_levels(raw, start_level=2)
+        if len(ex["enter_points"]) < ef:
+            raise RuntimeError(f"only {len(ex['enter_points'])} enter points for ef={ef}: corpus too small")
+        g = {"item_embs": bits if dtype == "bf16" else embs,
+             "item_ids": synth.make_item_ids(items, seed=1235 + 1000 * rank) + rank * items,
+             "nb_values": [v.astype(np.int32) for v in ex["nb_values"]],
+             "nb_row_splits": ex["nb_row_splits"], "enter_points": ex["enter_points"].astype(np.int32)}
+    else:
+        g = synth.make_index(items, dim, ef=ef, mode="hnsw" if graph == "synth" else "knn", noise=noise,
                              device=str(dev), shard=rank)
-        if cache:
-            np.savez(cache, item_embs=g["item_embs"], item_ids=g["item_ids"],
-                     nb_values_0=g["nb_values"][0], nb_values_1=g["nb_values"][1],
-                     nb_row_splits_0=g["nb_row_splits"][0], nb_row_splits_1=g["nb_row_splits"][1],
-                     enter_points=g["enter_points"])
+        if dtype == "bf16":
+            g["item_embs"] = to_bf16_bits(g["item_embs"].astype(np.float32))
+    if cache:
+        np.savez(cache, item_embs=g["item_embs"], item_ids=g["item_ids"],
+                 nb_values_0=g["nb_values"][0], nb_values_1=g["nb_values"][1],
+                 nb_row_splits_0=g["nb_row_splits"][0], nb_row_splits_1=g["nb_row_splits"][1],
+                 enter_points=g["enter_points"])
+    return g
+
+
+def make_query_batches(dim, batch, n_batches, noise, dev, seed=4321):
+    """comm_seq f16[n_batches, B, 50, d] generated on the device (seeded): each history is 7..50 draws
+    around one of the corpus' 256 cluster centres, zero-padded tail (convert_UB_to_tfrecord.py:121-137)."""
+    import torch
+    from nann_amd import synth
+    centres = torch.as_tensor(synth.make_centres(dim, 256, 1234)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        lens = torch.randint(7, 51, (batch,), generator=gen, device=dev)
+        cl = torch.randint(0, 256, (batch,), generator=gen, device=dev)
+        x = centres[cl][:, None, :] + noise * torch.randn((batch, 50, dim), generator=gen, device=dev)
+        x = x * (1.0 / np.sqrt(dim))
+        mask = torch.arange(50, device=dev)[None, :] < lens[:, None]
+        out.append((x * mask[:, :, None]).to(torch.float16))
+    return out
+
+
+def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False, want_parity=True, want_recall=True):
+    """Build/load the index, time `steps` passes, return the result dict for this workload."""
+    import torch
+    import torch.distributed as dist
+    from nann_amd import ops, retrieval, synth
+    items, dim, ef, topk, batch = cfg["items"], cfg["dim"], cfg["ef"], cfg["topk"], cfg["batch"]
+    steps, warmup, scorer_kind, dtype = cfg["steps"], cfg["warmup"], cfg["scorer"], cfg["dtype"]
+    topn = [ef] * 5 + [topk]
+    cores = usable_cores()
+    t0 = time.time()
+    g = cfg.get("_index") or make_index(items, dim, ef, cfg["graph"], args.noise, dtype, rank, dev,
+                                        max(1, cores // world), args.index_cache)
     index = retrieval.Index.from_dict(g, device=dev)
-    mlp_w = synth.make_mlp_weights(args.dim) if args.scorer == "mlp" else None
-    scorer = ops.Scorer(args.scorer, args.dim, weights=mlp_w)
-    seq_host = synth.make_queries_from_centres(args.dim, args.batch, noise=args.noise)
-    comm_seq = torch.as_tensor(seq_host).to(dev)
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    mlp_w = synth.make_mlp_weights(dim) if scorer_kind == "mlp" else None
+    scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w)
+    n_batches = min(steps + warmup, 24)
+    seqs = make_query_batches(dim, batch, n_batches, args.noise, dev)
     setup_s = time.time() - t0
+    retrieval.set_traversal_mode(cfg.get("traversal", "auto"))
 
-    sharded = shard.ShardedSearch(index, scorer, topn, world, merge=args.merge) if world > 1 else None
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
-    def step(i=None):
-        q = ops.user_seq_mean(comm_seq)
+    def step(j, i=None):
+        q = ops.user_seq_mean(seqs[j % n_batches])
         if i is not None:
             ev[i][0].record()
         r = retrieval.search(index, scorer, q, topn, want_counters=True)
         if i is not None:
             ev[i][1].record()
         if sharded is not None:
-            return sharded.merge(r), r
-        return (r.item_ids, r.scores), r
+            return sharded.merge(r), r, q
+        return (r.item_ids, r.scores), r, q
 
-    for _ in range(args.warmup):
-        out, r = step()
+    for j in range(warmup):
+        out, r, q = step(j)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        out, r = step(i)
+    for i in range(steps):
+        out, r, q = step(warmup + i, i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -185,143 +240,261 @@ def main():
     kern_ms = float(kern_all.mean())
     status = r.status.cpu().numpy()
     counters = r.counters.cpu().numpy().astype(np.int64)
-    n_valid = int((status == 0).sum())
-    bytes_per_launch = float(algorithmic_bytes(counters, args.dim, 2, len(g["enter_points"]),
-                                               args.topk).sum())
+    ok = status == 0
+    n_valid = int(ok.sum())
+    tot_b, hbm_b = algorithmic_bytes(counters[ok], dim, 2, len(g["enter_points"]), topk)
+    bytes_per_launch = float(tot_b.sum())
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    rows = float(counters[ok][:, 2, :].sum())
     roofline = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "kernel_ms": round(kern_ms, 4),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "algorithmic_bytes_per_query": round(bytes_per_launch / args.batch, 1),
-                "rows_scored_per_query": round(float(counters[:, 2, :].sum(1).mean()), 1)}
-    pmc = load_pmc_traffic(args)
+                "algorithmic_bytes_per_query": round(bytes_per_launch / max(n_valid, 1), 1),
+                # the same without the visited-set term, which never leaves LDS in the LDS modes
+                "frac_without_visited_set_bytes": round(float(hbm_b.sum()) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "rows_scored_per_query": round(rows / max(n_valid, 1), 1),
+                "gathered_per_query": round(float(counters[ok][:, 1, :].sum()) / max(n_valid, 1), 1)}
+    pmc = load_pmc_traffic(name)
     if pmc is not None:
         roofline["traffic"] = pmc["bytes_per_launch"]
         roofline["traffic_source"] = pmc["source"]
-    if args.scorer == "mlp":
-        # 2*(256*256 + 256*128 + 128) flop per scored row; f32-input MFMA dense
-        # peak 157.3 TFLOP/s (MI355X_MICROARCH.md).  The HBM figure is kept alongside.
-        # The kernel computes the query half of layer 1 (W1q.q) once per query instead of once
-        # per row, so the MFMA work it issues is d*256 + 256*128 MACs per row: `issued` below.
-        rows = float(counters[:, 2, :].sum())
-        flops = rows * 2.0 * (2 * args.dim * 256 + 256 * 128 + 128)
-        issued = rows * 2.0 * (args.dim * 256 + 256 * 128)
-        tf = flops / (kern_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer)", "achieved": round(tf, 2), "peak": 157.3,
-                    "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
-                    "kernel_ms": round(kern_ms, 4),
-                    "mfma_issued_TFLOPs": round(issued / (kern_ms * 1e-3) / 1e12, 2),
-                    "mfma_issued_frac": round(issued / (kern_ms * 1e-3) / 1e12 / 157.3, 4),
+    if scorer_kind == "mlp":
+        # SURVEY.md 8(d) charges 2*(2d*256 + 256*128 + 128) flop per scored row; the kernel computes the
+        # query half of layer 1 (W1q.q) once per query, so the MFMA work it ISSUES is d*256 + 256*128 MACs
+        # per row -- `frac` prices the issued work against the f32-input MFMA peak (157.3 TFLOP/s)
+        issued = rows * 2.0 * (dim * 256 + 256 * 128)
+        nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
+        tf = issued / (kern_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer)", "achieved": round(tf, 2),
+                    "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TF, 4),
+                    "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": "issued MFMA work (query half hoisted)",
+                    "nominal_TFLOPs_incl_hoisted": round(nominal / (kern_ms * 1e-3) / 1e12, 2),
                     "hbm_algorithmic_GBps": round(achieved, 1),
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
 
-    # ---- whole-job throughput: every rank searched every query on its 1M-item shard
-    qps = args.batch * args.steps / elapsed
-    value = qps * world
-    result = {
-        "metric": "retrieval QPS @ recall@200 parity, 1M items/128-d",
-        "value": round(value, 1), "unit": "queries/s x 1M-item shards searched",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16 rows / f32 L2" if args.scorer == "l2" else "f16 rows / f32 MFMA MLP",
-        "data": "synthetic",
-        "config": {"workload": f"{args.items} items/GPU x {args.dim}-d f16, M=32 {args.graph} graph, "
-                               f"ef_search={args.ef}, top-{args.topk}, "
-                               + ("L2 scoring (BASELINE configs[1]" if args.scorer == "l2"
-                                  else "3-layer MLP 256-128-1 scorer on MFMA (BASELINE configs[2]")
-                               + (", sharded as configs[3]" if world > 1 else "") + ")",
-                   "level_topn": topn, "batch": args.batch, "items_total": args.items * world,
-                   "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
-                   "merge": args.merge if world > 1 else None},
-        "qps_end_to_end": round(qps, 1), "valid_queries": n_valid, "setup_s": round(setup_s, 1),
-        "roofline": roofline,
-        # per-launch latency of the traversal for one batch (HIP events, this rank)
-        "batch_latency_ms": {"batch": args.batch, "p50": round(float(np.percentile(kern_all, 50)), 4),
-                             "p99": round(float(np.percentile(kern_all, 99)), 4),
-                             "max": round(float(kern_all.max()), 4)},
-    }
-    if args.batch_sweep:
-        # smaller request batches (B in {1, 64, 1024}): latency and QPS of one launch
-        sweep = []
-        for bsz in [int(x) for x in args.batch_sweep.split(",") if x]:
-            bsz = max(1, min(bsz, args.batch))
-            qb = ops.user_seq_mean(comm_seq[:bsz])
-            ts = []
-            for it in range(3 + 10):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                retrieval.search(index, scorer, qb, topn, want_counters=False)
-                e1.record()
-                torch.cuda.synchronize()
-                if it >= 3:
-                    ts.append(e0.elapsed_time(e1))
-            ts = np.asarray(ts)
-            sweep.append({"batch": bsz, "ms_p50": round(float(np.percentile(ts, 50)), 4),
-                          "ms_max": round(float(ts.max()), 4),
-                          "qps": round(bsz / (float(np.percentile(ts, 50)) * 1e-3), 1)})
-        result["batch_sweep"] = sweep
+    qps = batch * steps / elapsed
+    res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "batch": batch, "steps": steps, "valid_queries": n_valid, "setup_s": round(setup_s, 1),
+           "n_enter": int(len(g["enter_points"])),
+           "mean_degree_l0": round(float(len(g["nb_values"][0])) / items, 2),
+           "traversal": cfg.get("traversal", "auto"), "roofline": roofline,
+           "batch_latency_ms": {"batch": batch, "p50": round(float(np.percentile(kern_all, 50)), 4),
+                                "p99": round(float(np.percentile(kern_all, 99)), 4),
+                                "max": round(float(kern_all.max()), 4)}}
 
     if args.phase_ticks:
         from nann_amd import _lib
-        rr = retrieval.search(index, scorer, ops.user_seq_mean(comm_seq), topn, want_phase_ticks=True)
+        rr = retrieval.search(index, scorer, q, topn, want_phase_ticks=True)
         torch.cuda.synchronize()
         tk = rr.phase_ticks.cpu().numpy().astype(np.float64)
         tot = tk[:, :6].sum()  # the first six phases partition the query; the rest are sub-phases
-        result["phase_breakdown"] = {
+        res["phase_breakdown"] = {
             "ticks_per_query": {n: round(float(tk[:, i].mean()), 1) for i, n in enumerate(_lib.PHASE_NAMES)},
             "fraction": {n: round(float(tk[:, i].sum() / tot), 4) for i, n in enumerate(_lib.PHASE_NAMES)}}
 
-    if rank == 0 and world == 1:
-        from oracle import oracle as O  # checker / CPU baseline only
+    # ---- checker legs: oracle = test infrastructure, never inside the timed region
+    n_check = min(64, batch)
+    if want_parity or want_cpu:
+        from oracle import oracle as O
+        code = O.EMB_F16 if dtype == "f16" else O.EMB_BF16
         oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
-        osc = O.Scorer(args.scorer, args.dim, O.EMB_F16, mlp_w)
-        qh = ops.user_seq_mean(comm_seq).cpu().numpy()
-        cores = usable_cores()
-        if not args.no_cpu_baseline:
+        osc = O.Scorer(scorer_kind, dim, code, mlp_w)
+        qh = q.cpu().numpy()
+        threads = max(1, cores // world)
+        first = None
+        if want_cpu and rank == 0 and world == 1:
             # bounded sample: grow the chunk until the time budget is used
-            n_done, t_cpu, chunk = 0, 0.0, min(args.batch, 4 * cores)
-            first = None
-            while t_cpu < args.cpu_seconds and n_done < 50 * args.batch:
-                sel = np.arange(n_done, n_done + chunk) % args.batch
+            n_done, t_cpu, chunk = 0, 0.0, min(batch, max(n_check, 4 * cores))
+            while t_cpu < args.cpu_seconds and n_done < 50 * batch:
+                sel = np.arange(n_done, n_done + chunk) % batch
                 t1 = time.perf_counter()
-                res = O.search_batch(oix, osc, qh[sel], topn, n_threads=cores)
+                ores = O.search_batch(oix, osc, qh[sel], topn, n_threads=cores)
                 t_cpu += time.perf_counter() - t1
                 if first is None:
-                    first = (sel, res)
+                    first = (sel, ores)
                 n_done += chunk
-                chunk = min(args.batch, chunk * 2)
-            result["cpu_baseline"] = {"value": round(n_done / t_cpu, 1), "unit": "queries/s", "cores": cores,
-                                      "kind": "port",
-                                      "sample": f"{n_done} queries of the same batch, one query per thread, "
-                                                f"{t_cpu:.1f} s"}
-        else:
-            sel = np.arange(min(args.batch, 4 * cores))
-            first = (sel, O.search_batch(oix, osc, qh[sel], topn, n_threads=cores))
-        # parity on the first CPU chunk: identical ids/scores => identical recall
+                chunk = min(batch, chunk * 2)
+            res["cpu_baseline"] = {"value": round(n_done / t_cpu, 1), "unit": "queries/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": f"{n_done} queries of the last batch, one query per thread, "
+                                             f"{t_cpu:.1f} s"}
+        if first is None:
+            sel = np.arange(n_check)
+            first = (sel, O.search_batch(oix, osc, qh[sel], topn, n_threads=threads))
         sel, (st, ids, scores, idx, ctr) = first
-        gi = out[0].cpu().numpy()[sel]
-        gs = out[1].cpu().numpy()[sel]
-        ok = st == 0
-        result["parity"] = {"queries_checked": int(len(sel)),
-                            "status_equal": bool((status[sel] == st).all()),
-                            "ids_equal": bool((gi[ok] == ids[ok]).all()),
-                            "scores_bitwise_equal": bool((gs[ok].view(np.uint32) == scores[ok].view(np.uint32)).all())}
-    if rank == 0 and world == 1:
-        # recall@k of the traversal vs brute force under the same scorer (test_all,
-        # main.py:194-237).  Brute force = score ALL items with the device scorer (parity-tested
-        # against the oracle) + TopKV2 on the device; 16 queries.
+        sel, st, ids, scores = sel[:n_check], st[:n_check], ids[:n_check], scores[:n_check]
+        if world == 1:
+            gi, gs = out[0].cpu().numpy()[sel], out[1].cpu().numpy()[sel]
+            okc = st == 0
+            res["parity"] = {"queries_checked": int(len(sel)),
+                             "status_equal": bool((status[sel] == st).all()),
+                             "ids_equal": bool((gi[okc] == ids[okc]).all()),
+                             "scores_bitwise_equal": bool((gs[okc].view(np.uint32) == scores[okc].view(np.uint32)).all()),
+                             "counters_equal": bool((counters[sel][okc] == ctr[:n_check][okc]).all())}
+        else:
+            # merged result vs the oracle's per-shard searches merged with the same rule
+            box = [None] * world
+            dist.all_gather_object(box, (st, ids, scores))
+            if rank == 0:
+                s_all = np.stack([np.where((b[0] == 0)[:, None], b[2], -np.inf) for b in box], 1)
+                i_all = np.stack([np.where((b[0] == 0)[:, None], b[1], 0) for b in box], 1)
+                exp_i, exp_s = [], []
+                for b in range(len(sel)):
+                    rc, ms, mi = O.merge_topk(s_all[b], i_all[b], topk)
+                    exp_i.append(mi); exp_s.append(ms)
+                gi, gs = out[0].cpu().numpy()[sel], out[1].cpu().numpy()[sel]
+                res["parity"] = {"queries_checked": int(len(sel)), "shards": world,
+                                 "merged_ids_equal": bool((gi == np.stack(exp_i)).all()),
+                                 "merged_scores_bitwise_equal": bool(
+                                     (gs.view(np.uint32) == np.stack(exp_s).view(np.uint32)).all())}
+    if want_recall and world == 1:
+        # recall@k of the traversal vs brute force under the same scorer (test_all, main.py:194-237):
+        # score ALL items with the device scorer (parity-tested against the oracle) + TopKV2; 16 queries
         hits, nrec = 0, 0
         gidx = r.index.cpu().numpy()
-        qd = ops.user_seq_mean(comm_seq)
-        for b in range(min(16, args.batch)):
+        for b in range(min(16, batch)):
             if status[b]:
                 continue
-            sc_all = ops.blaze_score(scorer, qd[b], item_emb=index.item_embs)
-            _, bi = ops.top_k(sc_all, args.topk)
+            sc_all = ops.blaze_score(scorer, q[b], item_emb=index.item_embs)
+            _, bi = ops.top_k(sc_all, topk)
             hits += len(set(bi.cpu().tolist()) & set(gidx[b].tolist()))
-            nrec += args.topk
-        result["recall_at_k_vs_bruteforce"] = round(hits / max(nrec, 1), 4)
+            nrec += topk
+        res["recall_at_k_vs_bruteforce"] = round(hits / max(nrec, 1), 4)
+    retrieval.set_traversal_mode("auto")
+    res["_index"], res["_handles"] = g, (index, scorer, seqs)
+    return res
+
+
+def batch_sweep(handles, topn, sizes):
+    """smaller request batches (B in {1, 64, 1024}): latency and QPS of one launch"""
+    import torch
+    from nann_amd import ops, retrieval
+    index, scorer, seqs = handles
+    sweep = []
+    for bsz in sizes:
+        qb = ops.user_seq_mean(seqs[0][:bsz])
+        ts = []
+        for it in range(3 + 10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            retrieval.search(index, scorer, qb, topn, want_counters=False)
+            e1.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                ts.append(e0.elapsed_time(e1))
+        ts = np.asarray(ts)
+        sweep.append({"batch": bsz, "ms_p50": round(float(np.percentile(ts, 50)), 4),
+                      "ms_max": round(float(ts.max()), 4),
+                      "qps": round(bsz / (float(np.percentile(ts, 50)) * 1e-3), 1)})
+    return sweep
+
+
+def strip(res):
+    return {k: v for k, v in res.items() if not k.startswith("_")}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU through
+    torch.distributed.run and pass its output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import torch
+    import torch.distributed as dist
+    from nann_amd import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    sharded = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        sharded = shard.ShardedSearch([args.ef] * 5 + [args.topk], world, rank, merge=args.merge,
+                                      transport=args.transport)
+
+    primary_cfg = {"items": args.items, "dim": args.dim, "ef": args.ef, "topk": args.topk, "batch": args.batch,
+                   "steps": args.steps, "warmup": args.warmup, "scorer": args.scorer, "dtype": args.dtype,
+                   "graph": args.graph, "traversal": args.traversal}
+    is_headline = (args.items == 1_000_000 and args.dim == 128 and args.ef == 128 and args.topk == 200
+                   and args.dtype == "f16")
+    tag = f"{args.items}x{args.dim}{args.dtype}_ef{args.ef}_k{args.topk}_b{args.batch}_{args.scorer}_{args.graph}"
+    prim = run_workload(tag, args, dev, rank, world, primary_cfg, sharded=sharded,
+                        want_cpu=not args.no_cpu_baseline, want_parity=True, want_recall=True)
+
+    qps = prim["qps_end_to_end"]
+    desc = (f"{args.items} items/GPU x {args.dim}-d {args.dtype}, M=32 graph from "
+            + {"hnsw": "the shipped HNSW builder (efConstruction=40)", "synth": "synth.py (exact-search insertion)",
+               "knn": "exact k-NN rows"}[args.graph]
+            + f", ef_search={args.ef}, top-{args.topk}, "
+            + ("L2 scoring" if args.scorer == "l2" else "3-layer MLP 256-128-1 scorer on MFMA")
+            + (" (BASELINE configs[1])" if is_headline and args.scorer == "l2" else
+               " (BASELINE configs[2])" if is_headline else "")
+            + (f", sharded {world}-way as configs[3]" if world > 1 else ""))
+    result = {
+        "metric": "retrieval QPS @ recall@200 parity, 1M items/128-d",
+        # whole-job throughput: every rank searched every query on its own 1M-item shard, so the work done
+        # per second is queries/s x shards (weak scaling: the corpus grows with N); the rate at which
+        # complete answers over the N x 1M corpus leave the job is qps_end_to_end
+        "value": round(qps * world, 1), "unit": "queries/s x 1M-item shards searched",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": prim["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": f"{args.dtype} rows / f32 " + ("L2" if args.scorer == "l2" else "MFMA MLP"),
+        "data": "synthetic",
+        "config": {"workload": desc, "level_topn": [args.ef] * 5 + [args.topk], "batch": args.batch,
+                   "items_total": args.items * world,
+                   "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
+                   "exchange": (f"{args.transport} all-gather + {args.merge} merge" if world > 1 else None)},
+        "qps_end_to_end": qps,
+    }
+    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "roofline", "batch_latency_ms",
+              "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown"):
+        if k in prim:
+            result[k] = prim[k]
+
+    if rank == 0 and world == 1 and not args.no_secondary and args.scorer == "l2":
+        sec = {}
+        try:
+            sec["batch_sweep"] = batch_sweep(prim["_handles"], [args.ef] * 5 + [args.topk], [1, 64, 1024])
+        except Exception as e:  # a failing extra must not take the headline line with it
+            sec["batch_sweep"] = {"error": repr(e)}
+        try:  # BASELINE configs[2]: same index, MLP scorer on the matrix cores
+            cfg = dict(primary_cfg, scorer="mlp", batch=min(args.batch, 1024), steps=3, warmup=1, _index=prim["_index"])
+            sec["mlp_configs2"] = strip(run_workload(tag + "_mlp", args, dev, rank, world, cfg, want_cpu=False,
+                                                     want_parity=True, want_recall=False))
+        except Exception as e:
+            sec["mlp_configs2"] = {"error": repr(e)}
+        prim.pop("_handles", None)
+        prim.pop("_index", None)
+        torch.cuda.empty_cache()
+        try:  # HBM-honest: config 5's shard shape (256-d bf16, ef=256) at a size whose table is 4x the Infinity Cache
+            cfg = {"items": args.stress_items, "dim": 256, "ef": 256, "topk": 200, "batch": 2048, "steps": 5,
+                   "warmup": 2, "scorer": "l2", "dtype": "bf16", "graph": "hnsw", "traversal": "auto"}
+            sec["hbm_stress_config5_shape"] = strip(run_workload(
+                f"{args.stress_items}x256bf16_ef256", args, dev, rank, world, cfg, want_cpu=False,
+                want_parity=True, want_recall=False))
+        except Exception as e:
+            sec["hbm_stress_config5_shape"] = {"error": repr(e)}
+        result["secondary"] = sec
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -171,6 +171,31 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table,
                int64_t n_table_rows, const int32_t* indices, int64_t n, float* out_scores,
                int64_t* bad_i, nann_stream_t stream);
 
+/* ---- a4 (b): the scoring model a BlazeXlaOp node names ----------------------------------
+ * The reference's op takes a frozen TensorFlow GraphDef in its `graph_def` attr and runs it in a
+ * nested session (blaze_xla_kernel.cc:156-180, blaze_xla_predictor.cc:360-459).  This library has
+ * no TensorFlow: the model is handed over as a DIRECTORY of .npy weight files exported once from
+ * that graph / checkpoint (INTEGRATION.md shows the export), and the op shim passes the
+ * directory named by its `graph_def` attr:
+ *   scorer.txt   one word: l2 | mlp | attention
+ *   mlp          w1 [2d,256]  b1  alpha1  w2 [256,128]  b2  alpha2  w3 [128]     (nann_scorer_desc)
+ *   attention    wq1 bq1 aq wq2 bq2 wk1 bk1 ak wk2 bk2  w0..w3  b0..b2  bn_scale0..2  bn_shift0..2
+ *                alpha0..2                                                    (nann_attn_desc)
+ * nann_model_forward is forward() of build_opt_graph.py:91-107 for ONE user: user_seq f16
+ * [seq_len, d] (l2 / mlp: its non-pad mean is the query vector; attention: [seq_len, 64]),
+ * item_emb [n, d] rows as BlazeXlaOp receives them (already gathered) -> f32 logits[n].
+ * All pointers device; workspace = nann_model_workspace_bytes() bytes; asynchronous on stream. */
+typedef struct nann_model nann_model;
+enum nann_model_kind { NANN_MODEL_L2 = 0, NANN_MODEL_MLP = 1, NANN_MODEL_ATTENTION = 2 };
+int nann_model_load(const char* dir /*[host]*/, int32_t d, int32_t emb_dtype, int32_t seq_len, nann_model** out);
+void nann_model_destroy(nann_model* m);
+int nann_model_kind(const nann_model* m);
+/* the l2 / mlp model as the scorer nann_search takes (borrowed; NULL for attention) */
+const nann_scorer* nann_model_scorer(const nann_model* m);
+int nann_model_workspace_bytes(const nann_model* m, int64_t* nbytes);
+int nann_model_forward(const nann_model* m, const void* user_seq_f16, const void* item_emb, int64_t n,
+                       float* logits, void* workspace, nann_stream_t stream);
+
 /* ---- a6 + a7: resident index and the fused traversal -----------------------
  * The index is what the serving graph's HugeConst nodes hold
  * (build_opt_graph.py:83-90, 70): item_embs [N,d], item_ids i64[N], per level
@@ -197,13 +222,27 @@ void nann_index_destroy(nann_index* ix);
 int nann_index_info(const nann_index* ix, int64_t out[6]);
 
 #define NANN_NUM_ROUNDS 5
-/* Workspace bytes nann_search needs for (index, level_topn, n_queries). */
+/* Where a query's visited set lives (the reference: a TemporaryVariable bitmap of N/32 words,
+ * build_opt_graph.py:115-118).  AUTO picks per call: L2 scorer and shards below 4M items ->
+ * an exact hash set of visited ids in LDS -- LDS_HASH (16K slots, 64 KB, two queries per CU) or,
+ * for beams whose visited set is expected to outgrow it, LDS_HASH32 (32K slots, one query per
+ * CU); a query whose set could overflow is rerun on a bitmap kernel inside the same call.
+ * Otherwise LDS_BITMAP when ceil(N/32) words fit the CU's LDS next to the phase buffers
+ * (N <= ~1.07M), else HBM_BITMAP.  Results are identical in every mode (tested); the knob exists
+ * for tests and tuning.  Process-wide, thread-safe. */
+enum nann_traversal_mode { NANN_TRAVERSAL_AUTO = 0, NANN_TRAVERSAL_LDS_BITMAP = 1,
+                           NANN_TRAVERSAL_HBM_BITMAP = 2, NANN_TRAVERSAL_LDS_HASH = 3,
+                           NANN_TRAVERSAL_LDS_HASH32 = 4 };
+int nann_set_traversal_mode(int32_t mode);
+
+/* Workspace bytes nann_search needs for (index, level_topn, n_queries), any scorer. */
 int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6] /*[host]*/,
                                 int64_t n_queries, int64_t* nbytes);
 
 /* The whole schedule of build_model() (NANN_impls/nann/delivery/
  * build_opt_graph.py:109-149) for n_queries independent
- * queries, one persistent workgroup per query slot, visited bitmap in LDS.
+ * queries, persistent workgroups that pull queries from a device-wide queue, visited set in LDS
+ * (nann_traversal_mode).
  *   q            f32[n_queries, d]      (nann_user_seq_mean of comm_seq)
  *   level_topn   [host] i32[6]          (the `level_topn` feed)
  *   workspace    device, nann_search_workspace_bytes(...) bytes

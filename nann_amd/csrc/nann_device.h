@@ -17,29 +17,15 @@
 
 namespace nann {
 
-// Build-time knob (experimental library variant, tools/build_variants.py "compact"): the visited
-// set of a query is an exact open-addressing hash set of ids (64 KB) instead of the 1-bit-per-item
-// bitmap (125 KB at 1M items), every phase buffer is cut to what ef <= 256 needs, and the L2
-// traversal runs in 512-thread workgroups -- so that TWO queries fit one CU and their phases
-// overlap.  Not the default: written on the CPU, hardware run pending.
-#ifndef NANN_COMPACT
-#define NANN_COMPACT 0
-#endif
-constexpr int kNT = 1024;            // threads per traversal workgroup
+constexpr int kNT = 1024;            // threads per traversal workgroup (bitmap kernels)
 constexpr int kNW = kNT / 64;        // 16 wavefronts
 constexpr int kTopkEPT = 16;         // top-k keys held in registers per thread (n <= 16384)
-constexpr int kMaxK = NANN_COMPACT ? 256 : 1024;  // largest k / frontier a workgroup handles
-// Build-time knob: 1 = the LDS-bitmap filter without the pre-read (wg_filter_chunk_packed); needs a
-// 4096-slot hash table, i.e. 5.5 KB more phase scratch (LDS bitmap capacity 1.026 M instead of 1.07 M items)
-#ifndef NANN_FILTER_PACKED
-#define NANN_FILTER_PACKED 0
-#endif
-constexpr int kPhaseScratch = NANN_COMPACT ? 11264 : (NANN_FILTER_PACKED ? 33280 : 27648); // LDS bytes shared by the phases below
+constexpr int kMaxK = 1024;          // largest k / frontier a workgroup handles
+constexpr int kPhaseScratch = 27648; // LDS bytes shared by the phases of the bitmap kernels
 constexpr int kMaxD = 512;
-// candidate scores of a round are mirrored in LDS behind the top-k scratch (not in the compact variant)
+// bitmap kernels: candidate scores of a round are mirrored in LDS behind the top-k scratch
 constexpr int kLdsScoresOff = 10752;
-constexpr int kLdsScores = NANN_COMPACT ? 0 : 4096;
-constexpr int kVisSetSlots = 16384;  // compact variant: slots of the visited hash set (ids are stored +1, 0 = free)
+constexpr int kLdsScores = 4096;
 
 enum : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
 
@@ -310,10 +296,10 @@ __device__ __forceinline__ int wave_walk_span(const int32_t* src, int n, uint32_
 // All NT threads.  n_frontier <= kMaxK in CSR mode.  Outputs (uniform):
 // *gathered = length of the virtual list, return value = ids kept (appended
 // to out[0..)); -1 on an out-of-range frontier id or neighbour id.
-constexpr int kChunk = NANN_COMPACT ? 1024 : 2048;
+constexpr int kChunk = 2048;
 constexpr uint32_t kHashEmpty = 0xffffffffu;
 constexpr int kChunkTab = 64;
-constexpr int kHashSlots = NANN_FILTER_PACKED ? 2 * kChunk : kChunk;
+constexpr int kHashSlots = kChunk;
 struct ExpandWalkScratch {
   uint32_t off[kMaxK + 1];
   uint32_t rowstart[kMaxK];
@@ -327,37 +313,10 @@ struct ExpandWalkScratch {
 };
 
 __device__ __forceinline__ uint32_t chunk_hash(int32_t x) {
-  return ((uint32_t)x * 2654435761u) >> (NANN_COMPACT ? 22 : 21);  // 11 (10) bits: kChunk slots
+  return ((uint32_t)x * 2654435761u) >> 21;  // 11 bits: kChunk slots
 }
-static_assert(kChunk == (NANN_COMPACT ? 1024 : 2048), "chunk_hash yields log2(kChunk) bits");
+static_assert(kChunk == 2048, "chunk_hash yields log2(kChunk) bits");
 
-#if NANN_COMPACT
-// exact visited set: open addressing over kVisSetSlots words of LDS, entries = id + 1
-__device__ __forceinline__ uint32_t vis_hash(int32_t x) { return ((uint32_t)x * 2654435761u) >> 18; }
-static_assert(kVisSetSlots == 16384, "vis_hash yields 14 bits");
-__device__ __forceinline__ bool vis_contains(const uint32_t* V, int32_t x) {
-  uint32_t h = vis_hash(x);
-  for (;;) {
-    const uint32_t cur = V[h];
-    if (cur == (uint32_t)x + 1u) return true;
-    if (cur == 0u) return false;
-    h = (h + 1) & (kVisSetSlots - 1);
-  }
-}
-// true iff this call put x in (exactly one caller per id gets true, like a bit flipping 0 -> 1)
-__device__ __forceinline__ bool vis_insert(uint32_t* V, int32_t x) {
-  uint32_t h = vis_hash(x);
-  for (;;) {
-    uint32_t cur = V[h];
-    if (cur == 0u) {
-      cur = atomicCAS(&V[h], 0u, (uint32_t)x + 1u);
-      if (cur == 0u) return true;
-    }
-    if (cur == (uint32_t)x + 1u) return false;
-    h = (h + 1) & (kVisSetSlots - 1);
-  }
-}
-#endif
 
 template <bool kLdsBm, int NT>
 __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, uint32_t* bm,
@@ -384,15 +343,10 @@ __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, ui
     const bool valid = tid * PER + e < n_c;
     const bool inr = valid && (uint32_t)x[e] < n_items;
     bad |= valid && !inr;
-#if NANN_COMPACT
-    w[e] = bm; bit[e] = 0u;
-    fresh[e] = inr && !vis_contains(bm, x[e]);
-#else
     w[e] = bm + (inr ? ((uint32_t)x[e] >> 5) : 0u);
     bit[e] = inr ? (1u << (x[e] & 31)) : 0u;
     const uint32_t pre = kLdsBm ? *w[e] : atomicOr(w[e], 0u);  // global bitmap: served by L2 like the update
     fresh[e] = inr && !(pre & bit[e]);
-#endif
   }
 #pragma unroll
   for (int e = 1; e < PER; ++e)  // the same new id twice inside one thread: the later one is a copy
@@ -407,11 +361,7 @@ __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, ui
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     won[e] = false;
-#if NANN_COMPACT
-    if (fresh[e]) won[e] = vis_insert(bm, x[e]);
-#else
     if (fresh[e]) won[e] = !(atomicOr(w[e], bit[e]) & bit[e]);
-#endif
     cont[e] = fresh[e] && !won[e];
     slot[e] = kHashEmpty;
   }
@@ -488,118 +438,14 @@ __device__ __forceinline__ int wg_filter_chunk(ExpandWalkScratch* S, int n_c, ui
   return base + (int)tot;
 }
 
-#if NANN_FILTER_PACKED
-// wg_filter_chunk_packed: the same result with one bitmap access per id and three barriers (LDS
-// bitmap only; ids < 2^21).  Every id ORs its bit in straight away: the lane that finds it clear
-// is the winner and publishes (id << 11 | position) in a 4096-slot table; after a barrier the
-// lanes that found the bit set look their id up -- present means "new in this piece, another copy
-// won", and they join the minimum; absent means "visited before this piece".  An id is kept at
-// the position that survives in its slot.
-__device__ __forceinline__ uint32_t chunk_hash12(int32_t x) { return ((uint32_t)x * 2654435761u) >> 20; }
 
-template <int NT>
-__device__ __forceinline__ int wg_filter_chunk_packed(ExpandWalkScratch* S, int n_c, uint32_t* bm,
-                                                      uint32_t n_items, int32_t* out, int base) {
-  constexpr int PER = kChunk / NT;
-  constexpr int NWV = NT / 64;
-  constexpr uint32_t HM = kHashSlots - 1;
-  static_assert(kHashSlots == 4096, "chunk_hash12 yields 12 bits");
-  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
-  int32_t x[PER];
-  if constexpr (PER == 2) {
-    const int2 v = reinterpret_cast<const int2*>(S->stage)[tid];
-    x[0] = v.x; x[1] = v.y;
-  } else {
-    const int4 v = reinterpret_cast<const int4*>(S->stage)[tid];
-    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-  }
-  bool won[PER], lost[PER], keep[PER];
-  uint32_t entry[PER], slot[PER];
-  bool bad = false;
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {  // 1. set the bits (a lane's LDS operations execute in order)
-    const bool valid = tid * PER + e < n_c;
-    const bool inr = valid && (uint32_t)x[e] < n_items;
-    bad |= valid && !inr;
-    const uint32_t bit = 1u << (x[e] & 31);
-    uint32_t old = 0xffffffffu;
-    if (inr) old = atomicOr(bm + ((uint32_t)x[e] >> 5), bit);
-    won[e] = inr && !(old & bit);
-    lost[e] = inr && (old & bit);
-    entry[e] = ((uint32_t)x[e] << 11) | (uint32_t)(tid * PER + e);
-    slot[e] = 0;
-  }
-  if (bad) S->bad = 1;
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {  // 2. winners publish
-    if (won[e]) {
-      uint32_t h = chunk_hash12(x[e]);
-      while (atomicCAS(&S->hash[h], kHashEmpty, entry[e]) != kHashEmpty) h = (h + 1) & HM;
-      slot[e] = h;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {  // 3. other copies of an id that is new in this piece join the minimum
-    bool cont = false;
-    if (lost[e]) {
-      uint32_t h = chunk_hash12(x[e]);
-      for (;;) {
-        const uint32_t cur = S->hash[h];
-        if (cur == kHashEmpty) break;  // visited before this piece
-        if ((cur >> 11) == (uint32_t)x[e]) { atomicMin(&S->hash[h], entry[e]); slot[e] = h; cont = true; break; }
-        h = (h + 1) & HM;
-      }
-    }
-    lost[e] = cont;
-  }
-  __syncthreads();
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {  // 4. the surviving position keeps the id
-    keep[e] = (won[e] || lost[e]) && S->hash[slot[e]] == entry[e];
-    cnt += keep[e] ? 1u : 0u;
-  }
-  const uint32_t inc = wave_scan_add(cnt);  // 5. ordered compaction
-  if (lane == 63) S->wave_tot[wave] = inc;
-  __syncthreads();
-  uint32_t wbase = 0, tot = 0;
-#pragma unroll
-  for (int wv = 0; wv < NWV; ++wv) {
-    const uint32_t v = S->wave_tot[wv];
-    if (wv < wave) wbase += v;
-    tot += v;
-  }
-  int o = base + (int)(wbase + inc - cnt);
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {
-    if (keep[e]) out[o++] = x[e];
-    if (won[e]) S->hash[slot[e]] = kHashEmpty;  // every used slot belongs to exactly one winner
-  }
-  return base + (int)tot;
-}
-#endif
-
-// `stream` (optional): a scorer whose row loads fly underneath the filter.  Before piece c is
-// filtered, stream.issue_ids(b, e) / issue_rows() start the loads for the ids out[b..e) that earlier
-// pieces released (e - b <= Stream::kRows); after the filter, stream.finish() reduces them and
-// writes the scores.  *streamed = number of leading ids of out[] handled that way; the
-// caller scores the rest.  Both calls are made by all threads and contain no barrier.
-struct NoStream {
-  static constexpr int kRows = 0;
-  __device__ __forceinline__ void issue_ids(int, int) {}
-  __device__ __forceinline__ void issue_rows() {}
-  __device__ __forceinline__ void finish() {}
-};
-
-template <bool kLdsBm, int NT, typename Stream>
+template <bool kLdsBm, int NT = kNT>
 __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits,
                                               uint32_t n_items, uint32_t* bm, int32_t* out,
                                               unsigned char* scratch, int* gathered,
-                                              SubTimer pt, Stream& stream, bool stream_on,
-                                              int* streamed, int vis_count = 0) {
+                                              SubTimer pt = no_timer()) {
   ExpandWalkScratch* S = reinterpret_cast<ExpandWalkScratch*>(scratch);
   long long tsub = pt.now();
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
@@ -652,10 +498,6 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   *gathered = (int)total;
   pt.sub(PH_EX_PASS1, tsub);
   if (S->bad) return -1;
-#if NANN_COMPACT
-  // every gathered id may be new: keep the hash set below full so that probing always ends
-  if (vis_count + (int)total > kVisSetSlots - 64) return -2;
-#endif
   // ---- pass 2: fetch piece c+1 || filter piece c -------------------------------
   const int G = (int)total;
   const int n_chunks = (G + kChunk - 1) / kChunk;
@@ -737,23 +579,13 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   }
   __syncthreads();
   int base = 0;
-  int scored = 0;  // leading ids of out[] whose scores the stream has produced (uniform)
   for (int c = 0; c < n_chunks; ++c) {
     const bool more = c + 1 < n_chunks;
-    const int s_end = min(base, scored + Stream::kRows);
-    if (Stream::kRows > 0 && stream_on) stream.issue_ids(scored, s_end);  // ids released so far
     if (more) issue(c + 1, first_row(c + 1) + wave, B);  // adjacency loads in flight underneath the filter
-    if (Stream::kRows > 0 && stream_on) stream.issue_rows();
     const int n_c = min(kChunk, G - c * kChunk);
     long long tw = pt.now();
-#if NANN_FILTER_PACKED
-    if constexpr (kLdsBm) base = wg_filter_chunk_packed<NT>(S, n_c, bm, n_items, out, base);
-    else base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
-#else
     base = wg_filter_chunk<kLdsBm, NT>(S, n_c, bm, n_items, out, base);
-#endif
     pt.sub(PH_EX_WALKBUSY, tw);
-    if (Stream::kRows > 0 && stream_on) { stream.finish(); scored = s_end; }
     if (more) {
       commit(c + 1, B);
       rest(c + 1, B.r0);
@@ -763,22 +595,231 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
   pt.sub(PH_EX_LOOP, tsub);
   const int bad = S->bad;
   __syncthreads();
-  *streamed = scored;
   return bad ? -1 : base;
 }
 
-// without a stream
-template <bool kLdsBm, int NT = kNT>
-__device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_frontier,
+// ---------------------------------------------------------------------------
+// wg_expand_hash: GroupGather (one group) + BitmapRefDifference for the traversal that keeps TWO
+// queries per CU: the visited set is an exact open-addressing hash set of ids in LDS (64 KB)
+// instead of the 1-bit-per-item bitmap (125 KB at 1M items), so the memory phases of one query
+// overlap the LDS/VALU phases of the other.
+//
+// A slot holds (id << PB) | pos.  pos = 0 marks an id visited before the current piece;
+// the copies of an id inside the current piece meet in ONE slot (claimed by CAS on the empty
+// value, joined by id match) and ds_min_u32 leaves the SMALLEST position there -- the copy the
+// reference's serial scan keeps (bitmap_ops.cc:224-232).  After one barrier a position is kept
+// iff its own value survived in its slot, and the keeper resets pos to 0.  The virtual list
+// (CSR rows of the frontier, concatenated) is never staged: thread t owns positions
+// j * NT + t of the piece (coalesced over a wavefront), finds its row through a per-64-position
+// first-row table and fetches its id straight from the CSR.  Kept ids are compacted in position
+// order with the ballots themselves: wave w's j-th ballot IS the keep-mask of positions
+// [j * NT + 64 w, +64).  Two barriers per piece of up to NT * kHPer - 1 ids (five per 2048 in
+// wg_filter_chunk), no per-piece table.
+//
+// PB = position bits = min(12, 32 - bits(n_items)): 1M-item shards get pieces of 4095 ids, 4M-item
+// shards 1023.  Capacity: the set must stay below SLOTS - 64 entries; a piece that could
+// exceed it returns -2 and the host reruns that query on the bitmap kernel.
+constexpr uint32_t kVisEmpty = 0xffffffffu;
+constexpr int kVisMaxBlocks = 1024;  // 64-position blocks with a first-row entry (longer lists: binary search)
+template <int NT>
+struct ExpandHashScratch {
+  static constexpr int PER = 4096 / NT;   // positions per thread and piece
+  uint32_t off[kMaxK + 1];
+  uint32_t rowstart[kMaxK];
+  unsigned short blk_first[kVisMaxBlocks];
+  unsigned long long kept[64];            // keep-masks of the piece: word j * (NT/64) + wave
+  uint32_t wave_tot[kNW];
+  int bad;
+};
+
+// SLOTS = 16384 (64 KB: two 512-thread workgroups per CU) or 32768 (128 KB: one 1024-thread
+// workgroup per CU, for beams whose visited set outgrows the small table)
+template <int SLOTS>
+__device__ __forceinline__ uint32_t vis_hash(int32_t x) {
+  static_assert(SLOTS == 16384 || SLOTS == 32768, "14 or 15 hash bits");
+  return ((uint32_t)x * 2654435761u) >> (SLOTS == 16384 ? 18 : 17);
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void wg_vis_clear(uint32_t* vis) {
+  uint4* p4 = reinterpret_cast<uint4*>(vis);
+  for (int i = local_tid(); i < SLOTS / 4; i += (int)blockDim.x)
+    p4[i] = make_uint4(kVisEmpty, kVisEmpty, kVisEmpty, kVisEmpty);
+}
+
+// All NT threads.  Contract as wg_expand_walk; vis_count (uniform, in/out) = ids in the set.
+// Returns ids kept (appended to out[0..)), -1 on an out-of-range id, -2 when the set could overflow.
+template <int NT, int SLOTS>
+__device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
-                                              const int64_t* __restrict__ row_splits,
-                                              uint32_t n_items, uint32_t* bm, int32_t* out,
-                                              unsigned char* scratch, int* gathered,
-                                              SubTimer pt = no_timer(), int vis_count = 0) {
-  NoStream none;
-  int streamed = 0;
-  return wg_expand_walk<kLdsBm, NT, NoStream>(frontier, n_frontier, values, row_splits, n_items, bm, out,
-                                              scratch, gathered, pt, none, false, &streamed, vis_count);
+                                              const int64_t* __restrict__ row_splits, uint32_t n_items,
+                                              uint32_t* vis, int pos_bits, int& vis_count, int32_t* out,
+                                              unsigned char* scratch, int* gathered, SubTimer pt) {
+  using Scratch = ExpandHashScratch<NT>;
+  constexpr int PER = Scratch::PER;
+  constexpr int NWV = NT / 64;
+  static_assert(PER * NWV == 64, "one keep-mask word per lane");
+  Scratch* S = reinterpret_cast<Scratch*>(scratch);
+  long long tsub = pt.now();
+  const int tid = local_tid(), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: indexes readlane below
+  const uint64_t lt = lanemask_lt(lane);
+  const bool list_mode = row_splits == nullptr;
+  const int n_rows = list_mode ? 1 : n_frontier;
+  if (tid == 0) S->bad = 0;
+  __syncthreads();
+  // ---- pass 1: row lengths -> offsets of the virtual list, first row of every 64-position block
+  uint32_t total = 0;
+  for (int t0 = 0; t0 < n_rows; t0 += NT) {
+    const int t = t0 + tid;
+    uint32_t len = 0, start = 0;
+    if (list_mode) {
+      if (t == 0) len = (uint32_t)n_frontier;
+    } else if (t < n_frontier) {
+      const int32_t node = frontier[t];
+      if ((uint32_t)node < n_items) {
+        const int64_t s = row_splits[node], e = row_splits[node + 1];
+        start = (uint32_t)s;
+        len = (uint32_t)(e - s);
+      } else {
+        S->bad = 1;
+      }
+    }
+    const uint32_t inc = wave_scan_add(len);
+    if (lane == 63) S->wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const uint32_t v = S->wave_tot[w];
+      if (w < wave) wbase += v;
+      tot += v;
+    }
+    if (t < n_rows) {
+      const uint32_t my_off = total + wbase + inc - len;
+      S->off[t] = my_off;
+      S->rowstart[t] = start;
+      for (uint32_t b = (my_off + 63) >> 6; b < (uint32_t)kVisMaxBlocks && (b << 6) < my_off + len; ++b)
+        S->blk_first[b] = (unsigned short)t;
+    }
+    total += tot;
+    __syncthreads();
+  }
+  if (tid == 0) S->off[n_rows] = total;
+  __syncthreads();
+  *gathered = (int)total;
+  pt.sub(PH_EX_PASS1, tsub);
+  if (S->bad) return -1;
+  // ---- pass 2: pieces of PL positions
+  const int G = (int)total;
+  const int PL = min((1 << pos_bits) - 1, NT * PER - 1);
+  const uint32_t pmask = (1u << pos_bits) - 1u;
+  int base = 0;
+  bool bad = false;
+  for (int c0 = 0; c0 < G; c0 += PL) {
+    const int n_c = min(PL, G - c0);
+    if (vis_count + n_c > SLOTS - 64) return -2;  // uniform
+    // 1. position -> row -> CSR address -> id (PER loads in flight per thread)
+    int32_t x[PER];
+    bool act[PER];
+    uint32_t src[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int pl = j * NT + tid;
+      act[j] = pl < n_c;
+      const uint32_t p = (uint32_t)(c0 + pl);
+      src[j] = 0;
+      if (act[j]) {
+        if (list_mode) {
+          src[j] = p;
+        } else {
+          int r;
+          const uint32_t b = p >> 6;
+          if (b < (uint32_t)kVisMaxBlocks) {
+            r = S->blk_first[b];
+          } else {  // upper_bound over off[1..n_rows]
+            int lo = 0, hi = n_rows;
+            const uint32_t pb = b << 6;
+            while (lo < hi) {
+              const int m = (lo + hi) >> 1;
+              if (S->off[m + 1] > pb) hi = m; else lo = m + 1;
+            }
+            r = lo;
+          }
+          while (S->off[r + 1] <= p) ++r;
+          src[j] = S->rowstart[r] + (p - S->off[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) x[j] = values[src[j]];
+    // 2. test-and-insert: (id << PB) | (position in piece + 1)
+    uint32_t val[PER], h[PER];
+    bool in_set[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const bool inr = (uint32_t)x[j] < n_items;
+      bad |= act[j] && !inr;
+      act[j] = act[j] && inr;
+      in_set[j] = act[j];
+      val[j] = ((uint32_t)x[j] << pos_bits) | (uint32_t)(j * NT + tid + 1);
+      h[j] = vis_hash<SLOTS>(x[j]);
+    }
+    long long tw = pt.now();
+    for (;;) {
+      uint32_t cur[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) cur[j] = act[j] ? vis[h[j]] : 0u;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (act[j]) {
+          uint32_t c = cur[j];
+          if (c == kVisEmpty) c = atomicCAS(&vis[h[j]], kVisEmpty, val[j]);
+          if (c == kVisEmpty) {
+            act[j] = false;  // claimed the slot
+          } else if ((c >> pos_bits) == (uint32_t)x[j]) {
+            atomicMin(&vis[h[j]], val[j]);  // the smallest position of this id stays
+            act[j] = false;
+          } else {
+            h[j] = (h[j] + 1) & (SLOTS - 1);
+            any = true;
+          }
+        }
+      }
+      if (__ballot(any) == 0ull) break;
+    }
+    __syncthreads();
+    // 3. a position is kept iff its value survived; the keeper marks the id "visited before"
+    uint64_t km[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const bool keep = in_set[j] && vis[h[j]] == val[j];
+      if (keep) vis[h[j]] = val[j] & ~pmask;
+      km[j] = __ballot(keep);
+      if (lane == 0) S->kept[j * NWV + wave] = km[j];
+    }
+    __syncthreads();
+    pt.sub(PH_EX_WALKBUSY, tw);
+    // 4. ordered compaction: exclusive prefix over the 64 mask words (every wavefront on its own)
+    const uint32_t cnt = (uint32_t)popc64(S->kept[lane]);
+    const uint32_t inc = wave_scan_add(cnt);
+    const uint32_t exc = inc - cnt;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const uint32_t wb = (uint32_t)__builtin_amdgcn_readlane((int)exc, j * NWV + wave);
+      if ((km[j] >> lane) & 1ull) out[base + (int)wb + popc64(km[j] & lt)] = x[j];
+    }
+    const int tot = (int)wave_total(inc);
+    base += tot;
+    vis_count += tot;
+  }
+  pt.sub(PH_EX_LOOP, tsub);
+  if (__ballot(bad) != 0ull && lane == 0) S->bad = 1;
+  __syncthreads();
+  const int any_bad = S->bad;
+  __syncthreads();
+  return any_bad ? -1 : base;
 }
 
 // ---------------------------------------------------------------------------
@@ -853,15 +894,10 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
   return 0.0f - acc;
 }
 
-// Build-time knob: 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per CU).
-// The phase is latency-bound per CU; 12 / 16 are the next things to measure, and
-// NANN_SCORE_ROLL=1 (refill each slot as soon as it is reduced instead of batch by batch).
-#ifndef NANN_SCORE_U
+// 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per 1024-thread workgroup).
+// Measured on MI355X (profiles/r2a_variants.jsonl): 12 and 16 in flight, and a rolling window that
+// refills each slot as soon as it is reduced, are all slower (2.62 / 2.71 / 2.56 ms vs 2.56 ms).
 #define NANN_SCORE_U 8
-#endif
-#ifndef NANN_SCORE_ROLL
-#define NANN_SCORE_ROLL 0
-#endif
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
 // inside, so a subset of the workgroup can run it.
@@ -883,28 +919,6 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
 #pragma unroll
   for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
   // branch-free: positions past `end` re-read candidate end-1 and their result is dropped
-#if NANN_SCORE_ROLL
-  // rolling window: the oldest of the U row loads in flight is reduced and its slot refilled at
-  // once, so the number of loads in flight never drains to zero between batches
-  int32_t id1[U];
-  RowChunk<DT> ch[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) ch[u] = load_chunk<DT>(table, (size_t)ids[min(begin + u * RPI + slot, end - 1)], d, sub);
-#pragma unroll
-  for (int u = 0; u < U; ++u) id1[u] = ids[min(begin + (U + u) * RPI + slot, end - 1)];
-  for (int i0 = begin; i0 < end; i0 += RPI * U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * RPI + slot;
-      float x[8];
-      chunk_to_float<DT>(ch[u], x);
-      const float s = l2_finish<LPR>(q, x);
-      if (sub == 0 && i < end) scores[i] = s;
-      ch[u] = load_chunk<DT>(table, (size_t)id1[u], d, sub);            // position i + U * RPI
-      id1[u] = ids[min(i0 + (2 * U + u) * RPI + slot, end - 1)];        // position i + 2 U * RPI
-    }
-  }
-#else
   int32_t nxt[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) nxt[u] = ids[min(begin + u * RPI + slot, end - 1)];
@@ -924,64 +938,7 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
       if (sub == 0 && i < end) scores[i] = s;
     }
   }
-#endif
 }
-
-// Build-time knob: 16-byte row loads a lane keeps in flight across the filter; 0 = score after
-// the expand.  Measured on MI355X (1M x 128-d f16, ef=128, batch 4096, k_search ms): 0: 2.715,
-// 2: 2.755, 4: 2.812, 6: 2.943, 8: 3.175 -- the id -> row dependency adds an L2 round trip per piece and
-// the registers the rows pin slow the filter down (the memory system itself has headroom:
-// tools/ubench_gather.hip).  Kept for shards / row sizes where that balance differs.
-#ifndef NANN_STREAM_U
-#define NANN_STREAM_U 0
-#endif
-// L2Stream: the same scorer split into "start the row loads" / "reduce and store", so that a
-// batch of U row loads per lane stays in flight across other work (wg_expand_walk's filter).
-template <int LPR, int DT, int NT>
-struct L2Stream {
-  static constexpr int U = NANN_STREAM_U > 0 ? ((DT == DT_F32) ? (NANN_STREAM_U + 1) / 2 : NANN_STREAM_U) : 1;  // rows in flight per lane across the filter
-  static constexpr int GPW = 64 / LPR;
-  static constexpr int RPI = (NT / 64) * GPW;
-  static constexpr int kRows = U * RPI;
-  const void* table;
-  int d;
-  const int32_t* ids;
-  const float* qv;
-  float* scores;
-  RowChunk<DT> r[U];
-  int32_t id[U];
-  int begin, end;
-  __device__ __forceinline__ void issue_ids(int b, int e) {  // the ids first (an L2 round trip) ...
-    begin = b; end = e;
-    if (e <= b) return;
-    const int tid = local_tid(), lane = tid & 63;
-    const int slot = (tid >> 6) * GPW + lane / LPR;
-#pragma unroll
-    for (int u = 0; u < U; ++u) id[u] = ids[min(b + u * RPI + slot, e - 1)];
-  }
-  __device__ __forceinline__ void issue_rows() {  // ... then their rows
-    if (end <= begin) return;
-    const int sub = (local_tid() & 63) % LPR;
-#pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = load_chunk<DT>(table, (size_t)id[u], d, sub);
-  }
-  __device__ __forceinline__ void finish() {
-    if (end <= begin) return;
-    const int tid = local_tid(), lane = tid & 63;
-    const int sub = lane % LPR, slot = (tid >> 6) * GPW + lane / LPR;
-    float q[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float x[8];
-      chunk_to_float<DT>(r[u], x);
-      const float sc = l2_finish<LPR>(q, x);
-      const int i = begin + u * RPI + slot;
-      if (sub == 0 && i < end) scores[i] = sc;
-    }
-  }
-};
 
 // whole workgroup, i < n
 template <int LPR, int DT, int NTHREADS>
@@ -1014,14 +971,10 @@ struct TopkScratch {
 };
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
 // the selection does not wait on L2 (positions < kLdsScores only)
-static_assert(sizeof(TopkScratch) <= (NANN_COMPACT ? kPhaseScratch : kLdsScoresOff), "top-k scratch overlaps the LDS scores");
-static_assert(NANN_COMPACT || kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
+static_assert(sizeof(TopkScratch) <= kLdsScoresOff, "top-k scratch overlaps the LDS scores");
+static_assert(kLdsScoresOff + kLdsScores * 4 <= kPhaseScratch, "phase scratch too small");
 static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too small");
 
-// Build-time knob: 1 = radix search on key - min(key) instead of skipping the common prefix.
-#ifndef NANN_TOPK_MINSUB
-#define NANN_TOPK_MINSUB 0
-#endif
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
 // SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
 template <int NS, bool SCL, int NT>
@@ -1070,7 +1023,6 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     }                                                                         \
   }
 
-#if NANN_TOPK_MINSUB
   // ---- 2a. range of the keys: the search runs on key - min(key), whose leading digit is spread
   //          over the bins (the raw keys of scores within a few binades share all but 2-3 values of
   //          their top 8 undecided bits, and same-bin LDS atomics serialise)
@@ -1084,31 +1036,13 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   __syncthreads();
   const uint32_t kbase = S->andv;          // smallest key
   const uint32_t diff = S->orv - kbase;    // largest key - smallest key
-#else
-  // ---- 2a. common prefix of all keys: the search only has to resolve the bits
-  //          below the highest bit in which any two keys differ
-  {
-    uint32_t lo = 0u, la = 0xffffffffu;
-    NANN_FOR_KEYS({ if (valid) { lo |= kj; la &= kj; } })
-    lo = wave_or(lo);
-    la = wave_and(la);
-    if (lane == 0) { atomicOr(&S->orv, lo); atomicAnd(&S->andv, la); }
-  }
-  __syncthreads();
-  const uint32_t kbase = 0u;
-  const uint32_t diff = S->orv ^ S->andv;
-#endif
   // ---- 2b. k-th largest key: radix select over the undecided bits, 8 bits per pass
   //          (LDS histogram -> 256-bin suffix scan).  A pass ends the search early when the
   //          bin holding the k-th key is needed in full.  T is relative to kbase until the end.
   uint32_t T = 0, c_ge = (uint32_t)n, c_gt = 0;
   if (diff != 0u) {
     const int hb = 31 - __clz((int)diff);  // highest differing bit
-#if NANN_TOPK_MINSUB
     T = 0u;
-#else
-    T = S->andv & ~((hb == 31) ? 0xffffffffu : ((2u << hb) - 1u));
-#endif
     int top = hb + 1;          // undecided low bits
     uint32_t kk = (uint32_t)k;  // still to find among keys that match T above `top`
     bool exact = false;

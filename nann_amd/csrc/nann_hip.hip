@@ -5,6 +5,7 @@
 #include "nann_attn.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -504,9 +505,9 @@ static bool cast_payload(const std::string& from, int to, const std::vector<char
   return false;
 }
 
-int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
-                         int expect_rank, int allow_cast, void** dev_ptr, int64_t* nbytes) {
-  if (!path || !dev_ptr) return fail(NANN_ERR_BAD_ARGUMENT, "nann_huge_const_load: null argument");
+// .npy -> host bytes in `expect_dtype` (shared by HugeConst and the scorer-model loader)
+static int read_npy_host(const char* path, int expect_dtype, const int64_t* expect_shape, int expect_rank,
+                         int allow_cast, std::vector<char>* out, std::vector<int64_t>* out_shape) {
   std::ifstream f(path, std::ifstream::binary);
   if (!f) return fail(NANN_ERR_IO, std::string("Fail to open file: ") + path);  // huge_const_op.cc:96-98
   unsigned char head[12];
@@ -586,10 +587,28 @@ int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expe
       return fail(NANN_ERR_DTYPE_MISMATCH, "no cast from " + descr + " to " + want);
     host.swap(conv);
   }
-  const int64_t total = count * esz[expect_dtype];
+  host.resize((size_t)(count * esz[expect_dtype]));
+  out->swap(host);
+  if (out_shape) *out_shape = shape;
+  return NANN_OK;
+}
+
+int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
+                         int expect_rank, int allow_cast, void** dev_ptr, int64_t* nbytes) {
+  if (!path || !dev_ptr) return fail(NANN_ERR_BAD_ARGUMENT, "nann_huge_const_load: null argument");
+  std::vector<char> host;
+  const int rc = read_npy_host(path, expect_dtype, expect_shape, expect_rank, allow_cast, &host, nullptr);
+  if (rc) return rc;
+  const int64_t total = (int64_t)host.size();
   void* d = nullptr;
   HIP_TRY(hipMalloc(&d, (size_t)std::max<int64_t>(total, 1)));
-  if (total) HIP_TRY(hipMemcpy(d, host.data(), (size_t)total, hipMemcpyHostToDevice));
+  if (total) {
+    const hipError_t e = hipMemcpy(d, host.data(), (size_t)total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);  // do not leak the allocation on a failed copy
+      return fail(NANN_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+  }
   *dev_ptr = d;
   if (nbytes) *nbytes = total;
   return NANN_OK;
@@ -956,6 +975,112 @@ int nann_attn_score(const nann_attn_scorer* s, const float* kt, const float* upa
   return NANN_OK;
 }
 
+// ---- a4: the scoring model behind BlazeXlaOp, loaded from a weights directory ------------
+struct nann_model {
+  int kind = NANN_MODEL_L2;
+  int d = 0, seq_len = 0, emb_dtype = NANN_F16;
+  nann_scorer* scorer = nullptr;
+  nann_attn_scorer* attn = nullptr;
+};
+
+static int load_f32(const std::string& dir, const char* name, std::vector<std::vector<char>>* keep,
+                    const float** out, int64_t expect_count) {
+  keep->emplace_back();
+  std::vector<int64_t> shape;
+  const int rc = read_npy_host((dir + "/" + name + ".npy").c_str(), NANN_F32, nullptr, 0, /*allow_cast=*/1,
+                               &keep->back(), &shape);
+  if (rc) return rc;
+  int64_t count = 1;
+  for (int64_t v : shape) count *= v;
+  if (expect_count >= 0 && count != expect_count)
+    return fail(NANN_ERR_SHAPE_MISMATCH, std::string(name) + ".npy: " + std::to_string(count) + " values, expected " +
+                                             std::to_string(expect_count));
+  *out = reinterpret_cast<const float*>(keep->back().data());
+  return NANN_OK;
+}
+
+int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_len, nann_model** out) {
+  if (!dir || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_load: null argument");
+  const std::string D(dir);
+  std::ifstream kf(D + "/scorer.txt");
+  if (!kf) return fail(NANN_ERR_IO, "Fail to open file: " + D + "/scorer.txt");
+  std::string kind;
+  kf >> kind;
+  nann_model* m = new nann_model();
+  m->d = d; m->seq_len = seq_len; m->emb_dtype = emb_dtype;
+  std::vector<std::vector<char>> keep;
+  int rc = NANN_OK;
+  if (kind == "l2" || kind == "mlp") {
+    nann_scorer_desc sd = {};
+    sd.kind = kind == "l2" ? NANN_SCORER_L2 : NANN_SCORER_MLP;
+    sd.d = d; sd.emb_dtype = emb_dtype;
+    m->kind = kind == "l2" ? NANN_MODEL_L2 : NANN_MODEL_MLP;
+    if (kind == "mlp") {
+      sd.h1 = 256; sd.h2 = 128;
+      const struct { const char* n; const float** p; int64_t cnt; } w[] = {
+          {"w1", &sd.w1, 2ll * d * 256}, {"b1", &sd.b1, 256}, {"alpha1", &sd.alpha1, 256}, {"w2", &sd.w2, 256 * 128},
+          {"b2", &sd.b2, 128}, {"alpha2", &sd.alpha2, 128}, {"w3", &sd.w3, 128}};
+      for (const auto& e : w)
+        if (!rc) rc = load_f32(D, e.n, &keep, e.p, e.cnt);
+    }
+    if (!rc) rc = nann_scorer_create(&sd, &m->scorer);
+  } else if (kind == "attention") {
+    nann_attn_desc ad = {};
+    ad.d = d; ad.emb_dtype = emb_dtype; ad.seq_len = seq_len;
+    m->kind = NANN_MODEL_ATTENTION;
+    const struct { const char* n; const float** p; } w[] = {
+        {"wq1", &ad.wq1}, {"bq1", &ad.bq1}, {"aq", &ad.aq}, {"wq2", &ad.wq2}, {"bq2", &ad.bq2},
+        {"wk1", &ad.wk1}, {"bk1", &ad.bk1}, {"ak", &ad.ak}, {"wk2", &ad.wk2}, {"bk2", &ad.bk2},
+        {"w0", &ad.w[0]}, {"w1", &ad.w[1]}, {"w2", &ad.w[2]}, {"w3", &ad.w[3]},
+        {"b0", &ad.b[0]}, {"b1", &ad.b[1]}, {"b2", &ad.b[2]},
+        {"bn_scale0", &ad.bn_scale[0]}, {"bn_scale1", &ad.bn_scale[1]}, {"bn_scale2", &ad.bn_scale[2]},
+        {"bn_shift0", &ad.bn_shift[0]}, {"bn_shift1", &ad.bn_shift[1]}, {"bn_shift2", &ad.bn_shift[2]},
+        {"alpha0", &ad.alpha[0]}, {"alpha1", &ad.alpha[1]}, {"alpha2", &ad.alpha[2]}};
+    for (const auto& e : w)
+      if (!rc) rc = load_f32(D, e.n, &keep, e.p, -1);
+    if (!rc) rc = nann_attn_scorer_create(&ad, &m->attn);
+  } else {
+    rc = fail(NANN_ERR_UNSUPPORTED, "scorer.txt: expected l2, mlp or attention, got '" + kind + "'");
+  }
+  if (rc) { nann_model_destroy(m); return rc; }
+  *out = m;
+  return NANN_OK;
+}
+
+void nann_model_destroy(nann_model* m) {
+  if (!m) return;
+  if (m->scorer) nann_scorer_destroy(m->scorer);
+  if (m->attn) nann_attn_scorer_destroy(m->attn);
+  delete m;
+}
+
+int nann_model_kind(const nann_model* m) { return m ? m->kind : -1; }
+const nann_scorer* nann_model_scorer(const nann_model* m) { return m ? m->scorer : nullptr; }
+
+int nann_model_workspace_bytes(const nann_model* m, int64_t* nbytes) {
+  if (!m || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_workspace_bytes: null argument");
+  *nbytes = m->kind == NANN_MODEL_ATTENTION ? (int64_t)(256 * 64 + 64 * 64) * 4 : (int64_t)kMaxD * 4;
+  return NANN_OK;
+}
+
+int nann_model_forward(const nann_model* m, const void* user_seq_f16, const void* item_emb, int64_t n,
+                       float* logits, void* workspace, nann_stream_t stream) {
+  if (!m || !user_seq_f16 || !logits || !workspace) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_forward: null argument");
+  if (n <= 0)  // blaze_xla_predictor.cc:259-263
+    return fail(NANN_ERR_EMPTY_SCORE_BATCH, "Error when getting input address or size");
+  if (m->kind == NANN_MODEL_ATTENTION) {
+    float* kt = static_cast<float*>(workspace);
+    float* upad = kt + 256 * 64;
+    const int rc = nann_attn_prepare(m->attn, user_seq_f16, 1, kt, upad, stream);
+    if (rc) return rc;
+    return nann_attn_score(m->attn, kt, upad, item_emb, n, nullptr, n, logits, nullptr, stream);
+  }
+  float* q = static_cast<float*>(workspace);
+  const int rc = nann_user_seq_mean(user_seq_f16, 1, m->seq_len, m->d, q, stream);
+  if (rc) return rc;
+  return nann_score(m->scorer, q, item_emb, n, nullptr, n, logits, nullptr, stream);
+}
+
 // ---- index ---------------------------------------------------------------------------
 static int64_t dtype_bytes(int dt) { return dt == NANN_F32 ? 4 : 2; }
 
@@ -1046,7 +1171,12 @@ int nann_index_info(const nann_index* ix, int64_t out[6]) {
 }
 
 // ---- fused search -----------------------------------------------------------------------
-static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, SearchPlan* p) {
+static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
+
+static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+// kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
+static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p) {
   for (int i = 0; i < 6; ++i)
     if (t[i] < 0 || t[i] > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "level_topn entries must be in [0, 1024]");
   DeviceInfo di;
@@ -1061,41 +1191,68 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->max_cand = (int)max_cand;
   p->max_raw = (int)max_raw;
   p->pool_cap = std::max(t[1] + t[2] + t[3] + t[4], 1);
-  const size_t fixed = kPhaseScratch + kMaxD * 4 + 256;
+  const size_t tail = kMaxD * 4 + 256;  // q + misc behind the phase scratch
   const size_t bm_bytes = (size_t)ix->bm_words * 4;
-  p->lds_bitmap = bm_bytes + fixed <= di.lds_max;
-  p->nt = kNT;
-  int per_cu = p->lds_bitmap ? 1 : 2;  // LDS-resident bitmap: one workgroup per CU
-  // tuning / test knob: NANN_L2_VARIANT=glb512[:wgs] keeps the visited bitmap in HBM/L2 and
-  // runs half-size workgroups, `wgs` of them per CU (default 2), so that the phases of
-  // different queries overlap on one CU (measured slower: 4.14 ms vs 2.67 ms at 1M x 128-d);
-  // glb1024 forces the HBM bitmap with full-size workgroups (what > 1.05M-item shards use)
-  static const std::string variant = [] { const char* e = std::getenv("NANN_L2_VARIANT"); return std::string(e ? e : ""); }();
-  if (variant.rfind("glb512", 0) == 0) {
-    p->lds_bitmap = false;
-    p->nt = 512;
-    per_cu = variant.size() > 7 ? std::max(1, std::atoi(variant.c_str() + 7)) : 2;
-  } else if (variant == "glb1024") {  // the path shards beyond the LDS bitmap's capacity take
-    p->lds_bitmap = false;
-    per_cu = 2;
+  const bool bitmap_fits = bm_bytes + kPhaseScratch + tail <= di.lds_max;
+  const int mode = g_traversal_mode.load(std::memory_order_relaxed);
+  // the bitmap plan: what MLP traversals run, what oversized shards run, and the fallback of the hash plan
+  const int bm_vis = (bitmap_fits && mode != NANN_TRAVERSAL_HBM_BITMAP) ? VIS_LDS_BITMAP : VIS_HBM_BITMAP;
+  const size_t bm_lds = kPhaseScratch + tail + (bm_vis == VIS_LDS_BITMAP ? bm_bytes : 0);
+  const int bm_per_cu = bm_vis == VIS_LDS_BITMAP ? 1 : 2;
+  // the hash-set plans: L2 scorer, ids + a useful number of position bits in 32 bits.  Which table:
+  // the visited set of a level holds its marks plus every id the level's rounds keep.  Measured on
+  // HNSW(M=32) graphs (profiles/): the rows a beam walks are ~2.75x the mean degree and ~45% of the
+  // gathered ids are new.  16K slots (two queries per CU) when that estimate leaves headroom, 32K
+  // slots (one query per CU) for wider beams; beyond that the bitmap.  A wrong guess costs speed,
+  // not correctness: overflowing queries are rerun on the bitmap kernel.
+  const int pos_bits = std::min(12, 32 - bit_length((uint64_t)ix->desc.n_items));
+  const double mean_deg0 = (double)ix->desc.nb_nnz[0] / (double)std::max<int64_t>(ix->desc.n_items, 1);
+  const double walk_deg = std::min<double>((double)ix->max_deg[0], 2.75 * mean_deg0);
+  const double est_visited = t[1] + 0.45 * walk_deg * ((double)t[1] + t[2] + t[3]);
+  const double worst_visited = t[1] + (double)ix->max_deg[0] * ((double)t[1] + t[2] + t[3]);
+  const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512>() + tail;
+  const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT>() + tail;
+  const bool hash_ok = (kind == NANN_SCORER_L2 || kind < 0) && pos_bits >= 10 && 2 * hash16_lds <= di.lds_max &&
+                       hash32_lds <= di.lds_max;
+  int hash_vis = -1;
+  if (mode == NANN_TRAVERSAL_LDS_HASH) hash_vis = VIS_LDS_HASH;
+  else if (mode == NANN_TRAVERSAL_LDS_HASH32) hash_vis = VIS_LDS_HASH32;
+  else if (mode == NANN_TRAVERSAL_AUTO && kind != NANN_SCORER_MLP) {
+    if (worst_visited <= 16320.0 || est_visited <= 11000.0) hash_vis = VIS_LDS_HASH;
+    else if (worst_visited <= 32704.0 || est_visited <= 24000.0) hash_vis = VIS_LDS_HASH32;
   }
-#if NANN_COMPACT
-  // the visited structure is the 64 KB hash set whatever the shard size: two 512-thread workgroups per CU
-  p->lds_bitmap = true;
-  p->nt = 512;
-  per_cu = 2;
-  p->lds_bytes = fixed + (size_t)kVisSetSlots * 4;
-  {
-    unsigned long long off2[8];
-    p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, 0u, off2);
-    p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
-    return NANN_OK;
-  }
-#endif
-  p->lds_bytes = fixed + (p->lds_bitmap ? bm_bytes : 0);
+  if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0)
+    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: L2 scorer and shards below 4M items only");
   unsigned long long off[8];
-  p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, p->lds_bitmap ? 0u : ix->bm_words, off);
-  p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
+  p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u, off);
+  p->pos_bits = pos_bits;
+  p->fb_vis = bm_vis;
+  p->fb_lds_bytes = bm_lds;
+  p->fb_slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * bm_per_cu));
+  if (hash_ok && hash_vis == VIS_LDS_HASH) {
+    p->vis = VIS_LDS_HASH;
+    p->nt = 512;
+    p->lds_bytes = hash16_lds;
+    p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * 2));
+  } else if (hash_ok && hash_vis == VIS_LDS_HASH32) {
+    p->vis = VIS_LDS_HASH32;
+    p->nt = kNT;
+    p->lds_bytes = hash32_lds;
+    p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus));
+  } else {
+    p->vis = bm_vis;
+    p->nt = kNT;  // (the MLP kernels run kMlpNT threads; the launcher knows)
+    p->lds_bytes = bm_lds;
+    p->slots = p->fb_slots;
+  }
+  if (kind < 0) p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * 2));  // sizing: the widest plan
+  return NANN_OK;
+}
+
+int nann_set_traversal_mode(int32_t mode) {
+  if (mode < NANN_TRAVERSAL_AUTO || mode > NANN_TRAVERSAL_LDS_HASH32)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_set_traversal_mode: unknown mode");
+  g_traversal_mode.store(mode, std::memory_order_relaxed);
   return NANN_OK;
 }
 
@@ -1103,9 +1260,9 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
                                 int64_t* nbytes) {
   if (!ix || !level_topn || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_workspace_bytes: null argument");
   SearchPlan p;
-  const int rc = plan_search(ix, level_topn, n_queries, &p);
+  const int rc = plan_search(ix, level_topn, n_queries, -1, &p);
   if (rc) return rc;
-  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)p.slots);
+  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots));
   return NANN_OK;
 }
 
@@ -1113,17 +1270,17 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
 
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
 // nann_mlp_inst.hip (one per embedding dim): the heavy kernels compile in parallel.
-static int launch_search_any(int lpr, int dt, int kind, const SearchPlan& p, const SearchArgs& a,
-                             hipStream_t st) {
+static int launch_search_any(int lpr, int dt, int kind, int vis, int nt, int slots, size_t lds_bytes,
+                             const SearchArgs& a, hipStream_t st) {
   if (kind == NANN_SCORER_MLP) {
-    if (lpr == 8) return launch_search_mlp_d64(dt, p, a, st);
-    if (lpr == 16) return launch_search_mlp_d128(dt, p, a, st);
-    if (lpr == 32) return launch_search_mlp_d256(dt, p, a, st);
+    if (lpr == 8) return launch_search_mlp_d64(dt, vis, slots, lds_bytes, a, st);
+    if (lpr == 16) return launch_search_mlp_d128(dt, vis, slots, lds_bytes, a, st);
+    if (lpr == 32) return launch_search_mlp_d256(dt, vis, slots, lds_bytes, a, st);
     return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256 only");
   }
-  if (dt == NANN_F16) return launch_search_l2_f16(lpr, p, a, st);
-  if (dt == NANN_BF16) return launch_search_l2_bf16(lpr, p, a, st);
-  return launch_search_l2_f32(lpr, p, a, st);
+  if (dt == NANN_F16) return launch_search_l2_f16(lpr, vis, nt, slots, lds_bytes, a, st);
+  if (dt == NANN_BF16) return launch_search_l2_bf16(lpr, vis, nt, slots, lds_bytes, a, st);
+  return launch_search_l2_f32(lpr, vis, nt, slots, lds_bytes, a, st);
 }
 
 extern "C" {
@@ -1146,10 +1303,11 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
   if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
     return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  const int kind = scorer->desc.kind;
   SearchPlan p;
-  int rc = plan_search(ix, level_topn, n_queries, &p);
+  int rc = plan_search(ix, level_topn, n_queries, kind, &p);
   if (rc) return rc;
-  if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)p.slots))
+  if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots)))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");
   SearchArgs a;
   a.emb = ix->desc.item_embs;
@@ -1164,21 +1322,23 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   for (int i = 0; i < 6; ++i) a.t[i] = level_topn[i];
   a.ws = static_cast<unsigned char*>(workspace);
   a.slot_bytes = p.slot_bytes;
-#if NANN_COMPACT
-  a.bm_words = kVisSetSlots;  // words of the visited hash set
-#else
   a.bm_words = ix->bm_words;
-#endif
   a.max_cand = p.max_cand; a.max_raw = p.max_raw; a.pool_cap = p.pool_cap;
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index;
   a.status = status; a.counters = counters;
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
+  a.pos_bits = p.pos_bits;
+  a.redo = 0;
   hipStream_t st = as_stream(stream);
-  HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // the query queue head
+  HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // WsHeader: query queues, hand-back counter
   const int dt = ix->desc.emb_dtype;
-  const int kind = scorer->desc.kind;
   a.mlp = scorer->mlp;
-  return launch_search_any(ix->desc.d / 8, dt, kind, p, a, st);
+  rc = launch_search_any(ix->desc.d / 8, dt, kind, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
+  if (rc || (p.vis != VIS_LDS_HASH && p.vis != VIS_LDS_HASH32)) return rc;
+  // queries whose visited set could have overflowed the 64 KB hash set are rerun on the bitmap
+  // kernel (its workgroups leave at once when there is none)
+  a.redo = 1;
+  return launch_search_any(ix->desc.d / 8, dt, kind, p.fb_vis, kNT, p.fb_slots, p.fb_lds_bytes, a, st);
 }
 
 // ---- merge ------------------------------------------------------------------------------

@@ -11,32 +11,25 @@
 
 namespace nann {
 
-int NANN_CAT(launch_search_l2_, NANN_L2_NAME)(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
-#if NANN_COMPACT
-  // compact library variant: only the 512-thread kernel with the visited set in LDS exists
-  if (!(p.nt == 512 && p.lds_bitmap)) return fail(NANN_ERR_UNSUPPORTED, "compact build: plan not supported");
+template <int LPR>
+static int launch_l2(int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  if (vis == VIS_LDS_HASH && nt == 512)  // two queries per CU
+    return launch_search_as<LPR, NANN_L2_DT, VIS_LDS_HASH, NANN_SCORER_L2, 512>(slots, lds_bytes, a, st);
+  if (vis == VIS_LDS_HASH32 && nt == kNT)  // wide beams: one query per CU, 32K-slot set
+    return launch_search_as<LPR, NANN_L2_DT, VIS_LDS_HASH32, NANN_SCORER_L2, kNT>(slots, lds_bytes, a, st);
+  if ((vis == VIS_LDS_BITMAP || vis == VIS_HBM_BITMAP) && nt == kNT)
+    return launch_search_bitmap<LPR, NANN_L2_DT, NANN_SCORER_L2, kNT>(vis, slots, lds_bytes, a, st);
+  return fail(NANN_ERR_UNSUPPORTED, "L2 traversal: no kernel for this plan");
+}
+
+int NANN_CAT(launch_search_l2_, NANN_L2_NAME)(int lpr, int vis, int nt, int slots, size_t lds_bytes,
+                                              const SearchArgs& a, hipStream_t st) {
   switch (lpr) {
-    case 8: return launch_search_lds<8, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-    case 16: return launch_search_lds<16, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-    case 32: return launch_search_lds<32, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-    default: return launch_search_lds<64, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
+    case 8: return launch_l2<8>(vis, nt, slots, lds_bytes, a, st);
+    case 16: return launch_l2<16>(vis, nt, slots, lds_bytes, a, st);
+    case 32: return launch_l2<32>(vis, nt, slots, lds_bytes, a, st);
+    default: return launch_l2<64>(vis, nt, slots, lds_bytes, a, st);
   }
-#else
-  if (p.nt == 512) {  // global-bitmap variant: two half-size workgroups per CU
-    switch (lpr) {
-      case 8: return launch_search_global<8, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-      case 16: return launch_search_global<16, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-      case 32: return launch_search_global<32, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-      default: return launch_search_global<64, NANN_L2_DT, NANN_SCORER_L2, 512>(p, a, st);
-    }
-  }
-  switch (lpr) {
-    case 8: return launch_search<8, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
-    case 16: return launch_search<16, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
-    case 32: return launch_search<32, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
-    default: return launch_search<64, NANN_L2_DT, NANN_SCORER_L2, kNT>(p, a, st);
-  }
-#endif
 }
 
 }  // namespace nann

@@ -51,7 +51,7 @@ struct MlpScratch {
   float alpha2[256];
   float w3[256];
 };
-static_assert(NANN_COMPACT || sizeof(MlpScratch) <= kPhaseScratch, "phase scratch too small for the MLP");
+static_assert(sizeof(MlpScratch) <= kPhaseScratch, "phase scratch too small for the MLP");
 
 __device__ __forceinline__ float prelu(float x, float a) {
   const float pos = x > 0.0f ? x : 0.0f;

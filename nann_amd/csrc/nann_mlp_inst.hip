@@ -11,22 +11,12 @@
 
 namespace nann {
 
-#if NANN_COMPACT
-// the compact library variant carries the L2 traversal only (its phase scratch is too small for the MLP)
-int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int, const SearchPlan&, const SearchArgs&, hipStream_t) {
-  return fail(NANN_ERR_UNSUPPORTED, "compact build: L2 scorer only");
-}
-int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int, unsigned, hipStream_t, const MlpParams&, const void*, long long,
-                                             const int32_t*, long long, const float*, float*, OpResult*) {
-  return fail(NANN_ERR_UNSUPPORTED, "compact build: L2 scorer only");
-}
-}  // namespace nann
-#else
-
-int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
+int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a,
+                                              hipStream_t st) {
   constexpr int LPR = NANN_MLP_D / 8;
-  if (dt == NANN_F16) return launch_search<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT>(p, a, st);
-  if (dt == NANN_BF16) return launch_search<LPR, DT_BF16, NANN_SCORER_MLP, kMlpNT>(p, a, st);
+  if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: bitmap kernels only");
+  if (dt == NANN_F16) return launch_search_bitmap<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT>(vis, slots, lds_bytes, a, st);
+  if (dt == NANN_BF16) return launch_search_bitmap<LPR, DT_BF16, NANN_SCORER_MLP, kMlpNT>(vis, slots, lds_bytes, a, st);
   return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
 }
 
@@ -47,4 +37,3 @@ int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int dt, unsigned blocks, hipStream_
 }
 
 }  // namespace nann
-#endif

@@ -82,6 +82,8 @@ struct SearchArgs {
   int32_t* counters;
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
+  int pos_bits;            // VIS_LDS_HASH: position bits of a set entry
+  int redo;                // 1: fallback launch, only queries with status NANN_ERR_CAPACITY
 };
 
 static_assert(PH_COUNT == NANN_NUM_PHASES, "phase list out of sync with include/nann_hip.h");
@@ -112,15 +114,34 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
   return o;
 }
 
-template <int LPR, int DT, bool LDSBM, int SC, int NT>
+// where a query's visited set lives
+enum : int {
+  VIS_LDS_BITMAP = 0,  // 1 bit per item in LDS (N <= ~1.07M): one 1024-thread workgroup per CU
+  VIS_HBM_BITMAP = 1,  // 1 bit per item in the slot's HBM scratch (larger shards)
+  VIS_LDS_HASH = 2,    // exact hash set of visited ids in LDS, 16K slots (64 KB): two 512-thread workgroups per CU
+  VIS_LDS_HASH32 = 3   // the same with 32K slots (128 KB): one 1024-thread workgroup per CU (wide beams)
+};
+constexpr int vis_slots(int vis) { return vis == VIS_LDS_HASH ? 16384 : vis == VIS_LDS_HASH32 ? 32768 : 0; }
+
+// LDS layout of the hash-set traversal: [set | phase scratch | q f32[kMaxD] | misc]
+template <int NT>
+constexpr int hash_phase_scratch() {
+  constexpr int a = (int)sizeof(TopkScratch), b = (int)sizeof(ExpandHashScratch<NT>);
+  return ((a > b ? a : b) + 255) & ~255;
+}
+
+template <int LPR, int DT, int VIS, int SC, int NT>
 __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const SlotView& sv, uint32_t* bm,
                                           unsigned char* scratch, float* qv, int32_t* ctr,
                                           long long* ticks) {
+  constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
+  constexpr bool LDSBM = VIS == VIS_LDS_BITMAP;
+  constexpr int SLOTS = HASH ? vis_slots(VIS) : 16384;
   const int tid = local_tid();
   const int k5 = a.t[5];
-  // L2: candidate scores are mirrored in LDS for the selection; the MLP uses that space
-  // for its weight slices (and its selection time is negligible next to the MFMAs)
-  float* lds_scores = (SC == NANN_SCORER_L2 && !NANN_COMPACT) ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
+  // bitmap kernels, L2: candidate scores are mirrored in LDS for the selection; the MLP uses that
+  // space for its weight slices (and its selection time is negligible next to the MFMAs)
+  float* lds_scores = (SC == NANN_SCORER_L2 && !HASH) ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
   PhaseTimer timer;
   timer.start(ticks, a.phase_ticks != nullptr);
   const SubTimer pt{ticks, a.phase_ticks != nullptr};
@@ -133,12 +154,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
   // 2..4 = the three level-0 rounds (:129-141), 5 = final top-k (:143-149).
-#if NANN_COMPACT
-  int vis_count = 0;  // ids in the visited hash set (uniform)
-#define NANN_VIS_ARG , (ss == 0 ? 0 : vis_count)
-#else
-#define NANN_VIS_ARG
-#endif
+  int vis_count = 0;  // hash set: ids in it (uniform)
   const int E = a.n_enter;
   int nP = 0;                         // pool size so far
   const int32_t* frontier = nullptr;  // beam walked by the next stage
@@ -147,16 +163,13 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     const int32_t* sc_ids = nullptr;  // what this stage scores
     float* sc_out = nullptr;
     int sc_n = 0, base_off = 0;
-    int sc_done = 0;   // leading candidates already scored underneath the expand
-    int streamed = 0;
     if (r == 0) {
       sc_ids = a.enter; sc_out = sv.cand_scores; sc_n = E;
       if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
     } else if (r < NANN_NUM_ROUNDS) {
       const int level = (r == 1) ? 1 : 0;
       int nC = 0, G = 0;
-      sc_done = 0;
-      // sub-step 0 ("mark", only when a level starts): fresh bitmap, then the current
+      // sub-step 0 ("mark", only when a level starts): fresh visited set, then the current
       // result set goes through BitmapRefDifference (:115-120, :131-133).
       // sub-step 1: neighbours of the frontier, filtered (:116,121-122 / :136-137).
       for (int ss = (r <= 2) ? 0 : 1; ss < 2; ++ss) {
@@ -166,7 +179,8 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         int32_t* dst;
         if (ss == 0) {
           mark(PH_OTHER);
-          wg_zero_words(bm, a.bm_words);
+          if constexpr (HASH) { wg_vis_clear<SLOTS>(bm); vis_count = 0; }
+          else wg_zero_words(bm, a.bm_words);
           __syncthreads();
           mark(PH_ZERO);
           src = (r == 1) ? sv.beam_ids : sv.pool_ids;
@@ -177,61 +191,46 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           src = a.nbv[level]; rs = a.nbrs[level]; n_in = nB; dst = sv.cand_ids + base_off;
         }
         int gathered = 0;
-        int kept = -2;
-        streamed = 0;
-        if (ss == 0) {
-          // The list to mark is a TopKV2 output over distinct nodes, hence duplicate-free, and
-          // the bitmap is empty: BitmapRefDifference returns the list unchanged and the order
-          // in which bits are set does not matter -> every thread ORs its bit.  The returned
-          // words prove the premise; if it ever failed, redo the step with the ordered filter.
-          int* flags = reinterpret_cast<int*>(scratch);  // [0] duplicate seen, [1] id out of range
-          if (tid < 2) flags[tid] = 0;
-          __syncthreads();
-          for (int i = tid; i < n_in; i += NT) {
-            const int32_t id = src[i];
-            if ((uint32_t)id < a.n_items) {
-#if NANN_COMPACT
-              if (!vis_insert(bm, id)) flags[0] = 1;
-#else
-              const uint32_t bit = 1u << (id & 31);
-              if (atomicOr(&bm[(uint32_t)id >> 5], bit) & bit) flags[0] = 1;
-#endif
-              dst[i] = id;
+        int kept = -3;  // not done yet
+        if constexpr (!HASH) {
+          if (ss == 0) {
+            // The list to mark is a TopKV2 output over distinct nodes, hence duplicate-free, and
+            // the bitmap is empty: BitmapRefDifference returns the list unchanged and the order
+            // in which bits are set does not matter -> every thread ORs its bit.  The returned
+            // words prove the premise; if it ever failed, redo the step with the ordered filter.
+            int* flags = reinterpret_cast<int*>(scratch);  // [0] duplicate seen, [1] id out of range
+            if (tid < 2) flags[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_in; i += NT) {
+              const int32_t id = src[i];
+              if ((uint32_t)id < a.n_items) {
+                const uint32_t bit = 1u << (id & 31);
+                if (atomicOr(&bm[(uint32_t)id >> 5], bit) & bit) flags[0] = 1;
+                dst[i] = id;
+              } else {
+                flags[1] = 1;
+              }
+            }
+            __syncthreads();
+            const int dup = flags[0], oob = flags[1];
+            __syncthreads();
+            if (oob) return NANN_ERR_INDEX_OUT_OF_RANGE;
+            if (!dup) {
+              kept = n_in;
             } else {
-              flags[1] = 1;
+              wg_zero_words(bm, a.bm_words);
+              __syncthreads();
             }
           }
-          __syncthreads();
-          const int dup = flags[0], oob = flags[1];
-          __syncthreads();
-          if (oob) return NANN_ERR_INDEX_OUT_OF_RANGE;
-          if (!dup) {
-            kept = n_in;
-          } else {
-            wg_zero_words(bm, a.bm_words);
-            __syncthreads();
-          }
-        }
-        if (kept == -2) {
-          if constexpr (SC == NANN_SCORER_L2 && NANN_STREAM_U > 0) {
-            // GatherV2 + scorer of forward() (:91-107 / :124,138) ride along: the rows of the ids
-            // one piece releases are fetched while the next piece is filtered
-            L2Stream<LPR, DT, NT> stream;
-            stream.table = a.emb; stream.d = a.d; stream.ids = dst; stream.qv = qv;
-            stream.scores = sv.cand_scores + base_off;
-            kept = wg_expand_walk<LDSBM, NT, L2Stream<LPR, DT, NT>>(
-                ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst, scratch, &gathered,
-                ss == 0 ? no_timer() : pt, stream, ss != 0, &streamed NANN_VIS_ARG);
-          } else {
+          if (kept == -3)
             kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
-                                             scratch, &gathered, ss == 0 ? no_timer() : pt NANN_VIS_ARG);
-          }
+                                             scratch, &gathered, ss == 0 ? no_timer() : pt);
+        } else {
+          kept = wg_expand_hash<NT, SLOTS>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, a.pos_bits,
+                                    vis_count, dst, scratch, &gathered, ss == 0 ? no_timer() : pt);
         }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
-#if NANN_COMPACT
-        if (kept == -2) return NANN_ERR_CAPACITY;  // the visited set would overflow: rerun on the bitmap kernel
-        if (kept >= 0) vis_count = (ss == 0 ? 0 : vis_count) + kept;
-#endif
+        if (kept == -2) return NANN_ERR_CAPACITY;  // the hash set could overflow: the host reruns the query on a bitmap kernel
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {
           if (r == 1) {
@@ -241,7 +240,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
           nB = kept;
         } else {
-          nC = kept; G = gathered; sc_done = streamed;
+          nC = kept; G = gathered;
         }
       }
       if (r == 1) {  // sR in front of sC (:125-126); after the walk, whose staging shares this LDS
@@ -258,10 +257,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
       mark(PH_OTHER);
       if constexpr (SC == NANN_SCORER_L2) {
-        wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, sc_done, sc_n, qv, sc_out, tid >> 6);
-        __syncthreads();
-        for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
-          lds_scores[base_off + i] = sc_out[i];
+        wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, 0, sc_n, qv, sc_out, tid >> 6);
+        if (lds_scores != nullptr) {
+          __syncthreads();
+          for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
+            lds_scores[base_off + i] = sc_out[i];
+        }
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         wg_mlp_query_setup<NT>(a.mlp, qv, M);  // the phase scratch was reused since the last stage
@@ -304,21 +305,32 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   }
   mark(PH_OTHER);
   return NANN_OK;
-#undef NANN_VIS_ARG
 }
 
-template <int LPR, int DT, bool LDSBM, int SC, int NT>
+// header of the workspace (256 bytes, zeroed by the host before the first launch of a call)
+struct WsHeader {
+  unsigned int queue;        // next query of the main launch
+  unsigned int pad0[15];
+  unsigned int redo_queue;   // next query of the fallback launch
+  unsigned int pad1[15];
+  unsigned int n_redo;       // queries the hash-set kernel handed back (NANN_ERR_CAPACITY)
+};
+static_assert(sizeof(WsHeader) <= 256, "workspace header");
+
+template <int LPR, int DT, int VIS, int SC, int NT>
 __global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
+  constexpr int kScratchBytes = HASH ? hash_phase_scratch<NT>() : kPhaseScratch;
   uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
-  unsigned char* scratch = smem + (LDSBM ? (size_t)a.bm_words * 4 : 0);
-  float* qv = reinterpret_cast<float*>(scratch + kPhaseScratch);
+  unsigned char* scratch = smem + (VIS == VIS_LDS_BITMAP ? (size_t)a.bm_words * 4 : (size_t)vis_slots(VIS) * 4);
+  float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);
   int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] next query
   int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
   long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
 
   unsigned long long off[8];
-  slot_layout(a.max_cand, a.max_raw, a.pool_cap, LDSBM ? 0u : a.bm_words, off);
+  slot_layout(a.max_cand, a.max_raw, a.pool_cap, VIS == VIS_HBM_BITMAP ? a.bm_words : 0u, off);
   unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
   SlotView sv;
   sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
@@ -329,21 +341,31 @@ __global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
   sv.pool_ids = reinterpret_cast<int32_t*>(slot + off[5]);
   sv.pool_scores = reinterpret_cast<float*>(slot + off[6]);
   sv.gbitmap = reinterpret_cast<uint32_t*>(slot + off[7]);
-  uint32_t* bm = LDSBM ? bm_lds : sv.gbitmap;
+  uint32_t* bm = VIS == VIS_HBM_BITMAP ? sv.gbitmap : bm_lds;
   const int k5 = a.t[5];
-  unsigned int* queue = reinterpret_cast<unsigned int*>(a.ws);  // zeroed by the host before launch
+  WsHeader* hdr = reinterpret_cast<WsHeader*>(a.ws);
+  // fallback launch (a.redo != 0): only the queries the hash-set kernel handed back
+  if (a.redo) {
+    if (__hip_atomic_load(&hdr->n_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  }
+  unsigned int* queue = a.redo ? &hdr->redo_queue : &hdr->queue;
 
   // queries are pulled from one device-wide counter: a slot that finishes early takes
   // the next request instead of idling until the slowest slot is done
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) misc[0] = (int)atomicAdd(queue, 1u);
+    if (threadIdx.x == 0) {
+      int qn = (int)atomicAdd(queue, 1u);
+      if (a.redo)  // skip the queries that are done
+        while (qn < a.n_queries && a.status[qn] != NANN_ERR_CAPACITY) qn = (int)atomicAdd(queue, 1u);
+      misc[0] = qn;
+    }
     if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
     if (threadIdx.x < NANN_NUM_PHASES) s_ticks[threadIdx.x] = 0;
     __syncthreads();
     const int qi = misc[0];
     if (qi >= a.n_queries) break;
-    const int st = search_one<LPR, DT, LDSBM, SC, NT>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
+    const int st = search_one<LPR, DT, VIS, SC, NT>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
     __syncthreads();
     if (st) {  // a request the reference would fail: zeroed outputs + its code
       for (int i = threadIdx.x; i < k5; i += NT) {
@@ -352,7 +374,10 @@ __global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
         if (a.out_index) a.out_index[(size_t)qi * k5 + i] = 0;
       }
     }
-    if (threadIdx.x == 0) a.status[qi] = st;
+    if (threadIdx.x == 0) {
+      a.status[qi] = st;
+      if (HASH && st == NANN_ERR_CAPACITY) atomicAdd(&hdr->n_redo, 1u);
+    }
     if (a.counters && threadIdx.x < 3 * NANN_NUM_ROUNDS)
       a.counters[(size_t)qi * 3 * NANN_NUM_ROUNDS + threadIdx.x] = s_ctr[threadIdx.x];
     if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES)
@@ -362,57 +387,45 @@ __global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
 
 struct SearchPlan {
   int max_cand, max_raw, pool_cap;
-  bool lds_bitmap;
+  int vis;             // VIS_*
+  int pos_bits;        // VIS_LDS_HASH: position bits of a set entry
   size_t lds_bytes;
   unsigned long long slot_bytes;
   int slots;
-  int nt;  // threads per workgroup of the L2 traversal: kNT, or 512 for the global-bitmap variant
+  int nt;              // threads per workgroup
+  // VIS_LDS_HASH: the bitmap plan that reruns queries whose set would overflow
+  int fb_vis;
+  size_t fb_lds_bytes;
+  int fb_slots;
 };
 
-template <int LPR, int DT, int SC, int NT>
-inline int launch_search(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
-  if (p.lds_bitmap) {
-    auto kern = k_search<LPR, DT, true, SC, NT>;
+template <int LPR, int DT, int VIS, int SC, int NT>
+inline int launch_search_as(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  auto kern = k_search<LPR, DT, VIS, SC, NT>;
+  if (lds_bytes > 48 * 1024)
     NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
-  } else {
-    auto kern = k_search<LPR, DT, false, SC, NT>;
-    hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
-  }
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(slots), dim3(NT), lds_bytes, st, a);
   NANN_HIP_TRY(hipGetLastError());
   return NANN_OK;
 }
 
-
-// visited structure in LDS only
+// bitmap kernels (either residence) at NT threads
 template <int LPR, int DT, int SC, int NT>
-inline int launch_search_lds(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
-  auto kern = k_search<LPR, DT, true, SC, NT>;
-  NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
-  NANN_HIP_TRY(hipGetLastError());
-  return NANN_OK;
+inline int launch_search_bitmap(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  if (vis == VIS_LDS_BITMAP) return launch_search_as<LPR, DT, VIS_LDS_BITMAP, SC, NT>(slots, lds_bytes, a, st);
+  return launch_search_as<LPR, DT, VIS_HBM_BITMAP, SC, NT>(slots, lds_bytes, a, st);
 }
 
-// bitmap in HBM/L2 only (several workgroups per CU)
-template <int LPR, int DT, int SC, int NT>
-inline int launch_search_global(const SearchPlan& p, const SearchArgs& a, hipStream_t st) {
-  auto kern = k_search<LPR, DT, false, SC, NT>;
-  hipLaunchKernelGGL(kern, dim3(p.slots), dim3(NT), p.lds_bytes, st, a);
-  NANN_HIP_TRY(hipGetLastError());
-  return NANN_OK;
-}
-
-// L2 instantiations live in nann_l2_inst.hip (one object per row dtype)
-int launch_search_l2_f16(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
-int launch_search_l2_bf16(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
-int launch_search_l2_f32(int lpr, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
-// MLP instantiations live in nann_mlp_inst.hip (one object per embedding dim)
-int launch_search_mlp_d64(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
-int launch_search_mlp_d128(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
-int launch_search_mlp_d256(int dt, const SearchPlan& p, const SearchArgs& a, hipStream_t st);
+// L2 instantiations live in nann_l2_inst.hip (one object per row dtype): (vis, nt) in
+// {(VIS_LDS_BITMAP, 1024), (VIS_HBM_BITMAP, 1024), (VIS_LDS_HASH, 512), (VIS_LDS_HASH32, 1024)}
+int launch_search_l2_f16(int lpr, int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_l2_bf16(int lpr, int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_l2_f32(int lpr, int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+// MLP instantiations live in nann_mlp_inst.hip (one object per embedding dim): bitmap kernels, 512 threads
+int launch_search_mlp_d64(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_d128(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_d256(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_score_mlp_d64(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
                          float* out, OpResult* res);

@@ -307,6 +307,59 @@ class AttnScorer:
         return out[:n]
 
 
+def save_scorer_dir(path, kind, weights=None):
+    """Write a scoring model as the weights directory BlazeXlaOp's `graph_def` attr names on this
+    build (include/nann_hip.h, nann_model_load): scorer.txt + one .npy per weight tensor.
+    kind: "l2" | "mlp" (dict as synth.make_mlp_weights) | "attention" (dict as synth.make_attn_weights)."""
+    import os
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "scorer.txt"), "w") as f:
+        f.write(kind + "\n")
+    if kind == "mlp":
+        for name in ("w1", "b1", "alpha1", "w2", "b2", "alpha2", "w3"):
+            np.save(os.path.join(path, name + ".npy"), np.asarray(weights[name], np.float32))
+    elif kind == "attention":
+        for name in ("wq1", "bq1", "aq", "wq2", "bq2", "wk1", "bk1", "ak", "wk2", "bk2"):
+            np.save(os.path.join(path, name + ".npy"), np.asarray(weights[name], np.float32))
+        for i in range(4):
+            np.save(os.path.join(path, f"w{i}.npy"), np.asarray(weights["w"][i], np.float32))
+        for i in range(3):
+            for key, stem in (("b", "b"), ("bn_scale", "bn_scale"), ("bn_shift", "bn_shift"), ("alpha", "alpha")):
+                np.save(os.path.join(path, f"{stem}{i}.npy"), np.asarray(weights[key][i], np.float32))
+
+
+class Model:
+    """The scoring model a BlazeXlaOp node names, loaded from a weights directory
+    (nann_model_load; the reference loads a frozen GraphDef, blaze_xla_kernel.cc:156-180)."""
+
+    def __init__(self, path, d, seq_len=50, emb_dtype=torch.float16):
+        self.d, self.seq_len = d, seq_len
+        self.handle = C.c_void_p(0)
+        _check(lib().nann_model_load(path.encode(), C.c_int32(d), C.c_int32(_DT[emb_dtype]), C.c_int32(seq_len),
+                                     C.byref(self.handle)), "BlazeXlaOp model")
+        self.kind = ("l2", "mlp", "attention")[lib().nann_model_kind(self.handle)]
+        nb = C.c_int64(0)
+        _check(lib().nann_model_workspace_bytes(self.handle, C.byref(nb)))
+        self._ws_bytes = nb.value
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            lib().nann_model_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+    def forward(self, user_seq_emb, item_emb):
+        """forward() of build_opt_graph.py:91-107: user_seq_emb f16 [1, L, E], item_emb [n, d] -> logits f32 [n, 1]
+        (model.py:226-227)."""
+        u = _dev(user_seq_emb, torch.float16)
+        rows = item_emb.contiguous()
+        n = rows.shape[0]
+        out = torch.empty(max(n, 1), dtype=torch.float32, device=u.device)
+        ws = torch.empty(self._ws_bytes, dtype=torch.uint8, device=u.device)
+        _check(lib().nann_model_forward(self.handle, _ptr(u), _ptr(rows), C.c_int64(n), _ptr(out), _ptr(ws),
+                                        _stream()), "BlazeXlaOp")
+        return out[:n].reshape(-1, 1)
+
+
 def user_seq_mean(comm_seq):
     """comm_seq f16[B, L, d] (the `comm_seq` feed reshaped, build_opt_graph.py:76-79)
     -> q f32[B, d]: mean of the non-pad history rows."""

@@ -107,6 +107,16 @@ class Index:
         return torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
 
 
+TRAVERSAL_MODES = {"auto": 0, "lds_bitmap": 1, "hbm_bitmap": 2, "lds_hash": 3, "lds_hash32": 4}
+
+
+def set_traversal_mode(mode="auto"):
+    """Where nann_search keeps a query's visited set (include/nann_hip.h, nann_traversal_mode):
+    "auto" | "lds_bitmap" | "hbm_bitmap" | "lds_hash" | "lds_hash32".  Results are identical in every mode; the
+    knob exists for the parity tests and for tuning.  Process-wide."""
+    _check(lib().nann_set_traversal_mode(C.c_int32(TRAVERSAL_MODES[mode])), "traversal mode")
+
+
 class SearchResult:
     __slots__ = ("item_ids", "scores", "index", "status", "counters", "phase_ticks")
 

@@ -7,9 +7,12 @@ query.  The only exchange step is one all-gather of the per-shard top-k lists
 with TopKV2's order over the shard-major concatenation: score descending, ties -> lower
 shard, then lower local rank.
 
-torch.distributed is the transport (backend "nccl" is RCCL over xGMI on the MI355X box,
-"gloo" in the CPU tests); the merge is nann_merge_topk (device) or
-nann_merge_topk_host (the host-side merge north_star names).
+Two transports:
+  * "rccl"  -- the product path: the C ABI's own communicator (nann_comm_*, ncclAllGather of
+               ONE packed record per rank straight from the library, merge on the device);
+               torch.distributed only carries the 128-byte communicator id to the ranks once.
+  * "torch" -- torch.distributed collectives ("gloo" in the CPU tests of this logic, where no
+               GPU exists) + nann_merge_topk / nann_merge_topk_host.
 """
 import ctypes as C
 
@@ -56,20 +59,64 @@ def all_gather_topk(scores, ids, world, group=None):
             gi.view(world, nq, k).permute(1, 0, 2).contiguous())
 
 
+class Comm:
+    """nann_comm: the library's own RCCL communicator.  Collective: every rank constructs it.
+    The 128-byte id travels from rank 0 through the existing torch.distributed group (any
+    backend) -- a C++ host would hand it over by its own means."""
+
+    def __init__(self, world, rank, group=None):
+        self.world, self.rank = world, rank
+        idb = np.zeros(128, np.uint8)
+        if world > 1:
+            if rank == 0:
+                _check(lib().nann_comm_get_unique_id(idb.ctypes.data_as(C.c_void_p)), "comm id")
+            box = [idb.tobytes()]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idb = np.frombuffer(box[0], np.uint8).copy()
+        self.handle = C.c_void_p(0)
+        _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(rank), idb.ctypes.data_as(C.c_void_p),
+                                      C.byref(self.handle)), "comm create")
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            lib().nann_comm_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+
 class ShardedSearch:
     """Exchange + merge for one rank of a sharded search."""
 
-    def __init__(self, index, scorer, level_topn, world, merge="device", group=None):
+    def __init__(self, level_topn, world, rank=0, merge="device", group=None, transport="torch"):
         self.world, self.k, self.merge_kind, self.group = world, int(level_topn[5]), merge, group
+        self.transport = transport
+        self.comm = Comm(world, rank, group) if transport == "rccl" else None
+        self._ws = None
 
     def merge(self, result):
-        """result: this rank's retrieval.SearchResult.  A query that failed on a shard
-        contributes -inf scores (its slots are never selected while another shard has
-        real candidates)."""
+        """result: this rank's retrieval.SearchResult -> (item_ids i64[nq,k], scores f32[nq,k]) of
+        the whole corpus, identical on every rank.  A query that failed on a shard (status != 0)
+        contributes -inf scores / id 0 from that shard: never selected while another shard holds
+        real candidates."""
+        if self.transport == "rccl":
+            nq, k = result.scores.shape
+            dev = result.scores.device
+            nbytes = C.c_int64(0)
+            _check(lib().nann_sharded_topk_workspace_bytes(C.c_int32(self.world), C.c_int64(nq), C.c_int32(k),
+                                                          C.byref(nbytes)))
+            if self._ws is None or self._ws.numel() < nbytes.value:
+                self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+            out_s = torch.empty((nq, self.k), dtype=torch.float32, device=dev)
+            out_i = torch.empty((nq, self.k), dtype=torch.int64, device=dev)
+            _check(lib().nann_sharded_topk(self.comm.handle, _ptr(result.scores), _ptr(result.item_ids),
+                                           _ptr(result.status), C.c_int64(nq), C.c_int32(k), C.c_int32(self.k),
+                                           _ptr(self._ws), C.c_int64(self._ws.numel()), _ptr(out_s), _ptr(out_i),
+                                           _stream()), "sharded top-k")
+            return out_i, out_s
         scores = result.scores
         bad = (result.status != 0)[:, None]
         scores = torch.where(bad, torch.full_like(scores, float("-inf")), scores)
-        gs, gi = all_gather_topk(scores, result.item_ids, self.world, self.group)
+        ids = torch.where(bad, torch.zeros_like(result.item_ids), result.item_ids)
+        gs, gi = all_gather_topk(scores, ids, self.world, self.group)
         if self.merge_kind == "host":
             s, i = merge_host(gs.cpu().numpy(), gi.cpu().numpy(), self.k)
             return torch.as_tensor(i), torch.as_tensor(s)

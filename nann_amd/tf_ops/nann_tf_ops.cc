@@ -4,8 +4,10 @@
 //
 // Drop-in story: build this file against the NANN TensorFlow fork's
 // headers in place of
-//   tensorflow/core/user_ops/beam_search_op/GroupGather_kernel.cc   (GroupGather)
-//   tensorflow/core/user_ops/bitmap_op/bitmap_ops.cc                (BitmapRefDifference)
+//   tensorflow/core/user_ops/beam_search_op/GroupGather_kernel.cc   (GroupGather, T = int32 | int64)
+//   tensorflow/core/user_ops/bitmap_op/bitmap_ops.cc                (BitmapRefDifference, T = int32 | int64)
+//   tensorflow/core/user_ops/huge_const_op/huge_const_op.cc         (HugeConst)
+//   tensorflow/core/user_ops/blaze_op/blaze_xla_kernel.cc           (BlazeXlaOp)
 // or load it with tf.load_op_library (the way bitmap_test.py:11 loads ./bitmap_op.so).
 // Graphs produced by NANN_impls/nann/delivery/build_opt_graph.py pin these nodes to
 // /CPU:0 (:82,110), so the kernels are registered for DEVICE_CPU with host-memory I/O
@@ -15,7 +17,11 @@
 // Only TensorFlow's public op-kernel API is used; everything device-side happens
 // behind the C ABI.  Host code stays C++ inside the op kernel, as in the reference.
 #include <cstdint>
+#include <cstring>
+#include <limits>
 #include <mutex>
+#include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -74,31 +80,64 @@ class DeviceBuffer {
   void* ptr_ = nullptr;
 };
 
-// Constants the graph feeds from HugeConst nodes (CSR values / row_splits, hundreds of
-// MB) must not cross PCIe per call: the first time a host buffer is seen it is copied
-// to HBM and kept, keyed by (pointer, size) -- HugeConst's GPU kernel does the same
-// one-time copy (huge_const_op.cc:187-218).  HugeConst tensors live as long as their
-// kernel, i.e. as long as the session, so the key is stable.
-class ResidentCache {
+// Constants the graph feeds from HugeConst nodes (CSR values / row_splits, embeddings: hundreds
+// of MB) must not cross PCIe per call.  The HugeConst kernel below loads its file into the host
+// tensor it outputs (as the reference does, huge_const_op.cc:85-182) AND once into HBM, and
+// registers the pair here for its own lifetime; an op that receives a tensor whose buffer is a
+// registered HugeConst output uses the resident copy.  Anything else -- placeholders, Consts,
+// a re-used allocator address -- is not in the registry and is uploaded per call, so a stale
+// device copy cannot be served (the registry is exact, not a (pointer, size) guess).
+class HugeConstRegistry {
  public:
-  static ResidentCache& Get() { static ResidentCache c; return c; }
-  Status Lookup(const void* host, int64_t bytes, void** dev) {
+  static HugeConstRegistry& Get() { static HugeConstRegistry r; return r; }
+  void Add(const void* host, int64_t bytes, void* dev) {
+    std::lock_guard<std::mutex> lk(mu_);
+    map_[host] = {dev, bytes};
+  }
+  void Remove(const void* host) {
+    std::lock_guard<std::mutex> lk(mu_);
+    map_.erase(host);
+  }
+  // device copy of [host, host + bytes) if it is (a prefix-aligned whole of) a registered buffer
+  void* Find(const void* host, int64_t bytes) {
     std::lock_guard<std::mutex> lk(mu_);
     auto it = map_.find(host);
-    if (it != map_.end() && it->second.second == bytes) { *dev = it->second.first; return Status::OK(); }
-    void* d = nullptr;
-    TF_RETURN_IF_ERROR(ToStatus(nann_malloc(&d, bytes > 0 ? bytes : 1), "nann_malloc"));
-    TF_RETURN_IF_ERROR(ToStatus(nann_memcpy(d, host, bytes, 0, nullptr), "nann_memcpy"));
-    TF_RETURN_IF_ERROR(ToStatus(nann_stream_synchronize(nullptr), "sync"));
-    map_[host] = {d, bytes};
-    *dev = d;
-    return Status::OK();
+    return (it != map_.end() && it->second.second == bytes) ? it->second.first : nullptr;
   }
 
  private:
   std::mutex mu_;
   std::unordered_map<const void*, std::pair<void*, int64_t>> map_;
 };
+
+// a graph input on the device: the resident copy of a HugeConst output, or a per-call upload
+class DeviceInput {
+ public:
+  Status Bind(const void* host, int64_t bytes) {
+    ptr_ = HugeConstRegistry::Get().Find(host, bytes);
+    if (ptr_) return Status::OK();
+    TF_RETURN_IF_ERROR(staged_.Upload(host, bytes));
+    ptr_ = staged_.as<void>();
+    return Status::OK();
+  }
+  template <typename T> const T* as() const { return static_cast<const T*>(ptr_); }
+
+ private:
+  void* ptr_ = nullptr;
+  DeviceBuffer staged_;
+};
+
+// T = int64 ids (GroupGather_kernel.cc:177-182, bitmap_ops.cc:428-435): the device kernels work on
+// int32 ids, so int64 tensors are narrowed on the host (ids beyond int32 cannot index a shard)
+static Status NarrowToInt32(const int64* src, int64_t n, std::vector<int32_t>* out, const char* what) {
+  out->resize((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (src[i] < std::numeric_limits<int32_t>::min() || src[i] > std::numeric_limits<int32_t>::max())
+      return errors::InvalidArgument(what, "[", i, "] = ", src[i], " does not fit the int32 ids of the device kernels");
+    (*out)[(size_t)i] = (int32_t)src[i];
+  }
+  return Status::OK();
+}
 
 // ---------------------------------------------------------------------------------
 // GroupGather: same interface as GroupGather_kernel.cc:18-42
@@ -119,6 +158,7 @@ REGISTER_OP("GroupGather")
       return Status::OK();
     });
 
+template <typename T>
 class GroupGatherHip : public OpKernel {
  public:
   explicit GroupGatherHip(OpKernelConstruction* ctx) : OpKernel(ctx) {
@@ -135,10 +175,17 @@ class GroupGatherHip : public OpKernel {
     const Tensor& irs = ctx->input(3);
     const int64_t n_pv = pv.NumElements(), n_prs = prs.NumElements();
     const int64_t n_iv = iv.NumElements(), n_irs = irs.NumElements();
-    // graph constants stay resident; the per-request frontier is staged
-    void *d_pv = nullptr, *d_prs = nullptr;
-    OP_REQUIRES_OK(ctx, ResidentCache::Get().Lookup(pv.flat<int32>().data(), n_pv * 4, &d_pv));
-    OP_REQUIRES_OK(ctx, ResidentCache::Get().Lookup(prs.flat<int64>().data(), n_prs * 8, &d_prs));
+    // HugeConst outputs stay resident; everything else (the per-request frontier) is staged
+    DeviceInput d_pv, d_prs;
+    std::vector<int32_t> narrowed;
+    if (std::is_same<T, int32>::value) {
+      OP_REQUIRES_OK(ctx, d_pv.Bind(pv.flat<T>().data(), n_pv * 4));
+    } else {
+      OP_REQUIRES_OK(ctx, NarrowToInt32(reinterpret_cast<const int64*>(pv.flat<T>().data()), n_pv, &narrowed,
+                                        "params_values"));
+      OP_REQUIRES_OK(ctx, d_pv.Bind(narrowed.data(), n_pv * 4));
+    }
+    OP_REQUIRES_OK(ctx, d_prs.Bind(prs.flat<int64>().data(), n_prs * 8));
     DeviceBuffer d_iv, d_irs, d_rs, d_off, d_out;
     OP_REQUIRES_OK(ctx, d_iv.Upload(iv.flat<int64>().data(), n_iv * 8));
     OP_REQUIRES_OK(ctx, d_irs.Upload(irs.flat<int64>().data(), n_irs * 8));
@@ -147,7 +194,7 @@ class GroupGatherHip : public OpKernel {
     int64_t n_ret = 0, n_ret_splits = 0;
     int32_t code = 0;
     const int st = nann_group_gather_count(
-        static_cast<const int64_t*>(d_prs), n_prs, n_pv, d_iv.as<int64_t>(), n_iv, d_irs.as<int64_t>(),
+        d_prs.as<int64_t>(), n_prs, n_pv, d_iv.as<int64_t>(), n_iv, d_irs.as<int64_t>(),
         n_irs, d_rs.as<int64_t>(), d_off.as<int64_t>(), &n_ret, &n_ret_splits, &code, nullptr);
     if (st == NANN_ERR_INVALID_RAGGED_PARAMS) {  // GroupGather_kernel.cc:62-64
       OP_REQUIRES(ctx, false, errors::InvalidArgument("Invalid RaggedTensor input0 params, code: ", code));
@@ -162,12 +209,18 @@ class GroupGatherHip : public OpKernel {
     OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({n_ret_splits}), &out_rs));
     if (n_ret > 0) {
       OP_REQUIRES_OK(ctx, d_out.Alloc(n_ret * 4));
-      OP_REQUIRES_OK(ctx, ToStatus(nann_group_gather_fill(static_cast<const int32_t*>(d_pv),
-                                                          static_cast<const int64_t*>(d_prs),
+      OP_REQUIRES_OK(ctx, ToStatus(nann_group_gather_fill(d_pv.as<int32_t>(), d_prs.as<int64_t>(),
                                                           d_iv.as<int64_t>(), n_iv, d_off.as<int64_t>(),
                                                           d_out.as<int32_t>(), nullptr),
                                    "GroupGather"));
-      OP_REQUIRES_OK(ctx, d_out.Download(out_values->flat<int32>().data(), n_ret * 4));
+      if (std::is_same<T, int32>::value) {
+        OP_REQUIRES_OK(ctx, d_out.Download(out_values->flat<T>().data(), n_ret * 4));
+      } else {
+        std::vector<int32_t> host((size_t)n_ret);
+        OP_REQUIRES_OK(ctx, d_out.Download(host.data(), n_ret * 4));
+        T* o = out_values->flat<T>().data();
+        for (int64_t i = 0; i < n_ret; ++i) o[i] = (T)host[(size_t)i];
+      }
     }
     OP_REQUIRES_OK(ctx, d_rs.Download(out_rs->flat<int64>().data(), n_ret_splits * 8));
   }
@@ -176,7 +229,8 @@ class GroupGatherHip : public OpKernel {
   bool unique_ = false;
 };
 
-REGISTER_KERNEL_BUILDER(Name("GroupGather").Device(DEVICE_CPU).TypeConstraint<int32>("T"), GroupGatherHip);
+REGISTER_KERNEL_BUILDER(Name("GroupGather").Device(DEVICE_CPU).TypeConstraint<int32>("T"), GroupGatherHip<int32>);
+REGISTER_KERNEL_BUILDER(Name("GroupGather").Device(DEVICE_CPU).TypeConstraint<int64>("T"), GroupGatherHip<int64>);
 
 // ---------------------------------------------------------------------------------
 // BitmapRefDifference: same interface as bitmap_ops.cc:150-167
@@ -197,6 +251,7 @@ REGISTER_OP("BitmapRefDifference")
       return Status::OK();
     });
 
+template <typename T>
 class BitmapRefDifferenceHip : public OpKernel {
  public:
   explicit BitmapRefDifferenceHip(OpKernelConstruction* ctx) : OpKernel(ctx) {}
@@ -208,7 +263,14 @@ class BitmapRefDifferenceHip : public OpKernel {
     const int64_t n = values.NumElements(), n_rs = row_splits.NumElements();
     const int64_t n_words = flags.NumElements();
     DeviceBuffer d_v, d_rs, d_flags, d_out, d_out_rs;
-    OP_REQUIRES_OK(ctx, d_v.Upload(values.flat<int32>().data(), n * 4));
+    if (std::is_same<T, int32>::value) {
+      OP_REQUIRES_OK(ctx, d_v.Upload(values.flat<T>().data(), n * 4));
+    } else {
+      std::vector<int32_t> narrowed;
+      OP_REQUIRES_OK(ctx, NarrowToInt32(reinterpret_cast<const int64*>(values.flat<T>().data()), n, &narrowed,
+                                        "idx_next_values"));
+      OP_REQUIRES_OK(ctx, d_v.Upload(narrowed.data(), n * 4));
+    }
     OP_REQUIRES_OK(ctx, d_rs.Upload(row_splits.flat<int64>().data(), n_rs * 8));
     OP_REQUIRES_OK(ctx, d_flags.Upload(flags.flat<int32>().data(), n_words * 4));
     OP_REQUIRES_OK(ctx, d_out.Alloc((n > 0 ? n : 1) * 4));
@@ -226,7 +288,16 @@ class BitmapRefDifferenceHip : public OpKernel {
     Tensor* c_rs = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({n_out}), &c_values));
     OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({n_out_splits}), &c_rs));
-    if (n_out > 0) OP_REQUIRES_OK(ctx, d_out.Download(c_values->flat<int32>().data(), n_out * 4));
+    if (n_out > 0) {
+      if (std::is_same<T, int32>::value) {
+        OP_REQUIRES_OK(ctx, d_out.Download(c_values->flat<T>().data(), n_out * 4));
+      } else {
+        std::vector<int32_t> host((size_t)n_out);
+        OP_REQUIRES_OK(ctx, d_out.Download(host.data(), n_out * 4));
+        T* o = c_values->flat<T>().data();
+        for (int64_t i = 0; i < n_out; ++i) o[i] = (T)host[(size_t)i];
+      }
+    }
     OP_REQUIRES_OK(ctx, d_out_rs.Download(c_rs->flat<int64>().data(), n_out_splits * 8));
     OP_REQUIRES_OK(ctx, d_flags.Download(flags.flat<int32>().data(), n_words * 4));  // in place
     ctx->forward_ref_input_to_ref_output(2, 2);  // bitmap_ops.cc:238
@@ -234,7 +305,165 @@ class BitmapRefDifferenceHip : public OpKernel {
 };
 
 REGISTER_KERNEL_BUILDER(Name("BitmapRefDifference").Device(DEVICE_CPU).TypeConstraint<int32>("T"),
-                        BitmapRefDifferenceHip);
+                        BitmapRefDifferenceHip<int32>);
+REGISTER_KERNEL_BUILDER(Name("BitmapRefDifference").Device(DEVICE_CPU).TypeConstraint<int64>("T"),
+                        BitmapRefDifferenceHip<int64>);
+
+// ---------------------------------------------------------------------------------
+// HugeConst: same interface as huge_const_op.cc:58-70.  The file is read once at kernel
+// construction into the host tensor every Compute returns (zero-copy set_output, :184-226) and,
+// in the same breath, into HBM; the pair is registered so that the ops above find the resident
+// copy.  Validation of dtype / shape against the attrs follows :108-147.
+REGISTER_OP("HugeConst")
+    .Output("output: dtype")
+    .Attr("dtype: type")
+    .Attr("shape: shape")
+    .Attr("path: string")
+    .SetShapeFn([](shape_inference::InferenceContext* c) {
+      TensorShape shape_attr;
+      TF_RETURN_IF_ERROR(c->GetAttr("shape", &shape_attr));
+      shape_inference::ShapeHandle s;
+      TF_RETURN_IF_ERROR(c->MakeShapeFromTensorShape(shape_attr, &s));
+      c->set_output(0, s);
+      return Status::OK();
+    });
+
+static int NannDtype(DataType dt) {
+  switch (dt) {
+    case DT_HALF: return NANN_F16;
+    case DT_FLOAT: return NANN_F32;
+    case DT_DOUBLE: return NANN_F64;
+    case DT_INT32: return NANN_I32;
+    case DT_INT64: return NANN_I64;
+    default: return -1;
+  }
+}
+
+class HugeConstHip : public OpKernel {
+ public:
+  explicit HugeConstHip(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    DataType dtype;
+    TensorShape shape;
+    std::string path;
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("dtype", &dtype));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("shape", &shape));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("path", &path));
+    const int code = NannDtype(dtype);
+    OP_REQUIRES(ctx, code >= 0, errors::Unimplemented("Unsupported DataType."));  // huge_const_op.cc:143-146
+    std::vector<int64_t> dims;
+    for (int i = 0; i < shape.dims(); ++i) dims.push_back(shape.dim_size(i));
+    int64_t bytes = 0;
+    // no cast: the op checks the file against its attrs, the Python wrapper rewrote the file beforehand
+    OP_REQUIRES_OK(ctx, ToStatus(nann_huge_const_load(path.c_str(), code, dims.data(), (int)dims.size(),
+                                                      /*allow_cast=*/0, &dev_, &bytes), "HugeConst"));
+    tensor_ = Tensor(dtype, shape);
+    bytes_ = bytes;
+    OP_REQUIRES_OK(ctx, ToStatus(nann_memcpy(const_cast<char*>(tensor_.tensor_data().data()), dev_, bytes,
+                                             /*d2h*/ 1, nullptr), "HugeConst"));
+    OP_REQUIRES_OK(ctx, ToStatus(nann_stream_synchronize(nullptr), "HugeConst"));
+    HugeConstRegistry::Get().Add(tensor_.tensor_data().data(), bytes_, dev_);
+  }
+  ~HugeConstHip() override {
+    if (dev_) {
+      HugeConstRegistry::Get().Remove(tensor_.tensor_data().data());
+      nann_free(dev_);
+    }
+  }
+  void Compute(OpKernelContext* ctx) override { ctx->set_output(0, tensor_); }
+  bool IsExpensive() override { return false; }
+
+ private:
+  Tensor tensor_;
+  void* dev_ = nullptr;
+  int64_t bytes_ = 0;
+};
+
+REGISTER_KERNEL_BUILDER(Name("HugeConst").Device(DEVICE_CPU), HugeConstHip);
+
+// ---------------------------------------------------------------------------------
+// BlazeXlaOp: same interface as blaze_xla_kernel.cc:24-33.  The reference runs the frozen
+// scoring GraphDef named by `graph_def` in a nested session, padded to warmed-up static batch
+// sizes; here `graph_def` names the model's weights directory (include/nann_hip.h,
+// nann_model_load) and the batch is scored as it comes -- rows are independent, which is all
+// PadToStatic / SliceToDynamic rely on (blaze_xla_predictor.cc:227-315).  Inputs are matched by
+// `input_names` (constant.py:9-11): .../user_seq_emb f16 [1, L, E] and .../item_emb f16 [n, d];
+// the one output is .../logits f32 [n, 1] (model.py:226-227).  `blaze_option_path` is accepted
+// and ignored (XLA warm-up sizes, thread pool and wait_ms have no counterpart: there is no
+// compilation step and no nested session to throttle).
+REGISTER_OP("BlazeXlaOp")
+    .Attr("InT: list({int8,int64,float16,float32,int32})")
+    .Attr("OutT: list({int8,int64,float16,float32,int32})")
+    .Attr("input_names: list(string) >= 0")
+    .Attr("output_names: list(string) >= 0")
+    .Attr("graph_def: string")
+    .Attr("blaze_option_path: string")
+    .Input("in_tensor: InT")
+    .Output("out_tensor: OutT")
+    .SetShapeFn(shape_inference::UnknownShape);
+
+class BlazeXlaOpHip : public AsyncOpKernel {
+ public:
+  explicit BlazeXlaOpHip(OpKernelConstruction* ctx) : AsyncOpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("input_names", &input_names_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("output_names", &output_names_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("graph_def", &model_dir_));
+    OP_REQUIRES(ctx, output_names_.size() == 1, errors::InvalidArgument("BlazeXlaOp: one output (logits) expected"));
+    for (size_t i = 0; i < input_names_.size(); ++i) {
+      if (input_names_[i].find("user_seq_emb") != std::string::npos) user_in_ = (int)i;
+      if (input_names_[i].find("item_emb") != std::string::npos) item_in_ = (int)i;
+    }
+    OP_REQUIRES(ctx, user_in_ >= 0 && item_in_ >= 0,
+                errors::InvalidArgument("BlazeXlaOp: input_names must name user_seq_emb and item_emb"));
+  }
+  ~BlazeXlaOpHip() override { if (model_) nann_model_destroy(model_); }
+
+  void ComputeAsync(OpKernelContext* ctx, DoneCallback done) override {
+    OpInputList in;
+    OP_REQUIRES_OK_ASYNC(ctx, ctx->input_list("in_tensor", &in), done);
+    const Tensor& user = in[user_in_];
+    const Tensor& item = in[item_in_];
+    OP_REQUIRES_ASYNC(ctx, user.dtype() == DT_HALF && item.dtype() == DT_HALF,
+                      errors::InvalidArgument("BlazeXlaOp: float16 inputs expected (build_opt_graph.py:76-92)"), done);
+    OP_REQUIRES_ASYNC(ctx, user.dims() == 3 && item.dims() == 2,
+                      errors::InvalidArgument("BlazeXlaOp: user_seq_emb [1, L, E] and item_emb [n, d] expected"), done);
+    const int64_t n = item.dim_size(0), d = item.dim_size(1);
+    const int seq_len = (int)user.dim_size(1);
+    {  // the model is loaded on first use: d and L come with the first request
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!model_)
+        OP_REQUIRES_OK_ASYNC(ctx, ToStatus(nann_model_load(model_dir_.c_str(), (int32_t)d, NANN_F16, seq_len, &model_),
+                                           "BlazeXlaOp"), done);
+    }
+    // zero candidates: the reference fails in PadToStatic (blaze_xla_predictor.cc:259-263)
+    OP_REQUIRES_ASYNC(ctx, n > 0, errors::Internal("Error when getting input address or size"), done);
+    int64_t ws_bytes = 0;
+    OP_REQUIRES_OK_ASYNC(ctx, ToStatus(nann_model_workspace_bytes(model_, &ws_bytes), "BlazeXlaOp"), done);
+    DeviceInput d_item;  // resident when the rows come straight from a HugeConst, staged otherwise
+    DeviceBuffer d_user, d_ws, d_out;
+    OP_REQUIRES_OK_ASYNC(ctx, d_user.Upload(user.tensor_data().data(), user.NumElements() * 2), done);
+    OP_REQUIRES_OK_ASYNC(ctx, d_item.Bind(item.tensor_data().data(), n * d * 2), done);
+    OP_REQUIRES_OK_ASYNC(ctx, d_ws.Alloc(ws_bytes), done);
+    OP_REQUIRES_OK_ASYNC(ctx, d_out.Alloc(n * 4), done);
+    OP_REQUIRES_OK_ASYNC(ctx, ToStatus(nann_model_forward(model_, d_user.as<void>(), d_item.as<void>(), n,
+                                                          d_out.as<float>(), d_ws.as<void>(), nullptr),
+                                       "BlazeXlaOp"), done);
+    OpOutputList out;
+    OP_REQUIRES_OK_ASYNC(ctx, ctx->output_list("out_tensor", &out), done);
+    Tensor* logits = nullptr;
+    OP_REQUIRES_OK_ASYNC(ctx, out.allocate(0, TensorShape({n, 1}), &logits), done);  // model.py:226-227
+    OP_REQUIRES_OK_ASYNC(ctx, d_out.Download(logits->flat<float>().data(), n * 4), done);
+    done();
+  }
+
+ private:
+  std::vector<std::string> input_names_, output_names_;
+  std::string model_dir_;
+  int user_in_ = -1, item_in_ = -1;
+  std::mutex mu_;
+  nann_model* model_ = nullptr;
+};
+
+REGISTER_KERNEL_BUILDER(Name("BlazeXlaOp").Device(DEVICE_CPU), BlazeXlaOpHip);
 
 // ---------------------------------------------------------------------------------
 // NannHnswSearch: the fused schedule as ONE node.  Not a reference op: it replaces the
@@ -249,6 +478,7 @@ REGISTER_OP("NannHnswSearch")
     .Attr("index_dir: string")
     .Attr("item_embs_dir: string")
     .Attr("seq_len: int = 50")
+    .Attr("scorer_dir: string = ''")  // weights directory as for BlazeXlaOp's graph_def; '' = L2
     .SetShapeFn(shape_inference::UnknownShape);
 
 class NannHnswSearchHip : public OpKernel {
@@ -258,11 +488,13 @@ class NannHnswSearchHip : public OpKernel {
     OP_REQUIRES_OK(ctx, ctx->GetAttr("index_dir", &index_dir));
     OP_REQUIRES_OK(ctx, ctx->GetAttr("item_embs_dir", &embs_dir));
     OP_REQUIRES_OK(ctx, ctx->GetAttr("seq_len", &seq_len_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("scorer_dir", &scorer_dir_));
     OP_REQUIRES_OK(ctx, Load(index_dir, embs_dir));
   }
   ~NannHnswSearchHip() override {
     if (index_) nann_index_destroy(index_);
     if (scorer_) nann_scorer_destroy(scorer_);
+    if (model_) nann_model_destroy(model_);
     for (void* p : held_) nann_free(p);
   }
 
@@ -285,7 +517,8 @@ class NannHnswSearchHip : public OpKernel {
     OP_REQUIRES_OK(ctx, d_ws.Alloc(ws_bytes));
     OP_REQUIRES_OK(ctx, d_ids.Alloc(batch * k * 8));
     OP_REQUIRES_OK(ctx, d_status.Alloc(batch * 4));
-    OP_REQUIRES_OK(ctx, ToStatus(nann_search(index_, scorer_, d_q.as<float>(), batch, t, d_ws.as<void>(), ws_bytes,
+    const nann_scorer* scorer = model_ ? nann_model_scorer(model_) : scorer_;
+    OP_REQUIRES_OK(ctx, ToStatus(nann_search(index_, scorer, d_q.as<float>(), batch, t, d_ws.as<void>(), ws_bytes,
                                              d_ids.as<int64_t>(), nullptr, nullptr, d_status.as<int32_t>(),
                                              nullptr, nullptr),
                                  "NannHnswSearch"));
@@ -335,11 +568,20 @@ class NannHnswSearchHip : public OpKernel {
     s.kind = NANN_SCORER_L2;
     s.d = d.d;
     s.emb_dtype = NANN_F16;
+    if (!scorer_dir_.empty()) {  // the MLP scorer of BASELINE configs 3-5 (the attention model scores
+      // through BlazeXlaOp / nann_model_forward; its fused traversal is not built yet)
+      TF_RETURN_IF_ERROR(ToStatus(nann_model_load(scorer_dir_.c_str(), d.d, NANN_F16, seq_len_, &model_), "scorer"));
+      if (!nann_model_scorer(model_))
+        return errors::Unimplemented("NannHnswSearch: the fused traversal scores with l2 or mlp models");
+      return Status::OK();
+    }
     return ToStatus(nann_scorer_create(&s, &scorer_), "nann_scorer_create");
   }
 
   int seq_len_ = 50;
   int d_ = 0;
+  std::string scorer_dir_;
+  nann_model* model_ = nullptr;
   nann_index* index_ = nullptr;
   nann_scorer* scorer_ = nullptr;
   std::vector<void*> held_;

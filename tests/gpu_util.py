@@ -20,6 +20,22 @@ def bits(x):
     return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def traversal_mode(mode):
+    """Run a block with the visited set forced to one residence (lds_hash / lds_bitmap / hbm_bitmap)."""
+    from nann_amd import retrieval
+    retrieval.set_traversal_mode(mode)
+    try:
+        yield
+    finally:
+        retrieval.set_traversal_mode("auto")
+
+
+MODES = ["lds_hash", "lds_hash32", "lds_bitmap", "hbm_bitmap"]
+
 _CACHE = {}
 
 

@@ -3,10 +3,12 @@ against the reference semantics they must reproduce.  They are models (numpy / p
 the atomic operations of a phase applied in random lane order), kept next to the parity tests so
 that a change to the device code's logic can be tried here first:
 
-* wg_filter_chunk / wg_filter_chunk_packed -- BitmapRefDifference's ordered first-occurrence scan
+* wg_filter_chunk -- BitmapRefDifference's ordered first-occurrence scan
   (UO/bitmap_op/bitmap_ops.cc:224-232) done 2048 ids at a time with set-bits-then-arbitrate;
-* wg_topk_impl's radix search for the k-th largest key, on raw keys (common-prefix skip) and on
-  key - min(key) (NANN_TOPK_MINSUB)."""
+* wg_expand_hash's positional hash set: the same scan with the visited set as an open-addressing
+  table of (id << PB | position) entries, CAS to claim, ds_min to keep the first occurrence;
+* wg_topk_impl's radix search for the k-th largest key on key - min(key) (the shipped form) and on
+  raw keys with the common prefix skipped (the form it replaced)."""
 import numpy as np
 import pytest
 
@@ -75,39 +77,7 @@ def filter_with_preread(xs, visited, rng, per=2, slots=2048):
     return [int(xs[p]) for p in range(n) if keep[p]]
 
 
-def filter_packed(xs, visited, rng, per=2, slots=4096):
-    """wg_filter_chunk_packed: set, winners publish id<<11|pos, barrier, losers join, barrier."""
-    n = len(xs)
-    h0 = lambda x: ((x * 2654435761) & 0xFFFFFFFF) >> 20
-    entry = [(int(x) << 11) | p for p, x in enumerate(xs)]
-    won, lost, slot = [False] * n, [False] * n, [0] * n
-    for p in _thread_interleaving(n, per, rng):
-        if int(xs[p]) in visited:
-            lost[p] = True
-        else:
-            visited.add(int(xs[p]))
-            won[p] = True
-    H = [EMPTY] * slots
-    for p in rng.permutation(n):
-        if won[p]:
-            h = h0(int(xs[p]))
-            while H[h] != EMPTY:
-                h = (h + 1) % slots
-            H[h], slot[p] = entry[p], h
-    cont = [False] * n
-    for p in rng.permutation(n):
-        if lost[p]:
-            h = h0(int(xs[p]))
-            while H[h] != EMPTY:
-                if H[h] >> 11 == int(xs[p]):
-                    H[h] = min(H[h], entry[p])
-                    slot[p], cont[p] = h, True
-                    break
-                h = (h + 1) % slots
-    return [int(xs[p]) for p in range(n) if (won[p] or cont[p]) and H[slot[p]] == entry[p]]
-
-
-@pytest.mark.parametrize("model", [filter_with_preread, filter_packed])
+@pytest.mark.parametrize("model", [filter_with_preread])
 def test_chunk_filter_equals_serial_scan(model):
     rng = np.random.default_rng(5)
     for _ in range(150):
@@ -194,60 +164,42 @@ def test_min_subtraction_spreads_the_leading_digit():
     assert big_raw[0] > 10 * big_sub[0] and passes_sub <= passes_raw
 
 
-# ---- NANN_COMPACT: the visited set as an open-addressing table (vis_contains / vis_insert) ----------
-class VisTable:
-    """Each probe step of an insert is one atomic LDS operation; inserts of different lanes are
-    interleaved at that granularity (generator per insert, scheduled in random order)."""
+# ---- wg_expand_hash: the visited set as a positional open-addressing table ---------------------
+class PosHashSet:
+    """Model of the LDS table: every LDS operation of an insert (read, CAS, min) is one atomic step;
+    the inserts of a piece are interleaved at that granularity in random order."""
 
-    def __init__(self, slots=64):
-        self.v = [0] * slots
-        self.slots = slots
+    def __init__(self, slots, pos_bits):
+        self.v = [EMPTY] * slots
+        self.slots, self.pb = slots, pos_bits
 
     def hash(self, x):
         return ((x * 2654435761) & 0xFFFFFFFF) % self.slots
 
-    def contains(self, x):
+    def insert_steps(self, x, pos, slot_out, key):
+        val = (x << self.pb) | pos
         h = self.hash(x)
         while True:
-            cur = self.v[h]
-            if cur == x + 1:
-                return True
-            if cur == 0:
-                return False
-            h = (h + 1) % self.slots
-
-    def insert_steps(self, x, result, key):
-        h = self.hash(x)
-        while True:
-            cur = self.v[h]
+            cur = self.v[h]                                   # ds_read
             yield
-            if cur == 0:
-                cur = self.v[h]          # atomicCAS(&V[h], 0, x + 1): returns the old value
-                if cur == 0:
-                    self.v[h] = x + 1
-                    result[key] = True
-                    return
+            if cur == EMPTY:
+                cur = self.v[h]                               # ds_cmpst_rtn: returns the old value
+                if cur == EMPTY:
+                    self.v[h] = val
                 yield
-            if cur == x + 1:
-                result[key] = False
+            if cur == EMPTY or (cur >> self.pb) == x:
+                if cur != EMPTY:
+                    self.v[h] = min(self.v[h], val)           # ds_min_u32
+                    yield
+                slot_out[key] = h
                 return
             h = (h + 1) % self.slots
 
-
-def test_visited_hash_set_has_one_winner_per_id():
-    rng = np.random.default_rng(11)
-    for _ in range(200):
-        t = VisTable(64)
-        before = set(int(v) for v in rng.integers(0, 40, size=int(rng.integers(0, 20))))
-        for x in before:
-            res = {}
-            for _ in t.insert_steps(x, res, 0):
-                pass
-        xs = [int(v) for v in rng.integers(0, 40, size=int(rng.integers(1, 30)))]
-        if len(before | set(xs)) > 48:
-            continue
-        res = {}
-        gens = [t.insert_steps(x, res, i) for i, x in enumerate(xs)]
+    def filter_piece(self, xs, rng):
+        """One piece (len(xs) <= 2^pb - 1): insert all, barrier, keep iff own value survived; the
+        keeper resets the position field to 0 ("visited before")."""
+        slot = {}
+        gens = [self.insert_steps(int(x), p + 1, slot, p) for p, x in enumerate(xs)]
         live = list(range(len(gens)))
         while live:
             i = live[rng.integers(len(live))]
@@ -255,8 +207,32 @@ def test_visited_hash_set_has_one_winner_per_id():
                 next(gens[i])
             except StopIteration:
                 live.remove(i)
-        for x in set(xs):
-            winners = [i for i, y in enumerate(xs) if y == x and res[i]]
-            assert len(winners) == (0 if x in before else 1)
-        assert all(t.contains(x) for x in before | set(xs))
-        assert sum(1 for v in t.v if v) == len(before | set(xs))   # no id stored twice
+        keep = []
+        for p in rng.permutation(len(xs)):                    # check + reset race freely after the barrier
+            val = (int(xs[p]) << self.pb) | (p + 1)
+            if self.v[slot[p]] == val:
+                self.v[slot[p]] = val & ~((1 << self.pb) - 1)
+                keep.append(p)
+        return [int(xs[p]) for p in sorted(keep)]             # ordered compaction by position
+
+
+@pytest.mark.parametrize("pos_bits,slots", [(12, 16384), (6, 128)])
+def test_positional_hash_set_equals_serial_scan(pos_bits, slots):
+    rng = np.random.default_rng(21)
+    piece = (1 << pos_bits) - 1
+    for trial in range(60 if pos_bits == 6 else 12):
+        hi = int(rng.choice([8, 40, 3000, 1_000_000]))
+        hi = min(hi, 1 << (32 - pos_bits))
+        table, visited, expect_all, got_all = PosHashSet(slots, pos_bits), set(), [], []
+        cap = slots - 64 if slots > 128 else slots // 2
+        for _ in range(int(rng.integers(1, 5))):              # several pieces (rounds) against one set
+            n = int(rng.integers(1, piece + 1))
+            xs = rng.integers(0, hi, size=n)
+            if len(visited | set(int(v) for v in xs)) > cap:
+                break
+            expect_all += serial_scan(xs, visited)
+            got_all += table.filter_piece(xs, rng)
+        assert got_all == expect_all
+        stored = [v >> pos_bits for v in table.v if v != EMPTY]
+        assert sorted(stored) == sorted(visited)               # every id once, position fields reset
+        assert all((v & ((1 << pos_bits) - 1)) == 0 for v in table.v if v != EMPTY)

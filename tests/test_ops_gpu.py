@@ -324,8 +324,6 @@ def test_sibling_ops(oracle, ref_ops):
 
 
 # ---------------------------------------------------------------- f2: the reference scorer model
-@pytest.mark.skipif(os.environ.get("NANN_RUN_UNVERIFIED") != "1",
-                    reason="k_score_attn has not been run on hardware yet; opt in with NANN_RUN_UNVERIFIED=1")
 @pytest.mark.parametrize("d,dtype", [(64, "f16"), (128, "bf16")])
 def test_attn_scorer_matches_oracle(oracle, d, dtype):
     """Attention + DNN scorer (model.py:189-233) vs the oracle restatement: the per-user projection is
@@ -355,3 +353,36 @@ def test_attn_scorer_matches_oracle(oracle, d, dtype):
     with pytest.raises(ops.InvalidArgumentError) as e:
         sc.score(kt[0], upad[0], table=dev, indices=[0, n_table])
     assert e.value.status == 5
+
+
+# ---------------------------------------------------------------- BlazeXlaOp's model from a weights directory
+@pytest.mark.parametrize("kind", ["l2", "mlp", "attention"])
+def test_model_directory_forward(oracle, tmp_path, kind):
+    """nann_model_load / nann_model_forward -- what the BlazeXlaOp shim calls: the scoring model named
+    by the op's `graph_def` attr (a weights directory on this build), forward() of
+    build_opt_graph.py:91-107 for one user, logits [n, 1]."""
+    from nann_amd import ops, synth
+    d, L, n = 64, 50, 700
+    rng = np.random.default_rng(3)
+    u = (rng.standard_normal((L, 64)) / 8).astype(np.float16)
+    u[37:] = 0
+    rows = (rng.standard_normal((n, d)) / 8).astype(np.float16)
+    w = {"l2": None, "mlp": synth.make_mlp_weights(d), "attention": synth.make_attn_weights(d, 64)}[kind]
+    ops.save_scorer_dir(str(tmp_path), kind, w)
+    m = ops.Model(str(tmp_path), d, L)
+    assert m.kind == kind
+    got = m.forward(cuda(u)[None], cuda(rows))
+    assert tuple(got.shape) == (n, 1)
+    got = got.cpu().numpy().ravel()
+    if kind == "attention":
+        rc, exp = oracle.attn_score_rows(oracle.AttnModel(d, 64, L, oracle.EMB_F16, w), u.astype(np.float32), rows)
+        assert rc == 0 and np.abs(got - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max())
+    else:
+        q = oracle.user_seq_mean(u)
+        rc, exp = oracle.score_rows(oracle.Scorer(kind, d, oracle.EMB_F16, w), q, rows)
+        assert rc == 0 and (bits(got) == bits(exp)).all()
+    with pytest.raises(ops.InternalError) as e:  # zero candidates: blaze_xla_predictor.cc:259-263
+        m.forward(cuda(u)[None], cuda(rows[:0]))
+    assert e.value.status == 6
+    with pytest.raises(ops.NotFoundError):
+        ops.Model(str(tmp_path / "missing"), d, L)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import bits, cuda, queries_for, require_gpu, synth_index
+from gpu_util import MODES, bits, cuda, queries_for, require_gpu, synth_index, traversal_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -17,11 +17,12 @@ def _gpu():
     require_gpu()
 
 
-def _run(dix, q, topn):
+def _run(dix, q, topn, mode="auto"):
     from nann_amd import ops, retrieval
     sc = ops.Scorer("l2", dix.d, dix.item_embs.dtype)
-    r = retrieval.search(dix, sc, cuda(q), topn)
-    torch.cuda.synchronize()
+    with traversal_mode(mode):
+        r = retrieval.search(dix, sc, cuda(q), topn)
+        torch.cuda.synchronize()
     return (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
             r.index.cpu().numpy(), r.counters.cpu().numpy())
 
@@ -38,45 +39,49 @@ def _assert_same(got, exp):
     assert (ids[~ok] == 0).all()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["small_l2_d64.npz", "small_l2_d128.npz"])
-def test_committed_vectors(golden_dir, name):
+def test_committed_vectors(golden_dir, name, mode):
     from nann_amd import ops, retrieval
     z = np.load(os.path.join(golden_dir, name))
     dix = retrieval.Index(z["item_embs"], z["item_ids"], [z["nb_values_0"], z["nb_values_1"]],
                           [z["nb_row_splits_0"], z["nb_row_splits_1"]], z["enter_points"])
     q = ops.user_seq_mean(cuda(z["comm_seq"])).cpu().numpy()
     assert (bits(q) == bits(z["q"])).all()
-    got = _run(dix, q, z["level_topn"])
+    got = _run(dix, q, z["level_topn"], mode)
     _assert_same(got, (z["status"], z["out_item_ids"], z["out_scores"], z["out_index"], z["counters"]))
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n,d,ef,k,nq", [(20000, 64, 32, 20, 300), (60000, 128, 64, 50, 64)])
-def test_search_matches_oracle(oracle, n, d, ef, k, nq):
+def test_search_matches_oracle(oracle, n, d, ef, k, nq, mode):
     g, oix, dix = synth_index(n, d, ef)
     seq = queries_for(g, nq)
     q = np.stack([oracle.user_seq_mean(s) for s in seq])
     topn = [ef] * 5 + [k]
     exp = oracle.search_batch(oix, oracle.Scorer("l2", d, oracle.EMB_F16), q, topn, n_threads=8)
     assert (exp[0] == 0).mean() > 0.5, "workload should be mostly valid requests"
-    got = _run(dix, q, topn)
+    got = _run(dix, q, topn, mode)
     _assert_same(got, exp)
     # uneven level_topn, as in the reference's own benchmark feed (gen_runmeta.py:23)
     topn2 = [ef // 2, ef, 2 * ef, 2 * ef, 2 * ef, k]
     exp2 = oracle.search_batch(oix, oracle.Scorer("l2", d, oracle.EMB_F16), q[:40], topn2, n_threads=8)
-    _assert_same(_run(dix, q[:40], topn2), exp2)
+    _assert_same(_run(dix, q[:40], topn2, mode), exp2)
 
 
-def test_batch_size_independence(oracle):
+@pytest.mark.parametrize("mode", ["lds_hash", "lds_bitmap"])
+def test_batch_size_independence(oracle, mode):
     g, oix, dix = synth_index(20000, 64, 32)
-    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 700, seed=99)])
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 1400, seed=99)])
     topn = [32] * 5 + [20]
-    full = _run(dix, q, topn)  # more queries than workgroup slots: slots are reused
-    for b in (0, 255, 256, 699):
-        one = _run(dix, q[b:b + 1], topn)
+    full = _run(dix, q, topn, mode)  # more queries than workgroup slots: slots are reused
+    for b in (0, 255, 256, 511, 512, 1399):
+        one = _run(dix, q[b:b + 1], topn, mode)
         assert (one[1][0] == full[1][b]).all() and (bits(one[2][0]) == bits(full[2][b])).all()
 
 
-def test_failing_requests_get_reference_codes(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_failing_requests_get_reference_codes(oracle, mode):
     g, oix, dix = synth_index(20000, 64, 32)
     q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 8, seed=5)])
     E = len(g["enter_points"])
@@ -84,7 +89,7 @@ def test_failing_requests_get_reference_codes(oracle):
     for topn in ([E + 1, 8, 8, 8, 8, 8], [8, 8, 8, 8, 8, 33], [0, 8, 8, 8, 8, 8], [8, 1000, 8, 8, 8, 8]):
         exp = oracle.search_batch(oix, sc, q, topn)
         assert (exp[0] != 0).all()
-        got = _run(dix, q, topn)
+        got = _run(dix, q, topn, mode)
         assert (got[0] == exp[0]).all(), (topn, got[0], exp[0])
         assert (got[1] == 0).all()
 
@@ -109,7 +114,8 @@ def test_per_op_schedule_matches_oracle(oracle):
         assert (bits(scores.cpu().numpy()) == bits(exp[2][b])).all()
 
 
-def test_exact_ties_follow_position_order(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_exact_ties_follow_position_order(oracle, mode):
     """Duplicate embeddings give exactly equal scores: TopKV2's lower-position rule
     (topk_op.cc:134-142) must decide, which depends on the serial first-occurrence
     order of BitmapRefDifference."""
@@ -123,7 +129,7 @@ def test_exact_ties_follow_position_order(oracle):
     q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 40, seed=3)])
     topn = [16] * 5 + [20]
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn)
-    _assert_same(_run(dix, q, topn), exp)
+    _assert_same(_run(dix, q, topn, mode), exp)
 
 
 def test_mlp_search_matches_oracle(oracle):
@@ -143,7 +149,8 @@ def test_mlp_search_matches_oracle(oracle):
     _assert_same(got, exp)
 
 
-def test_long_rows_with_repeated_ids(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_long_rows_with_repeated_ids(oracle, mode):
     """A CSR whose rows exceed 64 ids and repeat ids inside a row (legal input for
     GroupGather / BitmapRefDifference, cf. group_gather_test.py's [0,1,1,2,...]): takes the
     flat 64-ids-per-step walker with its in-step duplicate resolution instead of the
@@ -172,7 +179,7 @@ def test_long_rows_with_repeated_ids(oracle):
     topn = [32] * 5 + [20]
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
     assert (exp[0] == 0).mean() > 0.5
-    _assert_same(_run(dix, q, topn), exp)
+    _assert_same(_run(dix, q, topn, mode), exp)
 
 
 def test_index_from_reference_files(oracle, tmp_path):
@@ -195,9 +202,10 @@ def test_index_from_reference_files(oracle, tmp_path):
     _assert_same(_run(dix, q, topn), exp)
 
 
+@pytest.mark.parametrize("mode", ["lds_hash", "lds_bitmap"])
 @pytest.mark.parametrize("d,dtype,ef,k", [(256, "bf16", 64, 40), (64, "f32", 32, 20), (256, "f16", 48, 30),
                                           (128, "bf16", 256, 200)])
-def test_search_row_dtypes_and_dims(oracle, d, dtype, ef, k):
+def test_search_row_dtypes_and_dims(oracle, d, dtype, ef, k, mode):
     """bf16 / f32 rows and 256-d (BASELINE configs[4] shape: 256-d bf16, ef_search=256) through the
     fused traversal."""
     from nann_amd import retrieval
@@ -217,20 +225,40 @@ def test_search_row_dtypes_and_dims(oracle, d, dtype, ef, k):
     topn = [min(ef, len(g["enter_points"]))] + [ef] * 4 + [k]
     exp = oracle.search_batch(oix, oracle.Scorer("l2", d, code), q, topn, n_threads=8)
     assert (exp[0] == 0).mean() > 0.5
-    _assert_same(_run(dix, q, topn), exp)
+    _assert_same(_run(dix, q, topn, mode), exp)
 
 
-@pytest.mark.parametrize("variant", ["glb1024", "glb512"])
-def test_global_bitmap_variants(variant):
-    """The visited bitmap in HBM/L2 instead of LDS (what shards beyond ~1.05M items use, and the
-    half-size-workgroup tuning variant): same results.  Fresh process: the knob is read once."""
-    import subprocess
-    import sys
-    env = dict(os.environ, NANN_L2_VARIANT=variant)
-    here = os.path.dirname(os.path.abspath(__file__))
-    p = subprocess.run([sys.executable, os.path.join(here, "gpu_variant_check.py")], env=env,
-                       capture_output=True, text=True, timeout=280)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+@pytest.mark.parametrize("mode,cap", [("lds_hash", 16320), ("lds_hash32", 32704)])
+def test_hash_set_overflow_falls_back_to_the_bitmap_kernel(oracle, mode, cap):
+    """A query whose visited set could outgrow the hash set (16 320 / 32 704 ids) is handed back with
+    NANN_ERR_CAPACITY and rerun on the bitmap kernel inside the same nann_search call: full-degree
+    exact-kNN rows walked by wide beams visit more than that, and the results still equal the oracle's."""
+    g, oix, dix = synth_index(120000, 64, 256, n_clusters=4, mode="knn")
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 48, seed=31)])
+    wide = 512 if cap < 20000 else 1024
+    topn = [256, wide, wide, wide, wide, 200]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
+    ok = exp[0] == 0
+    assert ok.mean() > 0.5
+    visited_l0 = topn[1] + exp[4][:, 2, 2:5].sum(1)  # marks + ids kept in the three level-0 rounds
+    assert (visited_l0[ok] > cap).any(), "workload must overflow the set for some query"
+    _assert_same(_run(dix, q, topn, mode), exp)
+
+
+def test_mlp_traversal_in_hbm_bitmap_mode(oracle):
+    """The MLP traversal with the visited bitmap in HBM (what MLP shards beyond ~1.07M items run)."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 64, 32)
+    w = synth.make_mlp_weights(64)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 24, seed=23)])
+    topn = [32] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("mlp", 64, oracle.EMB_F16, w), q, topn, n_threads=8)
+    with traversal_mode("hbm_bitmap"):
+        r = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w), cuda(q), topn)
+        torch.cuda.synchronize()
+    got = (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+           r.index.cpu().numpy(), r.counters.cpu().numpy())
+    _assert_same(got, exp)
 
 
 @pytest.mark.parametrize("kind", ["l2", "mlp"])

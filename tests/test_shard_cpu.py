@@ -40,7 +40,7 @@ def _worker(rank, world, port, tmp):
     st, ids, scores, idx, ctr = shard_result(rank)
     local = retrieval.SearchResult(torch.as_tensor(ids), torch.as_tensor(scores), torch.as_tensor(idx),
                                    torch.as_tensor(st), None)
-    merged_ids, merged_scores = shard.ShardedSearch(None, None, topn, world, merge="host").merge(local)
+    merged_ids, merged_scores = shard.ShardedSearch(topn, world, rank, merge="host", transport="torch").merge(local)
     if rank == 0:
         parts = [(st, ids, scores)] + [shard_result(r)[:3] for r in range(1, world)]
         exp_ids, exp_scores = [], []

@@ -32,5 +32,26 @@ def test_shim_registers_the_reference_op_surface():
                  '.Output("c_row_splits: int64")', '.Output("idx_flag_new: Ref (int32)")',
                  '.Attr("T: {int32, int64}")']:
         assert frag in bm[:900], frag
-    assert re.search(r'Name\("GroupGather"\)\.Device\(DEVICE_CPU\)\.TypeConstraint<int32>\("T"\)', text)
-    assert re.search(r'Name\("BitmapRefDifference"\)\.Device\(DEVICE_CPU\)\.TypeConstraint<int32>\("T"\)', text)
+    for op in ("GroupGather", "BitmapRefDifference"):  # both id types the reference registers
+        for t in ("int32", "int64"):                     # (GroupGather_kernel.cc:177-182, bitmap_ops.cc:428-435)
+            assert re.search(r'Name\("%s"\)\.Device\(DEVICE_CPU\)\.TypeConstraint<%s>\("T"\)' % (op, t), text), (op, t)
+
+
+def test_shim_registers_blaze_xla_op_and_huge_const():
+    """The other two surfaces of SURVEY.md 8(b): BlazeXlaOp (blaze_xla_kernel.cc:24-33) and HugeConst
+    (huge_const_op.cc:58-70), attr for attr."""
+    text = open(SHIM).read()
+    bx = text[text.index('REGISTER_OP("BlazeXlaOp")'):][:700]
+    for frag in ['.Attr("InT: list({int8,int64,float16,float32,int32})")',
+                 '.Attr("OutT: list({int8,int64,float16,float32,int32})")',
+                 '.Attr("input_names: list(string) >= 0")', '.Attr("output_names: list(string) >= 0")',
+                 '.Attr("graph_def: string")', '.Attr("blaze_option_path: string")',
+                 '.Input("in_tensor: InT")', '.Output("out_tensor: OutT")']:
+        assert frag in bx, frag
+    hc = text[text.index('REGISTER_OP("HugeConst")'):][:400]
+    for frag in ['.Output("output: dtype")', '.Attr("dtype: type")', '.Attr("shape: shape")', '.Attr("path: string")']:
+        assert frag in hc, frag
+    assert 'Name("BlazeXlaOp").Device(DEVICE_CPU)' in text and "public AsyncOpKernel" in text
+    assert 'Name("HugeConst").Device(DEVICE_CPU)' in text
+    # the fused node can score with the MLP model as well as L2
+    assert '.Attr("scorer_dir: string = \'\'")' in text

@@ -48,14 +48,24 @@ class TensorShape {
   std::vector<int64> dims_;
 };
 
+enum DataType { DT_INVALID = 0, DT_FLOAT = 1, DT_DOUBLE = 2, DT_INT32 = 3, DT_INT64 = 9, DT_HALF = 19 };
+
 template <typename T> struct FlatView { T* p; int64 n; T* data() const { return p; } };
+struct StringPieceStub { const char* p; const char* data() const { return p; } };
 
 class Tensor {
  public:
+  Tensor() = default;
+  Tensor(DataType dt, const TensorShape& s) : dt_(dt), shape_(s) {}
   int64 NumElements() const { return n_; }
   int64 dim_size(int) const { return n_; }
+  int dims() const { return shape_.dims(); }
+  DataType dtype() const { return dt_; }
+  StringPieceStub tensor_data() const { return StringPieceStub{static_cast<const char*>(buf_)}; }
   template <typename T> FlatView<T> flat() const { return FlatView<T>{static_cast<T*>(buf_), n_}; }
  private:
+  DataType dt_ = DT_INVALID;
+  TensorShape shape_;
   void* buf_ = nullptr;
   int64 n_ = 0;
 };
@@ -66,11 +76,27 @@ class OpKernelConstruction {
   void SetStatus(const Status&) {}
 };
 
+class OpInputList {
+ public:
+  const Tensor& operator[](int) const { return t_; }
+ private:
+  Tensor t_;
+};
+class OpOutputList {
+ public:
+  Status allocate(int, const TensorShape&, Tensor** out) { *out = &t_; return Status::OK(); }
+ private:
+  Tensor t_;
+};
+
 class OpKernelContext {
  public:
   const Tensor& input(int) { return t_; }
   Tensor mutable_input(int, bool) { return t_; }
+  Status input_list(const char*, OpInputList*) { return Status::OK(); }
+  Status output_list(const char*, OpOutputList*) { return Status::OK(); }
   Status allocate_output(int, const TensorShape&, Tensor** out) { *out = &t_; return Status::OK(); }
+  void set_output(int, const Tensor&) {}
   void forward_ref_input_to_ref_output(int, int) {}
   void SetStatus(const Status&) {}
  private:
@@ -82,6 +108,15 @@ class OpKernel {
   explicit OpKernel(OpKernelConstruction*) {}
   virtual ~OpKernel() = default;
   virtual void Compute(OpKernelContext*) = 0;
+  virtual bool IsExpensive() { return true; }
+};
+
+class AsyncOpKernel : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  typedef std::function<void()> DoneCallback;
+  virtual void ComputeAsync(OpKernelContext*, DoneCallback done) = 0;
+  void Compute(OpKernelContext*) override {}
 };
 
 namespace shape_inference {
@@ -94,6 +129,8 @@ class InferenceContext {
   void set_output(int, ShapeHandle) {}
   ShapeHandle MakeShape(std::initializer_list<DimensionHandle>) { return {}; }
   DimensionHandle UnknownDim() { return {}; }
+  template <typename T> Status GetAttr(const char*, T*) const { return Status::OK(); }
+  Status MakeShapeFromTensorShape(const TensorShape&, ShapeHandle*) { return Status::OK(); }
 };
 inline Status UnknownShape(InferenceContext*) { return Status::OK(); }
 }  // namespace shape_inference
@@ -118,5 +155,7 @@ static const char* const DEVICE_CPU = "CPU";
   static ::tensorflow::OpKernel* TF_STUB_CAT(mk_, __COUNTER__)(::tensorflow::OpKernelConstruction* c) { (void)(builder); return new cls(c); }
 #define OP_REQUIRES(ctx, cond, status) do { if (!(cond)) { (ctx)->SetStatus(status); return; } } while (0)
 #define OP_REQUIRES_OK(ctx, expr) do { ::tensorflow::Status _s = (expr); if (!_s.ok()) { (ctx)->SetStatus(_s); return; } } while (0)
+#define OP_REQUIRES_ASYNC(ctx, cond, status, done) do { if (!(cond)) { (ctx)->SetStatus(status); (done)(); return; } } while (0)
+#define OP_REQUIRES_OK_ASYNC(ctx, expr, done) do { ::tensorflow::Status _s = (expr); if (!_s.ok()) { (ctx)->SetStatus(_s); (done)(); return; } } while (0)
 #define TF_RETURN_IF_ERROR(expr) do { ::tensorflow::Status _s = (expr); if (!_s.ok()) return _s; } while (0)
 }  // namespace tensorflow
