@@ -427,8 +427,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        sharded = shard.ShardedSearch([args.ef] * 5 + [args.topk], world, rank, merge=args.merge,
-                                      transport=args.transport)
+        exchange_note = None
+        try:
+            sharded = shard.ShardedSearch([args.ef] * 5 + [args.topk], world, rank, merge=args.merge,
+                                          transport=args.transport)
+            ok = torch.ones(1, device=dev)
+        except Exception as e:  # the library's own RCCL communicator could not be made: say so, keep going
+            exchange_note = f"{args.transport} transport failed ({e!r}); fell back to torch.distributed collectives"
+            ok = torch.zeros(1, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            if exchange_note is None:
+                exchange_note = "another rank could not create the C-ABI communicator; fell back to torch.distributed"
+            args.transport = "torch"
+            sharded = shard.ShardedSearch([args.ef] * 5 + [args.topk], world, rank, merge=args.merge,
+                                          transport="torch")
 
     primary_cfg = {"items": args.items, "dim": args.dim, "ef": args.ef, "topk": args.topk, "batch": args.batch,
                    "steps": args.steps, "warmup": args.warmup, "scorer": args.scorer, "dtype": args.dtype,
@@ -465,6 +478,8 @@ def main():
                    "exchange": (f"{args.transport} all-gather + {args.merge} merge" if world > 1 else None)},
         "qps_end_to_end": qps,
     }
+    if world > 1 and exchange_note:
+        result["exchange_note"] = exchange_note
     for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "roofline", "batch_latency_ms",
               "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown"):
         if k in prim:

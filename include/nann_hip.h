@@ -264,9 +264,10 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
 /* Same, plus per-query time attribution for tuning: phase_ticks
  * i64[n_queries, NANN_NUM_PHASES] receives shader-clock ticks spent in
  * {bitmap zeroing, mark walks, CSR expand+walk, gather+score, top-k, other} followed by
- * sub-phases {top-k: load, search, collect, sort; expand: pass 1, pipeline loop}; NULL
+ * sub-phases {top-k: load, search, collect, sort; expand: pass 1, pipeline loop, filter; hash-set
+ * expand per piece: lookup + prefetch, id load wait, insert, barrier, check, rank + store}; NULL
  * disables the instrumentation (nann_search passes NULL). */
-#define NANN_NUM_PHASES 13
+#define NANN_NUM_PHASES 19
 int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q,
                    int64_t n_queries, const int32_t level_topn[6], void* workspace,
                    int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
@@ -296,7 +297,9 @@ int nann_merge_topk_host(const float* scores, const int64_t* ids, int64_t n_quer
  *   nann_comm_get_unique_id  one rank draws the 128-byte id (ncclGetUniqueId) and the host
  *                            hands it to the others by its own means (file, socket, MPI ...)
  *   nann_comm_create         collective over all ranks (ncclCommInitRank) on the calling
- *                            thread's current HIP device; world == 1 needs no id and no RCCL
+ *                            thread's current HIP device; world == 1 needs no id and no RCCL;
+ *                            world > 1 with id == NULL makes a LOOPBACK communicator for
+ *                            single-process tests (every shard returns this rank's record)
  *   status (may be NULL)     a query with status != 0 on this shard contributes scores -inf /
  *                            ids 0: it is never selected while another shard holds real
  *                            candidates, and surfaces as (-inf, 0) entries otherwise

@@ -20,9 +20,10 @@ STATUS_NAMES = {
 F16, BF16, F32, I32, I64, F64 = 0, 1, 2, 3, 4, 5
 SCORER_L2, SCORER_MLP = 0, 1
 NUM_ROUNDS = 5
-NUM_PHASES = 13
+NUM_PHASES = 19
 PHASE_NAMES = ("zero", "walk", "expand", "score", "topk", "other", "tk_load", "tk_search",
-               "tk_collect", "tk_sort", "ex_pass1", "ex_loop", "ex_walkbusy")
+               "tk_collect", "tk_sort", "ex_pass1", "ex_loop", "ex_walkbusy",
+               "ex_lookup", "ex_load", "ex_insert", "ex_bar_a", "ex_check", "ex_rank")
 
 # every symbol include/nann_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

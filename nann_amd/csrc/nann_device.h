@@ -111,6 +111,7 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // optional per-phase time attribution (thread 0 only; off unless a buffer is given)
 enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER,
        PH_TK_LOAD, PH_TK_SEARCH, PH_TK_COLLECT, PH_TK_SORT, PH_EX_PASS1, PH_EX_LOOP, PH_EX_WALKBUSY,
+       PH_EX_LOOKUP, PH_EX_LOAD, PH_EX_INSERT, PH_EX_BARA, PH_EX_CHECK, PH_EX_RANK,  // hash-set expand, per piece
        PH_COUNT };
 struct PhaseTimer {
   long long* ticks;  // LDS, [PH_COUNT]
@@ -610,26 +611,29 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
 // reference's serial scan keeps (bitmap_ops.cc:224-232).  After one barrier a position is kept
 // iff its own value survived in its slot, and the keeper resets pos to 0.  The virtual list
 // (CSR rows of the frontier, concatenated) is never staged: thread t owns positions
-// j * NT + t of the piece (coalesced over a wavefront), finds its row through a per-64-position
-// first-row table and fetches its id straight from the CSR.  Kept ids are compacted in position
-// order with the ballots themselves: wave w's j-th ballot IS the keep-mask of positions
-// [j * NT + 64 w, +64).  Two barriers per piece of up to NT * kHPer - 1 ids (five per 2048 in
-// wg_filter_chunk), no per-piece table.
+// j * NT + t of the piece (coalesced over a wavefront), finds its row in O(1) -- a bit per
+// list position marks where a row starts, so the row of position p is a prefix popcount -- and
+// fetches its id straight from the CSR, the ids of piece c+1 flying underneath piece c.  A probe
+// step is ONE LDS round trip (the CAS itself reports who holds the slot), the steps of a thread's
+// PER ids are issued together.  Kept ids are compacted in position order with the ballots
+// themselves: wave w's j-th ballot IS the keep-mask of positions [j * NT + 64 w, +64).  Two
+// barriers per piece of up to 4095 ids (five per 2048 in wg_filter_chunk), no per-piece table.
 //
 // PB = position bits = min(12, 32 - bits(n_items)): 1M-item shards get pieces of 4095 ids, 4M-item
 // shards 1023.  Capacity: the set must stay below SLOTS - 64 entries; a piece that could
 // exceed it returns -2 and the host reruns that query on the bitmap kernel.
 constexpr uint32_t kVisEmpty = 0xffffffffu;
-constexpr int kVisMaxBlocks = 1024;  // 64-position blocks with a first-row entry (longer lists: binary search)
-template <int NT>
+template <int NT, int SLOTS>
 struct ExpandHashScratch {
-  static constexpr int PER = 4096 / NT;   // positions per thread and piece
-  uint32_t off[kMaxK + 1];
-  uint32_t rowstart[kMaxK];
-  unsigned short blk_first[kVisMaxBlocks];
-  unsigned long long kept[64];            // keep-masks of the piece: word j * (NT/64) + wave
-  uint32_t wave_tot[kNW];
-  int bad;
+  static constexpr int PER = 4096 / NT;        // positions per thread and piece
+  static constexpr int kMaskBits = 2 * SLOTS;  // longest virtual list of a round (longer: bitmap kernel)
+  static constexpr int kMaskWords = kMaskBits / 32;
+  uint32_t rowdelta[kMaxK];                // per non-empty row, in list order: CSR start - offset in the virtual list
+  uint32_t startmask[kMaskWords];          // bit p: a row starts at position p of the virtual list
+  unsigned short maskprefix[kMaskWords];   // rows that start before word w
+  unsigned long long kept[64];             // keep-masks of the piece: word j * (NT/64) + wave
+  uint32_t wave_tot[2 * kNW];
+  int flags[4];                            // [0] bad id, [1] duplicate in a mark list
 };
 
 // SLOTS = 16384 (64 KB: two 512-thread workgroups per CU) or 32768 (128 KB: one 1024-thread
@@ -639,6 +643,15 @@ __device__ __forceinline__ uint32_t vis_hash(int32_t x) {
   static_assert(SLOTS == 16384 || SLOTS == 32768, "14 or 15 hash bits");
   return ((uint32_t)x * 2654435761u) >> (SLOTS == 16384 ? 18 : 17);
 }
+// Double hashing: the probe sequence of id x is h, h + s, h + 2s, ... with an odd stride s(x) (odd:
+// the sequence visits every slot of the power-of-two table).  A wavefront probes until its SLOWEST
+// lane is done, i.e. for the longest of 512 probe sequences; with linear probing that tail is the
+// longest cluster (measured: 14 k cycles per 4095-id piece), with a per-id stride it is ~log(512) /
+// log(1 / load) steps.  Every copy of an id walks the same sequence, which is all the set needs.
+template <int SLOTS>
+__device__ __forceinline__ uint32_t vis_stride(int32_t x) {
+  return (((uint32_t)x * 0x85ebca6bu) >> (SLOTS == 16384 ? 18 : 17)) | 1u;
+}
 
 template <int SLOTS>
 __device__ __forceinline__ void wg_vis_clear(uint32_t* vis) {
@@ -647,15 +660,51 @@ __device__ __forceinline__ void wg_vis_clear(uint32_t* vis) {
     p4[i] = make_uint4(kVisEmpty, kVisEmpty, kVisEmpty, kVisEmpty);
 }
 
+// The "mark" calls (build_opt_graph.py:119-120,132-133) on the hash set: the list is a TopKV2 output
+// over distinct nodes and the set is empty, so BitmapRefDifference returns the list unchanged and
+// every id goes in with position 0 ("visited before").  One CAS per probe step.  Returns n, or -1
+// on an out-of-range id, or -4 if an id occurs twice (premise violated: the caller clears the set
+// and runs the ordered filter instead).  All NT threads; ends with barriers.
+template <int NT, int SLOTS>
+__device__ __forceinline__ int wg_mark_hash(const int32_t* list, int n, uint32_t n_items, uint32_t* vis,
+                                            int pos_bits, int32_t* out, unsigned char* scratch) {
+  auto* S = reinterpret_cast<ExpandHashScratch<NT, SLOTS>*>(scratch);
+  const int tid = local_tid();
+  if (tid < 2) S->flags[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) {
+    const int32_t id = list[i];
+    if ((uint32_t)id < n_items) {
+      const uint32_t val = (uint32_t)id << pos_bits;
+      uint32_t h = vis_hash<SLOTS>(id);
+      const uint32_t step = vis_stride<SLOTS>(id);
+      for (;;) {
+        const uint32_t c = atomicCAS(&vis[h], kVisEmpty, val);
+        if (c == kVisEmpty) break;
+        if ((c >> pos_bits) == (uint32_t)id) { S->flags[1] = 1; break; }
+        h = (h + step) & (SLOTS - 1);
+      }
+      out[i] = id;
+    } else {
+      S->flags[0] = 1;
+    }
+  }
+  __syncthreads();
+  const int bad = S->flags[0], dup = S->flags[1];
+  __syncthreads();
+  return bad ? -1 : dup ? -4 : n;
+}
+
 // All NT threads.  Contract as wg_expand_walk; vis_count (uniform, in/out) = ids in the set.
-// Returns ids kept (appended to out[0..)), -1 on an out-of-range id, -2 when the set could overflow.
+// Returns ids kept (appended to out[0..)), -1 on an out-of-range id, -2 when the set could overflow
+// (or the round's list is longer than the start-bit mask).
 template <int NT, int SLOTS>
 __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits, uint32_t n_items,
                                               uint32_t* vis, int pos_bits, int& vis_count, int32_t* out,
                                               unsigned char* scratch, int* gathered, SubTimer pt) {
-  using Scratch = ExpandHashScratch<NT>;
+  using Scratch = ExpandHashScratch<NT, SLOTS>;
   constexpr int PER = Scratch::PER;
   constexpr int NWV = NT / 64;
   static_assert(PER * NWV == 64, "one keep-mask word per lane");
@@ -666,10 +715,13 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
   const uint64_t lt = lanemask_lt(lane);
   const bool list_mode = row_splits == nullptr;
   const int n_rows = list_mode ? 1 : n_frontier;
-  if (tid == 0) S->bad = 0;
+  if (tid < 4) S->flags[tid] = 0;
+  for (int i = tid; i < Scratch::kMaskWords; i += NT) S->startmask[i] = 0u;
   __syncthreads();
-  // ---- pass 1: row lengths -> offsets of the virtual list, first row of every 64-position block
-  uint32_t total = 0;
+  // ---- pass 1: row lengths -> offsets of the virtual list; a start bit per non-empty row, and per
+  //      non-empty row (in list order) the difference between its CSR address and its list offset,
+  //      so that position p of the list is values[p + rowdelta[#rows starting at or before p - 1]]
+  uint32_t total = 0, rows_ne = 0;
   for (int t0 = 0; t0 < n_rows; t0 += NT) {
     const int t = t0 + tid;
     uint32_t len = 0, start = 0;
@@ -682,115 +734,124 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
         start = (uint32_t)s;
         len = (uint32_t)(e - s);
       } else {
-        S->bad = 1;
+        S->flags[0] = 1;
       }
     }
-    const uint32_t inc = wave_scan_add(len);
-    if (lane == 63) S->wave_tot[wave] = inc;
+    const uint32_t ne = len ? 1u : 0u;
+    const uint32_t inc = wave_scan_add(len), inc_ne = wave_scan_add(ne);
+    if (lane == 63) { S->wave_tot[wave] = inc; S->wave_tot[kNW + wave] = inc_ne; }
     __syncthreads();
-    uint32_t wbase = 0, tot = 0;
+    uint32_t wbase = 0, tot = 0, wbase_ne = 0, tot_ne = 0;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) {
-      const uint32_t v = S->wave_tot[w];
-      if (w < wave) wbase += v;
-      tot += v;
+      const uint32_t v = S->wave_tot[w], vn = S->wave_tot[kNW + w];
+      if (w < wave) { wbase += v; wbase_ne += vn; }
+      tot += v; tot_ne += vn;
     }
-    if (t < n_rows) {
-      const uint32_t my_off = total + wbase + inc - len;
-      S->off[t] = my_off;
-      S->rowstart[t] = start;
-      for (uint32_t b = (my_off + 63) >> 6; b < (uint32_t)kVisMaxBlocks && (b << 6) < my_off + len; ++b)
-        S->blk_first[b] = (unsigned short)t;
+    const uint32_t my_off = total + wbase + inc - len;
+    if (len && my_off < (uint32_t)Scratch::kMaskBits) {
+      S->rowdelta[rows_ne + wbase_ne + inc_ne - 1u] = start - my_off;
+      atomicOr(&S->startmask[my_off >> 5], 1u << (my_off & 31));
     }
     total += tot;
+    rows_ne += tot_ne;
     __syncthreads();
   }
-  if (tid == 0) S->off[n_rows] = total;
-  __syncthreads();
   *gathered = (int)total;
-  pt.sub(PH_EX_PASS1, tsub);
-  if (S->bad) return -1;
-  // ---- pass 2: pieces of PL positions
   const int G = (int)total;
+  if (S->flags[0]) return -1;
+  if (G > Scratch::kMaskBits) return -2;
+  {  // rows that start before each mask word (exclusive prefix of the words' popcounts)
+    const int words = (G + 31) >> 5;
+    uint32_t run = 0;
+    for (int w0 = 0; w0 < words; w0 += NT) {
+      const int w = w0 + tid;
+      const uint32_t cnt = w < words ? (uint32_t)__popc(S->startmask[w]) : 0u;
+      const uint32_t inc = wave_scan_add(cnt);
+      if (lane == 63) S->wave_tot[wave] = inc;
+      __syncthreads();
+      uint32_t wbase = 0, tot = 0;
+#pragma unroll
+      for (int wv = 0; wv < NWV; ++wv) {
+        const uint32_t v = S->wave_tot[wv];
+        if (wv < wave) wbase += v;
+        tot += v;
+      }
+      if (w < words) S->maskprefix[w] = (unsigned short)(run + wbase + inc - cnt);
+      run += tot;
+      __syncthreads();
+    }
+  }
+  pt.sub(PH_EX_PASS1, tsub);
+  // ---- pass 2: pieces of PL positions; the ids of piece c+1 are fetched underneath piece c
   const int PL = min((1 << pos_bits) - 1, NT * PER - 1);
   const uint32_t pmask = (1u << pos_bits) - 1u;
-  int base = 0;
-  bool bad = false;
-  for (int c0 = 0; c0 < G; c0 += PL) {
-    const int n_c = min(PL, G - c0);
-    if (vis_count + n_c > SLOTS - 64) return -2;  // uniform
-    // 1. position -> row -> CSR address -> id (PER loads in flight per thread)
-    int32_t x[PER];
-    bool act[PER];
+  auto fetch = [&](int c0, int n_c, int32_t (&xx)[PER]) {
     uint32_t src[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int pl = j * NT + tid;
-      act[j] = pl < n_c;
-      const uint32_t p = (uint32_t)(c0 + pl);
-      src[j] = 0;
-      if (act[j]) {
-        if (list_mode) {
-          src[j] = p;
-        } else {
-          int r;
-          const uint32_t b = p >> 6;
-          if (b < (uint32_t)kVisMaxBlocks) {
-            r = S->blk_first[b];
-          } else {  // upper_bound over off[1..n_rows]
-            int lo = 0, hi = n_rows;
-            const uint32_t pb = b << 6;
-            while (lo < hi) {
-              const int m = (lo + hi) >> 1;
-              if (S->off[m + 1] > pb) hi = m; else lo = m + 1;
-            }
-            r = lo;
-          }
-          while (S->off[r + 1] <= p) ++r;
-          src[j] = S->rowstart[r] + (p - S->off[r]);
-        }
-      }
+      const uint32_t p = (uint32_t)(c0 + min(pl, n_c - 1));  // positions past the piece re-read its last id (dropped)
+      const uint32_t w = p >> 5;
+      const uint32_t m = S->startmask[w];
+      const uint32_t pre = S->maskprefix[w];
+      const uint32_t ord = pre + (uint32_t)__popc(m & (0xffffffffu >> (31u - (p & 31u)))) - 1u;
+      src[j] = p + S->rowdelta[ord];
     }
 #pragma unroll
-    for (int j = 0; j < PER; ++j) x[j] = values[src[j]];
-    // 2. test-and-insert: (id << PB) | (position in piece + 1)
+    for (int j = 0; j < PER; ++j) xx[j] = values[src[j]];
+  };
+  int base = 0;
+  bool bad = false;
+  int32_t x[PER], xn[PER];
+  if (G > 0) fetch(0, min(PL, G), x);
+  for (int c0 = 0; c0 < G; c0 += PL) {
+    const int n_c = min(PL, G - c0);
+    if (vis_count + n_c > SLOTS - 64) return -2;  // uniform
+    long long tw = pt.now();
+    if (c0 + PL < G) fetch(c0 + PL, min(PL, G - c0 - PL), xn);
+    pt.sub(PH_EX_LOOKUP, tw);
+    // 1. test-and-insert: (id << PB) | (position in piece + 1).  One CAS per probe step: an empty
+    //    slot is claimed, a slot of the same id is joined with ds_min (the smallest position of an
+    //    id stays), anything else sends the lane to the next slot.
     uint32_t val[PER], h[PER];
-    bool in_set[PER];
+    bool act[PER], in_set[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
+      const bool valid = j * NT + tid < n_c;
       const bool inr = (uint32_t)x[j] < n_items;
-      bad |= act[j] && !inr;
-      act[j] = act[j] && inr;
-      in_set[j] = act[j];
+      bad |= valid && !inr;
+      act[j] = in_set[j] = valid && inr;
       val[j] = ((uint32_t)x[j] << pos_bits) | (uint32_t)(j * NT + tid + 1);
       h[j] = vis_hash<SLOTS>(x[j]);
     }
-    long long tw = pt.now();
+    if (pt.on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pt.sub(PH_EX_LOAD, tw);
     for (;;) {
-      uint32_t cur[PER];
+      uint32_t c[PER];
 #pragma unroll
-      for (int j = 0; j < PER; ++j) cur[j] = act[j] ? vis[h[j]] : 0u;
+      for (int j = 0; j < PER; ++j) c[j] = act[j] ? atomicCAS(&vis[h[j]], kVisEmpty, val[j]) : 0u;
       bool any = false;
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
         if (act[j]) {
-          uint32_t c = cur[j];
-          if (c == kVisEmpty) c = atomicCAS(&vis[h[j]], kVisEmpty, val[j]);
-          if (c == kVisEmpty) {
+          if (c[j] == kVisEmpty) {
             act[j] = false;  // claimed the slot
-          } else if ((c >> pos_bits) == (uint32_t)x[j]) {
-            atomicMin(&vis[h[j]], val[j]);  // the smallest position of this id stays
+          } else if ((c[j] >> pos_bits) == (uint32_t)x[j]) {
+            atomicMin(&vis[h[j]], val[j]);
             act[j] = false;
           } else {
-            h[j] = (h[j] + 1) & (SLOTS - 1);
+            h[j] = (h[j] + vis_stride<SLOTS>(x[j])) & (SLOTS - 1);
             any = true;
           }
         }
       }
       if (__ballot(any) == 0ull) break;
     }
+    pt.sub(PH_EX_INSERT, tw);
     __syncthreads();
-    // 3. a position is kept iff its value survived; the keeper marks the id "visited before"
+    pt.sub(PH_EX_BARA, tw);
+    // 2. a position is kept iff its value survived; the keeper marks the id "visited before"
     uint64_t km[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -800,8 +861,8 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
       if (lane == 0) S->kept[j * NWV + wave] = km[j];
     }
     __syncthreads();
-    pt.sub(PH_EX_WALKBUSY, tw);
-    // 4. ordered compaction: exclusive prefix over the 64 mask words (every wavefront on its own)
+    pt.sub(PH_EX_CHECK, tw);
+    // 3. ordered compaction: exclusive prefix over the 64 mask words (every wavefront on its own)
     const uint32_t cnt = (uint32_t)popc64(S->kept[lane]);
     const uint32_t inc = wave_scan_add(cnt);
     const uint32_t exc = inc - cnt;
@@ -813,11 +874,14 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
     const int tot = (int)wave_total(inc);
     base += tot;
     vis_count += tot;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) x[j] = xn[j];
+    pt.sub(PH_EX_RANK, tw);
   }
   pt.sub(PH_EX_LOOP, tsub);
-  if (__ballot(bad) != 0ull && lane == 0) S->bad = 1;
+  if (__ballot(bad) != 0ull && lane == 0) S->flags[0] = 1;
   __syncthreads();
-  const int any_bad = S->bad;
+  const int any_bad = S->flags[0];
   __syncthreads();
   return any_bad ? -1 : base;
 }
@@ -897,7 +961,9 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 // 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per 1024-thread workgroup).
 // Measured on MI355X (profiles/r2a_variants.jsonl): 12 and 16 in flight, and a rolling window that
 // refills each slot as soon as it is reduced, are all slower (2.62 / 2.71 / 2.56 ms vs 2.56 ms).
+#ifndef NANN_SCORE_U
 #define NANN_SCORE_U 8
+#endif
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
 // inside, so a subset of the workgroup can run it.
@@ -1159,7 +1225,15 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     int pr = 0;
     if (e < k) {
       const unsigned long long mine = S->sel[e];
-      for (int o = o0; o < o1; ++o) pr += (S->sel[o] > mine) ? 1 : 0;
+      int o = o0;
+      for (; o + 8 <= o1; o += 8) {  // eight broadcast reads in flight per step (a one-by-one loop pays an LDS round trip per element)
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = S->sel[o + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pr += (v[u] > mine) ? 1 : 0;
+      }
+      for (; o < o1; ++o) pr += (S->sel[o] > mine) ? 1 : 0;
     }
     S->prank[tid] = (unsigned short)pr;
     __syncthreads();
@@ -1176,7 +1250,13 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     const int32_t idv = ids ? (e == tid ? my_id : ids[pos]) : pos;
     if (out_pos) out_pos[rank] = pos;
     if (out_ids) out_ids[rank] = idv;
-    if (out_scores) out_scores[rank] = SCL ? lds_scores[pos] : scores[pos];
+    if (out_scores) {
+      // the key is an invertible image of the score except that -0 was folded into +0: rebuild the
+      // score from the key (no dependent read of scores[pos]) unless it is a zero
+      const uint32_t kbits = (uint32_t)(mine >> 32);
+      const uint32_t u = (kbits & 0x80000000u) ? (kbits & 0x7fffffffu) : ~kbits;
+      out_scores[rank] = (u != 0u) ? __uint_as_float(u) : (SCL ? lds_scores[pos] : scores[pos]);
+    }
     if (out_mapped) out_mapped[rank] = id_map[idv];
   }
   __syncthreads();

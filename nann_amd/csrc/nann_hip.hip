@@ -1210,8 +1210,8 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   const double walk_deg = std::min<double>((double)ix->max_deg[0], 2.75 * mean_deg0);
   const double est_visited = t[1] + 0.45 * walk_deg * ((double)t[1] + t[2] + t[3]);
   const double worst_visited = t[1] + (double)ix->max_deg[0] * ((double)t[1] + t[2] + t[3]);
-  const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512>() + tail;
-  const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT>() + tail;
+  const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512, 16384>() + tail;
+  const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT, 32768>() + tail;
   const bool hash_ok = (kind == NANN_SCORER_L2 || kind < 0) && pos_bits >= 10 && 2 * hash16_lds <= di.lds_max &&
                        hash32_lds <= di.lds_max;
   int hash_vis = -1;

@@ -124,9 +124,9 @@ enum : int {
 constexpr int vis_slots(int vis) { return vis == VIS_LDS_HASH ? 16384 : vis == VIS_LDS_HASH32 ? 32768 : 0; }
 
 // LDS layout of the hash-set traversal: [set | phase scratch | q f32[kMaxD] | misc]
-template <int NT>
+template <int NT, int SLOTS>
 constexpr int hash_phase_scratch() {
-  constexpr int a = (int)sizeof(TopkScratch), b = (int)sizeof(ExpandHashScratch<NT>);
+  constexpr int a = (int)sizeof(TopkScratch), b = (int)sizeof(ExpandHashScratch<NT, SLOTS>);
   return ((a > b ? a : b) + 255) & ~255;
 }
 
@@ -226,8 +226,14 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
             kept = wg_expand_walk<LDSBM, NT>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, dst,
                                              scratch, &gathered, ss == 0 ? no_timer() : pt);
         } else {
-          kept = wg_expand_hash<NT, SLOTS>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, a.pos_bits,
-                                    vis_count, dst, scratch, &gathered, ss == 0 ? no_timer() : pt);
+          if (ss == 0) {  // distinct ids into an empty set: one CAS each; a duplicate redoes it in order
+            kept = wg_mark_hash<NT, SLOTS>(src, n_in, a.n_items, bm, a.pos_bits, dst, scratch);
+            if (kept == -4) { wg_vis_clear<SLOTS>(bm); __syncthreads(); kept = -3; }
+            else if (kept >= 0) vis_count = kept;
+          }
+          if (kept == -3)
+            kept = wg_expand_hash<NT, SLOTS>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, a.pos_bits,
+                                             vis_count, dst, scratch, &gathered, ss == 0 ? no_timer() : pt);
         }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
         if (kept == -2) return NANN_ERR_CAPACITY;  // the hash set could overflow: the host reruns the query on a bitmap kernel
@@ -321,7 +327,7 @@ template <int LPR, int DT, int VIS, int SC, int NT>
 __global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
-  constexpr int kScratchBytes = HASH ? hash_phase_scratch<NT>() : kPhaseScratch;
+  constexpr int kScratchBytes = HASH ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
   uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
   unsigned char* scratch = smem + (VIS == VIS_LDS_BITMAP ? (size_t)a.bm_words * 4 : (size_t)vis_slots(VIS) * 4);
   float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);

@@ -77,6 +77,14 @@ class Comm:
         _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(rank), idb.ctypes.data_as(C.c_void_p),
                                       C.byref(self.handle)), "comm create")
 
+    @classmethod
+    def loopback(cls, world):
+        """Single-process test communicator: every one of `world` shards returns this rank's record."""
+        self = cls.__new__(cls)
+        self.world, self.rank, self.handle = world, 0, C.c_void_p(0)
+        _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(0), None, C.byref(self.handle)), "comm create")
+        return self
+
     def __del__(self):
         if getattr(self, "handle", None) and self.handle.value:
             lib().nann_comm_destroy(self.handle)
@@ -86,10 +94,10 @@ class Comm:
 class ShardedSearch:
     """Exchange + merge for one rank of a sharded search."""
 
-    def __init__(self, level_topn, world, rank=0, merge="device", group=None, transport="torch"):
+    def __init__(self, level_topn, world, rank=0, merge="device", group=None, transport="torch", comm=None):
         self.world, self.k, self.merge_kind, self.group = world, int(level_topn[5]), merge, group
         self.transport = transport
-        self.comm = Comm(world, rank, group) if transport == "rccl" else None
+        self.comm = comm if comm is not None else (Comm(world, rank, group) if transport == "rccl" else None)
         self._ws = None
 
     def merge(self, result):

@@ -176,6 +176,9 @@ class PosHashSet:
     def hash(self, x):
         return ((x * 2654435761) & 0xFFFFFFFF) % self.slots
 
+    def stride(self, x):  # odd: the probe sequence h, h + s, h + 2s, ... visits every slot of the 2^n table
+        return (((x * 0x85EBCA6B) & 0xFFFFFFFF) % self.slots) | 1
+
     def insert_steps(self, x, pos, slot_out, key):
         val = (x << self.pb) | pos
         h = self.hash(x)
@@ -193,7 +196,7 @@ class PosHashSet:
                     yield
                 slot_out[key] = h
                 return
-            h = (h + 1) % self.slots
+            h = (h + self.stride(x)) % self.slots
 
     def filter_piece(self, xs, rng):
         """One piece (len(xs) <= 2^pb - 1): insert all, barrier, keep iff own value survived; the

@@ -386,3 +386,29 @@ def test_model_directory_forward(oracle, tmp_path, kind):
     assert e.value.status == 6
     with pytest.raises(ops.NotFoundError):
         ops.Model(str(tmp_path / "missing"), d, L)
+
+
+# ---------------------------------------------------------------- 8(e): exchange + merge through the C ABI
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_topk_single_process(oracle, world):
+    """nann_sharded_topk on one GPU: world == 1 (pack + merge, no RCCL) and loopback communicators
+    (every shard returns this rank's lists): the record layout, the strided merge straight from the
+    gathered records and TopKV2's tie order across shards (lower shard first), against the oracle's
+    merge.  A query that failed on the shard contributes (-inf, 0)."""
+    from nann_amd import retrieval, shard
+    rng = np.random.default_rng(world)
+    nq, k, k_out = 70, 200, 200 if world > 1 else 150
+    scores = -np.sort(rng.integers(0, 500, size=(nq, k)).astype(np.float32) / 8, axis=1)  # descending, many ties
+    ids = rng.integers(1, 1 << 40, size=(nq, k)).astype(np.int64)
+    status = np.zeros(nq, np.int32)
+    status[5::17] = 4
+    ss = shard.ShardedSearch([0, 0, 0, 0, 0, k_out], world, 0, transport="rccl", comm=shard.Comm.loopback(world))
+    local = retrieval.SearchResult(cuda(ids), cuda(scores), None, cuda(status), None)
+    mi, ms = ss.merge(local)
+    torch.cuda.synchronize()
+    s_in = np.where((status == 0)[:, None], scores, -np.inf)
+    i_in = np.where((status == 0)[:, None], ids, 0)
+    for b in range(nq):
+        rc, es, ei = oracle.merge_topk(np.repeat(s_in[b][None], world, 0), np.repeat(i_in[b][None], world, 0), k_out)
+        assert rc == 0
+        assert (mi[b].cpu().numpy() == ei).all() and (bits(ms[b].cpu().numpy()) == bits(es)).all(), b

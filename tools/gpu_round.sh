@@ -50,6 +50,14 @@ for M in $MODES; do
     show $OUT/bench_${TAG}_$M.json "MODE $M"
   fi
 done
+for d in $R/nann_amd/_build/var_*; do  # tools/build_variants.py
+  [ -f "$d/libnann_hip.so" ] || continue
+  V=$(basename $d | sed 's/^var_//')
+  if [ $(left) -gt 60 ]; then
+    NANN_HIP_LIB=$d/libnann_hip.so timeout 120 $BENCH --phase-ticks --no-cpu-baseline --no-secondary --steps 10 > $OUT/bench_${TAG}_var_$V.json 2> $OUT/bench_${TAG}_var_$V.err
+    show $OUT/bench_${TAG}_var_$V.json "VARIANT $V"
+  fi
+done
 if [ $(left) -gt 60 ]; then
   rm -rf /tmp/prof/kt
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o kt -- \
