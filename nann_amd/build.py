@@ -66,6 +66,21 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
     return _build_into(out, os.path.join(out, "libnann_hip.so"), tuple(extra_flags), verbose)
 
 
+def _check_occupancy(log_path):
+    """The 16K-slot hash-set traversal (k_search<.., VIS=2, .., 512>) only pays off with TWO workgroups per
+    CU = 4 waves per SIMD; one VGPR over 128 halves its occupancy without any other symptom (seen: 130
+    VGPRs -> 2.82 ms instead of 1.99 ms).  Refuse to link such an object."""
+    import re
+    name = None
+    for line in open(log_path, errors="replace"):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
+        if m and name and re.search(r"k_searchILi\d+ELi\d+ELi2ELi\d+ELi512E", name) and int(m.group(1)) < 4:
+            raise RuntimeError(f"{name}: occupancy {m.group(1)} waves/SIMD, the hash-set kernel needs 4")
+
+
 def _build_into(OUT_DIR, LIB, extra_flags, verbose):
     os.makedirs(OUT_DIR, exist_ok=True)
     procs = []
@@ -73,14 +88,17 @@ def _build_into(OUT_DIR, LIB, extra_flags, verbose):
         # one directory per object: --save-temps keeps the device assembly for the audit below
         odir = os.path.join(OUT_DIR, obj[:-2] + ".d")
         os.makedirs(odir, exist_ok=True)
-        cmd = [_hipcc()] + FLAGS + list(extra_flags) + extra + ["--save-temps=obj", "-c", os.path.join(SRC_DIR, src),
-                                            "-o", os.path.join(odir, obj)]
+        cmd = [_hipcc()] + FLAGS + list(extra_flags) + extra + ["--save-temps=obj", "-Rpass-analysis=kernel-resource-usage",
+                                            "-c", os.path.join(SRC_DIR, src), "-o", os.path.join(odir, obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, odir, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)))
+        log = open(os.path.join(odir, "compile.log"), "w")
+        procs.append((cmd, odir, subprocess.Popen(cmd, stderr=log, stdout=log)))
     for cmd, odir, p in procs:
         if p.wait() != 0:
+            sys.stderr.write(open(os.path.join(odir, "compile.log")).read()[-6000:])
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        _check_occupancy(os.path.join(odir, "compile.log"))
     # hipcc (ROCm 7.2) can place VGPR spill code ahead of the exec restore of a join block; the
     # lanes that were masked off then reload garbage (seen: top-k positions all -1).  Refuse
     # to ship an object with that pattern.
@@ -91,7 +109,7 @@ def _build_into(OUT_DIR, LIB, extra_flags, verbose):
                 hits = isa_audit.flow_hits(os.path.join(odir, f))
                 if hits:
                     raise RuntimeError("miscompiled spill placement in %s: %s" % (f, hits[:3]))
-            if not f.endswith(".o") and not os.environ.get("NANN_KEEP_TEMPS"):
+            if not f.endswith(".o") and f != "compile.log" and not os.environ.get("NANN_KEEP_TEMPS"):
                 os.remove(os.path.join(odir, f))  # preprocessed sources, bitcode, assembly: ~15 MB per object
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + \
            [os.path.join(OUT_DIR, obj[:-2] + ".d", obj) for _, _, obj in UNITS] + ["-ldl"]

@@ -323,8 +323,11 @@ struct WsHeader {
 };
 static_assert(sizeof(WsHeader) <= 256, "workspace header");
 
+// Second launch bound = waves per SIMD the register allocation must leave room for: the 16K-slot
+// hash-set kernel lives off TWO 512-thread workgroups per CU (16 waves = 4 per SIMD -> at most 128
+// VGPRs; at 130 the second workgroup silently stops fitting and the kernel runs at half occupancy).
 template <int LPR, int DT, int VIS, int SC, int NT>
-__global__ __launch_bounds__(NT) void k_search(SearchArgs a) {
+__global__ __launch_bounds__(NT, (VIS == VIS_LDS_HASH ? 2 : 1) * NT / 256) void k_search(SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int kScratchBytes = HASH ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
