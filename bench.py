@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # f32-input MFMA dense peak
+F16_MFMA_PEAK_TF = 2500.0  # f16/bf16 MFMA dense peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -67,6 +68,8 @@ def parse():
                     help="N > 1: rccl = ncclAllGather issued by the C ABI; torch = torch.distributed collectives")
     ap.add_argument("--scorer", default="l2", choices=["l2", "mlp"],
                     help="l2 = BASELINE configs[1] (the headline metric); mlp = configs[2]: 256-128-1 MLP on MFMA")
+    ap.add_argument("--mlp-precision", default="split", choices=["split", "exact"],
+                    help="--scorer mlp: split = split-f16 operands on the 16-bit MFMA (scores within 1e-5); exact = f32 MFMA")
     ap.add_argument("--traversal", default="auto", choices=["auto", "lds_bitmap", "hbm_bitmap", "lds_hash", "lds_hash32"])
     ap.add_argument("--index-cache", default=None, help="directory to cache built indices in")
     ap.add_argument("--stress-items", type=int, default=2_000_000)
@@ -197,7 +200,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     index = retrieval.Index.from_dict(g, device=dev)
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     mlp_w = synth.make_mlp_weights(dim) if scorer_kind == "mlp" else None
-    scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w)
+    precision = cfg.get("mlp_precision", "exact")
+    scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w, precision=precision)
     n_batches = min(steps + warmup, 24)
     seqs = make_query_batches(dim, batch, n_batches, args.noise, dev)
     setup_s = time.time() - t0
@@ -265,10 +269,18 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         # per row -- `frac` prices the issued work against the f32-input MFMA peak (157.3 TFLOP/s)
         issued = rows * 2.0 * (dim * 256 + 256 * 128)
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
+        peak = F32_MFMA_PEAK_TF
+        flops_note = "issued f32-MFMA work (query half hoisted)"
+        if precision == "split":
+            # split-f16: 2 (layer 1) / 3 (layer 2) 16-bit MFMA products per f32 product, priced against the
+            # dense f16 MFMA peak (2.5 PFLOP/s)
+            issued = rows * 2.0 * (2 * dim * 256 + 3 * 256 * 128)
+            peak = F16_MFMA_PEAK_TF
+            flops_note = "issued f16-MFMA work: 2 products per layer-1 MAC, 3 per layer-2 MAC (split-f16 operands)"
         tf = issued / (kern_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer)", "achieved": round(tf, 2),
-                    "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TF, 4),
-                    "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": "issued MFMA work (query half hoisted)",
+        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer, %s)" % precision, "achieved": round(tf, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                    "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": flops_note,
                     "nominal_TFLOPs_incl_hoisted": round(nominal / (kern_ms * 1e-3) / 1e12, 2),
                     "hbm_algorithmic_GBps": round(achieved, 1),
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
@@ -324,7 +336,19 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
             first = (sel, O.search_batch(oix, osc, qh[sel], topn, n_threads=threads))
         sel, (st, ids, scores, idx, ctr) = first
         sel, st, ids, scores = sel[:n_check], st[:n_check], ids[:n_check], scores[:n_check]
-        if world == 1:
+        if world == 1 and precision == "split":
+            # scores are equal within 1e-5, not bitwise: tie-aware comparison of the sorted lists
+            gx, gs = r.index.cpu().numpy()[sel], r.scores.cpu().numpy()[sel]
+            okc = (st == 0) & (status[sel] == 0)
+            kinds = [O.tolerant_parity(gx[b], gs[b], idx[:n_check][b], scores[b]) for b in np.nonzero(okc)[0]]
+            errs = [float(np.max(np.abs(gs[b] - scores[b]) / np.maximum(1.0, np.abs(scores[b]))))
+                    for b in np.nonzero(okc)[0] if (gx[b] == idx[:n_check][b]).all()]
+            res["parity"] = {"queries_checked": int(len(sel)), "tolerance": "1e-5 * max(1, |score|), tie-aware ids",
+                             "status_equal": bool((status[sel] == st).all()),
+                             "ids_identical": kinds.count("exact"), "near_tie_only": kinds.count("near-tie"),
+                             "diverged": kinds.count("diverged"),
+                             "max_rel_score_err_on_identical": max(errs) if errs else None}
+        elif world == 1:
             gi, gs = out[0].cpu().numpy()[sel], out[1].cpu().numpy()[sel]
             okc = st == 0
             res["parity"] = {"queries_checked": int(len(sel)),
@@ -445,7 +469,7 @@ def main():
 
     primary_cfg = {"items": args.items, "dim": args.dim, "ef": args.ef, "topk": args.topk, "batch": args.batch,
                    "steps": args.steps, "warmup": args.warmup, "scorer": args.scorer, "dtype": args.dtype,
-                   "graph": args.graph, "traversal": args.traversal}
+                   "graph": args.graph, "traversal": args.traversal, "mlp_precision": args.mlp_precision}
     is_headline = (args.items == 1_000_000 and args.dim == 128 and args.ef == 128 and args.topk == 200
                    and args.dtype == "f16")
     tag = f"{args.items}x{args.dim}{args.dtype}_ef{args.ef}_k{args.topk}_b{args.batch}_{args.scorer}_{args.graph}"
@@ -491,12 +515,14 @@ def main():
             sec["batch_sweep"] = batch_sweep(prim["_handles"], [args.ef] * 5 + [args.topk], [1, 64, 1024])
         except Exception as e:  # a failing extra must not take the headline line with it
             sec["batch_sweep"] = {"error": repr(e)}
-        try:  # BASELINE configs[2]: same index, MLP scorer on the matrix cores
-            cfg = dict(primary_cfg, scorer="mlp", batch=min(args.batch, 1024), steps=3, warmup=1, _index=prim["_index"])
-            sec["mlp_configs2"] = strip(run_workload(tag + "_mlp", args, dev, rank, world, cfg, want_cpu=False,
-                                                     want_parity=True, want_recall=False))
-        except Exception as e:
-            sec["mlp_configs2"] = {"error": repr(e)}
+        for prec, key in (("split", "mlp_configs2_split_f16"), ("exact", "mlp_configs2_exact_f32")):
+            try:  # BASELINE configs[2]: same index, MLP scorer on the matrix cores
+                cfg = dict(primary_cfg, scorer="mlp", mlp_precision=prec, batch=min(args.batch, 1024),
+                           steps=5 if prec == "split" else 3, warmup=1, _index=prim["_index"])
+                sec[key] = strip(run_workload(tag + "_mlp_" + prec, args, dev, rank, world, cfg, want_cpu=False,
+                                              want_parity=True, want_recall=prec == "split"))
+            except Exception as e:
+                sec[key] = {"error": repr(e)}
         prim.pop("_handles", None)
         prim.pop("_index", None)
         torch.cuda.empty_cache()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NANN_ABI_VERSION 1
+#define NANN_ABI_VERSION 2
 
 /* status codes; 1..8 share the oracle's numbering (oracle/nann_oracle.h) and
  * map to the TF errors the reference raises at the cited lines */
@@ -151,7 +151,15 @@ typedef struct {
   const float* b2;     /* [h2] */
   const float* alpha2; /* [h2] */
   const float* w3;     /* [h2]; last layer has no bias (model.py:218-219) */
+  int32_t precision;   /* MLP only: nann_mlp_precision */
 } nann_scorer_desc;
+/* How the MLP's contractions run on the matrix cores.
+ *   EXACT_F32  v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, scores BIT-identical to the oracle's
+ *              fp32 chain (and therefore identical top-k ids); 1/16 of the 16-bit MFMA rate.
+ *   SPLIT_F16  every f32 operand as two f16 values (22 significant bits), products on
+ *              v_mfma_f32_32x32x16_f16 with f32 accumulation: ~6x less matrix time; scores within
+ *              1e-5 relative of the fp32 chain (north_star's bound), ids equal up to near-ties. */
+enum nann_mlp_precision { NANN_MLP_EXACT_F32 = 0, NANN_MLP_SPLIT_F16 = 1 };
 int nann_scorer_create(const nann_scorer_desc* desc /*[host]*/, nann_scorer** out);
 void nann_scorer_destroy(nann_scorer* s);
 

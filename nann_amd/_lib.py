@@ -19,6 +19,7 @@ STATUS_NAMES = {
 }
 F16, BF16, F32, I32, I64, F64 = 0, 1, 2, 3, 4, 5
 SCORER_L2, SCORER_MLP = 0, 1
+MLP_EXACT_F32, MLP_SPLIT_F16 = 0, 1
 NUM_ROUNDS = 5
 NUM_PHASES = 19
 PHASE_NAMES = ("zero", "walk", "expand", "score", "topk", "other", "tk_load", "tk_search",
@@ -45,7 +46,7 @@ class ScorerDesc(C.Structure):
                 ("h1", C.c_int32), ("h2", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("alpha1", C.c_void_p),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("alpha2", C.c_void_p),
-                ("w3", C.c_void_p)]
+                ("w3", C.c_void_p), ("precision", C.c_int32)]
 
 
 class AttnDesc(C.Structure):

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(256) void k_score_l2(const void* table, long long n
 struct nann_scorer {
   nann_scorer_desc desc;
   float* dev_weights = nullptr;  // MLP weights block in HBM
+  uint4* dev_packed = nullptr;   // split-f16 planes in MFMA A-fragment order
   MlpParams mlp = {};
 };
 
@@ -757,6 +759,66 @@ int nann_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k, fl
 }
 
 // ---- scorer ------------------------------------------------------------------------
+static float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, out;
+  if (exp == 0) {
+    if (man == 0) { out = sign; }
+    else {  // subnormal: normalise
+      int e = -1;
+      do { ++e; man <<= 1; } while (!(man & 0x400u));
+      out = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    out = sign | 0x7f800000u | (man << 13);
+  } else {
+    out = sign | ((exp - 15 + 127) << 23) | (man << 13);
+  }
+  float f;
+  std::memcpy(&f, &out, 4);
+  return f;
+}
+
+// 2^7 v = hi + lo with hi = f16(2^7 v), lo = f16(2^7 v - hi)   (nann_mlp.h, split-f16 form: the scaling
+// keeps lo a normal f16 for every weight above ~1e-3 in magnitude)
+static void split_f16(float v, uint16_t* hi, uint16_t* lo) {
+  const float sv = v * 128.0f;
+  *hi = f32_to_f16_rne(sv);
+  *lo = f32_to_f16_rne(sv - f16_bits_to_f32(*hi));
+}
+
+// A fragments of v_mfma_f32_32x32x16_f16 for the item half of W1 and for W2, hi and lo planes:
+//   p1[t][kc][plane][lane][i] = W1[d + 16 kc + 8 g + i][32 t + j]                       (j = lane & 31, g = lane >> 5)
+//   p2[t][q][m][plane][lane][i] = W2[32 t + (r & 3) + 8 (r >> 2) + 4 g][32 m + j], r = 8 q + i
+// (layer 2's k order is the C/D register order of the finished layer-1 tile: nann_mlp.h)
+static void pack_split_weights(const float* w1, const float* w2, int d, int h1, int h2, std::vector<uint16_t>* out,
+                               size_t* p2_off) {
+  const int T = h1 / 32, KC = d / 16, M = h2 / 32;
+  const size_t n1 = (size_t)T * KC * 2 * 64 * 8, n2 = (size_t)T * 2 * M * 2 * 64 * 8;
+  out->assign(n1 + n2, 0);
+  *p2_off = n1;
+  for (int t = 0; t < T; ++t)
+    for (int kc = 0; kc < KC; ++kc)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 8; ++i) {
+          const int j = lane & 31, g = lane >> 5;
+          const float v = w1[(size_t)(d + 16 * kc + 8 * g + i) * h1 + 32 * t + j];
+          const size_t base = ((size_t)(t * KC + kc) * 2) * 64 * 8;
+          split_f16(v, &(*out)[base + (size_t)lane * 8 + i], &(*out)[base + 64 * 8 + (size_t)lane * 8 + i]);
+        }
+  for (int t = 0; t < T; ++t)
+    for (int q = 0; q < 2; ++q)
+      for (int m = 0; m < M; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 8; ++i) {
+            const int j = lane & 31, g = lane >> 5, r = 8 * q + i;
+            const int k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const float v = w2[(size_t)k * h2 + 32 * m + j];
+            const size_t base = n1 + ((size_t)((t * 2 + q) * M + m) * 2) * 64 * 8;
+            split_f16(v, &(*out)[base + (size_t)lane * 8 + i], &(*out)[base + 64 * 8 + (size_t)lane * 8 + i]);
+          }
+}
+
 int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
   if (!desc || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_scorer_create: null argument");
   const int d = desc->d;
@@ -800,6 +862,32 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
     s->mlp.w1 = w + o_w1; s->mlp.b1 = w + o_b1; s->mlp.alpha1 = w + o_a1;
     s->mlp.w2 = w + o_w2; s->mlp.b2 = w + o_b2; s->mlp.alpha2 = w + o_a2; s->mlp.w3 = w + o_w3;
     s->mlp.d = d; s->mlp.h1 = 256; s->mlp.h2 = 128;
+    if (desc->precision != NANN_MLP_EXACT_F32 && desc->precision != NANN_MLP_SPLIT_F16) {
+      nann_scorer_destroy(s);
+      return fail(NANN_ERR_BAD_ARGUMENT, "MLP scorer: unknown precision");
+    }
+    if (desc->precision == NANN_MLP_SPLIT_F16) {  // the pre-scaled weights must stay inside f16's range
+      float wmax = 0.0f;
+      for (size_t i2 = (size_t)d * h1; i2 < n_w1; ++i2) wmax = std::max(wmax, std::fabs(desc->w1[i2]));
+      for (size_t i2 = 0; i2 < n_w2; ++i2) wmax = std::max(wmax, std::fabs(desc->w2[i2]));
+      if (!(wmax <= 511.0f)) {
+        nann_scorer_destroy(s);
+        return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: split-f16 precision needs |w| <= 511; use NANN_MLP_EXACT_F32");
+      }
+    }
+    {  // the split-f16 planes are small (256 KB): always built, used when precision says so
+      std::vector<uint16_t> packed;
+      size_t p2_off = 0;
+      pack_split_weights(desc->w1, desc->w2, d, 256, 128, &packed, &p2_off);
+      e = hipMalloc(reinterpret_cast<void**>(&s->dev_packed), packed.size() * 2);
+      if (e == hipSuccess) e = hipMemcpy(s->dev_packed, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        nann_scorer_destroy(s);
+        return fail(NANN_ERR_HIP, std::string("scorer weights: ") + hipGetErrorString(e));
+      }
+      s->mlp.p1 = s->dev_packed;
+      s->mlp.p2 = s->dev_packed + p2_off / 8;
+    }
     // the host pointers of the descriptor are not kept
     s->desc.w1 = s->desc.b1 = s->desc.alpha1 = s->desc.w2 = s->desc.b2 = s->desc.alpha2 = s->desc.w3 = nullptr;
   }
@@ -810,6 +898,7 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
 void nann_scorer_destroy(nann_scorer* s) {
   if (!s) return;
   if (s->dev_weights) (void)hipFree(s->dev_weights);
+  if (s->dev_packed) (void)hipFree(s->dev_packed);
   delete s;
 }
 
@@ -855,9 +944,10 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table, int
   if (scorer->desc.kind == NANN_SCORER_MLP) {
     const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
     const MlpParams& P = scorer->mlp;
-    if (d == 64) rc = launch_score_mlp_d64(dt, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
-    else if (d == 128) rc = launch_score_mlp_d128(dt, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
-    else rc = launch_score_mlp_d256(dt, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
+    const int split = scorer->desc.precision == NANN_MLP_SPLIT_F16;
+    if (d == 64) rc = launch_score_mlp_d64(dt, split, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
+    else if (d == 128) rc = launch_score_mlp_d128(dt, split, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
+    else rc = launch_score_mlp_d256(dt, split, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     rc = fetch_result(rb, st);
@@ -1270,12 +1360,12 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
 
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
 // nann_mlp_inst.hip (one per embedding dim): the heavy kernels compile in parallel.
-static int launch_search_any(int lpr, int dt, int kind, int vis, int nt, int slots, size_t lds_bytes,
+static int launch_search_any(int lpr, int dt, int kind, int split, int vis, int nt, int slots, size_t lds_bytes,
                              const SearchArgs& a, hipStream_t st) {
   if (kind == NANN_SCORER_MLP) {
-    if (lpr == 8) return launch_search_mlp_d64(dt, vis, slots, lds_bytes, a, st);
-    if (lpr == 16) return launch_search_mlp_d128(dt, vis, slots, lds_bytes, a, st);
-    if (lpr == 32) return launch_search_mlp_d256(dt, vis, slots, lds_bytes, a, st);
+    if (lpr == 8) return launch_search_mlp_d64(dt, split, vis, slots, lds_bytes, a, st);
+    if (lpr == 16) return launch_search_mlp_d128(dt, split, vis, slots, lds_bytes, a, st);
+    if (lpr == 32) return launch_search_mlp_d256(dt, split, vis, slots, lds_bytes, a, st);
     return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256 only");
   }
   if (dt == NANN_F16) return launch_search_l2_f16(lpr, vis, nt, slots, lds_bytes, a, st);
@@ -1333,12 +1423,13 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // WsHeader: query queues, hand-back counter
   const int dt = ix->desc.emb_dtype;
   a.mlp = scorer->mlp;
-  rc = launch_search_any(ix->desc.d / 8, dt, kind, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
+  const int split = kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
+  rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
   if (rc || (p.vis != VIS_LDS_HASH && p.vis != VIS_LDS_HASH32)) return rc;
   // queries whose visited set could have overflowed the 64 KB hash set are rerun on the bitmap
   // kernel (its workgroups leave at once when there is none)
   a.redo = 1;
-  return launch_search_any(ix->desc.d / 8, dt, kind, p.fb_vis, kNT, p.fb_slots, p.fb_lds_bytes, a, st);
+  return launch_search_any(ix->desc.d / 8, dt, kind, split, p.fb_vis, kNT, p.fb_slots, p.fb_lds_bytes, a, st);
 }
 
 // ---- merge ------------------------------------------------------------------------------

@@ -38,6 +38,10 @@ struct MlpParams {  // device pointers
   const float* alpha2;
   const float* w3;
   int d, h1, h2;
+  // split-f16 form (NANN_MLP_SPLIT_F16): the item half of W1 and all of W2, times 2^7, as f16 (hi, lo) planes
+  // packed on the host in MFMA A-fragment order (pack_split_weights in nann_hip.hip)
+  const uint4* p1;  // [h1/32 tiles][d/16 chunks][hi, lo][64 lanes] x 8 halves
+  const uint4* p2;  // [h1/32 tiles][2 chunks][h2/32 tiles][hi, lo][64 lanes] x 8 halves
 };
 
 constexpr int kMlpNT = 512;  // 8 wavefronts: 2 per SIMD -> 256 VGPRs each for the accumulators
@@ -209,6 +213,161 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
     const float other = __shfl_xor(part, 32);
     const float p0 = slot == 0 ? part : other, p1 = slot == 0 ? other : part;
     if (slot == 0 && i < n) scores[i] = p0 + p1;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-f16 form of the same scorer (NANN_MLP_SPLIT_F16): the f32-input MFMA runs at 1/16 of the
+// 16-bit rate, and north_star only asks for scores within 1e-5 of fp32.  Every f32 operand v is
+// carried as two f16 values, v = hi + lo with hi = f16(v), lo = f16(v - hi) -- 22 significant bits --
+// and products go to v_mfma_f32_32x32x16_f16 with f32 accumulation:
+//   layer 1   W1e . e    : e is an f16 table row already (bf16 rows convert) -> Whi.e + Wlo.e         2 MFMAs per 16 k
+//   layer 2   W2  . h1   : Whi.hh + Whi.hl + Wlo.hh    (Wlo.hl is below 2^-22 of the product: dropped)  3 MFMAs per 16 k
+// For lo to be a NORMAL f16 (full 11 bits) the operands are pre-scaled by powers of two, which is
+// exact: weights by 2^7 (host side, at packing), activations h1 by 2^4; the accumulators then carry
+// 2^7 (layer 1) and 2^11 (layer 2) and are scaled back once.  One accumulator per output, as in the
+// f32 form.  Per 32 candidates a wavefront issues 8 x (2 d/16 + 24) MFMAs of 32 cycles instead of
+// 8 x (d/2 + 128) of 64: 6.4x less matrix time at d = 128.  Scores differ from the fp32 chain by
+// ~1e-6 relative (tests hold them to 1e-5), so this form is checked with tolerances and tie-aware
+// ids; the f32 form above stays the bit-exact one.
+//
+// The register layout trick carries over: in the 32x32 C/D layout lane (c, g) holds hidden units
+// (r & 3) + 8 (r >> 2) + 4 g of tile t; registers 0..7 / 8..15 of the finished layer-1 tile ARE the
+// B fragments (8 k-values per lane) of two 16-deep layer-2 steps, provided W2's A fragments are
+// packed with the same k order -- which the host packing does.  (The hardware pairs A's and B's
+// per-lane k slots; any k order shared by both sides gives the same dot product.)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kSplitWScale = 128.0f;  // weights x 2^7 (|w| <= 511 or the scorer is refused)
+constexpr float kSplitHScale = 16.0f;   // hidden activations x 2^4 (|h| <= 4094)
+
+__device__ __forceinline__ f16x8 as_f16x8(const uint4& v) {
+  union { uint4 u; f16x8 h; } c;
+  c.u = v;
+  return c.h;
+}
+
+template <int DT>
+__device__ __forceinline__ f16x8 row_chunk_f16(const uint4& v) {  // 8 table elements -> f16
+  if constexpr (DT == DT_F16) {
+    return as_f16x8(v);
+  } else {  // bf16 -> f32 (exact) -> f16 (exact above 2^-14 in magnitude, ~1e-8 absolute below)
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    f16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[2 * i] = (_Float16)bf16_bits_to_float(w[i] & 0xffffu);
+      r[2 * i + 1] = (_Float16)bf16_bits_to_float(w[i] >> 16);
+    }
+    return r;
+  }
+}
+
+template <int D, int H1T, int H2T, int DT, int NT>
+__device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const void* __restrict__ table,
+                                                   uint32_t n_table_rows, const int32_t* ids, int n,
+                                                   MlpScratch* S, float* scores) {
+  static_assert(DT == DT_F16 || DT == DT_BF16, "split form: 16-bit table rows");
+  static_assert(H2T == 4, "a layer-2 slice is [2 chunks][4 tiles][2 planes] KB");
+  constexpr int NWV = NT / 64;
+  constexpr int CPP = NWV * 32;            // candidates per pass
+  constexpr int KC = D / 16;               // 16-deep chunks of layer 1
+  constexpr int KCS = KC < 8 ? KC : 8;     // chunks per layer-1 slice (16 KB = 8 chunks x 2 planes x 1 KB)
+  constexpr int KS1 = (KC + 7) / 8;        // layer-1 slices per hidden tile
+  constexpr int SPT = KS1 + 1;             // + the tile's layer-2 slice
+  constexpr int NSLICE = H1T * SPT;
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  const int cand = lane & 31, g = lane >> 5;
+  uint4* slice = reinterpret_cast<uint4*>(S->slice);  // 1024 x 16 B
+
+  auto slice_src = [&](int s, int f) -> const uint4* {  // uint4 number f (0..1023) of slice s
+    const int t = s / SPT, ks = s % SPT;
+    if (ks < KS1) return P.p1 + ((size_t)(t * KC + ks * 8) * 2) * 64 + min(f, KCS * 128 - 1);
+    return P.p2 + (size_t)t * 1024 + f;
+  };
+
+  for (int i0 = 0; i0 < n; i0 += CPP) {
+    const int i = i0 + wave * 32 + cand;
+    const int ic = min(i, n - 1);
+    const uint32_t rid = ids ? (uint32_t)ids[ic] : (uint32_t)ic;
+    const size_t row = rid < n_table_rows ? rid : 0u;
+    // B fragments of layer 1: chunk kc of this lane = elements 16 kc + 8 g .. + 8 of the row (one 16-B load)
+    uint4 ev[KC];
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(static_cast<const char*>(table) + row * D * 2) + g;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
+    }
+    f32x16 a2[H2T];
+#pragma unroll
+    for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        a2[mt][r] = S->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g] * (kSplitWScale * kSplitHScale);
+    f32x16 a1;
+    f16x8 bh[2], bl[2];
+    uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
+#pragma unroll
+    for (int s = 0; s < NSLICE; ++s) {
+      const int t = s / SPT, ks = s % SPT;
+      __syncthreads();  // every wave is done with the previous slice
+      slice[tid] = pre0;
+      slice[tid + NT] = pre1;
+      __syncthreads();
+      if (s + 1 < NSLICE) {  // next slice from L2 while this one feeds the MFMAs
+        pre0 = *slice_src(s + 1, tid);
+        pre1 = *slice_src(s + 1, tid + NT);
+      }
+      if (ks == 0) {  // the per-query part seeds the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[r] = S->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g] * kSplitWScale;
+      }
+      if (ks < KS1) {
+#pragma unroll
+        for (int kl = 0; kl < KCS; ++kl) {
+          const int kc = ks * 8 + kl;
+          if (kc < KC) {
+            const f16x8 b = row_chunk_f16<DT>(ev[kc < KC ? kc : 0]);
+            const f16x8 whi = as_f16x8(slice[(kl * 2 + 0) * 64 + lane]);
+            const f16x8 wlo = as_f16x8(slice[(kl * 2 + 1) * 64 + lane]);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, b, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b, a1, 0, 0, 0);
+          }
+        }
+        if (ks == KS1 - 1) {  // tile complete: scale back, PReLU, split into the layer-2 B fragments (x 2^4)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float h = prelu(a1[r] * (1.0f / kSplitWScale), S->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g]) *
+                            kSplitHScale;
+            const _Float16 hh = (_Float16)h;
+            bh[r >> 3][r & 7] = hh;
+            bl[r >> 3][r & 7] = (_Float16)(h - (float)hh);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int mt = 0; mt < H2T; ++mt) {
+            const f16x8 whi = as_f16x8(slice[((q * H2T + mt) * 2 + 0) * 64 + lane]);
+            const f16x8 wlo = as_f16x8(slice[((q * H2T + mt) * 2 + 1) * 64 + lane]);
+            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh[q], a2[mt], 0, 0, 0);
+            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bl[q], a2[mt], 0, 0, 0);
+            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, bh[q], a2[mt], 0, 0, 0);
+          }
+      }
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+        part = __fmaf_rn(prelu(a2[mt][r] * (1.0f / (kSplitWScale * kSplitHScale)), S->alpha2[m]), S->w3[m], part);
+      }
+    const float other = __shfl_xor(part, 32);
+    const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
+    if (g == 0 && i < n) scores[i] = p0 + p1;
   }
   __syncthreads();
 }

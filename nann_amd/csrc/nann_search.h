@@ -31,7 +31,7 @@ int fail(int code, const std::string& msg);  // sets nann_last_error(); defined 
   } while (0)
 
 // stand-alone MLP scorer: one query vector, n rows; each workgroup takes passes of 256 rows
-template <int D, int DT>
+template <int D, int DT, bool SPLIT>
 __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* table, long long n_table_rows,
                                                       const int32_t* indices, long long n, const float* qv,
                                                       float* scores, OpResult* res) {
@@ -48,12 +48,11 @@ __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* t
   wg_mlp_query_setup<kMlpNT>(P, qv, S);
   for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
     const int cnt = (int)((n - c0) < CPP ? (n - c0) : CPP);
-    if (indices) {
-      wg_score_mlp<D, 8, 4, DT, kMlpNT>(P, table, (uint32_t)n_table_rows, indices + c0, cnt, S, scores + c0);
-    } else {  // rows c0.. of `table` itself
-      wg_score_mlp<D, 8, 4, DT, kMlpNT>(P, static_cast<const char*>(table) + (size_t)c0 * D * (DT == DT_F32 ? 4 : 2),
-                                        (uint32_t)(n_table_rows - c0), nullptr, cnt, S, scores + c0);
-    }
+    const void* tab = indices ? table : static_cast<const char*>(table) + (size_t)c0 * D * (DT == DT_F32 ? 4 : 2);
+    const uint32_t n_tab = indices ? (uint32_t)n_table_rows : (uint32_t)(n_table_rows - c0);  // rows c0.. of `table` itself
+    const int32_t* idx = indices ? indices + c0 : nullptr;
+    if constexpr (SPLIT) wg_score_mlp_split<D, 8, 4, DT, kMlpNT>(P, tab, n_tab, idx, cnt, S, scores + c0);
+    else wg_score_mlp<D, 8, 4, DT, kMlpNT>(P, tab, n_tab, idx, cnt, S, scores + c0);
   }
 }
 
@@ -113,6 +112,9 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
   put(7, 4ull * gbm_words); // bitmap in HBM (large shards only)
   return o;
 }
+
+// scorer template values: NANN_SCORER_L2 (0), NANN_SCORER_MLP (1, f32 MFMA, bit-exact) and the MLP's split-f16 form
+constexpr int kScorerMlpSplit = 2;
 
 // where a query's visited set lives
 enum : int {
@@ -272,7 +274,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         wg_mlp_query_setup<NT>(a.mlp, qv, M);  // the phase scratch was reused since the last stage
-        wg_score_mlp<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
+        if constexpr (SC == kScorerMlpSplit)
+          wg_score_mlp_split<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
+        else
+          wg_score_mlp<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
       }
       __syncthreads();
       mark(PH_SCORE);
@@ -432,16 +437,16 @@ int launch_search_l2_f16(int lpr, int vis, int nt, int slots, size_t lds_bytes, 
 int launch_search_l2_bf16(int lpr, int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_l2_f32(int lpr, int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 // MLP instantiations live in nann_mlp_inst.hip (one object per embedding dim): bitmap kernels, 512 threads
-int launch_search_mlp_d64(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
-int launch_search_mlp_d128(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
-int launch_search_mlp_d256(int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
-int launch_score_mlp_d64(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
+int launch_search_mlp_d64(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_d128(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_score_mlp_d64(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
                          float* out, OpResult* res);
-int launch_score_mlp_d128(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
+int launch_score_mlp_d128(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                           long long n_table_rows, const int32_t* indices, long long n, const float* q,
                           float* out, OpResult* res);
-int launch_score_mlp_d256(int dt, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
+int launch_score_mlp_d256(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                           long long n_table_rows, const int32_t* indices, long long n, const float* q,
                           float* out, OpResult* res);
 

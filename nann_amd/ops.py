@@ -228,9 +228,12 @@ class Scorer:
     """What the frozen scoring GraphDef is to BlazeXlaOp (blaze_xla_kernel.cc:24-33):
     kind 'l2' (s = -||q - x||^2) or 'mlp' (weights dict as synth.make_mlp_weights)."""
 
-    def __init__(self, kind, d, emb_dtype=torch.float16, weights=None):
-        self.kind, self.d, self.emb_dtype = kind, d, emb_dtype
+    def __init__(self, kind, d, emb_dtype=torch.float16, weights=None, precision="exact"):
+        """precision (mlp): "exact" = f32 MFMA, scores bit-identical to the oracle; "split" = split-f16
+        operands on the 16-bit MFMA, ~6x less matrix time, scores within 1e-5 (nann_mlp_precision)."""
+        self.kind, self.d, self.emb_dtype, self.precision = kind, d, emb_dtype, precision
         desc = _lib.ScorerDesc()
+        desc.precision = _lib.MLP_SPLIT_F16 if precision == "split" else _lib.MLP_EXACT_F32
         desc.kind = _lib.SCORER_L2 if kind == "l2" else _lib.SCORER_MLP
         desc.d = d
         desc.emb_dtype = _DT[emb_dtype]
@@ -245,9 +248,12 @@ class Scorer:
         _check(lib().nann_scorer_create(C.byref(desc), C.byref(self.handle)), "scorer")
 
     def __del__(self):
-        if getattr(self, "handle", None) and self.handle.value:
-            lib().nann_scorer_destroy(self.handle)
-            self.handle = C.c_void_p(0)
+        try:  # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "handle", None) and self.handle.value:
+                lib().nann_scorer_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
 
 
 class AttnScorer:
@@ -277,9 +283,12 @@ class AttnScorer:
         _check(lib().nann_attn_scorer_create(C.byref(desc), C.byref(self.handle)), "attention scorer")
 
     def __del__(self):
-        if getattr(self, "handle", None) and self.handle.value:
-            lib().nann_attn_scorer_destroy(self.handle)
-            self.handle = C.c_void_p(0)
+        try:  # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "handle", None) and self.handle.value:
+                lib().nann_attn_scorer_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
 
     def prepare(self, comm_seq):
         """comm_seq f16[B, L, 64] (the `comm_seq` feed reshaped) -> per-user (kt f32[B,256,64],
@@ -343,9 +352,12 @@ class Model:
         self._ws_bytes = nb.value
 
     def __del__(self):
-        if getattr(self, "handle", None) and self.handle.value:
-            lib().nann_model_destroy(self.handle)
-            self.handle = C.c_void_p(0)
+        try:  # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "handle", None) and self.handle.value:
+                lib().nann_model_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
 
     def forward(self, user_seq_emb, item_emb):
         """forward() of build_opt_graph.py:91-107: user_seq_emb f16 [1, L, E], item_emb [n, d] -> logits f32 [n, 1]
@@ -414,9 +426,12 @@ class HugeConst:
         self.tensor = _wrap_device_pointer(ptr.value, self.shape, tdt, self)
 
     def __del__(self):
-        if getattr(self, "_ptr", None) and self._ptr.value:
-            lib().nann_free(self._ptr)
-            self._ptr = C.c_void_p(0)
+        try:  # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "_ptr", None) and self._ptr.value:
+                lib().nann_free(self._ptr)
+                self._ptr = C.c_void_p(0)
+        except Exception:
+            pass
 
 
 def _wrap_device_pointer(ptr, shape, dtype, owner):

@@ -94,9 +94,12 @@ class Index:
                    device=device)
 
     def __del__(self):
-        if getattr(self, "handle", None) and self.handle.value:
-            lib().nann_index_destroy(self.handle)
-            self.handle = C.c_void_p(0)
+        try:  # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "handle", None) and self.handle.value:
+                lib().nann_index_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
 
     def workspace(self, level_topn, n_queries):
         t = (C.c_int32 * 6)(*[int(x) for x in level_topn])

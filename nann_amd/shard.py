@@ -86,9 +86,12 @@ class Comm:
         return self
 
     def __del__(self):
-        if getattr(self, "handle", None) and self.handle.value:
-            lib().nann_comm_destroy(self.handle)
-            self.handle = C.c_void_p(0)
+        try:  # at interpreter shutdown the module globals may already be gone
+            if getattr(self, "handle", None) and self.handle.value:
+                lib().nann_comm_destroy(self.handle)
+                self.handle = C.c_void_p(0)
+        except Exception:
+            pass
 
 
 class ShardedSearch:

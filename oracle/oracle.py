@@ -359,3 +359,23 @@ def attn_score_rows(model, user_seq, rows):
     out = np.zeros(max(n, 1), np.float32)
     rc = lib().oracle_attn_score_rows(C.byref(model.s), _p(u), _p(kproj), _p(rows), C.c_int64(n), _p(out))
     return rc, out[:n]
+
+
+def tolerant_parity(got_idx, got_scores, exp_idx, exp_scores, rtol=1e-5):
+    """Tie-aware comparison of one query's sorted top-k lists when scores are only equal within a
+    tolerance (split-f16 MLP): identical ids, or -- where a near-tie flipped an order or a boundary --
+    the two sorted score lists agree element by element within rtol * max(1, |score|) and the ids that
+    differ sit within that tolerance of the last kept score.  Returns "exact" | "near-tie" | "diverged"."""
+    if (got_idx == exp_idx).all():
+        ok = np.abs(got_scores - exp_scores) <= rtol * np.maximum(1.0, np.abs(exp_scores))
+        return "exact" if ok.all() else "diverged"
+    tol = rtol * np.maximum(1.0, np.abs(exp_scores))
+    if not (np.abs(got_scores - exp_scores) <= tol).all():
+        return "diverged"
+    if set(got_idx.tolist()) == set(exp_idx.tolist()):
+        return "near-tie"
+    kth = exp_scores[-1]
+    odd = set(got_idx.tolist()) ^ set(exp_idx.tolist())
+    pos = {int(i): float(s) for i, s in zip(exp_idx, exp_scores)}
+    pos.update({int(i): float(s) for i, s in zip(got_idx, got_scores)})
+    return "near-tie" if all(abs(pos[i] - kth) <= 2 * rtol * max(1.0, abs(kth)) for i in odd) else "diverged"

@@ -56,3 +56,8 @@ def synth_index(n, d, ef, seed=1234, noise=1.0, n_clusters=64, mode="hnsw"):
 def queries_for(g, nq, seed=4321):
     from nann_amd import synth
     return synth.make_queries(g["item_embs"], g["assign"], nq, seed=seed)
+
+
+def tolerant_parity(*args, **kw):
+    from oracle import oracle as O
+    return O.tolerant_parity(*args, **kw)

@@ -301,6 +301,41 @@ def test_mlp_score(oracle, d, dtype):
         ops.blaze_score(sc, cuda(q), table=dev, indices=[0, n_table])
 
 
+@pytest.mark.parametrize("d,dtype", [(128, "f16"), (64, "f16"), (256, "bf16"), (128, "bf16")])
+def test_mlp_score_split_f16(oracle, d, dtype):
+    """The split-f16 form (NANN_MLP_SPLIT_F16: operands as hi + lo f16 pairs on v_mfma_f32_32x32x16_f16,
+    f32 accumulation): scores within north_star's 1e-5 relative of the fp32 chain -- in practice ~1e-7,
+    the size of the fp32 chain's own rounding; tolerance written here: 1e-5 * max(1, |score|)."""
+    from nann_amd import ops, synth
+    rng = np.random.default_rng(d + 7)
+    n_table, n = 3000, 1500
+    w = synth.make_mlp_weights(d)
+    w["alpha1"] = rng.uniform(0.05, 0.4, 256).astype(np.float32)
+    w["alpha2"] = rng.uniform(0.05, 0.4, 128).astype(np.float32)
+    w["w2"] = (w["w2"] * rng.uniform(0.2, 3.0, (256, 128))).astype(np.float32)  # asymmetric: a row/column mix-up cannot pass
+    x = (rng.standard_normal((n_table, d)) / np.sqrt(d)).astype(np.float32)
+    q = (rng.standard_normal(d) / np.sqrt(d)).astype(np.float32)
+    idx = rng.integers(0, n_table, size=n).astype(np.int32)
+    if dtype == "f16":
+        host = x.astype(np.float16); dev = cuda(host); code, tdt = oracle.EMB_F16, torch.float16
+    else:
+        dev = cuda(x).to(torch.bfloat16)
+        host = dev.view(torch.int16).cpu().numpy().view(np.uint16)
+        code, tdt = oracle.EMB_BF16, torch.bfloat16
+    rc, exp = oracle.score_rows(oracle.Scorer("mlp", d, code, w), q, host[idx])
+    assert rc == 0
+    sc = ops.Scorer("mlp", d, tdt, w, precision="split")
+    got = ops.blaze_score(sc, cuda(q), table=dev, indices=idx).cpu().numpy()
+    err = np.abs(got - exp) / np.maximum(1.0, np.abs(exp))
+    assert err.max() <= 1e-5, err.max()
+    assert err.max() <= 2e-6, ("looser than expected from 22-bit operands", err.max())
+    got3 = ops.blaze_score(sc, cuda(q), table=dev, indices=idx[:37]).cpu().numpy()  # partial pass: same values
+    assert (bits(got3) == bits(got[:37])).all()
+    big = dict(w); big["w2"] = w["w2"] * 1e4  # pre-scaled weights would leave f16's range
+    with pytest.raises(ops.UnimplementedError):
+        ops.Scorer("mlp", d, tdt, big, precision="split")
+
+
 # ---------------------------------------------------------------- sibling ops (8 a8)
 def test_sibling_ops(oracle, ref_ops):
     from nann_amd import ops

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import MODES, bits, cuda, queries_for, require_gpu, synth_index, traversal_mode
+from gpu_util import MODES, bits, cuda, queries_for, require_gpu, synth_index, tolerant_parity, traversal_mode
 
 pytestmark = pytest.mark.gpu
 
@@ -147,6 +147,31 @@ def test_mlp_search_matches_oracle(oracle):
            r.index.cpu().numpy(), r.counters.cpu().numpy())
     assert (exp[0] == 0).mean() > 0.5
     _assert_same(got, exp)
+
+
+def test_mlp_split_f16_search_within_tolerance(oracle):
+    """The traversal with the split-f16 MLP (scores within 1e-5 of fp32, not bit-identical): status codes
+    equal, every query's result either identical to the oracle's or different only where scores tie within
+    the tolerance; a traversal that went another way because a near-tie fell differently at a beam
+    boundary is tolerated for a small fraction of queries and must still overlap the oracle's answer."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(60000, 128, 64)
+    w = synth.make_mlp_weights(128)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 96, seed=13)])
+    topn = [64] * 5 + [50]
+    est, eids, esc, eidx, ectr = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q, topn, n_threads=8)
+    r = retrieval.search(dix, ops.Scorer("mlp", 128, torch.float16, w, precision="split"), cuda(q), topn)
+    torch.cuda.synchronize()
+    st, idx, sc = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
+    ok = est == 0
+    assert ok.mean() > 0.5
+    kinds = [tolerant_parity(idx[b], sc[b], eidx[b], esc[b]) for b in np.nonzero(ok & (st == 0))[0]]
+    n_div = kinds.count("diverged")
+    assert (st == est).sum() >= len(st) - n_div - 1
+    assert kinds.count("exact") >= 0.85 * len(kinds), kinds
+    assert n_div <= max(1, len(kinds) // 20), kinds
+    for b in np.nonzero(ok & (st == 0))[0]:
+        assert len(set(idx[b].tolist()) & set(eidx[b].tolist())) >= 0.9 * topn[5]
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -14,7 +14,7 @@ T0=$(date +%s)
 left() { echo $(( DEADLINE - ($(date +%s) - T0) )); }
 mkdir -p $OUT /tmp/idx /tmp/prof
 cd $R
-timeout 420 python -m pytest tests -m gpu -q --timeout 180 -x > $OUT/pytest_$TAG.log 2>&1
+timeout 600 python -m pytest tests -m gpu -q --timeout 300 > $OUT/pytest_$TAG.log 2>&1
 RC=$?; tail -3 $OUT/pytest_$TAG.log
 if [ $RC -ne 0 ]; then echo "GPU TESTS FAILED"; grep -E "^(E  |FAILED|ERROR)" $OUT/pytest_$TAG.log | head -30; fi
 timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -1 $OUT/smoke_$TAG.log
