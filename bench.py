@@ -200,7 +200,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     index = retrieval.Index.from_dict(g, device=dev)
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     mlp_w = synth.make_mlp_weights(dim) if scorer_kind == "mlp" else None
-    precision = cfg.get("mlp_precision", "exact")
+    precision = cfg.get("mlp_precision", "exact") if scorer_kind == "mlp" else "exact"
     scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w, precision=precision)
     n_batches = min(steps + warmup, 24)
     seqs = make_query_batches(dim, batch, n_batches, args.noise, dev)
