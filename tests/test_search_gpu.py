@@ -307,3 +307,32 @@ def test_eval_graph_matches_oracle(oracle, kind):
             assert (bits(s.cpu().numpy()) == bits(esc)).all()
             n_ok += 1
     assert n_ok >= 6
+
+
+def test_serving_front_end_on_the_device(oracle):
+    """f4: the batching front end (nann_amd/serving.py) over the real backend -- single requests with the
+    reference's signature (comm_seq f16[1, L*d], level_topn -> top_k i64[1, k], build_opt_graph.py:151-159)
+    are aggregated into nann_search launches; every reply equals the oracle's answer for that request,
+    failing requests raise in their caller only; closed-loop load reports throughput and latency."""
+    from nann_amd import ops, serving
+    g, oix, dix = synth_index(20000, 64, 32)
+    seqs = queries_for(g, 300, seed=41)
+    topn = [32] * 5 + [20]
+    q = np.stack([oracle.user_seq_mean(s) for s in seqs])
+    est, eids, _, _, _ = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
+    srv = serving.BatchingServer(serving.device_backend(dix, ops.Scorer("l2", 64)), 50, 64, topn, max_batch=128,
+                                 max_wait_us=500)
+    try:
+        futs = [srv.submit(s.reshape(1, -1)) for s in seqs]
+        for b, f in enumerate(futs):
+            if est[b]:
+                with pytest.raises(serving.RequestFailed) as e:
+                    f.result(30)
+                assert e.value.status == est[b]
+            else:
+                assert (f.result(30) == eids[b][None]).all()
+        assert srv.batches < len(seqs)  # requests were aggregated
+        stats = serving.closed_loop(srv, lambda cid: seqs[cid % len(seqs)], n_clients=32, duration_s=1.0)
+        assert stats["requests"] > 100 and stats["latency_us"]["p50"] > 0
+    finally:
+        srv.close()
