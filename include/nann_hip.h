@@ -282,6 +282,19 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
                    int32_t* out_index, int32_t* status, int32_t* counters, int64_t* phase_ticks,
                    nann_stream_t stream);
 
+/* The serving signature in one call (build_opt_graph.py:151-159): comm_seq f16[n_queries, seq_len, E]
+ * + level_topn -> top_k, scored by whatever model the BlazeXlaOp nodes of the graph name.  l2 / mlp:
+ * nann_user_seq_mean + nann_search.  attention: the per-user projection once per request
+ * (nann_attn_prepare), then the fused traversal with the attention + DNN scorer on the matrix cores
+ * (scores within 1e-5 of the oracle restatement: device expf / MFMA order; ids tie-aware).
+ * workspace: nann_search_model_workspace_bytes(); other arguments as nann_search. */
+int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m, const int32_t level_topn[6],
+                                      int64_t n_queries, int64_t* nbytes);
+int nann_search_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                      const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                      int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                      int32_t* counters, nann_stream_t stream);
+
 /* ---- 8(e): merge of per-shard top-k lists ----------------------------------
  * scores f32[n_queries, n_shards, k_in], ids i64[n_queries, n_shards, k_in]
  * (shard-major as all-gathered); concat in shard order, then TopKV2 order

@@ -67,7 +67,7 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
 
 
 def _check_occupancy(log_path):
-    """The 16K-slot hash-set traversal (k_search<.., VIS=2, .., 512>) only pays off with TWO workgroups per
+    """The 16K-slot hash-set traversal with the L2 scorer (k_search<.., VIS=2, SC=0, 512>) only pays off with TWO workgroups per
     CU = 4 waves per SIMD; one VGPR over 128 halves its occupancy without any other symptom (seen: 130
     VGPRs -> 2.82 ms instead of 1.99 ms).  Refuse to link such an object."""
     import re
@@ -77,7 +77,7 @@ def _check_occupancy(log_path):
         if m:
             name = m.group(1)
         m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
-        if m and name and re.search(r"k_searchILi\d+ELi\d+ELi2ELi\d+ELi512E", name) and int(m.group(1)) < 4:
+        if m and name and re.search(r"k_searchILi\d+ELi\d+ELi2ELi0ELi512E", name) and int(m.group(1)) < 4:
             raise RuntimeError(f"{name}: occupancy {m.group(1)} waves/SIMD, the hash-set kernel needs 4")
 
 

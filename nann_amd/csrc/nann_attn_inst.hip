@@ -1,6 +1,6 @@
 // nann_attn_inst.hip -- kernels of the reference scorer model (nann_attn.h) and their launchers.
+#define NANN_ATTN_KERNELS_TU 1
 #include "nann_search.h"
-#include "nann_attn_kernels.h"
 
 namespace nann {
 
@@ -26,6 +26,23 @@ int launch_score_attn(int dt, unsigned blocks, hipStream_t st, const AttnParams&
 #undef NANN_ATTN_CASE
   NANN_HIP_TRY(hipGetLastError());
   return NANN_OK;
+}
+
+template <int D, int DT>
+static int launch_attn_vis(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  constexpr int LPR = D / 8;
+  if (vis == VIS_LDS_HASH) return launch_search_as<LPR, DT, VIS_LDS_HASH, kScorerAttn, kAttnNT>(slots, lds_bytes, a, st);
+  if (vis == VIS_LDS_BITMAP || vis == VIS_HBM_BITMAP)
+    return launch_search_bitmap<LPR, DT, kScorerAttn, kAttnNT>(vis, slots, lds_bytes, a, st);
+  return fail(NANN_ERR_UNSUPPORTED, "attention traversal: no kernel for this plan");
+}
+
+int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  if (d == 64 && dt == NANN_F16) return launch_attn_vis<64, DT_F16>(vis, slots, lds_bytes, a, st);
+  if (d == 64 && dt == NANN_BF16) return launch_attn_vis<64, DT_BF16>(vis, slots, lds_bytes, a, st);
+  if (d == 128 && dt == NANN_F16) return launch_attn_vis<128, DT_F16>(vis, slots, lds_bytes, a, st);
+  if (d == 128 && dt == NANN_BF16) return launch_attn_vis<128, DT_BF16>(vis, slots, lds_bytes, a, st);
+  return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d in {64, 128}, rows f16 or bf16");
 }
 
 }  // namespace nann

@@ -1,5 +1,7 @@
-// nann_attn_kernels.h -- device code of the reference scorer model (see nann_attn.h for the model,
-// the mapping and the status note).  Included by nann_attn_inst.hip only.
+// nann_attn_kernels.h -- device code of the reference scorer model (see nann_attn.h for the model and
+// the mapping).  The workgroup-level scorer (wg_score_attn) is a template any unit may include; the
+// non-template kernel k_attn_prepare is only defined in the unit that sets NANN_ATTN_KERNELS_TU
+// (nann_attn_inst.hip).
 #pragma once
 #include "nann_attn.h"
 #include "nann_mlp.h"
@@ -60,6 +62,7 @@ __device__ __forceinline__ void attn_act(f32x16 (&x)[N], int tile, int vec_tile,
   }
 }
 
+#ifdef NANN_ATTN_KERNELS_TU
 // ---- per user: kt[j][l] = k_l[j] (f32 [256][64], l >= L zero) and upad[l][k] (f32 [64][64]) ---------
 // One workgroup of 256 threads per user.  Same fmaf order as the oracle's dense(): bit-identical.
 __global__ __launch_bounds__(256) void k_attn_prepare(AttnParams P, const uint16_t* __restrict__ user_seq_f16,
@@ -96,27 +99,27 @@ __global__ __launch_bounds__(256) void k_attn_prepare(AttnParams P, const uint16
   }
 }
 
+#endif  // NANN_ATTN_KERNELS_TU
+
 // ---- candidates -------------------------------------------------------------------------------
-template <int D, int DT>
-__global__ __launch_bounds__(kAttnNT) void k_score_attn(AttnParams P, const float* __restrict__ kt,
-                                                        const float* __restrict__ upad, const void* table,
-                                                        long long n_table_rows, const int32_t* indices,
-                                                        long long n, float* scores, long long* bad_i) {
+// wg_score_attn: logits of candidates ids[0..n) (ids == nullptr: rows 0..n of `table`) for ONE user
+// (kt / upad of that user), by all NT threads (NT/64 wavefronts x 32 candidates per pass); `slice` =
+// kAttnSlice floats of LDS.  Rows outside [0, n_table_rows) are read as row 0 (the caller reports
+// them).  Shared by the stand-alone scorer (k_score_attn) and the fused traversal (k_search).
+template <int D, int DT, int NT>
+__device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* __restrict__ kt,
+                                              const float* __restrict__ upad, const void* table,
+                                              long long n_table_rows, const int32_t* indices, long long n,
+                                              float* slice, float* scores) {
   static_assert(D == 64 || D == 128, "item embedding dim");
   static_assert(DT == DT_F16 || DT == DT_BF16, "item rows are f16 or bf16");
+  static_assert(NT == kAttnNT, "attn_stage strides by kAttnNT");
   constexpr int ET = D / 32;  // tiles of the candidate row
-  __shared__ __attribute__((aligned(16))) float slice[kAttnSlice];
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, slot = lane >> 5;
-  constexpr int CPP = (kAttnNT / 64) * 32;
-  if (indices) {  // bounds first (gather_op.cc:170-175)
-    for (long long i = (long long)blockIdx.x * kAttnNT + tid; i < n; i += (long long)gridDim.x * kAttnNT) {
-      const long long r = indices[i];
-      if (r < 0 || r >= n_table_rows) atomicMin(reinterpret_cast<unsigned long long*>(bad_i), (unsigned long long)i);
-    }
-  }
+  constexpr int CPP = (NT / 64) * 32;
   const float inv_sqrt_dk = 1.0f / sqrtf(256.0f);  // model_util.py:89-91
-  for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
+  for (long long c0 = 0; c0 < n; c0 += CPP) {
     const long long i = c0 + wave * 32 + cand;
     const long long ic = i < n ? i : n - 1;
     const long long rid = indices ? (long long)indices[ic] : ic;
@@ -226,6 +229,32 @@ __global__ __launch_bounds__(kAttnNT) void k_score_attn(AttnParams P, const floa
     for (int r = 0; r < 16; ++r) part = __fmaf_rn(h3[0][r], P.w4[cd_row(r, slot)], part);
     part += __shfl_xor(part, 32);
     if (slot == 0 && i < n) scores[i] = part;
+  }
+  __syncthreads();
+}
+
+template <int D, int DT>
+__global__ __launch_bounds__(kAttnNT) void k_score_attn(AttnParams P, const float* __restrict__ kt,
+                                                        const float* __restrict__ upad, const void* table,
+                                                        long long n_table_rows, const int32_t* indices,
+                                                        long long n, float* scores, long long* bad_i) {
+  __shared__ __attribute__((aligned(16))) float slice[kAttnSlice];
+  const int tid = local_tid();
+  constexpr int CPP = (kAttnNT / 64) * 32;
+  if (indices) {  // bounds first (gather_op.cc:170-175)
+    for (long long i = (long long)blockIdx.x * kAttnNT + tid; i < n; i += (long long)gridDim.x * kAttnNT) {
+      const long long r = indices[i];
+      if (r < 0 || r >= n_table_rows) atomicMin(reinterpret_cast<unsigned long long*>(bad_i), (unsigned long long)i);
+    }
+  }
+  for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
+    const long long cnt = (n - c0) < CPP ? (n - c0) : CPP;
+    if (indices) {
+      wg_score_attn<D, DT, kAttnNT>(P, kt, upad, table, n_table_rows, indices + c0, cnt, slice, scores + c0);
+    } else {  // rows c0.. of `table` itself
+      wg_score_attn<D, DT, kAttnNT>(P, kt, upad, static_cast<const uint16_t*>(table) + (size_t)c0 * D,
+                                    n_table_rows - c0, nullptr, cnt, slice, scores + c0);
+    }
   }
 }
 

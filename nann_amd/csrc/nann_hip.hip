@@ -1265,6 +1265,7 @@ static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
 
 static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
+constexpr int kKindAttn = 2;  // plan_search: the attention model (NANN_MODEL_ATTENTION); 0 / 1 = nann_scorer_kind
 // kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
 static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p) {
   for (int i = 0; i < 6; ++i)
@@ -1283,11 +1284,12 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->pool_cap = std::max(t[1] + t[2] + t[3] + t[4], 1);
   const size_t tail = kMaxD * 4 + 256;  // q + misc behind the phase scratch
   const size_t bm_bytes = (size_t)ix->bm_words * 4;
-  const bool bitmap_fits = bm_bytes + kPhaseScratch + tail <= di.lds_max;
+  const size_t bm_scratch = kind == kKindAttn ? (size_t)kAttnScratch : (size_t)kPhaseScratch;
+  const bool bitmap_fits = bm_bytes + bm_scratch + tail <= di.lds_max;
   const int mode = g_traversal_mode.load(std::memory_order_relaxed);
   // the bitmap plan: what MLP traversals run, what oversized shards run, and the fallback of the hash plan
   const int bm_vis = (bitmap_fits && mode != NANN_TRAVERSAL_HBM_BITMAP) ? VIS_LDS_BITMAP : VIS_HBM_BITMAP;
-  const size_t bm_lds = kPhaseScratch + tail + (bm_vis == VIS_LDS_BITMAP ? bm_bytes : 0);
+  const size_t bm_lds = bm_scratch + tail + (bm_vis == VIS_LDS_BITMAP ? bm_bytes : 0);
   const int bm_per_cu = bm_vis == VIS_LDS_BITMAP ? 1 : 2;
   // the hash-set plans: L2 scorer, ids + a useful number of position bits in 32 bits.  Which table:
   // the visited set of a level holds its marks plus every id the level's rounds keep.  Measured on
@@ -1319,7 +1321,13 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->fb_vis = bm_vis;
   p->fb_lds_bytes = bm_lds;
   p->fb_slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * bm_per_cu));
-  if (hash_ok && hash_vis == VIS_LDS_HASH) {
+  if (kind == kKindAttn && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP && pos_bits >= 10) {
+    // attention model: 16K-slot set + its 32 KB weight slices, one 512-thread workgroup per CU
+    p->vis = VIS_LDS_HASH;
+    p->nt = 512;
+    p->lds_bytes = (size_t)vis_slots(VIS_LDS_HASH) * 4 + kAttnScratch + tail;
+    p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus));
+  } else if (hash_ok && hash_vis == VIS_LDS_HASH) {
     p->vis = VIS_LDS_HASH;
     p->nt = 512;
     p->lds_bytes = hash16_lds;
@@ -1383,17 +1391,17 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
                         out_scores, out_index, status, counters, nullptr, stream);
 }
 
-int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
-                   const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
-                   int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
-                   int32_t* counters, int64_t* phase_ticks, nann_stream_t stream) {
-  if (!ix || !scorer || !level_topn || !out_item_ids || !status)
-    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search: null argument");
-  if (n_queries <= 0) return NANN_OK;
+}  // extern "C"
+
+// the traversal for (index, scorer | attention model): plan, fill the arguments, launch (+ the
+// fallback launch of the hash-set plans)
+static int search_impl(const nann_index* ix, const nann_scorer* scorer, const nann_attn_scorer* attn,
+                       const float* q, const float* kt, const float* upad, int64_t n_queries,
+                       const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                       int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                       int32_t* counters, int64_t* phase_ticks, hipStream_t st) {
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
-  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
-    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
-  const int kind = scorer->desc.kind;
+  const int kind = attn ? kKindAttn : scorer->desc.kind;
   SearchPlan p;
   int rc = plan_search(ix, level_topn, n_queries, kind, &p);
   if (rc) return rc;
@@ -1419,17 +1427,91 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
   a.pos_bits = p.pos_bits;
   a.redo = 0;
-  hipStream_t st = as_stream(stream);
+  a.mlp = MlpParams{};
+  a.attn = AttnParams{};
+  a.kt = kt; a.upad = upad;
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // WsHeader: query queues, hand-back counter
   const int dt = ix->desc.emb_dtype;
+  const bool hashed = p.vis == VIS_LDS_HASH || p.vis == VIS_LDS_HASH32;
+  if (attn) {
+    a.attn = attn->P;
+    rc = launch_search_attn(ix->desc.d, dt, p.vis, p.slots, p.lds_bytes, a, st);
+    if (rc || !hashed) return rc;
+    a.redo = 1;
+    return launch_search_attn(ix->desc.d, dt, p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
+  }
   a.mlp = scorer->mlp;
   const int split = kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
   rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
-  if (rc || (p.vis != VIS_LDS_HASH && p.vis != VIS_LDS_HASH32)) return rc;
-  // queries whose visited set could have overflowed the 64 KB hash set are rerun on the bitmap
-  // kernel (its workgroups leave at once when there is none)
+  if (rc || !hashed) return rc;
+  // queries whose visited set could have overflowed the hash set are rerun on the bitmap kernel (its
+  // workgroups leave at once when there is none)
   a.redo = 1;
   return launch_search_any(ix->desc.d / 8, dt, kind, split, p.fb_vis, kNT, p.fb_slots, p.fb_lds_bytes, a, st);
+}
+
+extern "C" {
+
+int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                   const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                   int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                   int32_t* counters, int64_t* phase_ticks, nann_stream_t stream) {
+  if (!ix || !scorer || !level_topn || !out_item_ids || !status)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, workspace, workspace_bytes,
+                     out_item_ids, out_scores, out_index, status, counters, phase_ticks, as_stream(stream));
+}
+
+// ---- the serving signature: comm_seq + level_topn -> top_k, for whatever model the node names ----
+static size_t model_query_bytes(const nann_model* m, int64_t n_queries) {
+  const size_t per = m->kind == NANN_MODEL_ATTENTION ? (size_t)(256 * 64 + 64 * 64) * 4 : (size_t)m->d * 4;
+  return ((size_t)n_queries * per + 255) & ~(size_t)255;
+}
+
+int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m, const int32_t level_topn[6],
+                                      int64_t n_queries, int64_t* nbytes) {
+  if (!ix || !m || !level_topn || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_model_workspace_bytes: null argument");
+  SearchPlan p;
+  const int rc = plan_search(ix, level_topn, n_queries, m->kind == NANN_MODEL_ATTENTION ? kKindAttn : -1, &p);
+  if (rc) return rc;
+  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots) + 256 +
+                      model_query_bytes(m, n_queries));
+  return NANN_OK;
+}
+
+int nann_search_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                      const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                      int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                      int32_t* counters, nann_stream_t stream) {
+  if (!ix || !m || !comm_seq_f16 || !level_topn || !out_item_ids || !status || !workspace)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_model: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (m->d != ix->desc.d || m->emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "model and index disagree on d / dtype");
+  int64_t need = 0;
+  int rc = nann_search_model_workspace_bytes(ix, m, level_topn, n_queries, &need);
+  if (rc) return rc;
+  if (workspace_bytes < need) return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_model_workspace_bytes()");
+  const size_t qb = model_query_bytes(m, n_queries);
+  const int64_t search_bytes = need - (int64_t)qb - 256;
+  unsigned char* qbuf = static_cast<unsigned char*>(workspace) + ((search_bytes + 255) & ~255ll);
+  hipStream_t st = as_stream(stream);
+  if (m->kind == NANN_MODEL_ATTENTION) {  // per-user side once per request (build_opt_graph.py:91-107), then the traversal
+    float* kt = reinterpret_cast<float*>(qbuf);
+    float* upad = kt + (size_t)n_queries * 256 * 64;
+    rc = nann_attn_prepare(m->attn, comm_seq_f16, n_queries, kt, upad, stream);
+    if (rc) return rc;
+    return search_impl(ix, nullptr, m->attn, nullptr, kt, upad, n_queries, level_topn, workspace, search_bytes,
+                       out_item_ids, out_scores, out_index, status, counters, nullptr, st);
+  }
+  float* q = reinterpret_cast<float*>(qbuf);
+  rc = nann_user_seq_mean(comm_seq_f16, n_queries, m->seq_len, m->d, q, stream);
+  if (rc) return rc;
+  return search_impl(ix, m->scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, workspace, search_bytes,
+                     out_item_ids, out_scores, out_index, status, counters, nullptr, st);
 }
 
 // ---- merge ------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 #include "../../include/nann_hip.h"
 #include "nann_device.h"
 #include "nann_mlp.h"
+#include "nann_attn_kernels.h"
 
 #include <string>
 
@@ -81,6 +82,9 @@ struct SearchArgs {
   int32_t* counters;
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
+  AttnParams attn;         // kScorerAttn only
+  const float* kt;         //   per-query projected keys f32 [n_queries, 256, 64] (k_attn_prepare)
+  const float* upad;       //   per-query padded sequence f32 [n_queries, 64, 64]
   int pos_bits;            // VIS_LDS_HASH: position bits of a set entry
   int redo;                // 1: fallback launch, only queries with status NANN_ERR_CAPACITY
 };
@@ -115,6 +119,7 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
 
 // scorer template values: NANN_SCORER_L2 (0), NANN_SCORER_MLP (1, f32 MFMA, bit-exact) and the MLP's split-f16 form
 constexpr int kScorerMlpSplit = 2;
+constexpr int kScorerAttn = 3;  // the reference's attention + DNN model (nann_attn.h); "query" = kt / upad of the user
 
 // where a query's visited set lives
 enum : int {
@@ -130,6 +135,14 @@ template <int NT, int SLOTS>
 constexpr int hash_phase_scratch() {
   constexpr int a = (int)sizeof(TopkScratch), b = (int)sizeof(ExpandHashScratch<NT, SLOTS>);
   return ((a > b ? a : b) + 255) & ~255;
+}
+// phase scratch of a traversal kernel: the attention scorer stages 32 KB weight slices
+constexpr int kAttnScratch = kAttnSlice * 4;
+template <int VIS, int SC, int NT>
+constexpr int phase_scratch() {
+  constexpr int base = (VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32)
+                           ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
+  return (SC == kScorerAttn && base < kAttnScratch) ? kAttnScratch : base;
 }
 
 template <int LPR, int DT, int VIS, int SC, int NT>
@@ -149,7 +162,9 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   const SubTimer pt{ticks, a.phase_ticks != nullptr};
   auto mark = [&](int phase) { timer.mark(phase); };
 
-  for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
+  if constexpr (SC != kScorerAttn) {
+    for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
+  }
   __syncthreads();
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
 
@@ -271,6 +286,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
             lds_scores[base_off + i] = sc_out[i];
         }
+      } else if constexpr (SC == kScorerAttn) {
+        wg_score_attn<LPR * 8, DT, NT>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
+                                       a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
+                                       reinterpret_cast<float*>(scratch), sc_out);
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         wg_mlp_query_setup<NT>(a.mlp, qv, M);  // the phase scratch was reused since the last stage
@@ -332,10 +351,10 @@ static_assert(sizeof(WsHeader) <= 256, "workspace header");
 // hash-set kernel lives off TWO 512-thread workgroups per CU (16 waves = 4 per SIMD -> at most 128
 // VGPRs; at 130 the second workgroup silently stops fitting and the kernel runs at half occupancy).
 template <int LPR, int DT, int VIS, int SC, int NT>
-__global__ __launch_bounds__(NT, (VIS == VIS_LDS_HASH ? 2 : 1) * NT / 256) void k_search(SearchArgs a) {
+__global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) ? 2 : 1) * NT / 256) void k_search(SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
-  constexpr int kScratchBytes = HASH ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
+  constexpr int kScratchBytes = phase_scratch<VIS, SC, NT>();
   uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
   unsigned char* scratch = smem + (VIS == VIS_LDS_BITMAP ? (size_t)a.bm_words * 4 : (size_t)vis_slots(VIS) * 4);
   float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);
@@ -440,6 +459,9 @@ int launch_search_l2_f32(int lpr, int vis, int nt, int slots, size_t lds_bytes, 
 int launch_search_mlp_d64(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d128(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+// attention-scorer instantiations live in nann_attn_inst.hip: (vis, 512 threads) for vis in
+// {VIS_LDS_HASH (one workgroup per CU), VIS_LDS_BITMAP, VIS_HBM_BITMAP}
+int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_score_mlp_d64(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
                          float* out, OpResult* res);

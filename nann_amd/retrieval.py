@@ -155,6 +155,30 @@ def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=Fa
     return SearchResult(out_ids, out_scores, out_index, status, counters, ticks)
 
 
+def search_model(index, model, comm_seq, level_topn, want_counters=True):
+    """The serving signature (build_opt_graph.py:151-159) for a batch: comm_seq f16[B, seq_len, E] +
+    level_topn -> SearchResult, scored by `model` (ops.Model: l2 / mlp / the reference's attention + DNN
+    model -- the per-user projection runs once per request, then the fused traversal; nann_search_model)."""
+    seq = comm_seq.to(device=index.device, dtype=torch.float16).contiguous()
+    b = seq.shape[0]
+    t = (C.c_int32 * 6)(*[int(x) for x in level_topn])
+    k = int(level_topn[5])
+    dev = index.device
+    out_ids = torch.empty((b, k), dtype=torch.int64, device=dev)
+    out_scores = torch.empty((b, k), dtype=torch.float32, device=dev)
+    out_index = torch.empty((b, k), dtype=torch.int32, device=dev)
+    status = torch.empty(b, dtype=torch.int32, device=dev)
+    counters = torch.zeros((b, 3, _lib.NUM_ROUNDS), dtype=torch.int32, device=dev) if want_counters else None
+    nbytes = C.c_int64(0)
+    _check(lib().nann_search_model_workspace_bytes(index.handle, model.handle, t, C.c_int64(b), C.byref(nbytes)))
+    ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().nann_search_model(index.handle, model.handle, _ptr(seq), C.c_int64(b), t, _ptr(ws),
+                                       C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
+                                       _ptr(status), _ptr(counters), _stream()), "search")
+    return SearchResult(out_ids, out_scores, out_index, status, counters, None)
+
+
 # -----------------------------------------------------------------------------
 # build_model() spelled with the per-op drop-ins (one query)
 def _fake_row_splits(x):

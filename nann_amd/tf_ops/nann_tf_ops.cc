@@ -478,7 +478,7 @@ REGISTER_OP("NannHnswSearch")
     .Attr("index_dir: string")
     .Attr("item_embs_dir: string")
     .Attr("seq_len: int = 50")
-    .Attr("scorer_dir: string = ''")  // weights directory as for BlazeXlaOp's graph_def; '' = L2
+    .Attr("scorer_dir: string = ''")  // weights directory as for BlazeXlaOp's graph_def (l2 | mlp | attention); '' = L2
     .SetShapeFn(shape_inference::UnknownShape);
 
 class NannHnswSearchHip : public OpKernel {
@@ -509,19 +509,27 @@ class NannHnswSearchHip : public OpKernel {
     const int32_t k = t[5];
     DeviceBuffer d_seq, d_q, d_ws, d_ids, d_status;
     OP_REQUIRES_OK(ctx, d_seq.Upload(seq.flat<Eigen::half>().data(), seq.NumElements() * 2));
-    OP_REQUIRES_OK(ctx, d_q.Alloc(batch * d_ * 4));
-    OP_REQUIRES_OK(ctx, ToStatus(nann_user_seq_mean(d_seq.as<void>(), batch, seq_len_, d_, d_q.as<float>(), nullptr),
-                                 "NannHnswSearch"));
-    int64_t ws_bytes = 0;
-    OP_REQUIRES_OK(ctx, ToStatus(nann_search_workspace_bytes(index_, t, batch, &ws_bytes), "NannHnswSearch"));
-    OP_REQUIRES_OK(ctx, d_ws.Alloc(ws_bytes));
     OP_REQUIRES_OK(ctx, d_ids.Alloc(batch * k * 8));
     OP_REQUIRES_OK(ctx, d_status.Alloc(batch * 4));
-    const nann_scorer* scorer = model_ ? nann_model_scorer(model_) : scorer_;
-    OP_REQUIRES_OK(ctx, ToStatus(nann_search(index_, scorer, d_q.as<float>(), batch, t, d_ws.as<void>(), ws_bytes,
-                                             d_ids.as<int64_t>(), nullptr, nullptr, d_status.as<int32_t>(),
-                                             nullptr, nullptr),
-                                 "NannHnswSearch"));
+    int64_t ws_bytes = 0;
+    if (model_) {  // any model a BlazeXlaOp node could name, the attention + DNN model included
+      OP_REQUIRES_OK(ctx, ToStatus(nann_search_model_workspace_bytes(index_, model_, t, batch, &ws_bytes), "NannHnswSearch"));
+      OP_REQUIRES_OK(ctx, d_ws.Alloc(ws_bytes));
+      OP_REQUIRES_OK(ctx, ToStatus(nann_search_model(index_, model_, d_seq.as<void>(), batch, t, d_ws.as<void>(), ws_bytes,
+                                                     d_ids.as<int64_t>(), nullptr, nullptr, d_status.as<int32_t>(),
+                                                     nullptr, nullptr),
+                                   "NannHnswSearch"));
+    } else {
+      OP_REQUIRES_OK(ctx, d_q.Alloc(batch * d_ * 4));
+      OP_REQUIRES_OK(ctx, ToStatus(nann_user_seq_mean(d_seq.as<void>(), batch, seq_len_, d_, d_q.as<float>(), nullptr),
+                                   "NannHnswSearch"));
+      OP_REQUIRES_OK(ctx, ToStatus(nann_search_workspace_bytes(index_, t, batch, &ws_bytes), "NannHnswSearch"));
+      OP_REQUIRES_OK(ctx, d_ws.Alloc(ws_bytes));
+      OP_REQUIRES_OK(ctx, ToStatus(nann_search(index_, scorer_, d_q.as<float>(), batch, t, d_ws.as<void>(), ws_bytes,
+                                               d_ids.as<int64_t>(), nullptr, nullptr, d_status.as<int32_t>(),
+                                               nullptr, nullptr),
+                                   "NannHnswSearch"));
+    }
     std::vector<int32_t> status(batch);
     OP_REQUIRES_OK(ctx, d_status.Download(status.data(), batch * 4));
     for (int64_t b = 0; b < batch; ++b)  // a request the reference would have failed
@@ -568,13 +576,8 @@ class NannHnswSearchHip : public OpKernel {
     s.kind = NANN_SCORER_L2;
     s.d = d.d;
     s.emb_dtype = NANN_F16;
-    if (!scorer_dir_.empty()) {  // the MLP scorer of BASELINE configs 3-5 (the attention model scores
-      // through BlazeXlaOp / nann_model_forward; its fused traversal is not built yet)
-      TF_RETURN_IF_ERROR(ToStatus(nann_model_load(scorer_dir_.c_str(), d.d, NANN_F16, seq_len_, &model_), "scorer"));
-      if (!nann_model_scorer(model_))
-        return errors::Unimplemented("NannHnswSearch: the fused traversal scores with l2 or mlp models");
-      return Status::OK();
-    }
+    if (!scorer_dir_.empty())  // l2 | mlp | attention, as for BlazeXlaOp's graph_def
+      return ToStatus(nann_model_load(scorer_dir_.c_str(), d.d, NANN_F16, seq_len_, &model_), "scorer");
     return ToStatus(nann_scorer_create(&s, &scorer_), "nann_scorer_create");
   }
 

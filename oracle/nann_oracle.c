@@ -446,7 +446,19 @@ static float score_mlp_row(const oracle_scorer_t* sc, const float* u, const void
   return p[0] + p[1];
 }
 
+static int query_floats(const oracle_scorer_t* sc) { /* floats per query of a batch */
+  if (sc->kind == ORACLE_SCORER_ATTN && sc->attn) {
+    const oracle_attn_model_t* m = (const oracle_attn_model_t*)sc->attn;
+    return m->L * m->E;
+  }
+  return sc->d;
+}
+
 static int scorer_ok(const oracle_scorer_t* sc) {
+  if (sc && sc->kind == ORACLE_SCORER_ATTN) {
+    const oracle_attn_model_t* m = (const oracle_attn_model_t*)sc->attn;
+    return m && m->d == sc->d && m->emb_dtype == sc->emb_dtype;
+  }
   if (sc->d <= 0 || sc->d % 8 || sc->d > 512 || !is_pow2(sc->d / 8)) return 0;
   if (sc->kind == ORACLE_SCORER_MLP) {
     if (sc->h1 <= 0 || sc->h1 % 32 || sc->h2 <= 0 || sc->h2 % 32) return 0;
@@ -464,6 +476,15 @@ int oracle_score_rows(const oracle_scorer_t* sc, const float* q, const void* row
     for (int64_t i = 0; i < n; ++i)
       out[i] = score_l2_row(q, (const char*)rows + i * rb, sc->emb_dtype, sc->d);
     return ORACLE_OK;
+  }
+  if (sc->kind == ORACLE_SCORER_ATTN) { /* q = the user sequence; the per-user projection is redone per call */
+    const oracle_attn_model_t* m = (const oracle_attn_model_t*)sc->attn;
+    float* kproj = (float*)malloc((size_t)m->L * 4 * m->E * sizeof(float));
+    if (!kproj) return ORACLE_ERR_BAD_ARGUMENT;
+    int rc = oracle_attn_prepare(m, q, kproj);
+    if (!rc) rc = oracle_attn_score_rows(m, q, kproj, rows, n, out);
+    free(kproj);
+    return rc;
   }
   float u[1024], h1[1024], h2[1024];
   mlp_query_part(sc, q, u);
@@ -740,7 +761,7 @@ static void* batch_worker(void* arg) {
   for (;;) {
     const int64_t i = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
     if (i >= b->nq) break;
-    b->status[i] = oracle_search_ws(&W, b->ix, b->sc, b->q + i * b->ix->d, b->t, b->ids + i * k,
+    b->status[i] = oracle_search_ws(&W, b->ix, b->sc, b->q + i * query_floats(b->sc), b->t, b->ids + i * k,
                                     b->scores + i * k, b->index ? b->index + i * k : NULL,
                                     b->ctr ? b->ctr + i : NULL);
   }

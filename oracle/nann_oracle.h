@@ -50,7 +50,9 @@ enum {
 };
 
 enum { ORACLE_EMB_F16 = 0, ORACLE_EMB_BF16 = 1, ORACLE_EMB_F32 = 2 };
-enum { ORACLE_SCORER_L2 = 0, ORACLE_SCORER_MLP = 1 };
+enum { ORACLE_SCORER_L2 = 0, ORACLE_SCORER_MLP = 1,
+       ORACLE_SCORER_ATTN = 2 /* the reference's own model (oracle_attn_model_t); the "query" of a search is then the
+                                  user sequence f32[L, E] instead of a vector f32[d] */ };
 
 /* ragged validation, GroupGather_kernel.cc:9-16 / bitmap_ops.cc:12-19:
  * returns 0 or the reference's code 1/2/3. */
@@ -141,6 +143,7 @@ typedef struct {
   const float* b2;     /* [h2] */
   const float* alpha2; /* [h2] */
   const float* w3;     /* [h2] */
+  const void* attn;    /* ORACLE_SCORER_ATTN only: const oracle_attn_model_t* */
 } oracle_scorer_t;
 
 /* Score n item rows (already gathered, contiguous [n, d] in emb_dtype)

@@ -23,7 +23,7 @@ ERR_BAD_ARGUMENT = 7
 ERR_TOPK_SCALAR_INPUT = 8
 
 EMB_F16, EMB_BF16, EMB_F32 = 0, 1, 2
-SCORER_L2, SCORER_MLP = 0, 1
+SCORER_L2, SCORER_MLP, SCORER_ATTN = 0, 1, 2
 NUM_ROUNDS = 5
 
 
@@ -56,7 +56,7 @@ class ScorerStruct(C.Structure):
                 ("h1", C.c_int), ("h2", C.c_int),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("alpha1", C.c_void_p),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("alpha2", C.c_void_p),
-                ("w3", C.c_void_p)]
+                ("w3", C.c_void_p), ("attn", C.c_void_p)]
 
 
 class IndexStruct(C.Structure):
@@ -197,9 +197,14 @@ def _emb_dtype(a):
 class Scorer:
     """kind 'l2' or 'mlp' (weights: dict w1,b1,alpha1,w2,b2,alpha2,w3 as f32 arrays)."""
 
-    def __init__(self, kind, d, emb_dtype, weights=None):
+    def __init__(self, kind, d, emb_dtype, weights=None, attn_model=None):
+        """kind "attention": attn_model = AttnModel; the queries of search/search_batch are then the user
+        sequences f32[L * E] instead of vectors f32[d]."""
         self.s = ScorerStruct()
-        self.s.kind = SCORER_L2 if kind == "l2" else SCORER_MLP
+        self.s.kind = {"l2": SCORER_L2, "mlp": SCORER_MLP, "attention": SCORER_ATTN}[kind]
+        if kind == "attention":
+            self._attn = attn_model
+            self.s.attn = C.cast(C.pointer(attn_model.s), C.c_void_p)
         self.s.d = d
         self.s.emb_dtype = emb_dtype
         self._keep = {}

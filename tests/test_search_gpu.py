@@ -336,3 +336,40 @@ def test_serving_front_end_on_the_device(oracle):
         assert stats["requests"] > 100 and stats["latency_us"]["p50"] > 0
     finally:
         srv.close()
+
+
+@pytest.mark.parametrize("kind", ["l2", "mlp", "attention"])
+def test_search_model_serving_signature(oracle, tmp_path, kind):
+    """nann_search_model: comm_seq + level_topn -> top_k for the model a BlazeXlaOp node names (a weights
+    directory).  l2 / mlp: bit-identical to the oracle.  attention (f2): the reference's own scorer FUSED into
+    the traversal -- per-user projection once per request, candidates scored on the matrix cores inside
+    k_search; logits are equal to the oracle restatement within 1e-5 (device expf, MFMA order), so ids are
+    compared tie-aware."""
+    from nann_amd import ops, retrieval, synth
+    d, L, nq = 64, 50, 40
+    g, oix, dix = synth_index(20000, d, 32)
+    seqs = queries_for(g, nq, seed=17)                      # f16 [nq, 50, 64]
+    topn = [32] * 5 + [20]
+    w = {"l2": None, "mlp": synth.make_mlp_weights(d), "attention": synth.make_attn_weights(d, 64)}[kind]
+    ops.save_scorer_dir(str(tmp_path), kind, w)
+    m = ops.Model(str(tmp_path), d, L)
+    r = retrieval.search_model(dix, m, cuda(seqs), topn)
+    torch.cuda.synchronize()
+    st, idx, sc = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
+    if kind == "attention":
+        osc = oracle.Scorer("attention", d, oracle.EMB_F16, attn_model=oracle.AttnModel(d, 64, L, oracle.EMB_F16, w))
+        q = seqs.astype(np.float32).reshape(nq, -1)
+    else:
+        osc = oracle.Scorer(kind, d, oracle.EMB_F16, w)
+        q = np.stack([oracle.user_seq_mean(s) for s in seqs])
+    est, eids, esc, eidx, ectr = oracle.search_batch(oix, osc, q, topn, n_threads=8)
+    ok = est == 0
+    assert ok.mean() > 0.5
+    if kind != "attention":
+        assert (st == est).all() and (idx[ok] == eidx[ok]).all() and (bits(sc[ok]) == bits(esc[ok])).all()
+        assert (r.item_ids.cpu().numpy()[ok] == eids[ok]).all() and (r.counters.cpu().numpy()[ok] == ectr[ok]).all()
+        return
+    kinds = [tolerant_parity(idx[b], sc[b], eidx[b], esc[b]) for b in np.nonzero(ok & (st == 0))[0]]
+    assert (st == est).sum() >= nq - 2
+    assert kinds.count("exact") >= 0.8 * len(kinds), kinds
+    assert kinds.count("diverged") <= 2, kinds
