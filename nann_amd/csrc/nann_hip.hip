@@ -1265,7 +1265,7 @@ static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
 
 static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
-constexpr int kKindAttn = 2;  // plan_search: the attention model (NANN_MODEL_ATTENTION); 0 / 1 = nann_scorer_kind
+constexpr int kKindAttn = 2;      // plan_search: the attention model (NANN_MODEL_ATTENTION); 0 / 1 = nann_scorer_kind
 // kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
 static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p) {
   for (int i = 0; i < 6; ++i)
@@ -1309,7 +1309,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   int hash_vis = -1;
   if (mode == NANN_TRAVERSAL_LDS_HASH) hash_vis = VIS_LDS_HASH;
   else if (mode == NANN_TRAVERSAL_LDS_HASH32) hash_vis = VIS_LDS_HASH32;
-  else if (mode == NANN_TRAVERSAL_AUTO && kind != NANN_SCORER_MLP) {
+  else if (mode == NANN_TRAVERSAL_AUTO && (kind == NANN_SCORER_L2 || kind < 0)) {
     if (worst_visited <= 16320.0 || est_visited <= 11000.0) hash_vis = VIS_LDS_HASH;
     else if (worst_visited <= 32704.0 || est_visited <= 24000.0) hash_vis = VIS_LDS_HASH32;
   }

@@ -47,13 +47,16 @@ struct MlpParams {  // device pointers
 constexpr int kMlpNT = 512;  // 8 wavefronts: 2 per SIMD -> 256 VGPRs each for the accumulators
 constexpr int kMlpSlice = 4096;  // floats per weight slice in LDS (128 rows x 32 columns)
 
-struct MlpScratch {
-  float slice[kMlpSlice];
+struct MlpVectors {
   float u[512];       // b1 + W1q^T q of the current query
   float alpha1[512];
   float b2[256];
   float alpha2[256];
   float w3[256];
+};
+struct MlpScratch {
+  float slice[kMlpSlice];
+  MlpVectors v;
 };
 static_assert(sizeof(MlpScratch) <= kPhaseScratch, "phase scratch too small for the MLP");
 
@@ -66,18 +69,18 @@ __device__ __forceinline__ float prelu(float x, float a) {
 // Per query: u[j] = b1[j] + sum_k q[k] * W1[k][j] (k ascending, fmaf) and the small vectors
 // into LDS.  All NT threads; ends with a barrier.
 template <int NT>
-__device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpScratch* S) {
+__device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpVectors* V) {
   const int tid = local_tid();
   for (int j = tid; j < P.h1; j += NT) {
     float acc = P.b1[j];
     for (int k = 0; k < P.d; ++k) acc = __fmaf_rn(qv[k], P.w1[(size_t)k * P.h1 + j], acc);
-    S->u[j] = acc;
-    S->alpha1[j] = P.alpha1[j];
+    V->u[j] = acc;
+    V->alpha1[j] = P.alpha1[j];
   }
   for (int m = tid; m < P.h2; m += NT) {
-    S->b2[m] = P.b2[m];
-    S->alpha2[m] = P.alpha2[m];
-    S->w3[m] = P.w3[m];
+    V->b2[m] = P.b2[m];
+    V->alpha2[m] = P.alpha2[m];
+    V->w3[m] = P.w3[m];
   }
   __syncthreads();
 }
@@ -112,6 +115,7 @@ template <int D, int H1T, int H2T, int DT, int NT>
 __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __restrict__ table,
                                              uint32_t n_table_rows, const int32_t* ids, int n,
                                              MlpScratch* S, float* scores) {
+  const MlpVectors* V = &S->v;
   constexpr int NWV = NT / 64;
   constexpr int CPP = NWV * 32;                       // candidates per pass
   constexpr int HALF = D / 2;                         // elements per k-slot
@@ -158,7 +162,7 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[mt][r] = S->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot];
+      for (int r = 0; r < 16; ++r) acc2[mt][r] = V->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot];
     float4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
 #pragma unroll
     for (int s = 0; s < NSLICE; ++s) {
@@ -173,7 +177,7 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
       }
       if (ks == 0) {  // the per-query part seeds the tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = S->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot];
+        for (int r = 0; r < 16; ++r) acc1[r] = V->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot];
       }
       if (ks < KS1) {
 #pragma unroll
@@ -185,7 +189,7 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
         if (ks == KS1 - 1) {  // tile complete: PReLU in place
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            acc1[r] = prelu(acc1[r], S->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot]);
+            acc1[r] = prelu(acc1[r], V->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot]);
         }
       } else {
         // the accumulators of tile t ARE the B operand: lane (cand, slot) holds hidden units
@@ -208,7 +212,7 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * slot;
-        part = __fmaf_rn(prelu(acc2[mt][r], S->alpha2[m]), S->w3[m], part);
+        part = __fmaf_rn(prelu(acc2[mt][r], V->alpha2[m]), V->w3[m], part);
       }
     const float other = __shfl_xor(part, 32);
     const float p0 = slot == 0 ? part : other, p1 = slot == 0 ? other : part;
@@ -267,6 +271,7 @@ template <int D, int H1T, int H2T, int DT, int NT>
 __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const void* __restrict__ table,
                                                    uint32_t n_table_rows, const int32_t* ids, int n,
                                                    MlpScratch* S, float* scores) {
+  const MlpVectors* V = &S->v;
   static_assert(DT == DT_F16 || DT == DT_BF16, "split form: 16-bit table rows");
   static_assert(H2T == 4, "a layer-2 slice is [2 chunks][4 tiles][2 planes] KB");
   constexpr int NWV = NT / 64;
@@ -303,7 +308,7 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        a2[mt][r] = S->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g] * (kSplitWScale * kSplitHScale);
+        a2[mt][r] = V->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g] * (kSplitWScale * kSplitHScale);
     f32x16 a1;
     f16x8 bh[2], bl[2];
     uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
@@ -320,7 +325,7 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
       }
       if (ks == 0) {  // the per-query part seeds the tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a1[r] = S->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g] * kSplitWScale;
+        for (int r = 0; r < 16; ++r) a1[r] = V->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g] * kSplitWScale;
       }
       if (ks < KS1) {
 #pragma unroll
@@ -337,7 +342,7 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
         if (ks == KS1 - 1) {  // tile complete: scale back, PReLU, split into the layer-2 B fragments (x 2^4)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float h = prelu(a1[r] * (1.0f / kSplitWScale), S->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g]) *
+            const float h = prelu(a1[r] * (1.0f / kSplitWScale), V->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g]) *
                             kSplitHScale;
             const _Float16 hh = (_Float16)h;
             bh[r >> 3][r & 7] = hh;
@@ -363,7 +368,7 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
-        part = __fmaf_rn(prelu(a2[mt][r] * (1.0f / (kSplitWScale * kSplitHScale)), S->alpha2[m]), S->w3[m], part);
+        part = __fmaf_rn(prelu(a2[mt][r] * (1.0f / (kSplitWScale * kSplitHScale)), V->alpha2[m]), V->w3[m], part);
       }
     const float other = __shfl_xor(part, 32);
     const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;

@@ -14,8 +14,8 @@ namespace nann {
 int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int slots, size_t lds_bytes,
                                               const SearchArgs& a, hipStream_t st) {
   constexpr int LPR = NANN_MLP_D / 8;
-  if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: bitmap kernels only");
   if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
+  if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: no kernel for this plan");
   if (split) {
     if (dt == NANN_F16) return launch_search_bitmap<LPR, DT_F16, kScorerMlpSplit, kMlpNT>(vis, slots, lds_bytes, a, st);
     return launch_search_bitmap<LPR, DT_BF16, kScorerMlpSplit, kMlpNT>(vis, slots, lds_bytes, a, st);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* t
         atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
     }
   }
-  wg_mlp_query_setup<kMlpNT>(P, qv, S);
+  wg_mlp_query_setup<kMlpNT>(P, qv, &S->v);
   for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
     const int cnt = (int)((n - c0) < CPP ? (n - c0) : CPP);
     const void* tab = indices ? table : static_cast<const char*>(table) + (size_t)c0 * D * (DT == DT_F32 ? 4 : 2);
@@ -140,9 +140,10 @@ constexpr int hash_phase_scratch() {
 constexpr int kAttnScratch = kAttnSlice * 4;
 template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
-  constexpr int base = (VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32)
-                           ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
-  return (SC == kScorerAttn && base < kAttnScratch) ? kAttnScratch : base;
+  constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
+  constexpr int base = hash ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
+  if (SC == kScorerAttn && base < kAttnScratch) return kAttnScratch;
+  return base;
 }
 
 template <int LPR, int DT, int VIS, int SC, int NT>
@@ -292,7 +293,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                        reinterpret_cast<float*>(scratch), sc_out);
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
-        wg_mlp_query_setup<NT>(a.mlp, qv, M);  // the phase scratch was reused since the last stage
+        wg_mlp_query_setup<NT>(a.mlp, qv, &M->v);  // the phase scratch was reused since the last stage
         if constexpr (SC == kScorerMlpSplit)
           wg_score_mlp_split<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
         else
