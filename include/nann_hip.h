@@ -117,6 +117,18 @@ int nann_bitmap_ref_difference(const int32_t* idx_next_values, int64_t n_values,
                                int64_t* c_row_splits, int64_t* n_out, int64_t* n_out_splits,
                                int32_t* ragged_code, nann_stream_t stream);
 
+/* ---- a8: BloomFilterDifference<int32> (UO/bitmap_op/bitmap_ops.cc:264-425) ----------------
+ * The approximate sibling of BitmapRefDifference (registered by the reference, not wired into the
+ * serving graph): per node, in input order, four positions of a 32 * bucket_size-bit filter from
+ * tensorflow::Fingerprint64 (FarmHash) of the node's decimal string; kept iff one of them was clear;
+ * all four set.  idx_flag (device, int32[n_flag_words >= bucket_size]) mutated in place.  Buffers,
+ * counts and errors as nann_bitmap_ref_difference. */
+int nann_bloom_filter_difference(const int32_t* idx_next_values, int64_t n_values,
+                                 const int64_t* idx_next_row_splits, int64_t n_splits, int32_t* idx_flag,
+                                 int64_t n_flag_words, int64_t bucket, int64_t bucket_size, int32_t* c_values,
+                                 int64_t* c_row_splits, int64_t* n_out, int64_t* n_out_splits,
+                                 int32_t* ragged_code, nann_stream_t stream);
+
 /* ---- a3: GatherV2 axis 0 (core/kernels/gather_functor.h:38-116) ------------
  * out[i,:] = params[indices[i],:]; row_bytes must be a multiple of 4.
  * A bad index returns NANN_ERR_INDEX_OUT_OF_RANGE and its position in *bad_i

@@ -246,6 +246,114 @@ __global__ __launch_bounds__(kNT) void k_bitmap_ref_difference(
   }
 }
 
+// ---- BloomFilterDifference (bitmap_ops.cc:264-425) ------------------------------------------------
+// tensorflow::Fingerprint64 = FarmHash farmhashna::Hash64, restated for the <= 11-byte decimal strings
+// of int32 ids (oracle/nann_oracle.c carries the longer branches and the pinning note).
+__device__ __forceinline__ uint64_t fh_rot(uint64_t v, int s) { return (v >> s) | (v << (64 - s)); }
+__device__ __forceinline__ uint64_t fh_len16(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul; a ^= (a >> 47);
+  uint64_t b = (v ^ a) * mul; b ^= (b >> 47);
+  return b * mul;
+}
+__device__ __forceinline__ uint64_t fingerprint64_short(const unsigned char* s, int len) {  // len in [1, 16]
+  constexpr uint64_t K0 = 0xc3a5c85c97cb3127ULL, K2 = 0x9ae16a3b2f90404fULL;
+  auto fetch = [&](int at, int bytes) { uint64_t v = 0; for (int i = 0; i < bytes; ++i) v |= (uint64_t)s[at + i] << (8 * i); return v; };
+  const uint64_t n = (uint64_t)len;
+  if (len >= 8) {
+    const uint64_t mul = K2 + n * 2, a = fetch(0, 8) + K2, b = fetch(len - 8, 8);
+    return fh_len16(fh_rot(b, 37) * mul + a, (fh_rot(a, 25) + b) * mul, mul);
+  }
+  if (len >= 4) {
+    const uint64_t mul = K2 + n * 2;
+    return fh_len16(n + (fetch(0, 4) << 3), fetch(len - 4, 4), mul);
+  }
+  const uint32_t y = (uint32_t)s[0] + ((uint32_t)s[len >> 1] << 8), z = (uint32_t)n + ((uint32_t)s[len - 1] << 2);
+  uint64_t v = (y * K2) ^ (z * K0);
+  v ^= v >> 47;
+  return v * K2;
+}
+
+struct BloomParams { long long bucket, bucket_size; unsigned long long prime[4]; };
+
+__device__ __forceinline__ void bloom_positions(int32_t node, const BloomParams& B, uint32_t pos[4]) {
+  unsigned char buf[12];  // std::to_string(node), bitmap_ops.cc:346
+  int len = 0;
+  uint32_t mag = node < 0 ? 0u - (uint32_t)node : (uint32_t)node;
+  unsigned char rev[10];
+  int nd = 0;
+  do { rev[nd++] = (unsigned char)('0' + mag % 10u); mag /= 10u; } while (mag);
+  if (node < 0) buf[len++] = '-';
+  while (nd) buf[len++] = rev[--nd];
+  uint64_t raw = fingerprint64_short(buf, len);
+  if (B.bucket > 0) raw = raw % (uint64_t)B.bucket;
+  const uint64_t mult[4] = {1, 3, 5, 7};
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const uint64_t tmp = ((raw * mult[l]) % B.prime[l] + B.prime[l]) % B.prime[l];
+    pos[l] = (uint32_t)(tmp % (uint64_t)(B.bucket_size * 32));
+  }
+}
+
+// One workgroup; the filter is staged in LDS when it fits.  Positions are hashed by all lanes of
+// wavefront 0, 64 nodes per step; the test-and-set of a step runs in node order on one lane (the four
+// positions of a node and of its neighbours may coincide, and which node "misses" decides what is kept).
+template <bool kLds>
+__global__ __launch_bounds__(kNT) void k_bloom_filter_difference(
+    const int32_t* values, long long n_values, const int64_t* row_splits, long long n_splits, uint32_t* flags,
+    long long n_words, BloomParams B, int32_t* c_values, int64_t* c_row_splits, OpResult* res) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = lane_id();
+  if (tid == 0) { res->n_out = 0; res->n_out_splits = 0; res->bad_i = -1; res->code = 0; res->err = 0; }
+  __syncthreads();
+  const int code = validate_ragged(n_values, row_splits, n_splits);
+  if (code) {
+    if (tid == 0) { res->code = code; res->err = NANN_ERR_INVALID_RAGGED_INPUT; }
+    return;
+  }
+  if (n_splits == 1) {  // void input :315-325; filter forwarded untouched
+    if (tid == 0) { c_row_splits[0] = 0; res->n_out = 0; res->n_out_splits = 1; }
+    return;
+  }
+  uint32_t* bm = kLds ? reinterpret_cast<uint32_t*>(smem) : flags;
+  if (kLds) for (long long w = tid; w < n_words; w += kNT) bm[w] = flags[w];
+  __syncthreads();
+  if (wave_id() == 0) {
+    long long out = 0;
+    if (lane == 0) c_row_splits[0] = 0;
+    for (long long g = 0; g + 1 < n_splits; ++g) {
+      const long long s = row_splits[g], e = row_splits[g + 1];
+      for (long long j0 = s; j0 < e; j0 += 64) {
+        const int cnt = (int)((e - j0) < 64 ? (e - j0) : 64);
+        uint32_t pos[4] = {0, 0, 0, 0};
+        int32_t node = 0;
+        if (lane < cnt) { node = values[j0 + lane]; bloom_positions(node, B, pos); }
+        uint64_t keepmask = 0;
+        for (int i = 0; i < cnt; ++i) {  // node order
+          uint32_t p[4];
+#pragma unroll
+          for (int l = 0; l < 4; ++l) p[l] = (uint32_t)__builtin_amdgcn_readlane((int)pos[l], i);
+          int miss = 0;
+          if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+              const uint32_t bit = 1u << (p[l] & 31), w = bm[p[l] >> 5];
+              if (!(w & bit)) { ++miss; bm[p[l] >> 5] = w | bit; }
+            }
+          }
+          miss = __builtin_amdgcn_readfirstlane(miss);
+          if (miss > 0) keepmask |= 1ull << i;
+        }
+        if ((keepmask >> lane) & 1ull) c_values[out + popc64(keepmask & lanemask_lt(lane))] = node;
+        out += popc64(keepmask);
+      }
+      if (lane == 0) c_row_splits[g + 1] = out;
+    }
+    if (lane == 0) { res->n_out = out; res->n_out_splits = n_splits; }
+  }
+  __syncthreads();
+  if (kLds) for (long long w = tid; w < n_words; w += kNT) flags[w] = bm[w];
+}
+
 // GatherV2 axis 0 (gather_functor.h:96-103): word-wise coalesced row copy.
 template <typename W>
 __global__ __launch_bounds__(256) void k_gather_rows(const W* __restrict__ params, long long n_rows,
@@ -693,6 +801,58 @@ int nann_bitmap_ref_difference(const int32_t* values, int64_t n_values, const in
   *n_out = rb->host->n_out;
   *n_out_splits = rb->host->n_out_splits;
   if (rb->host->err) return fail(rb->host->err, "BitmapRefDifference: invalid input");
+  return NANN_OK;
+}
+
+// ---- BloomFilterDifference ---------------------------------------------------------
+static long long bloom_prime_below(long long num) {  // bitmap_ops.cc:384-403
+  for (long long n = num; n > 1; --n) {
+    bool prime = true;
+    for (long long i = (long long)(std::sqrt((double)n) + 1e-6); i > 1; --i)
+      if (n % i == 0) { prime = false; break; }
+    if (prime) return n;
+  }
+  return 1;
+}
+
+int nann_bloom_filter_difference(const int32_t* values, int64_t n_values, const int64_t* row_splits,
+                                 int64_t n_splits, int32_t* idx_flag, int64_t n_flag_words, int64_t bucket,
+                                 int64_t bucket_size, int32_t* c_values, int64_t* c_row_splits, int64_t* n_out,
+                                 int64_t* n_out_splits, int32_t* ragged_code, nann_stream_t stream) {
+  if (!n_out || !n_out_splits) return fail(NANN_ERR_BAD_ARGUMENT, "nann_bloom_filter_difference: null out");
+  if (bucket < 0 || bucket_size < 1 || n_flag_words < bucket_size)
+    return fail(NANN_ERR_BAD_ARGUMENT, "BloomFilterDifference: bucket >= 0, bucket_size >= 1, idx_flag >= bucket_size words");
+  if (bucket_size > (1ll << 26)) return fail(NANN_ERR_UNSUPPORTED, "BloomFilterDifference: filter beyond 2^31 bits");
+  DeviceInfo di;
+  int rc = device_info(&di);
+  if (rc) return rc;
+  ResultBuf* rb;
+  rc = get_result_buf(&rb);
+  if (rc) return rc;
+  BloomParams B;
+  B.bucket = bucket; B.bucket_size = bucket_size;
+  const int modp[4] = {29, 47, 67, 83};  // multi_hash_mod_param, bitmap_ops.cc:297
+  for (int l = 0; l < 4; ++l) B.prime[l] = (unsigned long long)bloom_prime_below((long long)modp[l] * bucket_size * 32);
+  hipStream_t st = as_stream(stream);
+  const size_t lds_need = align_up((size_t)n_flag_words * 4, 16);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(idx_flag);
+  if (lds_need <= di.lds_max) {
+    auto kern = k_bloom_filter_difference<true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)std::max<size_t>(lds_need, 16)));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kNT), std::max<size_t>(lds_need, 16), st, values, (long long)n_values,
+                       row_splits, (long long)n_splits, flags, (long long)n_flag_words, B, c_values, c_row_splits, rb->dev);
+  } else {
+    hipLaunchKernelGGL(k_bloom_filter_difference<false>, dim3(1), dim3(kNT), 16, st, values, (long long)n_values,
+                       row_splits, (long long)n_splits, flags, (long long)n_flag_words, B, c_values, c_row_splits, rb->dev);
+  }
+  HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  if (ragged_code) *ragged_code = rb->host->code;
+  *n_out = rb->host->n_out;
+  *n_out_splits = rb->host->n_out_splits;
+  if (rb->host->err) return fail(rb->host->err, "BloomFilterDifference: invalid input");
   return NANN_OK;
 }
 

@@ -68,17 +68,19 @@ __device__ __forceinline__ float prelu(float x, float a) {
 
 // Per query: u[j] = b1[j] + sum_k q[k] * W1[k][j] (k ascending, fmaf) and the small vectors
 // into LDS.  All NT threads; ends with a barrier.
+// u_scale / b2_scale: the split-f16 form keeps both pre-multiplied by its accumulator scales (exact powers of two)
 template <int NT>
-__device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpVectors* V) {
+__device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpVectors* V,
+                                                   float u_scale = 1.0f, float b2_scale = 1.0f) {
   const int tid = local_tid();
   for (int j = tid; j < P.h1; j += NT) {
     float acc = P.b1[j];
     for (int k = 0; k < P.d; ++k) acc = __fmaf_rn(qv[k], P.w1[(size_t)k * P.h1 + j], acc);
-    V->u[j] = acc;
+    V->u[j] = acc * u_scale;
     V->alpha1[j] = P.alpha1[j];
   }
   for (int m = tid; m < P.h2; m += NT) {
-    V->b2[m] = P.b2[m];
+    V->b2[m] = P.b2[m] * b2_scale;
     V->alpha2[m] = P.alpha2[m];
     V->w3[m] = P.w3[m];
   }
@@ -304,11 +306,15 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
       for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
     }
     f32x16 a2[H2T];
+    // (b2 and u sit in LDS pre-multiplied by the accumulator scales; the lane's 16 rows of a 32-unit tile are
+    //  four runs of 4 consecutive floats: one ds_read_b128 each)
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        a2[mt][r] = V->b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g] * (kSplitWScale * kSplitHScale);
+      for (int rr = 0; rr < 4; ++rr) {
+        const float4 v = *reinterpret_cast<const float4*>(&V->b2[32 * mt + 8 * rr + 4 * g]);
+        a2[mt][4 * rr] = v.x; a2[mt][4 * rr + 1] = v.y; a2[mt][4 * rr + 2] = v.z; a2[mt][4 * rr + 3] = v.w;
+      }
     f32x16 a1;
     f16x8 bh[2], bl[2];
     uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
@@ -325,7 +331,10 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
       }
       if (ks == 0) {  // the per-query part seeds the tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a1[r] = V->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g] * kSplitWScale;
+        for (int rr = 0; rr < 4; ++rr) {
+          const float4 v = *reinterpret_cast<const float4*>(&V->u[32 * t + 8 * rr + 4 * g]);
+          a1[4 * rr] = v.x; a1[4 * rr + 1] = v.y; a1[4 * rr + 2] = v.z; a1[4 * rr + 3] = v.w;
+        }
       }
       if (ks < KS1) {
 #pragma unroll
@@ -339,14 +348,28 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b, a1, 0, 0, 0);
           }
         }
-        if (ks == KS1 - 1) {  // tile complete: scale back, PReLU, split into the layer-2 B fragments (x 2^4)
+        if (ks == KS1 - 1) {  // tile complete: PReLU, scale (x 2^-7 x 2^4; PReLU commutes with a positive
+          // factor) and split into the layer-2 B fragments.  hi is cut with round-toward-zero (one packed
+          // conversion per pair); lo = h - hi is exact in f32 and rounds into 11 more bits.
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float h = prelu(a1[r] * (1.0f / kSplitWScale), V->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * g]) *
-                            kSplitHScale;
-            const _Float16 hh = (_Float16)h;
-            bh[r >> 3][r & 7] = hh;
-            bl[r >> 3][r & 7] = (_Float16)(h - (float)hh);
+          for (int rr = 0; rr < 4; ++rr) {
+            const float4 al = *reinterpret_cast<const float4*>(&V->alpha1[32 * t + 8 * rr + 4 * g]);
+            const float alv[4] = {al.x, al.y, al.z, al.w};
+            float h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float x = a1[4 * rr + k];
+              h[k] = (x > 0.0f ? x : alv[k] * x) * (kSplitHScale / kSplitWScale);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+              typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+              const h2_t hi = __builtin_amdgcn_cvt_pkrtz(h[k], h[k + 1]);
+              const h2_t lo = __builtin_amdgcn_cvt_pkrtz(h[k] - (float)hi[0], h[k + 1] - (float)hi[1]);
+              const int r = 4 * rr + k;
+              bh[r >> 3][r & 7] = (_Float16)hi[0]; bh[r >> 3][(r & 7) + 1] = (_Float16)hi[1];
+              bl[r >> 3][r & 7] = (_Float16)lo[0]; bl[r >> 3][(r & 7) + 1] = (_Float16)lo[1];
+            }
           }
         }
       } else {
@@ -368,11 +391,11 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
-        part = __fmaf_rn(prelu(a2[mt][r] * (1.0f / (kSplitWScale * kSplitHScale)), V->alpha2[m]), V->w3[m], part);
+        part = __fmaf_rn(prelu(a2[mt][r], V->alpha2[m]), V->w3[m], part);  // still x 2^11: scaled back once below
       }
     const float other = __shfl_xor(part, 32);
     const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
-    if (g == 0 && i < n) scores[i] = p0 + p1;
+    if (g == 0 && i < n) scores[i] = (p0 + p1) * (1.0f / (kSplitWScale * kSplitHScale));
   }
   __syncthreads();
 }

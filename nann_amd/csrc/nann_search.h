@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* t
         atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
     }
   }
-  wg_mlp_query_setup<kMlpNT>(P, qv, &S->v);
+  if constexpr (SPLIT) wg_mlp_query_setup<kMlpNT>(P, qv, &S->v, kSplitWScale, kSplitWScale * kSplitHScale);
+  else wg_mlp_query_setup<kMlpNT>(P, qv, &S->v);
   for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
     const int cnt = (int)((n - c0) < CPP ? (n - c0) : CPP);
     const void* tab = indices ? table : static_cast<const char*>(table) + (size_t)c0 * D * (DT == DT_F32 ? 4 : 2);
@@ -293,7 +294,9 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                        reinterpret_cast<float*>(scratch), sc_out);
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
-        wg_mlp_query_setup<NT>(a.mlp, qv, &M->v);  // the phase scratch was reused since the last stage
+        // (the phase scratch was reused since the last stage)
+        if constexpr (SC == kScorerMlpSplit) wg_mlp_query_setup<NT>(a.mlp, qv, &M->v, kSplitWScale, kSplitWScale * kSplitHScale);
+        else wg_mlp_query_setup<NT>(a.mlp, qv, &M->v);
         if constexpr (SC == kScorerMlpSplit)
           wg_score_mlp_split<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
         else

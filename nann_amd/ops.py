@@ -158,6 +158,37 @@ def bitmap_difference(idx_next, idx_flag):
     return out, flags
 
 
+def bloom_filter_difference(idx_next_values, idx_next_row_splits, idx_flag, bucket=0, bucket_size=1):
+    """tf.bloom_filter_difference (UO/bitmap_op/bitmap_ops.cc:264-425): BitmapRefDifference's approximate
+    sibling -- four Fingerprint64-derived positions per node in a 32 * bucket_size-bit filter; a node is kept
+    iff one of them was clear.  `idx_flag` (int32 CUDA tensor) is the Ref input, mutated IN PLACE."""
+    if not (isinstance(idx_flag, torch.Tensor) and idx_flag.is_cuda and idx_flag.dtype == torch.int32
+            and idx_flag.is_contiguous()):
+        raise InvalidArgumentError(7, "idx_flag must be a contiguous int32 CUDA tensor (Ref input)")
+    v = _dev(idx_next_values, torch.int32)
+    rs = _dev(idx_next_row_splits, torch.int64)
+    out = torch.empty(max(v.numel(), 1), dtype=torch.int32, device=v.device)
+    out_rs = torch.zeros(max(rs.numel(), 1), dtype=torch.int64, device=v.device)
+    n_out, n_rs, code = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    st = lib().nann_bloom_filter_difference(
+        _ptr(v), C.c_int64(v.numel()), _ptr(rs), C.c_int64(rs.numel()), _ptr(idx_flag), C.c_int64(idx_flag.numel()),
+        C.c_int64(bucket), C.c_int64(bucket_size), _ptr(out), _ptr(out_rs), C.byref(n_out), C.byref(n_rs),
+        C.byref(code), _stream())
+    _check(st, "BloomFilterDifference")
+    return out[: n_out.value], out_rs[: n_rs.value], idx_flag
+
+
+def blaze_top_k(values, k):
+    """tf.blaze_top_k (UO/topk_op/BlazeTopK_kernel.cc:13-101): the k largest values of each row, sorted by
+    value, and their int32 indices.  The reference finds them by a sampled threshold + std::partial_sort and
+    leaves the order of EQUAL values unspecified; TopKV2's answer (ties -> lower index) is one of its
+    answers, so the same kernel serves.  0 <= k <= input_len is required (:47-48)."""
+    v = _dev(values, torch.float32)
+    if k < 0 or k > v.shape[-1]:
+        raise InvalidArgumentError(7, f"require: 0 <= k <= input_len, but{k} > {v.shape[-1]}")
+    return top_k(v, k)
+
+
 def batch_top_k_on_rt(values, row_splits, k, ascending=False):
     """tf.batch_top_k_on_rt (UO/topk_op/BatchTopKOnRT_kernel.cc:24-155): per ragged row the
     min(k, len) best values, row-local int64 indices and the output row_splits.  Equal values

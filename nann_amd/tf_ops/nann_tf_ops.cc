@@ -310,6 +310,127 @@ REGISTER_KERNEL_BUILDER(Name("BitmapRefDifference").Device(DEVICE_CPU).TypeConst
                         BitmapRefDifferenceHip<int64>);
 
 // ---------------------------------------------------------------------------------
+// BloomFilterDifference: same interface as bitmap_ops.cc:264-286 (registered by the reference next to
+// BitmapRefDifference; not wired into the serving graph).  T = int32 (int64 narrowed as above).
+REGISTER_OP("BloomFilterDifference")
+    .Input("idx_next_values: T")
+    .Input("idx_next_row_splits: int64")
+    .Input("idx_flag: Ref (int32)")
+    .Output("c_values: T")
+    .Output("c_row_splits: int64")
+    .Output("idx_flag_new: Ref (int32)")
+    .Attr("bucket: int >= 0 = 0")
+    .Attr("bucket_size: int >= 1")
+    .Attr("T: {int32, int64}")
+    .SetShapeFn([](shape_inference::InferenceContext* c) {
+      shape_inference::ShapeHandle unused;
+      for (int i = 0; i < 3; ++i) TF_RETURN_IF_ERROR(c->WithRank(c->input(i), 1, &unused));
+      c->set_output(0, c->MakeShape({c->UnknownDim()}));
+      c->set_output(1, c->input(1));
+      c->set_output(2, c->input(2));
+      return Status::OK();
+    });
+
+template <typename T>
+class BloomFilterDifferenceHip : public OpKernel {
+ public:
+  explicit BloomFilterDifferenceHip(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("bucket", &bucket_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("bucket_size", &bucket_size_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor& values = ctx->input(0);
+    const Tensor& row_splits = ctx->input(1);
+    Tensor flags = ctx->mutable_input(2, /*lock_held=*/false);
+    const int64_t n = values.NumElements(), n_rs = row_splits.NumElements(), n_words = flags.NumElements();
+    DeviceBuffer d_v, d_rs, d_flags, d_out, d_out_rs;
+    if (std::is_same<T, int32>::value) {
+      OP_REQUIRES_OK(ctx, d_v.Upload(values.flat<T>().data(), n * 4));
+    } else {
+      std::vector<int32_t> narrowed;
+      OP_REQUIRES_OK(ctx, NarrowToInt32(reinterpret_cast<const int64*>(values.flat<T>().data()), n, &narrowed,
+                                        "idx_next_values"));
+      OP_REQUIRES_OK(ctx, d_v.Upload(narrowed.data(), n * 4));
+    }
+    OP_REQUIRES_OK(ctx, d_rs.Upload(row_splits.flat<int64>().data(), n_rs * 8));
+    OP_REQUIRES_OK(ctx, d_flags.Upload(flags.flat<int32>().data(), n_words * 4));
+    OP_REQUIRES_OK(ctx, d_out.Alloc((n > 0 ? n : 1) * 4));
+    OP_REQUIRES_OK(ctx, d_out_rs.Alloc((n_rs > 0 ? n_rs : 1) * 8));
+    int64_t n_out = 0, n_out_splits = 0;
+    int32_t code = 0;
+    const int st = nann_bloom_filter_difference(d_v.as<int32_t>(), n, d_rs.as<int64_t>(), n_rs, d_flags.as<int32_t>(),
+                                                n_words, bucket_, bucket_size_, d_out.as<int32_t>(),
+                                                d_out_rs.as<int64_t>(), &n_out, &n_out_splits, &code, nullptr);
+    if (st == NANN_ERR_INVALID_RAGGED_INPUT) {  // bitmap_ops.cc:310-312
+      OP_REQUIRES(ctx, false, errors::InvalidArgument("Invalid RaggedTensor input0 a, code: ", code));
+    }
+    OP_REQUIRES_OK(ctx, ToStatus(st, "BloomFilterDifference"));
+    Tensor* c_values = nullptr;
+    Tensor* c_rs = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({n_out}), &c_values));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({n_out_splits}), &c_rs));
+    if (n_out > 0) {
+      std::vector<int32_t> host((size_t)n_out);
+      OP_REQUIRES_OK(ctx, d_out.Download(host.data(), n_out * 4));
+      T* o = c_values->flat<T>().data();
+      for (int64_t i = 0; i < n_out; ++i) o[i] = (T)host[(size_t)i];
+    }
+    OP_REQUIRES_OK(ctx, d_out_rs.Download(c_rs->flat<int64>().data(), n_out_splits * 8));
+    OP_REQUIRES_OK(ctx, d_flags.Download(flags.flat<int32>().data(), n_words * 4));  // in place
+    ctx->forward_ref_input_to_ref_output(2, 2);
+  }
+
+ private:
+  int64 bucket_ = 0, bucket_size_ = 1;
+};
+
+REGISTER_KERNEL_BUILDER(Name("BloomFilterDifference").Device(DEVICE_CPU).TypeConstraint<int32>("T"),
+                        BloomFilterDifferenceHip<int32>);
+REGISTER_KERNEL_BUILDER(Name("BloomFilterDifference").Device(DEVICE_CPU).TypeConstraint<int64>("T"),
+                        BloomFilterDifferenceHip<int64>);
+
+// ---------------------------------------------------------------------------------
+// BlazeTopK: same interface as BlazeTopK_kernel.cc:13-26, T = float (the reference also registers half and
+// double).  Its tie order is unspecified (std::partial_sort), so TopKV2's order is one of its answers.
+REGISTER_OP("BlazeTopK")
+    .Input("input: T")
+    .Input("k: Tindices")
+    .Output("value: T")
+    .Output("index: Tindices")
+    .Attr("T: {half, float, double}")
+    .Attr("Tindices: {int32}")
+    .SetShapeFn(shape_inference::UnknownShape);
+
+class BlazeTopKHip : public OpKernel {
+ public:
+  explicit BlazeTopKHip(OpKernelConstruction* ctx) : OpKernel(ctx) {}
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor& input = ctx->input(0);
+    const int32 k = *ctx->input(1).flat<int32>().data();
+    OP_REQUIRES(ctx, input.dims() >= 1, errors::InvalidArgument("input must be >= 1-D"));
+    const int64_t cols = input.dim_size(input.dims() - 1);
+    const int64_t rows = cols ? input.NumElements() / cols : 0;
+    OP_REQUIRES(ctx, 0 <= k && k <= cols,  // BlazeTopK_kernel.cc:47-48
+                errors::InvalidArgument("require: 0 <= k <= input_len, but", k, " > ", cols));
+    Tensor* value = nullptr;
+    Tensor* index = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({rows, k}), &value));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({rows, k}), &index));
+    if (k == 0 || rows == 0) return;
+    DeviceBuffer d_in, d_v, d_i;
+    OP_REQUIRES_OK(ctx, d_in.Upload(input.flat<float>().data(), rows * cols * 4));
+    OP_REQUIRES_OK(ctx, d_v.Alloc(rows * k * 4));
+    OP_REQUIRES_OK(ctx, d_i.Alloc(rows * k * 4));
+    OP_REQUIRES_OK(ctx, ToStatus(nann_topk(d_in.as<float>(), rows, cols, k, d_v.as<float>(), d_i.as<int32_t>(), nullptr),
+                                 "BlazeTopK"));
+    OP_REQUIRES_OK(ctx, d_v.Download(value->flat<float>().data(), rows * k * 4));
+    OP_REQUIRES_OK(ctx, d_i.Download(index->flat<int32>().data(), rows * k * 4));
+  }
+};
+
+REGISTER_KERNEL_BUILDER(Name("BlazeTopK").Device(DEVICE_CPU).TypeConstraint<float>("T"), BlazeTopKHip);
+
+// ---------------------------------------------------------------------------------
 // HugeConst: same interface as huge_const_op.cc:58-70.  The file is read once at kernel
 // construction into the host tensor every Compute returns (zero-copy set_output, :184-226) and,
 // in the same breath, into HBM; the pair is registered so that the ops above find the resident

@@ -34,6 +34,7 @@
 #ifdef __F16C__
 #include <immintrin.h>
 #endif
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -180,6 +181,107 @@ static int rt_cmp(const void* pa, const void* pb, void* ctx) {
   if (c->asc ? va < vb : va > vb) return -1;
   if (c->asc ? va > vb : va < vb) return 1;
   return a < b ? -1 : (a > b ? 1 : 0); /* ties: lower position (unspecified in the reference) */
+}
+
+/* ------------------------------------------------------------------------ */
+/* FarmHash Fingerprint64 (farmhashna::Hash64) for len <= 32                  */
+static const uint64_t FH_K0 = 0xc3a5c85c97cb3127ULL, FH_K1 = 0xb492b66fbe98f273ULL, FH_K2 = 0x9ae16a3b2f90404fULL;
+static uint64_t fh_fetch64(const char* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static uint64_t fh_fetch32(const char* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t fh_rot(uint64_t v, int s) { return s == 0 ? v : ((v >> s) | (v << (64 - s))); }
+static uint64_t fh_len16(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul; a ^= (a >> 47);
+  uint64_t b = (v ^ a) * mul; b ^= (b >> 47);
+  return b * mul;
+}
+uint64_t oracle_fingerprint64(const char* s, int64_t len) {
+  const uint64_t n = (uint64_t)len;
+  if (len <= 16) {
+    if (len >= 8) {
+      const uint64_t mul = FH_K2 + n * 2, a = fh_fetch64(s) + FH_K2, b = fh_fetch64(s + len - 8);
+      const uint64_t c = fh_rot(b, 37) * mul + a, d = (fh_rot(a, 25) + b) * mul;
+      return fh_len16(c, d, mul);
+    }
+    if (len >= 4) {
+      const uint64_t mul = FH_K2 + n * 2, a = fh_fetch32(s);
+      return fh_len16(n + (a << 3), fh_fetch32(s + len - 4), mul);
+    }
+    if (len > 0) {
+      const uint8_t a = (uint8_t)s[0], b = (uint8_t)s[len >> 1], c = (uint8_t)s[len - 1];
+      const uint32_t y = (uint32_t)a + ((uint32_t)b << 8), z = (uint32_t)n + ((uint32_t)c << 2);
+      uint64_t v = (y * FH_K2) ^ (z * FH_K0);
+      v ^= v >> 47;
+      return v * FH_K2;
+    }
+    return FH_K2;
+  }
+  if (len <= 32) {
+    const uint64_t mul = FH_K2 + n * 2, a = fh_fetch64(s) * FH_K1, b = fh_fetch64(s + 8);
+    const uint64_t c = fh_fetch64(s + len - 8) * mul, d = fh_fetch64(s + len - 16) * FH_K2;
+    return fh_len16(fh_rot(a + b, 43) + fh_rot(c, 30) + d, a + fh_rot(b + FH_K2, 18) + c, mul);
+  }
+  return 0;
+}
+
+/* bitmap_ops.cc:384-411: the largest prime <= multi_hash_mod_param[l] * bucket_size * 32 */
+static int64_t bloom_prime_below(int64_t num) {
+  for (int64_t n = num; n > 1; --n) {
+    int prime = 1;
+    for (int64_t i = (int64_t)(sqrt((double)n) + 1e-6); i > 1; --i)
+      if (n % i == 0) { prime = 0; break; }
+    if (prime) return n;
+  }
+  return 1;
+}
+
+void oracle_bloom_positions(int32_t node, int64_t bucket, int64_t bucket_size, int64_t pos[4]) {
+  static const int mult[4] = {1, 3, 5, 7}, modp[4] = {29, 47, 67, 83}; /* :296-297 */
+  char buf[24];
+  const int len = snprintf(buf, sizeof buf, "%d", node); /* std::to_string(node) :346 */
+  uint64_t raw = oracle_fingerprint64(buf, len);
+  if (bucket > 0) raw = raw % (uint64_t)bucket; /* :348 */
+  for (int l = 0; l < 4; ++l) {
+    const int64_t prime = bloom_prime_below((int64_t)modp[l] * bucket_size * 32);
+    /* uint64 arithmetic as written at :352 (rawHash * mult wraps mod 2^64) */
+    const uint64_t tmp = ((raw * (uint64_t)mult[l]) % (uint64_t)prime + (uint64_t)prime) % (uint64_t)prime;
+    pos[l] = (int64_t)(tmp % (uint64_t)(bucket_size * 32)); /* :353 */
+  }
+}
+
+int oracle_bloom_filter_difference_i32(const int32_t* values, int64_t n_values, const int64_t* row_splits,
+                                       int64_t n_splits, int32_t* idx_flag, int64_t n_flag_words,
+                                       int64_t bucket, int64_t bucket_size, int32_t* out_values,
+                                       int64_t* out_rs, int64_t* n_out, int64_t* n_out_splits,
+                                       int* ragged_code) {
+  const int code = oracle_validate_ragged(n_values, row_splits, n_splits);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_INPUT; /* :310-312 */
+  if (bucket < 0 || bucket_size < 1 || n_flag_words < bucket_size) return ORACLE_ERR_BAD_ARGUMENT;
+  if (n_splits == 1) { /* void input :315-325 */
+    out_rs[0] = 0;
+    *n_out = 0;
+    *n_out_splits = 1;
+    return ORACLE_OK;
+  }
+  uint32_t* bm = (uint32_t*)idx_flag;
+  int64_t w = 0;
+  out_rs[0] = 0;
+  for (int64_t i = 0; i < n_splits - 1; ++i) {
+    for (int64_t j = row_splits[i]; j < row_splits[i + 1]; ++j) {
+      int64_t pos[4];
+      oracle_bloom_positions(values[j], bucket, bucket_size, pos);
+      int miss = 0;
+      for (int l = 0; l < 4; ++l) { /* :350-361: test and set, one position after the other */
+        const uint32_t bit = 1u << (pos[l] & 31);
+        if (!(bm[pos[l] >> 5] & bit)) { ++miss; bm[pos[l] >> 5] |= bit; }
+      }
+      if (miss > 0) out_values[w++] = values[j];
+    }
+    out_rs[i + 1] = w;
+  }
+  *n_out = w;
+  *n_out_splits = n_splits;
+  return ORACLE_OK;
 }
 
 int oracle_batch_topk_on_rt_f32(const float* values, int64_t n_values, const int64_t* row_splits,

@@ -101,6 +101,27 @@ int oracle_bitmap_difference_i32(const int32_t* idx_next, int64_t n, const int32
  * uses std::partial_sort_copy, whose order among EQUAL values is unspecified; this
  * restatement breaks ties by lower position (one of the valid outcomes).
  * k_is_scalar: k[0] applies to every row (:99-101). */
+/* tensorflow::Fingerprint64 (core/platform/fingerprint.h) = farmhash::Fingerprint64, an un-vendored
+ * dependency of the fork (FarmHash, farmhashna::Hash64): restated from the published algorithm for
+ * strings of up to 32 bytes (decimal ids never exceed 20).  Pinned by the fork's own known answers,
+ * core/platform/fingerprint_test.cc:27-28 ("Hello", "World": the 4..7-byte branch); the other length
+ * branches follow the published text only -> parity unpinned there.  Longer input returns 0. */
+uint64_t oracle_fingerprint64(const char* s, int64_t len);
+
+/* BloomFilterDifference<int32> (UO/bitmap_op/bitmap_ops.cc:264-425): per node, in input order, four
+ * positions of a 32 * bucket_size-bit filter derived from Fingerprint64 of its DECIMAL STRING (:346-357,
+ * primes from init_prime_array :405-411); the node is kept iff at least one of the four bits was clear,
+ * and all four are set.  Approximate by design (false "visited"), exact in its arithmetic.  One filter
+ * for all groups; void input -> ([], [0]).  n_flag_words >= bucket_size is the caller's contract (the
+ * reference indexes without a check); here a shorter array is ORACLE_ERR_BAD_ARGUMENT. */
+int oracle_bloom_filter_difference_i32(const int32_t* values, int64_t n_values, const int64_t* row_splits,
+                                       int64_t n_splits, int32_t* idx_flag, int64_t n_flag_words,
+                                       int64_t bucket, int64_t bucket_size, int32_t* out_values,
+                                       int64_t* out_rs, int64_t* n_out, int64_t* n_out_splits,
+                                       int* ragged_code);
+/* the four filter positions of one node (exposed for the device kernel's parity test) */
+void oracle_bloom_positions(int32_t node, int64_t bucket, int64_t bucket_size, int64_t pos[4]);
+
 int oracle_batch_topk_on_rt_f32(const float* values, int64_t n_values, const int64_t* row_splits,
                                 int64_t n_splits, const int64_t* k, int k_is_scalar, int ascending,
                                 float* values_out, int64_t* idx_out, int64_t* row_splits_out,

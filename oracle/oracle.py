@@ -143,6 +143,33 @@ def bitmap_difference(idx_next, idx_flag):
     return rc, out[:n_out.value].copy(), fnew[:len(f)]
 
 
+def fingerprint64(s):
+    b = s.encode() if isinstance(s, str) else bytes(s)
+    lib().oracle_fingerprint64.restype = C.c_uint64
+    return int(lib().oracle_fingerprint64(C.c_char_p(b), C.c_int64(len(b))))
+
+
+def bloom_filter_difference(values, row_splits, idx_flag, bucket=0, bucket_size=1):
+    """idx_flag: int32 array, mutated in place.  -> (status, ragged_code, c_values, c_row_splits)"""
+    v = _c(values, np.int32); rs = _c(row_splits, np.int64)
+    assert idx_flag.dtype == np.int32 and idx_flag.flags["C_CONTIGUOUS"]
+    out = np.zeros(max(len(v), 1), np.int32); out_rs = np.zeros(max(len(rs), 1), np.int64)
+    n_out, n_rs, code = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    rc = lib().oracle_bloom_filter_difference_i32(_p(v), C.c_int64(len(v)), _p(rs), C.c_int64(len(rs)), _p(idx_flag),
+                                                  C.c_int64(len(idx_flag)), C.c_int64(bucket), C.c_int64(bucket_size),
+                                                  _p(out), _p(out_rs), C.byref(n_out), C.byref(n_rs), C.byref(code))
+    return rc, code.value, out[: n_out.value], out_rs[: n_rs.value]
+
+
+def blaze_topk(values, k):
+    """BlazeTopK (UO/topk_op/BlazeTopK_kernel.cc:64-101): the k largest values, sorted by value; the order of
+    equal values is unspecified there (std::partial_sort), so any top_k answer is one of its answers."""
+    v = _c(values, np.float32)
+    if k < 0 or k > len(v):
+        return ERR_BAD_ARGUMENT, np.zeros(0, np.float32), np.zeros(0, np.int32)
+    return topk(v, k)
+
+
 def batch_topk_on_rt(values, row_splits, k, ascending=False):
     v = _c(values, np.float32); rs = _c(row_splits, np.int64)
     scalar = np.ndim(k) == 0

@@ -9,6 +9,7 @@ Sources (relative to /root/reference/tensorflow/tensorflow/):
   python/kernel_tests/gather_op_test.py  GatherV2 axis-0 literals :64-76, :92-108,
                                          :257-272 (batch_dims=0 == tf.gather); error :214-220
   core/user_ops/beam_search_op/group_gather_test.py:7-10   GroupGather docstring example
+  core/platform/fingerprint_test.cc:27-28                  Fingerprint64 known answers
 
 "recipe" cases: the reference test builds the input with np.random.permutation(np.linspace
 (...)) and the expected output with np.argsort / np.sort (mergesort where it says so); the
@@ -121,6 +122,12 @@ def main():
             "params_values": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9], "params_row_splits": [0, 2, 5, 7, 10],
             "indices_values": [0, 1, 3], "indices_row_splits": [0, 2, 3],
             "ret_values": [0, 1, 2, 3, 4, 7, 8, 9], "ret_row_splits": [0, 5, 8]}],
+        # tensorflow::Fingerprint64 (FarmHash, un-vendored): what BloomFilterDifference hashes node strings with
+        "fingerprint64": [
+            {"name": "Fingerprint64(\"Hello\")", "kind": "literal", "src": "core/platform/fingerprint_test.cc:27",
+             "input": "Hello", "expected": 15404698994557526151},
+            {"name": "Fingerprint64(\"World\")", "kind": "literal", "src": "core/platform/fingerprint_test.cc:28",
+             "input": "World", "expected": 18308117990299812472}],
     }
     with open(os.path.join(HERE, "reference_held.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
