@@ -373,3 +373,30 @@ def test_search_model_serving_signature(oracle, tmp_path, kind):
     assert (st == est).sum() >= nq - 2
     assert kinds.count("exact") >= 0.8 * len(kinds), kinds
     assert kinds.count("diverged") <= 2, kinds
+
+
+def test_recall_harness_test_and_test_all(oracle):
+    """f3: the reference's evaluation jobs (main.py:144-237) on the HIP ops -- `test` (eval-graph retrieval)
+    and `test_all` (brute force), scored with calc_pr (util.py:14-25): one ground-truth item per user.
+    Ground truth here = the item the brute force ranks first, so test_all's recall@k is 1 by construction and
+    test's recall says how often the traversal keeps the best item."""
+    from nann_amd import evaluate, ops
+    assert evaluate.calc_pr(5, [1, 5, 9, 9]) == (1 / 3, 1.0, 0.5)   # a set of 3 retrieved ids, one hit
+    assert evaluate.calc_pr(4, [1, 5]) == (0.0, 0.0, 0.0)
+    g, oix, dix = synth_index(20000, 64, 32)
+    seqs = queries_for(g, 24, seed=3)
+    sc = ops.Scorer("l2", 64)
+    truths = []
+    for s in seqs:
+        q = ops.user_seq_mean(cuda(s)[None])[0]
+        _, bi = ops.top_k(ops.blaze_score(sc, q, item_emb=dix.item_embs), 1)
+        truths.append(int(dix.item_ids[bi.long()].cpu()[0]))
+    all_ = evaluate.test_all(dix, sc, seqs, truths, topk_eval=(10, 50))
+    assert all_["recall"][10].avg == 1.0 and abs(all_["precision"][50].avg - 1 / 50) < 1e-12
+    got = evaluate.test(dix, sc, seqs, truths, topk_eval=(10, 50), num_scoring_per_level=(2, 1, 1),
+                        top_k_per_level=(100, 60, 30))
+    assert got["recall"][50].avg >= 0.7 and got["recall"][10].avg <= got["recall"][50].avg
+    # the traversal's first hit is the oracle's eval-graph answer for the same user
+    q0 = oracle.user_seq_mean(seqs[0])
+    rc, eids, _, _ = oracle.search_eval(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q0, (2, 1, 1), (100, 60, 30), 50)
+    assert rc == 0 and (truths[0] in eids[:50].tolist()) == (evaluate.calc_pr(truths[0], eids[:50])[1] == 1.0)
