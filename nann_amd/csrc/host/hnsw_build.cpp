@@ -179,10 +179,23 @@ void insert(Hnsw& h, int64_t id, Visited& vis, std::vector<std::mutex>& locks, s
     std::vector<Cand> sel = w;
     shrink(h, sel, h.nb_at(level));                                         // alg. 1 l.10
     {
+      // A multi-threaded build makes `id` discoverable on level L before its level L-1 list is written:
+      // another thread may already have back-linked into that (still empty) list.  Those entries are
+      // merged with our selection instead of being overwritten (Faiss holds the node's lock for the
+      // whole insertion; the links it would have seen are the ones kept here).
       std::lock_guard<std::mutex> lk(locks[(size_t)id]);
       int32_t* l = h.links(id, level);
+      const int cap = h.nb_at(level);
+      std::vector<Cand> merged = sel;
+      for (int i = 0; i < cap && l[i] >= 0; ++i) {
+        bool have = false;
+        for (const Cand& c : sel) have |= c.second == (int64_t)l[i];
+        if (!have) merged.emplace_back(h.dist(q, l[i]), (int64_t)l[i]);
+      }
+      if ((int)merged.size() > cap) shrink(h, merged, cap);
       int i = 0;
-      for (const Cand& c : sel) l[i++] = (int32_t)c.second;
+      for (const Cand& c : merged) l[i++] = (int32_t)c.second;
+      for (; i < cap; ++i) l[i] = -1;
     }
     for (const Cand& c : sel) {                                             // alg. 1 l.11-16
       std::lock_guard<std::mutex> lk(locks[(size_t)c.second]);

@@ -264,8 +264,8 @@ def search_eval_per_op(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=
     q = q.reshape(-1)
 
     def get_scores(idx):                                                     # :240-262
-        if idx.numel() == 0:
-            raise ops.InternalError(6, "Error when getting input address or size")
+        if idx.numel() == 0:  # plain TF scoring of an empty batch: an empty tensor, the level loop goes on
+            return torch.empty(0, dtype=torch.float32, device=idx.device)   # (only the serving graph's BlazeXlaOp fails here)
         return B.blaze_score(scorer, q, table=index.item_embs, indices=idx)
 
     def top_k(ids, scores, k):                                               # :264-283, k = min(k, n)

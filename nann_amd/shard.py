@@ -68,10 +68,13 @@ class Comm:
         self.world, self.rank = world, rank
         idb = np.zeros(128, np.uint8)
         if world > 1:
-            if rank == 0:
-                _check(lib().nann_comm_get_unique_id(idb.ctypes.data_as(C.c_void_p)), "comm id")
-            box = [idb.tobytes()]
+            box = [None]
+            if rank == 0:  # a failure here must reach every rank, or the others would wait in the broadcast forever
+                st = lib().nann_comm_get_unique_id(idb.ctypes.data_as(C.c_void_p))
+                box = [idb.tobytes() if st == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise RuntimeError("nann_comm_get_unique_id failed on rank 0 (RCCL not loadable?)")
             idb = np.frombuffer(box[0], np.uint8).copy()
         self.handle = C.c_void_p(0)
         _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(rank), idb.ctypes.data_as(C.c_void_p),

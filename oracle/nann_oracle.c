@@ -950,7 +950,14 @@ int oracle_search_eval(const oracle_index_t* ix, const oracle_scorer_t* sc, cons
       }
       qsort(nxt, (size_t)n_next, 4, cmp_i32);
       for (int64_t i = 0; i < n_next; ++i) { seen[nxt[i]] = 0; visited[nxt[i]] = 1; } /* :321 */
-      if (n_next == 0) { rc = ORACLE_ERR_EMPTY_SCORE_BATCH; goto done; }
+      if (n_next == 0) {
+        /* exhausted frontier: the eval graph scores with plain TF ops (get_scores, :240-262), which return
+         * an empty tensor for an empty batch -- unlike the serving graph's BlazeXlaOp, nothing fails.  The
+         * concat adds nothing, top_k keeps min(k, n) of the (sorted) result, no candidate passes the mask. */
+        if (top_k_per_level[level] < n_res) n_res = top_k_per_level[level];
+        n_cand = 0;
+        continue;
+      }
       rc = forward(ix, sc, q, nxt, n_next, nxt_sc, &tmp, &tmp_cap); /* :323 */
       if (rc == ORACLE_ERR_TOPK_SCALAR_INPUT) rc = ORACLE_OK;
       if (rc) goto done;

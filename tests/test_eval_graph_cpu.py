@@ -60,6 +60,8 @@ def cpu_index(z):
     ((2, 2, 1), (50, 30, 10), 20),
     ((1, 1, 1), (5000, 5000, 5000), 64),  # every k above what exists: the min(k, n) guard
     ((3, 1, 1), (16, 8, 4), 200),         # topk_eval above the result size
+    ((40, 12, 1), (5000, 5000, 5000), 200),  # more rounds than the graph has nodes to offer: the frontier runs
+                                             # dry and the eval graph carries on with empty tensors (no error)
 ])
 def test_eval_graph_composition_matches_oracle(oracle, golden_dir, name, num_scoring, top_k_per_level, topk_eval):
     from nann_amd import retrieval
