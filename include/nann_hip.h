@@ -307,6 +307,31 @@ int nann_search_model(const nann_index* ix, const nann_model* m, const void* com
                       int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                       int32_t* counters, nann_stream_t stream);
 
+/* ---- 8(f3): the evaluation graph's traversal, one kernel per batch of users ---------------
+ * Model.retrieval + search_level (NANN_impls/nann/model.py:299-362), the traversal behind
+ * main.py --job-type test: start level scored whole, then levels 1 and 0 with
+ * num_scoring_per_level[level] rounds each; neighbours taken as an ascending SET minus visited
+ * (tf.unique + tf.sets.difference), top_k = min(k, n), next frontier = new nodes scoring at least
+ * the worst kept result, an exhausted frontier is not an error.  Arrays are indexed by level
+ * (config.py:50-58); num_scoring_per_level[2] must be 1, top_k_per_level and topk_eval in [1, 1024].
+ * Outputs [n_queries, topk_eval] (out_scores / out_index may be NULL); n_out[q] = valid rows of
+ * query q (the rest is zero); status[q] as nann_search (NANN_ERR_CAPACITY: more than 1024 new nodes
+ * tie at the threshold of one round).  Bit-identical to oracle_search_eval for the l2 and exact mlp
+ * scorers.  workspace: nann_search_eval_workspace_bytes(ix, model or NULL, n_queries).
+ * nann_search_eval_model: comm_seq f16[n_queries, seq_len, E] in, as nann_search_model. */
+int nann_search_eval_workspace_bytes(const nann_index* ix, const nann_model* m, int64_t n_queries,
+                                     int64_t* nbytes);
+int nann_search_eval(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                     const int32_t num_scoring_per_level[3], const int32_t top_k_per_level[3],
+                     int32_t topk_eval, void* workspace, int64_t workspace_bytes, int64_t* out_item_ids,
+                     float* out_scores, int32_t* out_index, int32_t* n_out, int32_t* status,
+                     nann_stream_t stream);
+int nann_search_eval_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16,
+                           int64_t n_queries, const int32_t num_scoring_per_level[3],
+                           const int32_t top_k_per_level[3], int32_t topk_eval, void* workspace,
+                           int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
+                           int32_t* out_index, int32_t* n_out, int32_t* status, nann_stream_t stream);
+
 /* ---- 8(e): merge of per-shard top-k lists ----------------------------------
  * scores f32[n_queries, n_shards, k_in], ids i64[n_queries, n_shards, k_in]
  * (shard-major as all-gathered); concat in shard order, then TopKV2 order

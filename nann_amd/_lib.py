@@ -34,7 +34,8 @@ SYMBOLS = [
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
     "nann_search", "nann_search_ex", "nann_set_traversal_mode", "nann_search_model_workspace_bytes",
-    "nann_search_model", "nann_merge_topk", "nann_merge_topk_host",
+    "nann_search_model", "nann_search_eval_workspace_bytes", "nann_search_eval", "nann_search_eval_model",
+    "nann_merge_topk", "nann_merge_topk_host",
     "nann_attn_scorer_create", "nann_attn_scorer_destroy", "nann_attn_prepare", "nann_attn_score",
     "nann_model_load", "nann_model_destroy", "nann_model_kind", "nann_model_scorer", "nann_model_workspace_bytes", "nann_model_forward",
     "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_sharded_topk_workspace_bytes",

@@ -1,7 +1,7 @@
 // nann_hip.hip -- kernels + C ABI of libnann_hip.so (gfx950 only).
 // The ABI is documented in include/nann_hip.h; the workgroup building blocks
 // in nann_device.h.  Reference citations are relative to /root/reference/.
-#include "nann_search.h"
+#include "nann_eval.h"
 #include "nann_attn.h"
 
 #include <algorithm>
@@ -1672,6 +1672,133 @@ int nann_search_model(const nann_index* ix, const nann_model* m, const void* com
   if (rc) return rc;
   return search_impl(ix, m->scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, workspace, search_bytes,
                      out_item_ids, out_scores, out_index, status, counters, nullptr, st);
+}
+
+// ---- the evaluation graph's traversal (nann_eval.h) ----------------------------------------
+}  // extern "C"
+
+static int eval_plan(const nann_index* ix, int64_t n_queries, int* cat_cap, unsigned long long* slot_bytes, int* slots) {
+  DeviceInfo di;
+  const int rc = device_info(&di);
+  if (rc) return rc;
+  // result || next: a frontier holds at most kMaxK rows, a set at most every item
+  const int64_t deg = std::max<int64_t>(std::max(ix->max_deg[0], ix->max_deg[1]), 1);
+  const int64_t nxt = std::max<int64_t>(std::min<int64_t>(ix->desc.n_items, (int64_t)kMaxK * deg), ix->desc.n_enter);
+  if (kMaxK + nxt > 0x3fffffffll) return fail(NANN_ERR_UNSUPPORTED, "candidate bound too large");
+  *cat_cap = (int)(kMaxK + nxt);
+  unsigned long long off[7];
+  *slot_bytes = eval_slot_layout(ix->bm_words, *cat_cap, off);
+  *slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * 2));
+  return NANN_OK;
+}
+
+static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann_attn_scorer* attn, const float* q,
+                     const float* kt, const float* upad, int64_t n_queries, const int32_t num_scoring[3],
+                     const int32_t top_k[3], int32_t topk_eval, void* workspace, int64_t workspace_bytes,
+                     int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* n_out, int32_t* status,
+                     hipStream_t st) {
+  if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
+  if (num_scoring[2] != 1) return fail(NANN_ERR_BAD_ARGUMENT, "num_scoring_per_level[2] must be 1 (model.py:347)");
+  for (int l = 0; l < 3; ++l)
+    if (top_k[l] < 1 || top_k[l] > kMaxK || num_scoring[l] < 0)
+      return fail(NANN_ERR_UNSUPPORTED, "top_k_per_level entries must be in [1, 1024]");
+  if (topk_eval < 1 || topk_eval > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "topk_eval must be in [1, 1024]");
+  EvalArgs a;
+  int slots = 0;
+  int rc = eval_plan(ix, n_queries, &a.cat_cap, &a.slot_bytes, &slots);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < (int64_t)(256 + a.slot_bytes * (unsigned long long)slots))
+    return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_eval_workspace_bytes()");
+  a.emb = ix->desc.item_embs;
+  a.item_ids = ix->desc.item_ids;
+  for (int l = 0; l < 2; ++l) { a.nbv[l] = ix->desc.nb_values[l]; a.nbrs[l] = ix->desc.nb_row_splits[l]; }
+  a.enter = ix->desc.enter_points;
+  a.n_enter = (int)ix->desc.n_enter;
+  a.n_items = (uint32_t)ix->desc.n_items;
+  a.d = ix->desc.d;
+  a.q = q;
+  a.n_queries = (int)n_queries;
+  for (int l = 0; l < 3; ++l) { a.num_scoring[l] = num_scoring[l]; a.top_k[l] = top_k[l]; }
+  a.topk_eval = topk_eval;
+  a.ws = static_cast<unsigned char*>(workspace);
+  a.bm_words = ix->bm_words;
+  a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index; a.n_out = n_out; a.status = status;
+  a.mlp = MlpParams{};
+  a.attn = AttnParams{};
+  a.kt = kt; a.upad = upad;
+  HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+  const int dt = ix->desc.emb_dtype, d = ix->desc.d;
+  if (attn) {
+    a.attn = attn->P;
+    return launch_eval_attn(d, dt, slots, a, st);
+  }
+  if (scorer->desc.kind == NANN_SCORER_MLP) {
+    a.mlp = scorer->mlp;  // (always the f32 MFMA form: the evaluation job is the accuracy reference)
+    if (d == 64) return launch_eval_mlp_d64(dt, slots, a, st);
+    if (d == 128) return launch_eval_mlp_d128(dt, slots, a, st);
+    if (d == 256) return launch_eval_mlp_d256(dt, slots, a, st);
+    return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d in {64, 128, 256}");
+  }
+  return launch_eval_l2(d / 8, dt, slots, a, st);
+}
+
+extern "C" {
+
+int nann_search_eval_workspace_bytes(const nann_index* ix, const nann_model* m, int64_t n_queries, int64_t* nbytes) {
+  if (!ix || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_eval_workspace_bytes: null argument");
+  int cat_cap = 0, slots = 0;
+  unsigned long long slot_bytes = 0;
+  const int rc = eval_plan(ix, n_queries, &cat_cap, &slot_bytes, &slots);
+  if (rc) return rc;
+  *nbytes = (int64_t)(256 + slot_bytes * (unsigned long long)slots + 256 + (m ? model_query_bytes(m, n_queries) : 0));
+  return NANN_OK;
+}
+
+int nann_search_eval(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                     const int32_t num_scoring_per_level[3], const int32_t top_k_per_level[3], int32_t topk_eval,
+                     void* workspace, int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
+                     int32_t* out_index, int32_t* n_out, int32_t* status, nann_stream_t stream) {
+  if (!ix || !scorer || !q || !num_scoring_per_level || !top_k_per_level || !out_item_ids || !n_out || !status)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_eval: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  return eval_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, num_scoring_per_level, top_k_per_level, topk_eval,
+                   workspace, workspace_bytes, out_item_ids, out_scores, out_index, n_out, status, as_stream(stream));
+}
+
+int nann_search_eval_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                           const int32_t num_scoring_per_level[3], const int32_t top_k_per_level[3],
+                           int32_t topk_eval, void* workspace, int64_t workspace_bytes, int64_t* out_item_ids,
+                           float* out_scores, int32_t* out_index, int32_t* n_out, int32_t* status,
+                           nann_stream_t stream) {
+  if (!ix || !m || !comm_seq_f16 || !num_scoring_per_level || !top_k_per_level || !out_item_ids || !n_out || !status ||
+      !workspace)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_eval_model: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (m->d != ix->desc.d || m->emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "model and index disagree on d / dtype");
+  int64_t need = 0;
+  int rc = nann_search_eval_workspace_bytes(ix, m, n_queries, &need);
+  if (rc) return rc;
+  if (workspace_bytes < need) return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_eval_workspace_bytes()");
+  const size_t qb = model_query_bytes(m, n_queries);
+  const int64_t search_bytes = need - (int64_t)qb - 256;
+  unsigned char* qbuf = static_cast<unsigned char*>(workspace) + ((search_bytes + 255) & ~255ll);
+  hipStream_t st = as_stream(stream);
+  if (m->kind == NANN_MODEL_ATTENTION) {
+    float* kt = reinterpret_cast<float*>(qbuf);
+    float* upad = kt + (size_t)n_queries * 256 * 64;
+    rc = nann_attn_prepare(m->attn, comm_seq_f16, n_queries, kt, upad, stream);
+    if (rc) return rc;
+    return eval_impl(ix, nullptr, m->attn, nullptr, kt, upad, n_queries, num_scoring_per_level, top_k_per_level,
+                     topk_eval, workspace, search_bytes, out_item_ids, out_scores, out_index, n_out, status, st);
+  }
+  float* q = reinterpret_cast<float*>(qbuf);
+  rc = nann_user_seq_mean(comm_seq_f16, n_queries, m->seq_len, m->d, q, stream);
+  if (rc) return rc;
+  return eval_impl(ix, m->scorer, nullptr, q, nullptr, nullptr, n_queries, num_scoring_per_level, top_k_per_level,
+                   topk_eval, workspace, search_bytes, out_item_ids, out_scores, out_index, n_out, status, st);
 }
 
 // ---- merge ------------------------------------------------------------------------------

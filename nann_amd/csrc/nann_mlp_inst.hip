@@ -1,7 +1,7 @@
 // nann_mlp_inst.hip -- MLP-scorer instantiations of the fused traversal and of the
 // stand-alone scorer for ONE embedding dim (-DNANN_MLP_D=64|128|256), so that the three
 // heavy objects (1024 unrolled MFMAs each) compile in parallel.
-#include "nann_search.h"
+#include "nann_eval.h"
 
 #ifndef NANN_MLP_D
 #error "compile with -DNANN_MLP_D=64|128|256"
@@ -22,6 +22,14 @@ int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int sl
   }
   if (dt == NANN_F16) return launch_search_bitmap<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT>(vis, slots, lds_bytes, a, st);
   return launch_search_bitmap<LPR, DT_BF16, NANN_SCORER_MLP, kMlpNT>(vis, slots, lds_bytes, a, st);
+}
+
+// evaluation-graph traversal (nann_eval.h), f32 MFMA scorer
+int NANN_CAT(launch_eval_mlp_d, NANN_MLP_D)(int dt, int slots, const EvalArgs& a, hipStream_t st) {
+  constexpr int LPR = NANN_MLP_D / 8;
+  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT>(slots, a, st);
+  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_MLP, kMlpNT>(slots, a, st);
+  return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
 }
 
 int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P,

@@ -46,20 +46,33 @@ def _query(scorer, seq):
 
 
 def test(index, scorer, user_seqs, ground_truths, topk_eval=(200,), num_scoring_per_level=(3, 1, 1),
-         top_k_per_level=(400, 200, 100), num_test_batch=None):
-    """main.py:144-188 -> ({topk: recall meter}, mean number of scored items per user).  Retrieval =
-    retrieval.search_eval_per_op (threshold frontier, min(k, n) guard, per-level round counts)."""
+         top_k_per_level=(400, 200, 100), num_test_batch=None, fused=True):
+    """main.py:144-188 -> {"precision" | "recall" | "f1": {topk: meter}}.  Retrieval = Model.retrieval's
+    traversal (threshold frontier, min(k, n) guard, per-level round counts): all users in ONE kernel
+    (retrieval.search_eval, the default) or op by op (retrieval.search_eval_per_op, fused=False).  `scorer`:
+    ops.Scorer (the query is the mean of the user's history rows) or ops.Model (user_seqs go in as they are)."""
     n = len(ground_truths) if num_test_batch is None else min(num_test_batch, len(ground_truths))
     prec, rec, f1m = defaultdict(AverageMeter), defaultdict(AverageMeter), defaultdict(AverageMeter)
-    seqs = torch.as_tensor(np.asarray(user_seqs)).to(index.device)
+    seqs = torch.as_tensor(np.asarray(user_seqs)).to(index.device)[:n]
+    kmax = max(topk_eval)
+    if fused:
+        q = seqs if isinstance(scorer, ops.Model) else ops.user_seq_mean(seqs)
+        r = retrieval.search_eval(index, scorer, q, num_scoring_per_level, top_k_per_level, kmax)
+        status, n_out, all_ids = r.status.cpu().numpy(), r.n_out.cpu().numpy(), r.item_ids.cpu().numpy()
+        if status.any():
+            raise RuntimeError(f"eval traversal failed for users {np.nonzero(status)[0][:8].tolist()}: "
+                               f"status {status[status != 0][:8].tolist()}")
     for u in range(n):
-        ids, _, _ = retrieval.search_eval_per_op(index, scorer, _query(scorer, seqs[u]), num_scoring_per_level,
-                                                 top_k_per_level, max(topk_eval))
-        ids = ids.cpu().numpy()
+        if fused:
+            ids = all_ids[u, :n_out[u]]
+        else:
+            ids, _, _ = retrieval.search_eval_per_op(index, scorer, _query(scorer, seqs[u]), num_scoring_per_level,
+                                                     top_k_per_level, kmax)
+            ids = ids.cpu().numpy()
         for k in topk_eval:
             assert ids.shape[0] >= k  # main.py:169
-            p, r, f = calc_pr(ground_truths[u], ids[:k])
-            prec[k].update(p); rec[k].update(r); f1m[k].update(f)
+            p, r_, f = calc_pr(ground_truths[u], ids[:k])
+            prec[k].update(p); rec[k].update(r_); f1m[k].update(f)
     return {"precision": prec, "recall": rec, "f1": f1m}
 
 

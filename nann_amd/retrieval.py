@@ -179,6 +179,40 @@ def search_model(index, model, comm_seq, level_topn, want_counters=True):
     return SearchResult(out_ids, out_scores, out_index, status, counters, None)
 
 
+class EvalResult:
+    """Outputs of search_eval: rows [b, :n_out[b]] are valid (the rest is zero)."""
+
+    def __init__(self, item_ids, scores, index, n_out, status):
+        self.item_ids, self.scores, self.index, self.n_out, self.status = item_ids, scores, index, n_out, status
+
+
+def search_eval(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 200, 100), topk_eval=200):
+    """Model.retrieval() (model.py:299-362) for a batch of users in ONE kernel (nann_search_eval /
+    nann_search_eval_model).  `scorer`: ops.Scorer with q f32[B, d], or ops.Model with q = comm_seq
+    f16[B, seq_len, E].  Same results as search_eval_per_op, user by user."""
+    is_model = isinstance(scorer, ops.Model)
+    dev = index.device
+    q = q.to(device=dev, dtype=torch.float16 if is_model else torch.float32).contiguous()
+    b, k = q.shape[0], int(topk_eval)
+    ns = (C.c_int32 * 3)(*[int(x) for x in num_scoring])
+    tk = (C.c_int32 * 3)(*[int(x) for x in top_k_per_level])
+    out_ids = torch.empty((b, k), dtype=torch.int64, device=dev)
+    out_scores = torch.empty((b, k), dtype=torch.float32, device=dev)
+    out_index = torch.empty((b, k), dtype=torch.int32, device=dev)
+    n_out = torch.empty(b, dtype=torch.int32, device=dev)
+    status = torch.empty(b, dtype=torch.int32, device=dev)
+    nbytes = C.c_int64(0)
+    _check(lib().nann_search_eval_workspace_bytes(index.handle, scorer.handle if is_model else None, C.c_int64(b),
+                                                  C.byref(nbytes)))
+    ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+    fn = lib().nann_search_eval_model if is_model else lib().nann_search_eval
+    with torch.cuda.device(dev):
+        _check(fn(index.handle, scorer.handle, _ptr(q), C.c_int64(b), ns, tk, C.c_int32(k), _ptr(ws),
+                  C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index), _ptr(n_out), _ptr(status),
+                  _stream()), "search_eval")
+    return EvalResult(out_ids, out_scores, out_index, n_out, status)
+
+
 # -----------------------------------------------------------------------------
 # build_model() spelled with the per-op drop-ins (one query)
 def _fake_row_splits(x):

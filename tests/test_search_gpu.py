@@ -309,6 +309,78 @@ def test_eval_graph_matches_oracle(oracle, kind):
     assert n_ok >= 6
 
 
+@pytest.mark.parametrize("kind", ["l2", "mlp"])
+def test_fused_eval_graph_matches_oracle(oracle, kind):
+    """f3 in one kernel (nann_search_eval): every user of a batch equals oracle_search_eval bit for bit --
+    ids, scores, internal indices, number of rows -- for the reference's defaults (config.py:50-58), narrow
+    levels, and a shape whose frontier runs dry (min(k, n) guard, empty score batch is not an error)."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 64, 32)
+    w = synth.make_mlp_weights(64) if kind == "mlp" else None
+    osc = oracle.Scorer(kind, 64, oracle.EMB_F16, w)
+    sc = ops.Scorer(kind, 64, torch.float16, w)
+    qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 40 if kind == "l2" else 12, seed=9)])
+    for cfg in [((3, 1, 1), (400, 200, 100), 200), ((2, 2, 1), (60, 40, 16), 30), ((1, 0, 1), (50, 50, 8), 64),
+                ((3, 2, 1), (1024, 700, 300), 1024)]:
+        r = retrieval.search_eval(dix, sc, cuda(qs), *cfg)
+        torch.cuda.synchronize()
+        st, n_out = r.status.cpu().numpy(), r.n_out.cpu().numpy()
+        ids, scs, idx = r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy()
+        for b, q in enumerate(qs):
+            rc, eids, esc, eidx = oracle.search_eval(oix, osc, q, *cfg)
+            assert st[b] == rc, (cfg, b, st[b], rc)
+            if rc:
+                assert n_out[b] == 0 and not ids[b].any()
+                continue
+            n = len(eids)
+            assert n_out[b] == n
+            assert (idx[b, :n] == eidx).all() and (ids[b, :n] == eids).all()
+            assert (bits(scs[b, :n]) == bits(esc)).all()
+            assert not ids[b, n:].any() and not scs[b, n:].any()
+
+
+def test_fused_eval_graph_tiny_graph_and_per_op_agree(oracle):
+    """A graph small enough that every level's frontier exhausts (n_out < topk_eval), and the fused kernel
+    against the per-op spelling on the same users."""
+    from nann_amd import ops, retrieval
+    g, oix, dix = synth_index(300, 64, 8)
+    sc, osc = ops.Scorer("l2", 64), oracle.Scorer("l2", 64, oracle.EMB_F16)
+    qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 8, seed=2)])
+    cfg = ((4, 3, 1), (400, 400, 400), 350)
+    r = retrieval.search_eval(dix, sc, cuda(qs), *cfg)
+    torch.cuda.synchronize()
+    for b, q in enumerate(qs):
+        rc, eids, esc, eidx = oracle.search_eval(oix, osc, q, *cfg)
+        assert rc == 0 and int(r.status[b]) == 0
+        n = int(r.n_out[b])
+        assert n == len(eids) <= 300 and (r.index[b, :n].cpu().numpy() == eidx).all()
+        ids, s, idx = retrieval.search_eval_per_op(dix, sc, cuda(q), *cfg)
+        assert (idx.cpu().numpy() == eidx).all() and (bits(s.cpu().numpy()) == bits(r.scores[b, :n].cpu().numpy())).all()
+
+
+def test_fused_eval_graph_with_the_attention_model(oracle, tmp_path):
+    """nann_search_eval_model: comm_seq in, the reference's attention + DNN model as the scorer; scores within
+    1e-5 of the oracle's, ids tie-aware (the tolerance the attention scorer is held to everywhere)."""
+    from nann_amd import ops, retrieval, synth
+    d, L = 64, 50
+    g, oix, dix = synth_index(20000, d, 32)
+    w = synth.make_attn_weights(d, 64)
+    ops.save_scorer_dir(str(tmp_path), "attention", w)
+    model = ops.Model(str(tmp_path), d, L)
+    seqs = queries_for(g, 8, seed=5)
+    cfg = ((2, 1, 1), (100, 60, 30), 50)
+    r = retrieval.search_eval(dix, model, cuda(seqs), *cfg)
+    torch.cuda.synchronize()
+    osc = oracle.Scorer("attention", d, oracle.EMB_F16, attn_model=oracle.AttnModel(d, 64, L, oracle.EMB_F16, w))
+    kinds = []
+    for b, s in enumerate(seqs):
+        rc, eids, esc, eidx = oracle.search_eval(oix, osc, s.astype(np.float32).reshape(-1), *cfg)
+        assert rc == 0 and int(r.status[b]) == 0 and int(r.n_out[b]) == len(eids)
+        n = len(eids)
+        kinds.append(tolerant_parity(r.index[b, :n].cpu().numpy(), r.scores[b, :n].cpu().numpy(), eidx, esc))
+    assert kinds.count("diverged") <= 1 and kinds.count("exact") >= 5, kinds
+
+
 def test_serving_front_end_on_the_device(oracle):
     """f4: the batching front end (nann_amd/serving.py) over the real backend -- single requests with the
     reference's signature (comm_seq f16[1, L*d], level_topn -> top_k i64[1, k], build_opt_graph.py:151-159)
@@ -396,6 +468,9 @@ def test_recall_harness_test_and_test_all(oracle):
     got = evaluate.test(dix, sc, seqs, truths, topk_eval=(10, 50), num_scoring_per_level=(2, 1, 1),
                         top_k_per_level=(100, 60, 30))
     assert got["recall"][50].avg >= 0.7 and got["recall"][10].avg <= got["recall"][50].avg
+    per_op = evaluate.test(dix, sc, seqs, truths, topk_eval=(10, 50), num_scoring_per_level=(2, 1, 1),
+                           top_k_per_level=(100, 60, 30), fused=False)
+    assert all(per_op[m][k].avg == got[m][k].avg for m in ("precision", "recall", "f1") for k in (10, 50))
     # the traversal's first hit is the oracle's eval-graph answer for the same user
     q0 = oracle.user_seq_mean(seqs[0])
     rc, eids, _, _ = oracle.search_eval(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q0, (2, 1, 1), (100, 60, 30), 50)
