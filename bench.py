@@ -414,6 +414,27 @@ def batch_sweep(handles, topn, sizes):
     return sweep
 
 
+def eval_graph_rate(handles, n_users=1024):
+    """f3: users/s of the evaluation graph's traversal in one kernel (nann_search_eval), the reference's
+    defaults (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned)"""
+    import torch
+    from nann_amd import ops, retrieval
+    index, scorer, seqs = handles
+    q = ops.user_seq_mean(seqs[0][:n_users])
+    ts = []
+    for it in range(1 + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = retrieval.search_eval(index, scorer, q, (3, 1, 1), (400, 200, 100), 200)
+        e1.record()
+        torch.cuda.synchronize()
+        if it >= 1:
+            ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    return {"users": int(q.shape[0]), "ms": round(ms, 3), "users_per_s": round(q.shape[0] / (ms * 1e-3), 1),
+            "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1)}
+
+
 def strip(res):
     return {k: v for k, v in res.items() if not k.startswith("_")}
 
@@ -515,6 +536,10 @@ def main():
             sec["batch_sweep"] = batch_sweep(prim["_handles"], [args.ef] * 5 + [args.topk], [1, 64, 1024])
         except Exception as e:  # a failing extra must not take the headline line with it
             sec["batch_sweep"] = {"error": repr(e)}
+        try:
+            sec["eval_graph_f3"] = eval_graph_rate(prim["_handles"])
+        except Exception as e:
+            sec["eval_graph_f3"] = {"error": repr(e)}
         for prec, key in (("split", "mlp_configs2_split_f16"), ("exact", "mlp_configs2_exact_f32")):
             try:  # BASELINE configs[2]: same index, MLP scorer on the matrix cores
                 cfg = dict(primary_cfg, scorer="mlp", mlp_precision=prec, batch=min(args.batch, 1024),

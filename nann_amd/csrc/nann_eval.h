@@ -105,7 +105,7 @@ __device__ __forceinline__ void wg_sync_mem() {
 
 template <int LPR, int DT, int SC, int NT>
 __device__ __forceinline__ void eval_score(const EvalArgs& a, int qi, const int32_t* ids, int n, float* out,
-                                           unsigned char* scratch, const float* qv) {
+                                           unsigned char* scratch, const float* qv, float mlp_u) {
   const int tid = local_tid();
   if constexpr (SC == NANN_SCORER_L2) {
     wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, ids, 0, n, qv, out, tid >> 6);
@@ -115,7 +115,7 @@ __device__ __forceinline__ void eval_score(const EvalArgs& a, int qi, const int3
                                    reinterpret_cast<float*>(scratch), out);
   } else {
     MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
-    wg_mlp_query_setup<NT>(a.mlp, qv, &M->v);
+    wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v);
     wg_score_mlp<LPR * 8, 8, 4, DT, NT>(a.mlp, a.emb, a.n_items, ids, n, M, out);
   }
   __syncthreads();
@@ -131,11 +131,13 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   }
   wg_zero_words(sv.seen, a.bm_words);
   wg_sync_mem();
+  float mlp_u = 0.0f;
+  if constexpr (SC == NANN_SCORER_MLP) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
 
   // start level: score every enter point, keep min(k, n) (:349-353)
   const int E = a.n_enter;
   if (E <= 0) return NANN_ERR_EMPTY_SCORE_BATCH;
-  eval_score<LPR, DT, SC, NT>(a, qi, a.enter, E, sv.cat_sc, scratch, qv);
+  eval_score<LPR, DT, SC, NT>(a, qi, a.enter, E, sv.cat_sc, scratch, qv, mlp_u);
   int n_res = min(a.top_k[2], E);
   int st = wg_topk<NT>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr, scratch);
   if (st) return st;
@@ -209,7 +211,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
         n_cand = 0;
         continue;
       }
-      eval_score<LPR, DT, SC, NT>(a, qi, sv.cat_ids + n_res, n_next, sv.cat_sc + n_res, scratch, qv);  // :323
+      eval_score<LPR, DT, SC, NT>(a, qi, sv.cat_ids + n_res, n_next, sv.cat_sc + n_res, scratch, qv, mlp_u);  // :323
       const int n_cat = n_res + n_next;
       const int k = min(a.top_k[level], n_cat);
       st = wg_topk<NT>(sv.cat_ids, sv.cat_sc, nullptr, n_cat, k, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr,

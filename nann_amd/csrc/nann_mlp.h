@@ -66,18 +66,39 @@ __device__ __forceinline__ float prelu(float x, float a) {
   return pos + a * neg;
 }
 
-// Per query: u[j] = b1[j] + sum_k q[k] * W1[k][j] (k ascending, fmaf) and the small vectors
-// into LDS.  All NT threads; ends with a barrier.
-// u_scale / b2_scale: the split-f16 form keeps both pre-multiplied by its accumulator scales (exact powers of two)
+// Per query: u[j] = b1[j] + sum_k q[k] * W1[k][j] (k ascending, fmaf).  Thread j < h1 returns u[j] and keeps
+// it in a register for the whole traversal of the query (h1 <= NT); the loads of a run of 8 rows are issued
+// together, the chain stays in k order.
 template <int NT>
-__device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpVectors* V,
-                                                   float u_scale = 1.0f, float b2_scale = 1.0f) {
+__device__ __forceinline__ float wg_mlp_query_u(const MlpParams& P, const float* qv) {
+  const int j = local_tid();
+  if (j >= P.h1) return 0.0f;
+  float acc = P.b1[j];
+  const float* w = P.w1 + j;
+  int k = 0;
+  for (; k + 8 <= P.d; k += 8) {
+    float wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wv[i] = w[(size_t)(k + i) * P.h1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = __fmaf_rn(qv[k + i], wv[i], acc);
+  }
+  for (; k < P.d; ++k) acc = __fmaf_rn(qv[k], w[(size_t)k * P.h1], acc);
+  return acc;
+}
+
+// Per scoring call (the phase scratch was reused since the last one): u and the small vectors into LDS.
+// All NT threads; ends with a barrier.
+// u_scale / b2_scale / alpha1_scale: the split-f16 form keeps these pre-multiplied by its accumulator scales
+// (exact powers of two)
+template <int NT>
+__device__ __forceinline__ void wg_mlp_stage_setup(const MlpParams& P, float u, MlpVectors* V, float u_scale = 1.0f,
+                                                   float b2_scale = 1.0f, float alpha1_scale = 1.0f) {
   const int tid = local_tid();
-  for (int j = tid; j < P.h1; j += NT) {
-    float acc = P.b1[j];
-    for (int k = 0; k < P.d; ++k) acc = __fmaf_rn(qv[k], P.w1[(size_t)k * P.h1 + j], acc);
-    V->u[j] = acc * u_scale;
-    V->alpha1[j] = P.alpha1[j];
+  static_assert(NT >= 256, "one hidden unit per thread");
+  if (tid < P.h1) {
+    V->u[tid] = u * u_scale;
+    V->alpha1[tid] = P.alpha1[tid] * alpha1_scale;
   }
   for (int m = tid; m < P.h2; m += NT) {
     V->b2[m] = P.b2[m] * b2_scale;
@@ -85,6 +106,13 @@ __device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const flo
     V->w3[m] = P.w3[m];
   }
   __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void wg_mlp_query_setup(const MlpParams& P, const float* qv, MlpVectors* V,
+                                                   float u_scale = 1.0f, float b2_scale = 1.0f,
+                                                   float alpha1_scale = 1.0f) {
+  wg_mlp_stage_setup<NT>(P, wg_mlp_query_u<NT>(P, qv), V, u_scale, b2_scale, alpha1_scale);
 }
 
 template <int DT>
@@ -269,6 +297,14 @@ __device__ __forceinline__ f16x8 row_chunk_f16(const uint4& v) {  // 8 table ele
   }
 }
 
+// Where a 256-row pass spends its 27 us at d = 128 (tools/mlp_rate.py on the stand-alone scorer, timing builds with
+// parts compiled out, profiles/r2_mlp_split_experiments.md): the 320 MFMAs per wavefront alone take 17-19 us
+// (two wavefronts per SIMD, ~50 shader cycles per MFMA at the 1.9 GHz the chip holds under this load, against 32
+// at the documented issue rate), everything else alone -- weight slices L2 -> LDS -> registers, barriers, PReLU /
+// split arithmetic -- 5 us, and the two overlap poorly.  Halving the LDS reads, dropping the barriers or the
+// vector arithmetic each moved the total by under 7 %; giving neighbouring MFMAs different accumulators (four
+// partial sums in layer 1, product-major order in layer 2) sped the bare MFMA stream up by 10 % and the whole
+// kernel by nothing, and its extra registers spill inside k_search.  So the order below is the plain one.
 template <int D, int H1T, int H2T, int DT, int NT>
 __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const void* __restrict__ table,
                                                    uint32_t n_table_rows, const int32_t* ids, int n,
@@ -292,22 +328,24 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
     if (ks < KS1) return P.p1 + ((size_t)(t * KC + ks * 8) * 2) * 64 + min(f, KCS * 128 - 1);
     return P.p2 + (size_t)t * 1024 + f;
   };
+  auto row_of = [&](int i0) -> size_t {
+    const int ic = min(i0 + wave * 32 + cand, n - 1);
+    const uint32_t rid = ids ? (uint32_t)ids[ic] : (uint32_t)ic;
+    return rid < n_table_rows ? rid : 0u;
+  };
+  // B fragments of layer 1: chunk kc of this lane = elements 16 kc + 8 g .. + 8 of the row (one 16-B load)
+  uint4 ev[KC];
+  auto load_row = [&](size_t row) {
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const char*>(table) + row * D * 2) + g;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
+  };
+  if (n > 0) load_row(row_of(0));
 
   for (int i0 = 0; i0 < n; i0 += CPP) {
     const int i = i0 + wave * 32 + cand;
-    const int ic = min(i, n - 1);
-    const uint32_t rid = ids ? (uint32_t)ids[ic] : (uint32_t)ic;
-    const size_t row = rid < n_table_rows ? rid : 0u;
-    // B fragments of layer 1: chunk kc of this lane = elements 16 kc + 8 g .. + 8 of the row (one 16-B load)
-    uint4 ev[KC];
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(static_cast<const char*>(table) + row * D * 2) + g;
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
-    }
+    const size_t next_row = i0 + CPP < n ? row_of(i0 + CPP) : 0;
     f32x16 a2[H2T];
-    // (b2 and u sit in LDS pre-multiplied by the accumulator scales; the lane's 16 rows of a 32-unit tile are
-    //  four runs of 4 consecutive floats: one ds_read_b128 each)
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
@@ -348,28 +386,22 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b, a1, 0, 0, 0);
           }
         }
-        if (ks == KS1 - 1) {  // tile complete: PReLU, scale (x 2^-7 x 2^4; PReLU commutes with a positive
-          // factor) and split into the layer-2 B fragments.  hi is cut with round-toward-zero (one packed
-          // conversion per pair); lo = h - hi is exact in f32 and rounds into 11 more bits.
+        if (t == H1T - 1 && ks == KS1 - 1 && i0 + CPP < n) load_row(next_row);  // the rows are consumed: fetch the next pass's
+        if (ks == KS1 - 1) {  // tile complete: PReLU, scale (x 2^-7 x 2^4, folded into alpha1 and the positive
+          // branch: PReLU commutes with a positive factor) and split into the layer-2 B fragments.  hi is cut
+          // with round-toward-zero (one packed conversion per pair); lo = h - hi is exact in f32 and rounds
+          // into 11 more bits.
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const float4 al = *reinterpret_cast<const float4*>(&V->alpha1[32 * t + 8 * rr + 4 * g]);
-            const float alv[4] = {al.x, al.y, al.z, al.w};
-            float h[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float x = a1[4 * rr + k];
-              h[k] = (x > 0.0f ? x : alv[k] * x) * (kSplitHScale / kSplitWScale);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k += 2) {
-              typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
-              const h2_t hi = __builtin_amdgcn_cvt_pkrtz(h[k], h[k + 1]);
-              const h2_t lo = __builtin_amdgcn_cvt_pkrtz(h[k] - (float)hi[0], h[k + 1] - (float)hi[1]);
-              const int r = 4 * rr + k;
-              bh[r >> 3][r & 7] = (_Float16)hi[0]; bh[r >> 3][(r & 7) + 1] = (_Float16)hi[1];
-              bl[r >> 3][r & 7] = (_Float16)lo[0]; bl[r >> 3][(r & 7) + 1] = (_Float16)lo[1];
-            }
+          for (int r = 0; r < 16; r += 2) {
+            typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+            const float2 al = *reinterpret_cast<const float2*>(&V->alpha1[32 * t + 8 * (r >> 2) + 4 * g + (r & 3)]);
+            const float x0 = a1[r], x1 = a1[r + 1];
+            const float h0 = x0 * (x0 > 0.0f ? kSplitHScale / kSplitWScale : al.x);
+            const float h1 = x1 * (x1 > 0.0f ? kSplitHScale / kSplitWScale : al.y);
+            const h2_t hi = __builtin_amdgcn_cvt_pkrtz(h0, h1);
+            const h2_t lo = __builtin_amdgcn_cvt_pkrtz(h0 - (float)hi[0], h1 - (float)hi[1]);
+            bh[r >> 3][r & 7] = (_Float16)hi[0]; bh[r >> 3][(r & 7) + 1] = (_Float16)hi[1];
+            bl[r >> 3][r & 7] = (_Float16)lo[0]; bl[r >> 3][(r & 7) + 1] = (_Float16)lo[1];
           }
         }
       } else {
@@ -385,13 +417,19 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
           }
       }
     }
-    float part = 0.0f;
+    float part = 0.0f;  // (still x 2^11: scaled back once below)
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
-        part = __fmaf_rn(prelu(a2[mt][r], V->alpha2[m]), V->w3[m], part);  // still x 2^11: scaled back once below
+      for (int rr = 0; rr < 4; ++rr) {
+        const float4 al = *reinterpret_cast<const float4*>(&V->alpha2[32 * mt + 8 * rr + 4 * g]);
+        const float4 w3 = *reinterpret_cast<const float4*>(&V->w3[32 * mt + 8 * rr + 4 * g]);
+        const float alv[4] = {al.x, al.y, al.z, al.w}, w3v[4] = {w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x = a2[mt][4 * rr + k];
+          part = __fmaf_rn(x > 0.0f ? x : alv[k] * x, w3v[k], part);
+        }
       }
     const float other = __shfl_xor(part, 32);
     const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* t
         atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
     }
   }
-  if constexpr (SPLIT) wg_mlp_query_setup<kMlpNT>(P, qv, &S->v, kSplitWScale, kSplitWScale * kSplitHScale);
+  if constexpr (SPLIT) wg_mlp_query_setup<kMlpNT>(P, qv, &S->v, kSplitWScale, kSplitWScale * kSplitHScale, kSplitHScale / kSplitWScale);
   else wg_mlp_query_setup<kMlpNT>(P, qv, &S->v);
   for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
     const int cnt = (int)((n - c0) < CPP ? (n - c0) : CPP);
@@ -169,6 +169,8 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   }
   __syncthreads();
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
+  float mlp_u = 0.0f;              // MLP: thread j's per-query part of hidden unit j, once per query
+  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
 
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
@@ -295,8 +297,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         // (the phase scratch was reused since the last stage)
-        if constexpr (SC == kScorerMlpSplit) wg_mlp_query_setup<NT>(a.mlp, qv, &M->v, kSplitWScale, kSplitWScale * kSplitHScale);
-        else wg_mlp_query_setup<NT>(a.mlp, qv, &M->v);
+        if constexpr (SC == kScorerMlpSplit)
+          wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v, kSplitWScale, kSplitWScale * kSplitHScale, kSplitHScale / kSplitWScale);
+        else
+          wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v);
         if constexpr (SC == kScorerMlpSplit)
           wg_score_mlp_split<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
         else
