@@ -417,19 +417,13 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
           }
       }
     }
-    float part = 0.0f;  // (still x 2^11: scaled back once below)
+    float part = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float4 al = *reinterpret_cast<const float4*>(&V->alpha2[32 * mt + 8 * rr + 4 * g]);
-        const float4 w3 = *reinterpret_cast<const float4*>(&V->w3[32 * mt + 8 * rr + 4 * g]);
-        const float alv[4] = {al.x, al.y, al.z, al.w}, w3v[4] = {w3.x, w3.y, w3.z, w3.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float x = a2[mt][4 * rr + k];
-          part = __fmaf_rn(x > 0.0f ? x : alv[k] * x, w3v[k], part);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+        part = __fmaf_rn(prelu(a2[mt][r], V->alpha2[m]), V->w3[m], part);  // still x 2^11: scaled back once below
       }
     const float other = __shfl_xor(part, 32);
     const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
