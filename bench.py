@@ -282,6 +282,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                     "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                     "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": flops_note,
                     "nominal_TFLOPs_incl_hoisted": round(nominal / (kern_ms * 1e-3) / 1e12, 2),
+                    # tools/ubench_mfma.hip (profiles/r2_ubench_mfma.txt): a bare loop of this MFMA on every SIMD
+                    # holds 1.6-1.9 PFLOP/s (f16) -- the chip clocks ~1.75 GHz under it, not 2.4
+                    "frac_of_measured_mfma_loop": (round(tf / 1830.0, 4) if precision == "split" else None),
                     "hbm_algorithmic_GBps": round(achieved, 1),
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
 
