@@ -438,7 +438,7 @@ def eval_graph_rate(handles, n_users=1024):
             "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1)}
 
 
-def attention_model_rate(handles, dim, topn, n_users=512):
+def attention_model_rate(handles, dim, topn, precision, n_users=512):
     """f2: the serving signature with the reference's attention + DNN model as the scorer (nann_search_model:
     per-user projection once per request, then the fused traversal), random-init weights of that architecture"""
     import tempfile
@@ -446,7 +446,7 @@ def attention_model_rate(handles, dim, topn, n_users=512):
     from nann_amd import ops, retrieval, synth
     index = handles[0]
     with tempfile.TemporaryDirectory() as tmp:
-        ops.save_scorer_dir(tmp, "attention", synth.make_attn_weights(dim, 64))
+        ops.save_scorer_dir(tmp, "attention", synth.make_attn_weights(dim, 64), precision=precision)
         model = ops.Model(tmp, dim, 50)
     g = torch.Generator(device=index.device).manual_seed(77)
     seq = (torch.randn((n_users, 50, 64), generator=g, device=index.device) * 0.5).to(torch.float16)
@@ -460,8 +460,8 @@ def attention_model_rate(handles, dim, topn, n_users=512):
         if it >= 1:
             ts.append(e0.elapsed_time(e1))
     ms = float(np.median(ts))
-    return {"users": n_users, "ms": round(ms, 3), "queries_per_s": round(n_users / (ms * 1e-3), 1),
-            "failed": int((r.status != 0).sum())}
+    return {"users": n_users, "precision": precision, "ms": round(ms, 3),
+            "queries_per_s": round(n_users / (ms * 1e-3), 1), "failed": int((r.status != 0).sum())}
 
 
 def strip(res):
@@ -569,10 +569,12 @@ def main():
             sec["eval_graph_f3"] = eval_graph_rate(prim["_handles"])
         except Exception as e:
             sec["eval_graph_f3"] = {"error": repr(e)}
-        try:
-            sec["attention_model_f2"] = attention_model_rate(prim["_handles"], args.dim, [args.ef] * 5 + [args.topk])
-        except Exception as e:
-            sec["attention_model_f2"] = {"error": repr(e)}
+        for prec in ("split", "exact"):
+            try:
+                sec["attention_model_f2_" + prec] = attention_model_rate(prim["_handles"], args.dim,
+                                                                         [args.ef] * 5 + [args.topk], prec)
+            except Exception as e:
+                sec["attention_model_f2_" + prec] = {"error": repr(e)}
         for prec, key in (("split", "mlp_configs2_split_f16"), ("exact", "mlp_configs2_exact_f32")):
             try:  # BASELINE configs[2]: same index, MLP scorer on the matrix cores
                 cfg = dict(primary_cfg, scorer="mlp", mlp_precision=prec, batch=min(args.batch, 1024),

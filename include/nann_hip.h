@@ -394,6 +394,9 @@ typedef struct {
   const float* bn_scale[3];
   const float* bn_shift[3];
   const float* alpha[3];
+  int32_t precision;  /* enum nann_mlp_precision: NANN_MLP_EXACT_F32 (0, f32-input MFMA) or NANN_MLP_SPLIT_F16
+                       * (every f32 operand as hi + lo f16 on the 16-bit MFMA, 3x fewer matrix cycles; logits
+                       * within ~1e-6 of the exact form) */
 } nann_attn_desc;
 int nann_attn_scorer_create(const nann_attn_desc* desc /*[host]*/, nann_attn_scorer** out);
 void nann_attn_scorer_destroy(nann_attn_scorer* s);

@@ -55,7 +55,7 @@ class AttnDesc(C.Structure):
     _fields_ = ([("d", C.c_int32), ("emb_dtype", C.c_int32), ("seq_len", C.c_int32)] +
                 [(n, C.c_void_p) for n in ("wq1", "bq1", "aq", "wq2", "bq2", "wk1", "bk1", "ak", "wk2", "bk2")] +
                 [("w", C.c_void_p * 4), ("b", C.c_void_p * 3), ("bn_scale", C.c_void_p * 3),
-                 ("bn_shift", C.c_void_p * 3), ("alpha", C.c_void_p * 3)])
+                 ("bn_shift", C.c_void_p * 3), ("alpha", C.c_void_p * 3), ("precision", C.c_int32)])
 
 
 class IndexDesc(C.Structure):

@@ -42,6 +42,10 @@ struct AttnParams {  // device pointers, f32
   const float *w3, *b3, *s3, *t3, *a3;  // [64,32]
   const float* w4;                       // [32]
   int d, L;
+  // split-f16 form (nann_attn_split.h): A fragments of every weight matrix, hi / lo f16 planes x 2^7, packed on
+  // the host in MFMA lane order, [output tile][16-deep chunk][plane][64 lanes] x 16 B; and the pre-scaled vectors
+  const uint4 *pq1, *pq2, *pw1a, *pw1e, *pw2, *pw3;
+  const float* pvec;
 };
 
 // defined in nann_attn_inst.hip
@@ -50,5 +54,12 @@ int launch_attn_prepare(hipStream_t st, const AttnParams& P, const void* user_se
 int launch_score_attn(int dt, unsigned blocks, hipStream_t st, const AttnParams& P, const float* kt,
                       const float* upad, const void* table, long long n_table_rows, const int32_t* indices,
                       long long n, float* scores, long long* bad_i);
+
+// split-f16 form, defined in nann_attn_split_inst.hip
+int launch_attn_prepare_split(hipStream_t st, const AttnParams& P, const void* user_seq_f16, long long n_users,
+                              float* kt, float* upad);
+int launch_score_attn_split(int dt, unsigned blocks, hipStream_t st, const AttnParams& P, const float* kt,
+                            const float* upad, const void* table, long long n_table_rows, const int32_t* indices,
+                            long long n, float* scores, long long* bad_i);
 
 }  // namespace nann

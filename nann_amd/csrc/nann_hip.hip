@@ -499,7 +499,9 @@ struct nann_scorer {
 struct nann_attn_scorer {
   AttnParams P = {};
   int emb_dtype = 0;
+  int precision = NANN_MLP_EXACT_F32;  // NANN_MLP_SPLIT_F16: the split-f16 kernels (nann_attn_split.h)
   float* dev_weights = nullptr;
+  uint4* dev_packed = nullptr;         // split form: A fragments + pre-scaled vectors
 };
 
 struct nann_index {
@@ -1139,6 +1141,34 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table, int
 }
 
 // ---- 8(f2): the reference scorer model -------------------------------------------------
+}  // extern "C"
+
+// A fragments of v_mfma_f32_32x32x16_f16 for W [K][n_out] (row-major), hi and lo planes of W * 2^7:
+//   out[m][kc][plane][lane][i] = W[krow(kc, lane >> 5, i)][32 m + (lane & 31)]
+// natural k order (the operand is a table row): krow = 16 kc + 8 g + i
+// cd order (the operand is a finished 32-unit tile in C/D register order, two chunks per tile):
+//   krow = 32 (kc >> 1) + (i & 3) + 16 (kc & 1) + 8 (i >> 2) + 4 g                      (nann_attn_split.h)
+static bool pack_attn_frags(const float* W, int n_out, int n_chunks, bool cd_order, std::vector<uint16_t>* out) {
+  const int M = n_out / 32;
+  const size_t base0 = out->size();
+  out->resize(base0 + (size_t)M * n_chunks * 2 * 64 * 8);
+  bool ok = true;
+  for (int m = 0; m < M; ++m)
+    for (int kc = 0; kc < n_chunks; ++kc)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 8; ++i) {
+          const int g = lane >> 5;
+          const int k = cd_order ? 32 * (kc >> 1) + (i & 3) + 16 * (kc & 1) + 8 * (i >> 2) + 4 * g : 16 * kc + 8 * g + i;
+          const float v = W[(size_t)k * n_out + 32 * m + (lane & 31)];
+          if (!(std::fabs(v) <= 511.0f)) ok = false;  // v * 2^7 must stay inside f16
+          const size_t base = base0 + ((size_t)(m * n_chunks + kc) * 2) * 64 * 8;
+          split_f16(v, &(*out)[base + (size_t)lane * 8 + i], &(*out)[base + 64 * 8 + (size_t)lane * 8 + i]);
+        }
+  return ok;
+}
+
+extern "C" {
+
 int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) {
   if (!desc || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_attn_scorer_create: null argument");
   const int d = desc->d, L = desc->seq_len;
@@ -1182,6 +1212,63 @@ int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) 
   P.d = d;
   P.L = L;
   s->emb_dtype = desc->emb_dtype;
+  if (desc->precision != NANN_MLP_EXACT_F32 && desc->precision != NANN_MLP_SPLIT_F16) {
+    nann_attn_scorer_destroy(s);
+    return fail(NANN_ERR_BAD_ARGUMENT, "attention scorer: unknown precision");
+  }
+  s->precision = desc->precision;
+  {  // the split-f16 planes (~0.5 MB) are always built; `precision` picks the kernels
+    std::vector<uint16_t> packed;
+    bool ok = true;
+    const size_t o_q1 = packed.size(); ok &= pack_attn_frags(desc->wq1, 128, d / 16, false, &packed);
+    const size_t o_q2 = packed.size(); ok &= pack_attn_frags(desc->wq2, 256, 8, true, &packed);
+    const size_t o_1a = packed.size(); ok &= pack_attn_frags(desc->w[0], 128, 4, true, &packed);                    // rows of a
+    const size_t o_1e = packed.size(); ok &= pack_attn_frags(desc->w[0] + (size_t)64 * 128, 128, d / 16, false, &packed);  // rows of e
+    const size_t o_2 = packed.size(); ok &= pack_attn_frags(desc->w[1], 64, 8, true, &packed);
+    const size_t o_3 = packed.size(); ok &= pack_attn_frags(desc->w[2], 32, 4, true, &packed);
+    const size_t o_v = (packed.size() + 7) & ~(size_t)7;  // halves; 16-byte aligned
+    if (!ok && s->precision == NANN_MLP_SPLIT_F16) {
+      nann_attn_scorer_destroy(s);
+      return fail(NANN_ERR_UNSUPPORTED, "attention scorer, split-f16 form: |w| must be <= 511");
+    }
+    std::vector<float> pv(PV_COUNT, 0.0f);
+    const float WS = kAttnWS, HS = kAttnHS;
+    for (int j = 0; j < 128; ++j) {
+      pv[PV_BQ1 + j] = desc->bq1[j] * WS;
+      pv[PV_AQ + j] = desc->aq[j] * (HS / WS);
+      pv[PV_B1 + j] = desc->b[0][j] * (WS * HS);
+      pv[PV_S1 + j] = desc->bn_scale[0][j] / (WS * HS);
+      pv[PV_T1 + j] = desc->bn_shift[0][j];
+      pv[PV_A1 + j] = desc->alpha[0][j] * HS;
+    }
+    for (int j = 0; j < 256; ++j) pv[PV_BQ2 + j] = desc->bq2[j] * (WS * HS);
+    for (int j = 0; j < 64; ++j) {
+      pv[PV_B2 + j] = desc->b[1][j] * (WS * HS);
+      pv[PV_S2 + j] = desc->bn_scale[1][j] / (WS * HS);
+      pv[PV_T2 + j] = desc->bn_shift[1][j];
+      pv[PV_A2 + j] = desc->alpha[1][j] * HS;
+    }
+    for (int j = 0; j < 32; ++j) {
+      pv[PV_B3 + j] = desc->b[2][j] * (WS * HS);
+      pv[PV_S3 + j] = desc->bn_scale[2][j] / (WS * HS);
+      pv[PV_T3 + j] = desc->bn_shift[2][j];
+      pv[PV_A3 + j] = desc->alpha[2][j];
+      pv[PV_W4 + j] = desc->w[3][j];
+    }
+    const size_t bytes = o_v * 2 + pv.size() * 4;
+    e = hipMalloc(reinterpret_cast<void**>(&s->dev_packed), bytes);
+    if (e == hipSuccess) e = hipMemcpy(s->dev_packed, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpy(reinterpret_cast<char*>(s->dev_packed) + o_v * 2, pv.data(), pv.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      nann_attn_scorer_destroy(s);
+      return fail(NANN_ERR_HIP, std::string("attention scorer weights: ") + hipGetErrorString(e));
+    }
+    const uint4* base = s->dev_packed;
+    P.pq1 = base + o_q1 / 8; P.pq2 = base + o_q2 / 8; P.pw1a = base + o_1a / 8; P.pw1e = base + o_1e / 8;
+    P.pw2 = base + o_2 / 8; P.pw3 = base + o_3 / 8;
+    P.pvec = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + o_v * 2);
+  }
   *out = s;
   return NANN_OK;
 }
@@ -1189,6 +1276,7 @@ int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) 
 void nann_attn_scorer_destroy(nann_attn_scorer* s) {
   if (!s) return;
   if (s->dev_weights) (void)hipFree(s->dev_weights);
+  if (s->dev_packed) (void)hipFree(s->dev_packed);
   delete s;
 }
 
@@ -1196,6 +1284,8 @@ int nann_attn_prepare(const nann_attn_scorer* s, const void* user_seq_f16, int64
                       float* upad, nann_stream_t stream) {
   if (!s || !user_seq_f16 || !kt || !upad) return fail(NANN_ERR_BAD_ARGUMENT, "nann_attn_prepare: null argument");
   if (n_users <= 0) return NANN_OK;
+  if (s->precision == NANN_MLP_SPLIT_F16)
+    return launch_attn_prepare_split(as_stream(stream), s->P, user_seq_f16, n_users, kt, upad);
   return launch_attn_prepare(as_stream(stream), s->P, user_seq_f16, n_users, kt, upad);
 }
 
@@ -1212,8 +1302,12 @@ int nann_attn_score(const nann_attn_scorer* s, const float* kt, const float* upa
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, st, rb->dev);
   const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 2048);
-  rc = launch_score_attn(s->emb_dtype, blocks, st, s->P, kt, upad, table, n_table_rows, indices, n, out_scores,
-                         &rb->dev->bad_i);
+  if (s->precision == NANN_MLP_SPLIT_F16)
+    rc = launch_score_attn_split(s->emb_dtype, std::min(blocks, 512u), st, s->P, kt, upad, table, n_table_rows, indices, n,
+                                 out_scores, &rb->dev->bad_i);
+  else
+    rc = launch_score_attn(s->emb_dtype, blocks, st, s->P, kt, upad, table, n_table_rows, indices, n, out_scores,
+                           &rb->dev->bad_i);
   if (rc) return rc;
   rc = fetch_result(rb, st);
   if (rc) return rc;
@@ -1288,6 +1382,14 @@ int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_l
         {"alpha0", &ad.alpha[0]}, {"alpha1", &ad.alpha[1]}, {"alpha2", &ad.alpha[2]}};
     for (const auto& e : w)
       if (!rc) rc = load_f32(D, e.n, &keep, e.p, -1);
+    {  // optional precision.txt: "exact" (f32 MFMA, the default) | "split" (split-f16 operands)
+      std::ifstream pf(D + "/precision.txt");
+      std::string prec;
+      if (pf && (pf >> prec)) {
+        if (prec == "split") ad.precision = NANN_MLP_SPLIT_F16;
+        else if (prec != "exact" && !rc) rc = fail(NANN_ERR_BAD_ARGUMENT, "precision.txt: expected exact or split, got '" + prec + "'");
+      }
+    }
     if (!rc) rc = nann_attn_scorer_create(&ad, &m->attn);
   } else {
     rc = fail(NANN_ERR_UNSUPPORTED, "scorer.txt: expected l2, mlp or attention, got '" + kind + "'");
@@ -1595,10 +1697,11 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   const bool hashed = p.vis == VIS_LDS_HASH || p.vis == VIS_LDS_HASH32;
   if (attn) {
     a.attn = attn->P;
-    rc = launch_search_attn(ix->desc.d, dt, p.vis, p.slots, p.lds_bytes, a, st);
+    auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_split : launch_search_attn;
+    rc = launch(ix->desc.d, dt, p.vis, p.slots, p.lds_bytes, a, st);
     if (rc || !hashed) return rc;
     a.redo = 1;
-    return launch_search_attn(ix->desc.d, dt, p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
+    return launch(ix->desc.d, dt, p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
   }
   a.mlp = scorer->mlp;
   const int split = kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;

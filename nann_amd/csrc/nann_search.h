@@ -6,6 +6,7 @@
 #include "nann_device.h"
 #include "nann_mlp.h"
 #include "nann_attn_kernels.h"
+#include "nann_attn_split.h"
 
 #include <string>
 
@@ -121,6 +122,8 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
 // scorer template values: NANN_SCORER_L2 (0), NANN_SCORER_MLP (1, f32 MFMA, bit-exact) and the MLP's split-f16 form
 constexpr int kScorerMlpSplit = 2;
 constexpr int kScorerAttn = 3;  // the reference's attention + DNN model (nann_attn.h); "query" = kt / upad of the user
+constexpr int kScorerAttnSplit = 4;  //   the same on the 16-bit MFMA with split operands (nann_attn_split.h)
+constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit; }
 
 // where a query's visited set lives
 enum : int {
@@ -143,7 +146,7 @@ template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int base = hash ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
-  if (SC == kScorerAttn && base < kAttnScratch) return kAttnScratch;
+  if (is_attn(SC) && base < kAttnScratch) return kAttnScratch;
   return base;
 }
 
@@ -164,7 +167,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   const SubTimer pt{ticks, a.phase_ticks != nullptr};
   auto mark = [&](int phase) { timer.mark(phase); };
 
-  if constexpr (SC != kScorerAttn) {
+  if constexpr (!is_attn(SC)) {
     for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
   }
   __syncthreads();
@@ -294,6 +297,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         wg_score_attn<LPR * 8, DT, NT>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
                                        a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
                                        reinterpret_cast<float*>(scratch), sc_out);
+      } else if constexpr (SC == kScorerAttnSplit) {
+        wg_score_attn_split<LPR * 8, DT, NT>(a.attn, reinterpret_cast<const uint4*>(a.kt + (size_t)qi * 256 * kAttnLP),
+                                             reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
+                                             a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
+                                             reinterpret_cast<float*>(scratch), sc_out);
       } else {
         MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         // (the phase scratch was reused since the last stage)
@@ -470,6 +478,7 @@ int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_byt
 // attention-scorer instantiations live in nann_attn_inst.hip: (vis, 512 threads) for vis in
 // {VIS_LDS_HASH (one workgroup per CU), VIS_LDS_BITMAP, VIS_HBM_BITMAP}
 int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_attn_split(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);  // nann_attn_split_inst.hip
 int launch_score_mlp_d64(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
                          float* out, OpResult* res);

@@ -289,13 +289,14 @@ class Scorer:
 
 class AttnScorer:
     """The reference's own scorer model behind the BlazeXlaOp contract (SURVEY.md 8 f2;
-    model.py:189-233, model_util.py:70-97): weights dict as synth.make_attn_weights.  The kernel
-    has not been run on hardware yet."""
+    model.py:189-233, model_util.py:70-97): weights dict as synth.make_attn_weights.
+    precision: "exact" (f32-input MFMA) | "split" (split-f16 operands on the 16-bit MFMA, nann_attn_split.h)."""
 
-    def __init__(self, d, seq_len, emb_dtype=torch.float16, weights=None):
-        self.d, self.seq_len, self.emb_dtype = d, seq_len, emb_dtype
+    def __init__(self, d, seq_len, emb_dtype=torch.float16, weights=None, precision="exact"):
+        self.d, self.seq_len, self.emb_dtype, self.precision = d, seq_len, emb_dtype, precision
         desc = _lib.AttnDesc()
         desc.d, desc.seq_len, desc.emb_dtype = d, seq_len, _DT[emb_dtype]
+        desc.precision = {"exact": _lib.MLP_EXACT_F32, "split": _lib.MLP_SPLIT_F16}[precision]
         self._keep = []
 
         def hold(a):
@@ -347,7 +348,7 @@ class AttnScorer:
         return out[:n]
 
 
-def save_scorer_dir(path, kind, weights=None):
+def save_scorer_dir(path, kind, weights=None, precision=None):
     """Write a scoring model as the weights directory BlazeXlaOp's `graph_def` attr names on this
     build (include/nann_hip.h, nann_model_load): scorer.txt + one .npy per weight tensor.
     kind: "l2" | "mlp" (dict as synth.make_mlp_weights) | "attention" (dict as synth.make_attn_weights)."""
@@ -355,6 +356,9 @@ def save_scorer_dir(path, kind, weights=None):
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "scorer.txt"), "w") as f:
         f.write(kind + "\n")
+    if precision is not None:  # attention: "exact" | "split" (precision.txt, read by nann_model_load)
+        with open(os.path.join(path, "precision.txt"), "w") as f:
+            f.write(precision + "\n")
     if kind == "mlp":
         for name in ("w1", "b1", "alpha1", "w2", "b2", "alpha2", "w3"):
             np.save(os.path.join(path, name + ".npy"), np.asarray(weights[name], np.float32))

@@ -390,6 +390,49 @@ def test_attn_scorer_matches_oracle(oracle, d, dtype):
     assert e.value.status == 5
 
 
+@pytest.mark.parametrize("d,dtype", [(64, "f16"), (128, "f16"), (128, "bf16")])
+def test_attn_scorer_split_f16_matches_oracle(oracle, d, dtype):
+    """The split-f16 form of the attention + DNN scorer (nann_attn_split.h: hi + lo f16 operands on the 16-bit
+    MFMA, per-user keys / sequence packed by k_attn_prepare_split) against the fp32 oracle: logits within the
+    1e-5 every attention-scorer test is held to; gathered and pre-gathered rows agree bit for bit; ragged pass
+    sizes (n not a multiple of 256, n < 32) and a sequence shorter than its padding."""
+    from nann_amd import ops, synth
+    E, L, n_table = 64, 50, 3000
+    w = synth.make_attn_weights(d, E)
+    rng = np.random.default_rng(100 + d)
+    u = (rng.standard_normal((L, E)) / 8).astype(np.float16)
+    u[44:] = 0
+    x = (rng.standard_normal((n_table, d)) / 8).astype(np.float32)
+    if dtype == "f16":
+        host, dev, code, tdt = x.astype(np.float16), cuda(x.astype(np.float16)), oracle.EMB_F16, torch.float16
+    else:
+        dev = cuda(x).to(torch.bfloat16)
+        host, code, tdt = dev.view(torch.int16).cpu().numpy().view(np.uint16), oracle.EMB_BF16, torch.bfloat16
+    m = oracle.AttnModel(d, E, L, code, w)
+    sc = ops.AttnScorer(d, L, tdt, w, precision="split")
+    kt, upad = sc.prepare(cuda(u)[None])
+    worst = 0.0
+    for n in (1500, 256, 31, 1):
+        idx = rng.integers(0, n_table, size=n).astype(np.int32)
+        rc, exp = oracle.attn_score_rows(m, u.astype(np.float32), host[idx])
+        got = sc.score(kt[0], upad[0], table=dev, indices=idx).cpu().numpy()
+        assert rc == 0
+        err = np.abs(got - exp).max() / max(1.0, np.abs(exp).max())
+        worst = max(worst, err)
+        assert err <= 1e-5, (n, err)
+        got2 = sc.score(kt[0], upad[0], item_emb=dev[torch.as_tensor(idx).long().cuda()]).cpu().numpy()
+        assert (bits(got2) == bits(got)).all()
+    exact = ops.AttnScorer(d, L, tdt, w)  # and against the f32 form on the device
+    kt2, upad2 = exact.prepare(cuda(u)[None])
+    idx = np.arange(700, dtype=np.int32)
+    a = sc.score(kt[0], upad[0], table=dev, indices=idx).cpu().numpy()
+    b = exact.score(kt2[0], upad2[0], table=dev, indices=idx).cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+    with pytest.raises(ops.InvalidArgumentError) as e:
+        sc.score(kt[0], upad[0], table=dev, indices=[0, n_table])
+    assert e.value.status == 5
+
+
 # ---------------------------------------------------------------- BlazeXlaOp's model from a weights directory
 @pytest.mark.parametrize("kind", ["l2", "mlp", "attention"])
 def test_model_directory_forward(oracle, tmp_path, kind):
