@@ -114,7 +114,7 @@ __device__ __forceinline__ void split_tile(const f32x16& x, f16x8 (&h)[2], f16x8
 }
 
 // the lane's 16 rows of a 32-unit vector tile: four runs of 4 consecutive floats
-__device__ __forceinline__ void load_tile_vec(const float* __restrict__ v, int g, float (&out)[16]) {
+__device__ __forceinline__ void load_tile_vec(const float* v, int g, float (&out)[16]) {
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const float4 x = *reinterpret_cast<const float4*>(v + 8 * rr + 4 * g);
@@ -123,9 +123,21 @@ __device__ __forceinline__ void load_tile_vec(const float* __restrict__ v, int g
 }
 
 #define NANN_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+// Scheduling shape of a step of N chunks, each R LDS reads (its A fragments) + M MFMAs: the reads of chunks 0
+// and 1 first, then the MFMAs of chunk k beside the reads of chunk k + 2 -- without it hipcc issues every read
+// right before its MFMA and the wavefront waits out the LDS latency N times.
+#define NANN_PIPE_READS_MFMAS(N_, R_, M_)                                  \
+  do {                                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (R_), 0);              \
+    _Pragma("unroll") for (int k_ = 0; k_ < (N_) - 2; ++k_) {              \
+      __builtin_amdgcn_sched_group_barrier(0x008, (M_), 0);                \
+      __builtin_amdgcn_sched_group_barrier(0x100, (R_), 0);                \
+    }                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * (M_), 0);              \
+  } while (0)
 
 // wg_score_attn_split: as wg_score_attn.  kt / ua = the packed per-user fragments (k_attn_prepare_split);
-// `slice` = 32 KB of LDS (two buffers).
+// `slice` = kAttnSlice + kAttnVecFloats floats of LDS (two 16 KB buffers + the small vectors).
 template <int D, int DT, int NT>
 __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const uint4* __restrict__ kt,
                                                     const uint4* __restrict__ ua, const void* table,
@@ -140,7 +152,12 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, g = lane >> 5;
   uint4* buf = reinterpret_cast<uint4*>(slice_f);  // [2][1024]
-  const float* pv = P.pvec;
+  float* pv = slice_f + kAttnSlice;                // the small vectors, in LDS: a step's seeds must not wait on L2
+  static_assert(PV_COUNT <= kAttnVecFloats, "vector block");
+  __syncthreads();
+  for (int k = tid; k < PV_COUNT / 4; k += NT)
+    reinterpret_cast<float4*>(pv)[k] = reinterpret_cast<const float4*>(P.pvec)[k];
+  // (visible after the barriers that open the first pass)
   const float att_scale = (1.0f / sqrtf(256.0f)) / (kAttnWS * kAttnHS);  // model_util.py:89-91, and the operand scales
 
   // slice s of a pass -> (global source, number of uint4)
@@ -244,6 +261,7 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
             acc = NANN_MFMA16(whi, q1l[kc >> 1][kc & 1], acc);
             acc = NANN_MFMA16(wlo, q1h[kc >> 1][kc & 1], acc);
           }
+          NANN_PIPE_READS_MFMAS(8, 2, 3);
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] *= 1.0f / kAttnWS;  // q_ x 2^4
           split_tile(acc, qh, ql);
@@ -257,6 +275,7 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
               att[p] = NANN_MFMA16(khi, ql[q], att[p]);
               att[p] = NANN_MFMA16(klo, qh[q], att[p]);
             }
+          NANN_PIPE_READS_MFMAS(4, 2, 3);
           if (t == 7) {  // softmax over the L positions (:93); positions >= L are padding of the layout
             float mx = -INFINITY;
 #pragma unroll
@@ -301,6 +320,7 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
             }
           split_tile(acc, ah[m], al[m]);  // a x 2^4
         }
+        load_row(row);  // the item row again for DNN layer 1 (L1 / L2 hit): 4 KC registers not held through the attention loop
       } else if (s < 29) {  // DNN layer 1 on [a ; e] (model.py:211-214)
         const int m = (s - 21) >> 1;
         if (((s - 21) & 1) == 0) {
@@ -396,5 +416,6 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
 }
 
 #undef NANN_MFMA16
+#undef NANN_PIPE_READS_MFMAS
 
 }  // namespace nann

@@ -10,7 +10,7 @@ __global__ __launch_bounds__(kAttnNT) void k_score_attn_split(AttnParams P, cons
                                                               const float* __restrict__ upad, const void* table,
                                                               long long n_table_rows, const int32_t* indices,
                                                               long long n, float* scores, long long* bad_i) {
-  __shared__ __attribute__((aligned(16))) float slice[kAttnSlice];
+  __shared__ __attribute__((aligned(16))) float slice[kAttnSlice + kAttnVecFloats];
   const int tid = local_tid();
   constexpr int CPP = (kAttnNT / 64) * 32;
   if (indices) {  // bounds first (gather_op.cc:170-175)

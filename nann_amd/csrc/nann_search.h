@@ -141,7 +141,7 @@ constexpr int hash_phase_scratch() {
   return ((a > b ? a : b) + 255) & ~255;
 }
 // phase scratch of a traversal kernel: the attention scorer stages 32 KB weight slices
-constexpr int kAttnScratch = kAttnSlice * 4;
+constexpr int kAttnScratch = (kAttnSlice + kAttnVecFloats) * 4;
 template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
