@@ -123,18 +123,14 @@ __device__ __forceinline__ void load_tile_vec(const float* v, int g, float (&out
 }
 
 #define NANN_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
-// Scheduling shape of a step of N chunks, each R LDS reads (its A fragments) + M MFMAs: the reads of chunks 0
-// and 1 first, then the MFMAs of chunk k beside the reads of chunk k + 2 -- without it hipcc issues every read
-// right before its MFMA and the wavefront waits out the LDS latency N times.
-#define NANN_PIPE_READS_MFMAS(N_, R_, M_)                                  \
-  do {                                                                     \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (R_), 0);              \
-    _Pragma("unroll") for (int k_ = 0; k_ < (N_) - 2; ++k_) {              \
-      __builtin_amdgcn_sched_group_barrier(0x008, (M_), 0);                \
-      __builtin_amdgcn_sched_group_barrier(0x100, (R_), 0);                \
-    }                                                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * (M_), 0);              \
-  } while (0)
+// All A fragments of a step are read from LDS in one burst before its first MFMA (and the compiler is kept from
+// sinking them back next to their uses): one exposed LDS latency per step instead of one per chunk.
+template <int N>
+__device__ __forceinline__ void load_frags(const uint4* A, int lane, f16x8 (&f)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) f[k] = as_f16x8(A[k * 64 + lane]);
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 // wg_score_attn_split: as wg_score_attn.  kt / ua = the packed per-user fragments (k_attn_prepare_split);
 // `slice` = kAttnSlice + kAttnVecFloats floats of LDS (two 16 KB buffers + the small vectors).
@@ -201,6 +197,21 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
     for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
   };
 
+  // one step of the slice pipeline: slice s is in buf[s & 1]; the next one travels L2 -> registers while this
+  // one feeds the MFMAs, then registers -> the other buffer, one barrier
+  auto step_begin = [&](int s) -> const uint4* {
+    if (s + 1 < NS) fetch(s + 1);
+    return buf + (s & 1) * 1024;
+  };
+  auto step_end = [&](int s) {
+    if (s + 1 < NS) {
+      uint4* nb = buf + ((s + 1) & 1) * 1024;
+      nb[tid] = pre0;
+      nb[tid + NT] = pre1;
+      __syncthreads();
+    }
+  };
+
   for (long long c0 = 0; c0 < n; c0 += CPP) {
     const long long i = c0 + wave * 32 + cand;
     const size_t row = row_of(c0);
@@ -211,203 +222,235 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
     buf[tid + NT] = pre1;
     __syncthreads();
 
-    f16x8 q1h[4][2], q1l[4][2];  // q1 x 2^4, split
+    f32x16 acc;
+    // ---- q1 = prelu(e Wq1 + bq1), x 2^4, split: the B fragments of the next layer
+    f16x8 q1h[4][2], q1l[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint4* A = step_begin(m);
+      float seed[16];
+      load_tile_vec(pv + PV_BQ1 + 32 * m, g, seed);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = seed[r];
+      f16x8 W[2 * KC];
+      load_frags(A, lane, W);
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const f16x8 b = row_chunk_f16<DT>(ev[kc]);
+        acc = NANN_MFMA16(W[kc * 2 + 0], b, acc);
+        acc = NANN_MFMA16(W[kc * 2 + 1], b, acc);
+      }
+      float al_[16];
+      load_tile_vec(pv + PV_AQ + 32 * m, g, al_);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = acc[r] * (acc[r] > 0.0f ? kAttnHS / kAttnWS : al_[r]);
+      split_tile(acc, q1h[m], q1l[m]);
+      step_end(m);
+    }
+    // ---- attention logits, q_ tile by q_ tile: att[l] += sum_{j in tile} q_[j] k_l[j].  A ROLLED loop: unrolled,
+    // a pass is ~40 KB of straight-line code that no instruction cache holds, and the kernel runs at the speed of
+    // instruction fetch.
     f32x16 att[2];
-    f16x8 ph[2][2], pl[2][2];    // softmax weights x 2^4, split
-    f16x8 ah[2][2], al[2][2];    // a x 2^4, split
-    f16x8 h1h[4][2], h1l[4][2];
-    f16x8 h2h[2][2], h2l[2][2];
-    f32x16 acc, acc_e;
-    f16x8 qh[2], ql[2];
-    float logit = 0.0f;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) att[p][r] = 0.0f;
-
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const uint4* A = buf + (s & 1) * 1024;
-      if (s + 1 < NS) fetch(s + 1);
-      // ---------------------------------------------------------------- compute on slice s
-      if (s < 4) {  // q1 tile m = s: prelu(e Wq1 + bq1)
-        const int m = s;
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+      f16x8 qh[2], ql[2];
+      {  // q_ tile t = q1 Wq2 + bq2
+        const uint4* A = step_begin(4 + 2 * t);
         float seed[16];
-        load_tile_vec(pv + PV_BQ1 + 32 * m, g, seed);
+        load_tile_vec(pv + PV_BQ2 + 32 * t, g, seed);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = seed[r];
+        f16x8 W[16];
+        load_frags(A, lane, W);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          acc = NANN_MFMA16(W[kc * 2], q1h[kc >> 1][kc & 1], acc);
+          acc = NANN_MFMA16(W[kc * 2], q1l[kc >> 1][kc & 1], acc);
+          acc = NANN_MFMA16(W[kc * 2 + 1], q1h[kc >> 1][kc & 1], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= 1.0f / kAttnWS;  // q_ x 2^4
+        split_tile(acc, qh, ql);
+        step_end(4 + 2 * t);
+      }
+      {
+        const uint4* A = step_begin(5 + 2 * t);
+        f16x8 K[8];
+        load_frags(A, lane, K);
+        // product-major, the two position tiles alternating
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) att[p] = NANN_MFMA16(K[(p * 2 + q) * 2], qh[q], att[p]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) att[p] = NANN_MFMA16(K[(p * 2 + q) * 2], ql[q], att[p]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) att[p] = NANN_MFMA16(K[(p * 2 + q) * 2 + 1], qh[q], att[p]);
+        step_end(5 + 2 * t);
+      }
+    }
+    // ---- softmax over the L positions (:93); positions >= L are padding of the layout
+    f16x8 ph[2][2], pl[2][2];  // softmax weights x 2^4, split
+    {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int l = 32 * p + cd_unit(r >> 3, g, r & 7);
+          att[p][r] = l < P.L ? att[p][r] * att_scale : -INFINITY;
+          mx = fmaxf(mx, att[p][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          att[p][r] = expf(att[p][r] - mx);
+          sum += att[p][r];
+        }
+      sum += __shfl_xor(sum, 32);
+      const float inv = kAttnHS / sum;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) att[p][r] *= inv;
+        split_tile(att[p], ph[p], pl[p]);
+      }
+    }
+    // ---- a = sum_l p_l u_l (:95, model.py:204-206): u is exact f16
+    f16x8 ah[2][2], al[2][2];  // a x 2^4, split
+    {
+      const uint4* A = step_begin(20);
+      f16x8 U[8];
+      load_frags(A, lane, U);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            acc = NANN_MFMA16(U[(m * 2 + p) * 2 + q], ph[p][q], acc);
+            acc = NANN_MFMA16(U[(m * 2 + p) * 2 + q], pl[p][q], acc);
+          }
+        split_tile(acc, ah[m], al[m]);
+      }
+      load_row(row);  // the item row again for DNN layer 1 (L1 / L2 hit): not held through the attention loop
+      step_end(20);
+    }
+    // ---- DNN layer 1 on [a ; e] (model.py:211-214)
+    f16x8 h1h[4][2], h1l[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      {
+        const uint4* A = step_begin(21 + 2 * m);
+        float seed[16];
+        load_tile_vec(pv + PV_B1 + 32 * m, g, seed);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = seed[r];
+        f16x8 W[8];
+        load_frags(A, lane, W);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          acc = NANN_MFMA16(W[kc * 2], ah[kc >> 1][kc & 1], acc);
+          acc = NANN_MFMA16(W[kc * 2], al[kc >> 1][kc & 1], acc);
+          acc = NANN_MFMA16(W[kc * 2 + 1], ah[kc >> 1][kc & 1], acc);
+        }
+        step_end(21 + 2 * m);
+      }
+      {
+        const uint4* A = step_begin(22 + 2 * m);
+        f32x16 acc_e;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_e[r] = 0.0f;
+        f16x8 W[2 * KC];
+        load_frags(A, lane, W);
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
           const f16x8 b = row_chunk_f16<DT>(ev[kc]);
-          acc = NANN_MFMA16(as_f16x8(A[(kc * 2 + 0) * 64 + lane]), b, acc);
-          acc = NANN_MFMA16(as_f16x8(A[(kc * 2 + 1) * 64 + lane]), b, acc);
-        }
-        float al_[16];
-        load_tile_vec(pv + PV_AQ + 32 * m, g, al_);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = acc[r] * (acc[r] > 0.0f ? kAttnHS / kAttnWS : al_[r]);
-        split_tile(acc, q1h[m], q1l[m]);
-      } else if (s < 20) {
-        const int t = (s - 4) >> 1;
-        if (((s - 4) & 1) == 0) {  // q_ tile t = q1 Wq2 + bq2
-          float seed[16];
-          load_tile_vec(pv + PV_BQ2 + 32 * t, g, seed);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = seed[r];
-#pragma unroll
-          for (int kc = 0; kc < 8; ++kc) {
-            const f16x8 whi = as_f16x8(A[(kc * 2 + 0) * 64 + lane]), wlo = as_f16x8(A[(kc * 2 + 1) * 64 + lane]);
-            acc = NANN_MFMA16(whi, q1h[kc >> 1][kc & 1], acc);
-            acc = NANN_MFMA16(whi, q1l[kc >> 1][kc & 1], acc);
-            acc = NANN_MFMA16(wlo, q1h[kc >> 1][kc & 1], acc);
-          }
-          NANN_PIPE_READS_MFMAS(8, 2, 3);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] *= 1.0f / kAttnWS;  // q_ x 2^4
-          split_tile(acc, qh, ql);
-        } else {  // att[l] += sum over the tile's units of q_[j] k_l[j]
-#pragma unroll
-          for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const f16x8 khi = as_f16x8(A[((p * 2 + q) * 2 + 0) * 64 + lane]), klo = as_f16x8(A[((p * 2 + q) * 2 + 1) * 64 + lane]);
-              att[p] = NANN_MFMA16(khi, qh[q], att[p]);
-              att[p] = NANN_MFMA16(khi, ql[q], att[p]);
-              att[p] = NANN_MFMA16(klo, qh[q], att[p]);
-            }
-          NANN_PIPE_READS_MFMAS(4, 2, 3);
-          if (t == 7) {  // softmax over the L positions (:93); positions >= L are padding of the layout
-            float mx = -INFINITY;
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int l = 32 * p + cd_unit(r >> 3, g, r & 7);
-                att[p][r] = l < P.L ? att[p][r] * att_scale : -INFINITY;
-                mx = fmaxf(mx, att[p][r]);
-              }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.0f;
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                att[p][r] = expf(att[p][r] - mx);
-                sum += att[p][r];
-              }
-            sum += __shfl_xor(sum, 32);
-            const float inv = kAttnHS / sum;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) att[p][r] *= inv;
-              split_tile(att[p], ph[p], pl[p]);
-            }
-          }
-        }
-      } else if (s < 21) {  // a = sum_l p_l u_l (:95, model.py:204-206): u is exact f16
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-          for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const f16x8 uu = as_f16x8(A[((m * 2 + p) * 2 + q) * 64 + lane]);
-              acc = NANN_MFMA16(uu, ph[p][q], acc);
-              acc = NANN_MFMA16(uu, pl[p][q], acc);
-            }
-          split_tile(acc, ah[m], al[m]);  // a x 2^4
-        }
-        load_row(row);  // the item row again for DNN layer 1 (L1 / L2 hit): 4 KC registers not held through the attention loop
-      } else if (s < 29) {  // DNN layer 1 on [a ; e] (model.py:211-214)
-        const int m = (s - 21) >> 1;
-        if (((s - 21) & 1) == 0) {
-          float seed[16];
-          load_tile_vec(pv + PV_B1 + 32 * m, g, seed);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = seed[r];
-#pragma unroll
-          for (int kc = 0; kc < 4; ++kc) {
-            const f16x8 whi = as_f16x8(A[(kc * 2 + 0) * 64 + lane]), wlo = as_f16x8(A[(kc * 2 + 1) * 64 + lane]);
-            acc = NANN_MFMA16(whi, ah[kc >> 1][kc & 1], acc);
-            acc = NANN_MFMA16(whi, al[kc >> 1][kc & 1], acc);
-            acc = NANN_MFMA16(wlo, ah[kc >> 1][kc & 1], acc);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc_e[r] = 0.0f;
-#pragma unroll
-          for (int kc = 0; kc < KC; ++kc) {
-            const f16x8 b = row_chunk_f16<DT>(ev[kc]);
-            acc_e = NANN_MFMA16(as_f16x8(A[(kc * 2 + 0) * 64 + lane]), b, acc_e);
-            acc_e = NANN_MFMA16(as_f16x8(A[(kc * 2 + 1) * 64 + lane]), b, acc_e);
-          }
-          float sc[16], sh[16], al_[16];
-          load_tile_vec(pv + PV_S1 + 32 * m, g, sc);
-          load_tile_vec(pv + PV_T1 + 32 * m, g, sh);
-          load_tile_vec(pv + PV_A1 + 32 * m, g, al_);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = __fmaf_rn(__fmaf_rn(acc_e[r], kAttnHS, acc[r]), sc[r], sh[r]);  // bn(x W + b)
-            acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
-          }
-          split_tile(acc, h1h[m], h1l[m]);
-        }
-      } else if (s < 31) {  // layer 2
-        const int m = s - 29;
-        float seed[16];
-        load_tile_vec(pv + PV_B2 + 32 * m, g, seed);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = seed[r];
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-          const f16x8 whi = as_f16x8(A[(kc * 2 + 0) * 64 + lane]), wlo = as_f16x8(A[(kc * 2 + 1) * 64 + lane]);
-          acc = NANN_MFMA16(whi, h1h[kc >> 1][kc & 1], acc);
-          acc = NANN_MFMA16(whi, h1l[kc >> 1][kc & 1], acc);
-          acc = NANN_MFMA16(wlo, h1h[kc >> 1][kc & 1], acc);
+          acc_e = NANN_MFMA16(W[kc * 2], b, acc_e);
+          acc_e = NANN_MFMA16(W[kc * 2 + 1], b, acc_e);
         }
         float sc[16], sh[16], al_[16];
-        load_tile_vec(pv + PV_S2 + 32 * m, g, sc);
-        load_tile_vec(pv + PV_T2 + 32 * m, g, sh);
-        load_tile_vec(pv + PV_A2 + 32 * m, g, al_);
+        load_tile_vec(pv + PV_S1 + 32 * m, g, sc);
+        load_tile_vec(pv + PV_T1 + 32 * m, g, sh);
+        load_tile_vec(pv + PV_A1 + 32 * m, g, al_);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
+          const float v = __fmaf_rn(__fmaf_rn(acc_e[r], kAttnHS, acc[r]), sc[r], sh[r]);  // bn(x W + b)
           acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
         }
-        split_tile(acc, h2h[m], h2l[m]);
-      } else {  // layer 3 and the bias-free output (:218-219)
-        float seed[16];
-        load_tile_vec(pv + PV_B3, g, seed);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = seed[r];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-          const f16x8 whi = as_f16x8(A[(kc * 2 + 0) * 64 + lane]), wlo = as_f16x8(A[(kc * 2 + 1) * 64 + lane]);
-          acc = NANN_MFMA16(whi, h2h[kc >> 1][kc & 1], acc);
-          acc = NANN_MFMA16(whi, h2l[kc >> 1][kc & 1], acc);
-          acc = NANN_MFMA16(wlo, h2h[kc >> 1][kc & 1], acc);
-        }
-        float sc[16], sh[16], al_[16], w4[16];
-        load_tile_vec(pv + PV_S3, g, sc);
-        load_tile_vec(pv + PV_T3, g, sh);
-        load_tile_vec(pv + PV_A3, g, al_);
-        load_tile_vec(pv + PV_W4, g, w4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
-          logit = __fmaf_rn(v > 0.0f ? v : al_[r] * v, w4[r], logit);
-        }
+        split_tile(acc, h1h[m], h1l[m]);
+        step_end(22 + 2 * m);
       }
-      // ---------------------------------------------------------------- hand the next slice over
-      if (s + 1 < NS) {
-        uint4* nb = buf + ((s + 1) & 1) * 1024;
-        nb[tid] = pre0;
-        nb[tid + NT] = pre1;
-        __syncthreads();
+    }
+    // ---- layer 2
+    f16x8 h2h[2][2], h2l[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const uint4* A = step_begin(29 + m);
+      float seed[16];
+      load_tile_vec(pv + PV_B2 + 32 * m, g, seed);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = seed[r];
+      f16x8 W[16];
+      load_frags(A, lane, W);
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        acc = NANN_MFMA16(W[kc * 2], h1h[kc >> 1][kc & 1], acc);
+        acc = NANN_MFMA16(W[kc * 2], h1l[kc >> 1][kc & 1], acc);
+        acc = NANN_MFMA16(W[kc * 2 + 1], h1h[kc >> 1][kc & 1], acc);
       }
+      float sc[16], sh[16], al_[16];
+      load_tile_vec(pv + PV_S2 + 32 * m, g, sc);
+      load_tile_vec(pv + PV_T2 + 32 * m, g, sh);
+      load_tile_vec(pv + PV_A2 + 32 * m, g, al_);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
+        acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
+      }
+      split_tile(acc, h2h[m], h2l[m]);
+      step_end(29 + m);
+    }
+    // ---- layer 3 and the bias-free output (:218-219)
+    float logit = 0.0f;
+    {
+      const uint4* A = step_begin(31);
+      float seed[16];
+      load_tile_vec(pv + PV_B3, g, seed);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = seed[r];
+      f16x8 W[8];
+      load_frags(A, lane, W);
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        acc = NANN_MFMA16(W[kc * 2], h2h[kc >> 1][kc & 1], acc);
+        acc = NANN_MFMA16(W[kc * 2], h2l[kc >> 1][kc & 1], acc);
+        acc = NANN_MFMA16(W[kc * 2 + 1], h2h[kc >> 1][kc & 1], acc);
+      }
+      float sc[16], sh[16], al_[16], w4[16];
+      load_tile_vec(pv + PV_S3, g, sc);
+      load_tile_vec(pv + PV_T3, g, sh);
+      load_tile_vec(pv + PV_A3, g, al_);
+      load_tile_vec(pv + PV_W4, g, w4);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
+        logit = __fmaf_rn(v > 0.0f ? v : al_[r] * v, w4[r], logit);
+      }
+      step_end(31);
     }
     logit += __shfl_xor(logit, 32);
     if (g == 0 && i < n) scores[i] = logit;
@@ -416,6 +459,5 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
 }
 
 #undef NANN_MFMA16
-#undef NANN_PIPE_READS_MFMAS
 
 }  // namespace nann

@@ -36,6 +36,8 @@ def main():
         o = out.float().cpu().numpy()
         err = "" if ref is None else f"; max |split - exact| / max(1, |exact|) = {np.abs(ref - o).max() / max(1.0, np.abs(o).max()):.2e}"
         ref = o if ref is None else ref
+        if os.environ.get("NANN_ATTN_TIMING") and prec == "split":  # a timing build wrote per-step shader cycles there
+            print("per-step cycles of the last pass of block 0:", [int(x) for x in o[:34]], flush=True)
         print(f"d={d} {prec}: {ms:.3f} ms for {n} rows = {n / ms / 1e3:.1f} M rows/s; "
               f"{ms * 1e3 / (n / 256 / 256):.2f} us per 256-row pass per CU{err}", flush=True)
 
