@@ -247,9 +247,9 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
       split_tile(acc, q1h[m], q1l[m]);
       step_end(m);
     }
-    // ---- attention logits, q_ tile by q_ tile: att[l] += sum_{j in tile} q_[j] k_l[j].  A ROLLED loop: unrolled,
-    // a pass is ~40 KB of straight-line code that no instruction cache holds, and the kernel runs at the speed of
-    // instruction fetch.
+    // ---- attention logits, q_ tile by q_ tile: att[l] += sum_{j in tile} q_[j] k_l[j].  A ROLLED loop: measured
+    // 15 % faster than the unrolled form (61.6 -> 52.1 us per pass; spills 724 -> 236 B/lane, half the code);
+    // rolling the q1 and DNN-1 tile loops as well (fragments stored through uniform branches) LOSES 20 %.
     f32x16 att[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p)

@@ -356,9 +356,13 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
     f32x16 a1;
     f16x8 bh[2], bl[2];
     uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
+    // the hidden-tile loop is ROLLED: same speed as the unrolled form (27.3 us per pass, 4.75 ms per 1024 queries), an
+    // eighth of the code, and k_search keeps its registers (d = 256: 468 -> 68 B/lane of spills)
+#pragma unroll 1
+    for (int t = 0; t < H1T; ++t)
 #pragma unroll
-    for (int s = 0; s < NSLICE; ++s) {
-      const int t = s / SPT, ks = s % SPT;
+    for (int ks = 0; ks < SPT; ++ks) {
+      const int s = t * SPT + ks;
       __syncthreads();  // every wave is done with the previous slice
       slice[tid] = pre0;
       slice[tid + NT] = pre1;
