@@ -223,6 +223,10 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
     __syncthreads();
 
     f32x16 acc;
+#ifdef NANN_ATTN_TIMING  // timing build: shader-clock stamps per section, written over the first scores by thread 0
+    long long tk[6];
+    tk[0] = __builtin_readcyclecounter();
+#endif
     // ---- q1 = prelu(e Wq1 + bq1), x 2^4, split: the B fragments of the next layer
     f16x8 q1h[4][2], q1l[4][2];
 #pragma unroll
@@ -247,6 +251,9 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
       split_tile(acc, q1h[m], q1l[m]);
       step_end(m);
     }
+#ifdef NANN_ATTN_TIMING
+    tk[1] = __builtin_readcyclecounter();
+#endif
     // ---- attention logits, q_ tile by q_ tile: att[l] += sum_{j in tile} q_[j] k_l[j].  A ROLLED loop: measured
     // 15 % faster than the unrolled form (61.6 -> 52.1 us per pass; spills 724 -> 236 B/lane, half the code);
     // rolling the q1 and DNN-1 tile loops as well (fragments stored through uniform branches) LOSES 20 %.
@@ -297,6 +304,9 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
         step_end(5 + 2 * t);
       }
     }
+#ifdef NANN_ATTN_TIMING
+    tk[2] = __builtin_readcyclecounter();
+#endif
     // ---- softmax over the L positions (:93); positions >= L are padding of the layout
     f16x8 ph[2][2], pl[2][2];  // softmax weights x 2^4, split
     {
@@ -349,6 +359,9 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
       load_row(row);  // the item row again for DNN layer 1 (L1 / L2 hit): not held through the attention loop
       step_end(20);
     }
+#ifdef NANN_ATTN_TIMING
+    tk[3] = __builtin_readcyclecounter();
+#endif
     // ---- DNN layer 1 on [a ; e] (model.py:211-214)
     f16x8 h1h[4][2], h1l[4][2];
 #pragma unroll
@@ -395,6 +408,9 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
         step_end(22 + 2 * m);
       }
     }
+#ifdef NANN_ATTN_TIMING
+    tk[4] = __builtin_readcyclecounter();
+#endif
     // ---- layer 2
     f16x8 h2h[2][2], h2l[2][2];
 #pragma unroll
@@ -454,6 +470,12 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
     }
     logit += __shfl_xor(logit, 32);
     if (g == 0 && i < n) scores[i] = logit;
+#ifdef NANN_ATTN_TIMING
+    tk[5] = __builtin_readcyclecounter();
+    __syncthreads();
+    if (tid == 0 && c0 + CPP >= n)
+      for (int k = 0; k < 5; ++k) scores[k] = (float)(tk[k + 1] - tk[k]);
+#endif
   }
   __syncthreads();
 }

@@ -37,7 +37,8 @@ def main():
         err = "" if ref is None else f"; max |split - exact| / max(1, |exact|) = {np.abs(ref - o).max() / max(1.0, np.abs(o).max()):.2e}"
         ref = o if ref is None else ref
         if os.environ.get("NANN_ATTN_TIMING") and prec == "split":  # a timing build wrote per-step shader cycles there
-            print("per-step cycles of the last pass of block 0:", [int(x) for x in o[:34]], flush=True)
+            print("cycles of the last pass of block 0 [q1 x4 | q_/att x16 | softmax + a | DNN1 x8 | DNN2, 3]:",
+                  [int(x) for x in o[:5]], flush=True)
         print(f"d={d} {prec}: {ms:.3f} ms for {n} rows = {n / ms / 1e3:.1f} M rows/s; "
               f"{ms * 1e3 / (n / 256 / 256):.2f} us per 256-row pass per CU{err}", flush=True)
 
