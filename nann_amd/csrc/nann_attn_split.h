@@ -123,14 +123,6 @@ __device__ __forceinline__ void load_tile_vec(const float* v, int g, float (&out
 }
 
 #define NANN_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
-// All A fragments of a step are read from LDS in one burst before its first MFMA (and the compiler is kept from
-// sinking them back next to their uses): one exposed LDS latency per step instead of one per chunk.
-template <int N>
-__device__ __forceinline__ void load_frags(const uint4* A, int lane, f16x8 (&f)[N]) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) f[k] = as_f16x8(A[k * 64 + lane]);
-  __builtin_amdgcn_sched_barrier(0);
-}
 
 // wg_score_attn_split: as wg_score_attn.  kt / ua = the packed per-user fragments (k_attn_prepare_split);
 // `slice` = kAttnSlice + kAttnVecFloats floats of LDS (two 16 KB buffers + the small vectors).

@@ -1104,7 +1104,7 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table, int
   hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, st, rb->dev);
   const int d = scorer->desc.d, lpr = d / 8, dt = scorer->desc.emb_dtype;
   if (scorer->desc.kind == NANN_SCORER_MLP) {
-    const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 512);  // (each takes a contiguous run of passes)
     const MlpParams& P = scorer->mlp;
     const int split = scorer->desc.precision == NANN_MLP_SPLIT_F16;
     if (d == 64) rc = launch_score_mlp_d64(dt, split, blocks, st, P, table, n_table_rows, indices, n, q, out_scores, rb->dev);
@@ -1528,6 +1528,7 @@ static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
 static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
 constexpr int kKindAttn = 2;      // plan_search: the attention model (NANN_MODEL_ATTENTION); 0 / 1 = nann_scorer_kind
+constexpr int kKindMlpSplit = 3;  //   the MLP scorer in split-f16 form (two slice buffers: the scratch of an attention plan)
 // kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
 static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p) {
   for (int i = 0; i < 6; ++i)
@@ -1546,7 +1547,12 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->pool_cap = std::max(t[1] + t[2] + t[3] + t[4], 1);
   const size_t tail = kMaxD * 4 + 256;  // q + misc behind the phase scratch
   const size_t bm_bytes = (size_t)ix->bm_words * 4;
-  const size_t bm_scratch = kind == kKindAttn ? (size_t)kAttnScratch : (size_t)kPhaseScratch;
+  // scratch behind the visited set: "any" (workspace sizing) assumes the largest, so that its slots can hold the HBM
+  // bitmap of whatever plan the call ends up with
+  const size_t big_scratch = (size_t)std::max(kAttnScratch, kMlpSplitScratch);
+  const size_t bm_scratch = kind == kKindAttn ? (size_t)kAttnScratch
+                            : kind == kKindMlpSplit ? (size_t)kMlpSplitScratch
+                            : kind < 0 ? big_scratch : (size_t)kPhaseScratch;
   const bool bitmap_fits = bm_bytes + bm_scratch + tail <= di.lds_max;
   const int mode = g_traversal_mode.load(std::memory_order_relaxed);
   // the bitmap plan: what MLP traversals run, what oversized shards run, and the fallback of the hash plan
@@ -1583,11 +1589,12 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   p->fb_vis = bm_vis;
   p->fb_lds_bytes = bm_lds;
   p->fb_slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * bm_per_cu));
-  if (kind == kKindAttn && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP && pos_bits >= 10) {
-    // attention model: 16K-slot set + its 32 KB weight slices, one 512-thread workgroup per CU
+  if ((kind == kKindAttn || kind == kKindMlpSplit) && mode != NANN_TRAVERSAL_LDS_BITMAP &&
+      mode != NANN_TRAVERSAL_HBM_BITMAP && pos_bits >= 10) {
+    // attention model / split-f16 MLP: 16K-slot set + two weight-slice buffers, one 512-thread workgroup per CU
     p->vis = VIS_LDS_HASH;
     p->nt = 512;
-    p->lds_bytes = (size_t)vis_slots(VIS_LDS_HASH) * 4 + kAttnScratch + tail;
+    p->lds_bytes = (size_t)vis_slots(VIS_LDS_HASH) * 4 + bm_scratch + tail;
     p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus));
   } else if (hash_ok && hash_vis == VIS_LDS_HASH) {
     p->vis = VIS_LDS_HASH;
@@ -1664,8 +1671,9 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
                        int32_t* counters, int64_t* phase_ticks, hipStream_t st) {
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
   const int kind = attn ? kKindAttn : scorer->desc.kind;
+  const bool mlp_split = !attn && kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
   SearchPlan p;
-  int rc = plan_search(ix, level_topn, n_queries, kind, &p);
+  int rc = plan_search(ix, level_topn, n_queries, mlp_split ? kKindMlpSplit : kind, &p);
   if (rc) return rc;
   if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots)))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");

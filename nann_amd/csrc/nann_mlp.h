@@ -59,6 +59,11 @@ struct MlpScratch {
   MlpVectors v;
 };
 static_assert(sizeof(MlpScratch) <= kPhaseScratch, "phase scratch too small for the MLP");
+// split-f16 form: two slice buffers (slice s+1 lands in one while slice s feeds the MFMAs from the other)
+struct MlpSplitScratch {
+  uint4 buf[2][1024];
+  MlpVectors v;
+};
 
 __device__ __forceinline__ float prelu(float x, float a) {
   const float pos = x > 0.0f ? x : 0.0f;
@@ -297,6 +302,15 @@ __device__ __forceinline__ f16x8 row_chunk_f16(const uint4& v) {  // 8 table ele
   }
 }
 
+// All A fragments of a step are read from LDS in one burst before its first MFMA (and the compiler is kept from
+// sinking them back next to their uses): one exposed LDS latency per step instead of one per chunk.
+template <int N>
+__device__ __forceinline__ void load_frags(const uint4* A, int lane, f16x8 (&f)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) f[k] = as_f16x8(A[k * 64 + lane]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Where a 256-row pass spends its 27 us at d = 128 (tools/mlp_rate.py on the stand-alone scorer, timing builds with
 // parts compiled out, profiles/r2_mlp_split_experiments.md): the 320 MFMAs per wavefront alone take 17-19 us
 // (two wavefronts per SIMD, ~50 shader cycles per MFMA at the 1.9 GHz the chip holds under this load, against 32
@@ -308,7 +322,7 @@ __device__ __forceinline__ f16x8 row_chunk_f16(const uint4& v) {  // 8 table ele
 template <int D, int H1T, int H2T, int DT, int NT>
 __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const void* __restrict__ table,
                                                    uint32_t n_table_rows, const int32_t* ids, int n,
-                                                   MlpScratch* S, float* scores) {
+                                                   MlpSplitScratch* S, float* scores) {
   const MlpVectors* V = &S->v;
   static_assert(DT == DT_F16 || DT == DT_BF16, "split form: 16-bit table rows");
   static_assert(H2T == 4, "a layer-2 slice is [2 chunks][4 tiles][2 planes] KB");
@@ -321,7 +335,7 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
   constexpr int NSLICE = H1T * SPT;
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, g = lane >> 5;
-  uint4* slice = reinterpret_cast<uint4*>(S->slice);  // 1024 x 16 B
+  uint4* buf = &S->buf[0][0];  // [2][1024] x 16 B
 
   auto slice_src = [&](int s, int f) -> const uint4* {  // uint4 number f (0..1023) of slice s
     const int t = s / SPT, ks = s % SPT;
@@ -341,6 +355,14 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
     for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
   };
   if (n > 0) load_row(row_of(0));
+  // slice pipeline: slice s sits in buf[s & 1]; slice s+1 (of this pass or the first of the next) travels
+  // L2 -> registers while s feeds the MFMAs, then registers -> the other buffer; ONE barrier per slice
+  uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
+  __syncthreads();  // the caller is done with the scratch (the vectors were staged before, behind a barrier)
+  buf[tid] = pre0;
+  buf[tid + NT] = pre1;
+  __syncthreads();
+  static_assert(NSLICE % 2 == 0, "slice 0 of the next pass lands in buffer 0 again");
 
   for (int i0 = 0; i0 < n; i0 += CPP) {
     const int i = i0 + wave * 32 + cand;
@@ -355,7 +377,6 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
       }
     f32x16 a1;
     f16x8 bh[2], bl[2];
-    uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
     // the hidden-tile loop is ROLLED: same speed as the unrolled form (27.3 us per pass, 4.75 ms per 1024 queries), an
     // eighth of the code, and k_search keeps its registers (d = 256: 468 -> 68 B/lane of spills)
 #pragma unroll 1
@@ -363,13 +384,11 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
 #pragma unroll
     for (int ks = 0; ks < SPT; ++ks) {
       const int s = t * SPT + ks;
-      __syncthreads();  // every wave is done with the previous slice
-      slice[tid] = pre0;
-      slice[tid + NT] = pre1;
-      __syncthreads();
-      if (s + 1 < NSLICE) {  // next slice from L2 while this one feeds the MFMAs
-        pre0 = *slice_src(s + 1, tid);
-        pre1 = *slice_src(s + 1, tid + NT);
+      const uint4* A = buf + (s & 1) * 1024;
+      {  // next slice from L2 while this one feeds the MFMAs
+        const int sn = s + 1 < NSLICE ? s + 1 : 0;
+        pre0 = *slice_src(sn, tid);
+        pre1 = *slice_src(sn, tid + NT);
       }
       if (ks == 0) {  // the per-query part seeds the tile
 #pragma unroll
@@ -379,15 +398,15 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
         }
       }
       if (ks < KS1) {
+        f16x8 W[2 * KCS];
+        load_frags(A, lane, W);
 #pragma unroll
         for (int kl = 0; kl < KCS; ++kl) {
           const int kc = ks * 8 + kl;
           if (kc < KC) {
             const f16x8 b = row_chunk_f16<DT>(ev[kc < KC ? kc : 0]);
-            const f16x8 whi = as_f16x8(slice[(kl * 2 + 0) * 64 + lane]);
-            const f16x8 wlo = as_f16x8(slice[(kl * 2 + 1) * 64 + lane]);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, b, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, b, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[kl * 2], b, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[kl * 2 + 1], b, a1, 0, 0, 0);
           }
         }
         if (t == H1T - 1 && ks == KS1 - 1 && i0 + CPP < n) load_row(next_row);  // the rows are consumed: fetch the next pass's
@@ -409,16 +428,22 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
           }
         }
       } else {
+        f16x8 W[4 * H2T];
+        load_frags(A, lane, W);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
           for (int mt = 0; mt < H2T; ++mt) {
-            const f16x8 whi = as_f16x8(slice[((q * H2T + mt) * 2 + 0) * 64 + lane]);
-            const f16x8 wlo = as_f16x8(slice[((q * H2T + mt) * 2 + 1) * 64 + lane]);
-            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh[q], a2[mt], 0, 0, 0);
-            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bl[q], a2[mt], 0, 0, 0);
-            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, bh[q], a2[mt], 0, 0, 0);
+            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[(q * H2T + mt) * 2], bh[q], a2[mt], 0, 0, 0);
+            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[(q * H2T + mt) * 2], bl[q], a2[mt], 0, 0, 0);
+            a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[(q * H2T + mt) * 2 + 1], bh[q], a2[mt], 0, 0, 0);
           }
+      }
+      {  // hand the next slice over
+        uint4* nb = buf + ((s + 1) & 1) * 1024;
+        nb[tid] = pre0;
+        nb[tid + NT] = pre1;
+        __syncthreads();
       }
     }
     float part = 0.0f;

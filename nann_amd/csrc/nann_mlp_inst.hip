@@ -15,6 +15,10 @@ int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int sl
                                               const SearchArgs& a, hipStream_t st) {
   constexpr int LPR = NANN_MLP_D / 8;
   if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
+  if (split && vis == VIS_LDS_HASH) {  // one 512-thread workgroup per CU: 16K-slot set + two weight-slice buffers
+    if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
+    return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
+  }
   if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: no kernel for this plan");
   if (split) {
     if (dt == NANN_F16) return launch_search_bitmap<LPR, DT_F16, kScorerMlpSplit, kMlpNT>(vis, slots, lds_bytes, a, st);

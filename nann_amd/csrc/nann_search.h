@@ -2,6 +2,7 @@
 // helper, shared by the translation units that instantiate it (nann_hip.hip: L2 scorer;
 // nann_mlp_inst.hip: MLP scorer, one object per embedding dim so they compile in parallel).
 #pragma once
+#include <type_traits>
 #include "../../include/nann_hip.h"
 #include "nann_device.h"
 #include "nann_mlp.h"
@@ -37,8 +38,9 @@ template <int D, int DT, bool SPLIT>
 __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* table, long long n_table_rows,
                                                       const int32_t* indices, long long n, const float* qv,
                                                       float* scores, OpResult* res) {
-  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(MlpScratch)];
-  MlpScratch* S = reinterpret_cast<MlpScratch*>(scratch);
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[SPLIT ? sizeof(MlpSplitScratch) : sizeof(MlpScratch)];
+  typedef typename std::conditional<SPLIT, MlpSplitScratch, MlpScratch>::type Scratch;
+  Scratch* S = reinterpret_cast<Scratch*>(scratch);
   constexpr int CPP = (kMlpNT / 64) * 32;
   if (indices) {  // bounds first (gather_op.cc:170-175)
     for (long long i = (long long)blockIdx.x * kMlpNT + threadIdx.x; i < n; i += (long long)gridDim.x * kMlpNT) {
@@ -49,8 +51,11 @@ __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* t
   }
   if constexpr (SPLIT) wg_mlp_query_setup<kMlpNT>(P, qv, &S->v, kSplitWScale, kSplitWScale * kSplitHScale, kSplitHScale / kSplitWScale);
   else wg_mlp_query_setup<kMlpNT>(P, qv, &S->v);
-  for (long long c0 = (long long)blockIdx.x * CPP; c0 < n; c0 += (long long)gridDim.x * CPP) {
-    const int cnt = (int)((n - c0) < CPP ? (n - c0) : CPP);
+  // each workgroup takes ONE contiguous run of passes: the slice pipeline and the row prefetch stay primed
+  const long long passes = (n + CPP - 1) / CPP, per = (passes + gridDim.x - 1) / gridDim.x;
+  const long long c0 = (long long)blockIdx.x * per * CPP;
+  if (c0 < n) {
+    const int cnt = (int)((n - c0) < per * CPP ? (n - c0) : per * CPP);
     const void* tab = indices ? table : static_cast<const char*>(table) + (size_t)c0 * D * (DT == DT_F32 ? 4 : 2);
     const uint32_t n_tab = indices ? (uint32_t)n_table_rows : (uint32_t)(n_table_rows - c0);  // rows c0.. of `table` itself
     const int32_t* idx = indices ? indices + c0 : nullptr;
@@ -142,11 +147,13 @@ constexpr int hash_phase_scratch() {
 }
 // phase scratch of a traversal kernel: the attention scorer stages 32 KB weight slices
 constexpr int kAttnScratch = (kAttnSlice + kAttnVecFloats) * 4;
+constexpr int kMlpSplitScratch = (int)((sizeof(MlpSplitScratch) + 255) & ~(size_t)255);  // two slice buffers + the vectors
 template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int base = hash ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
   if (is_attn(SC) && base < kAttnScratch) return kAttnScratch;
+  if (SC == kScorerMlpSplit && base < kMlpSplitScratch) return kMlpSplitScratch;
   return base;
 }
 
@@ -303,16 +310,16 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                              a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
                                              reinterpret_cast<float*>(scratch), sc_out);
       } else {
-        MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
         // (the phase scratch was reused since the last stage)
-        if constexpr (SC == kScorerMlpSplit)
+        if constexpr (SC == kScorerMlpSplit) {
+          MlpSplitScratch* M = reinterpret_cast<MlpSplitScratch*>(scratch);
           wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v, kSplitWScale, kSplitWScale * kSplitHScale, kSplitHScale / kSplitWScale);
-        else
-          wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v);
-        if constexpr (SC == kScorerMlpSplit)
           wg_score_mlp_split<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
-        else
+        } else {
+          MlpScratch* M = reinterpret_cast<MlpScratch*>(scratch);
+          wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v);
           wg_score_mlp<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
+        }
       }
       __syncthreads();
       mark(PH_SCORE);
