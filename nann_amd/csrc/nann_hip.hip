@@ -1900,7 +1900,8 @@ int nann_search_eval_model(const nann_index* ix, const nann_model* m, const void
   if (m->kind == NANN_MODEL_ATTENTION) {
     float* kt = reinterpret_cast<float*>(qbuf);
     float* upad = kt + (size_t)n_queries * 256 * 64;
-    rc = nann_attn_prepare(m->attn, comm_seq_f16, n_queries, kt, upad, stream);
+    // (the evaluation job always runs the f32 form of the model, whatever precision serving uses)
+    rc = launch_attn_prepare(st, m->attn->P, comm_seq_f16, n_queries, kt, upad);
     if (rc) return rc;
     return eval_impl(ix, nullptr, m->attn, nullptr, kt, upad, n_queries, num_scoring_per_level, top_k_per_level,
                      topk_eval, workspace, search_bytes, out_item_ids, out_scores, out_index, n_out, status, st);

@@ -379,6 +379,12 @@ def test_fused_eval_graph_with_the_attention_model(oracle, tmp_path):
         n = len(eids)
         kinds.append(tolerant_parity(r.index[b, :n].cpu().numpy(), r.scores[b, :n].cpu().numpy(), eidx, esc))
     assert kinds.count("diverged") <= 1 and kinds.count("exact") >= 5, kinds
+    # the evaluation job runs the f32 form of the model whatever precision the weights directory asks serving for
+    ops.save_scorer_dir(str(tmp_path / "split"), "attention", w, precision="split")
+    r2 = retrieval.search_eval(dix, ops.Model(str(tmp_path / "split"), d, L), cuda(seqs), *cfg)
+    torch.cuda.synchronize()
+    assert (r2.index.cpu().numpy() == r.index.cpu().numpy()).all() and (r2.n_out.cpu().numpy() == r.n_out.cpu().numpy()).all()
+    assert (bits(r2.scores.cpu().numpy()) == bits(r.scores.cpu().numpy())).all()
 
 
 def test_serving_front_end_on_the_device(oracle):
