@@ -1581,16 +1581,17 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     if (worst_visited <= 16320.0 || est_visited <= 11000.0) hash_vis = VIS_LDS_HASH;
     else if (worst_visited <= 32704.0 || est_visited <= 24000.0) hash_vis = VIS_LDS_HASH32;
   }
-  if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0)
-    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: L2 scorer and shards below 4M items only");
+  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && pos_bits >= 10;  // 16K slots, one workgroup per CU
+  if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
+      !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
+    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards below 4M items; the 32K-slot set: L2 scorer only");
   unsigned long long off[8];
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u, off);
   p->pos_bits = pos_bits;
   p->fb_vis = bm_vis;
   p->fb_lds_bytes = bm_lds;
   p->fb_slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * bm_per_cu));
-  if ((kind == kKindAttn || kind == kKindMlpSplit) && mode != NANN_TRAVERSAL_LDS_BITMAP &&
-      mode != NANN_TRAVERSAL_HBM_BITMAP && pos_bits >= 10) {
+  if (own_hash_plan && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP) {
     // attention model / split-f16 MLP: 16K-slot set + two weight-slice buffers, one 512-thread workgroup per CU
     p->vis = VIS_LDS_HASH;
     p->nt = 512;

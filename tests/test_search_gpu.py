@@ -149,8 +149,10 @@ def test_mlp_search_matches_oracle(oracle):
     _assert_same(got, exp)
 
 
-def test_mlp_split_f16_search_within_tolerance(oracle):
-    """The traversal with the split-f16 MLP (scores within 1e-5 of fp32, not bit-identical): status codes
+@pytest.mark.parametrize("mode", ["auto", "lds_hash", "lds_bitmap", "hbm_bitmap"])
+def test_mlp_split_f16_search_within_tolerance(oracle, mode):
+    """(auto = the 16K-slot hash set with one 512-thread workgroup per CU; the bitmap kernels are its overflow
+    fallback and what a forced mode runs.)  The traversal with the split-f16 MLP (scores within 1e-5 of fp32, not bit-identical): status codes
     equal, every query's result either identical to the oracle's or different only where scores tie within
     the tolerance; a traversal that went another way because a near-tie fell differently at a beam
     boundary is tolerated for a small fraction of queries and must still overlap the oracle's answer."""
@@ -160,8 +162,9 @@ def test_mlp_split_f16_search_within_tolerance(oracle):
     q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 96, seed=13)])
     topn = [64] * 5 + [50]
     est, eids, esc, eidx, ectr = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q, topn, n_threads=8)
-    r = retrieval.search(dix, ops.Scorer("mlp", 128, torch.float16, w, precision="split"), cuda(q), topn)
-    torch.cuda.synchronize()
+    with traversal_mode(mode):
+        r = retrieval.search(dix, ops.Scorer("mlp", 128, torch.float16, w, precision="split"), cuda(q), topn)
+        torch.cuda.synchronize()
     st, idx, sc = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
     ok = est == 0
     assert ok.mean() > 0.5
