@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="primary workload only")
     ap.add_argument("--merge", default="device", choices=["device", "host"])
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N>1 run (nccl = RCCL; gloo + NANN_BENCH_SHARED_GPU=1: "
+                         "dry run of the multi-rank flow with every rank on cuda:0, exchange staged through the host)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: rccl = ncclAllGather issued by the C ABI; torch = torch.distributed collectives")
     ap.add_argument("--scorer", default="l2", choices=["l2", "mlp"],
@@ -491,7 +494,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("NANN_BENCH_SHARED_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
@@ -500,7 +503,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            args.transport = "torch"
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         exchange_note = None
         try:
             sharded = shard.ShardedSearch([args.ef] * 5 + [args.topk], world, rank, merge=args.merge,

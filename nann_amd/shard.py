@@ -51,12 +51,15 @@ def merge_device(scores, ids, k_out):
 def all_gather_topk(scores, ids, world, group=None):
     """[nq, k] per rank -> [nq, world, k] on every rank (shard-major per query)."""
     nq, k = scores.shape
+    dev = scores.device
+    if scores.is_cuda and dist.get_backend(group) == "gloo":  # gloo gathers host tensors only (dry runs on one GPU)
+        scores, ids = scores.cpu(), ids.cpu()
     gs = torch.empty((world * nq, k), dtype=scores.dtype, device=scores.device)
     gi = torch.empty((world * nq, k), dtype=ids.dtype, device=ids.device)
     dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)  # rank-major concatenation
     dist.all_gather_into_tensor(gi, ids.contiguous(), group=group)
-    return (gs.view(world, nq, k).permute(1, 0, 2).contiguous(),
-            gi.view(world, nq, k).permute(1, 0, 2).contiguous())
+    return (gs.view(world, nq, k).permute(1, 0, 2).contiguous().to(dev),
+            gi.view(world, nq, k).permute(1, 0, 2).contiguous().to(dev))
 
 
 class Comm:
