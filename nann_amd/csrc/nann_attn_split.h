@@ -11,12 +11,13 @@
 // to ~1e-6 relative; tests hold them to 1e-5 like every attention-scorer test.
 //
 // A fragments (weights; per user: keys and the sequence) are packed ahead of time in MFMA lane order, hi and
-// lo planes, one <= 16 KB slice per (layer, output tile): nann_hip.cc packs the weights at scorer creation
-// (pack_attn_split), k_attn_prepare_split the per-user side.  "cd order" of a k index: the C/D register
+// lo planes, one <= 16 KB slice per (layer, output tile): nann_hip.hip packs the weights at scorer creation
+// (pack_attn_frags), k_attn_prepare_split the per-user side.  "cd order" of a k index: the C/D register
 // order of the tile that produced it -- chunk q, lane group g, element i <-> unit (i&3) + 16q + 8(i>>2) + 4g.
 //
 // Staging: two 16 KB LDS buffers; slice s+1 travels L2 -> registers -> LDS while slice s feeds the MFMAs;
-// one barrier per slice.
+// one barrier per slice.  The pre-scaled small vectors sit in LDS behind the buffers.  NANN_ATTN_TIMING builds
+// stamp the shader clock per section (tools/attn_rate.py prints them).
 #pragma once
 #include "nann_attn.h"
 #include "nann_mlp.h"

@@ -312,13 +312,16 @@ __device__ __forceinline__ void load_frags(const uint4* A, int lane, f16x8 (&f)[
 }
 
 // Where a 256-row pass spends its 27 us at d = 128 (tools/mlp_rate.py on the stand-alone scorer, timing builds with
-// parts compiled out, profiles/r2_mlp_split_experiments.md): the 320 MFMAs per wavefront alone take 17-19 us
-// (two wavefronts per SIMD, ~50 shader cycles per MFMA at the 1.9 GHz the chip holds under this load, against 32
-// at the documented issue rate), everything else alone -- weight slices L2 -> LDS -> registers, barriers, PReLU /
-// split arithmetic -- 5 us, and the two overlap poorly.  Halving the LDS reads, dropping the barriers or the
-// vector arithmetic each moved the total by under 7 %; giving neighbouring MFMAs different accumulators (four
-// partial sums in layer 1, product-major order in layer 2) sped the bare MFMA stream up by 10 % and the whole
-// kernel by nothing, and its extra registers spill inside k_search.  So the order below is the plain one.
+// parts compiled out, profiles/r2_mlp_split_experiments.md): the 320 MFMAs per wavefront alone take 17-19 us =
+// 26.5-30 ns per MFMA per SIMD, where a bare loop of this MFMA holds 18.4 ns on this chip (tools/ubench_mfma.hip:
+// one per 32 shader cycles, chained or not, at the ~1.7 GHz the chip clocks under it -- 1.8 PFLOP/s, not the
+// 2.5 of 2.4 GHz); everything else alone -- weight slices L2 -> LDS -> registers, barriers, PReLU / split
+// arithmetic -- takes 5 us, and the two overlap poorly.  Halving the LDS reads, dropping the barriers or the vector
+// arithmetic, a second slice buffer with one barrier per slice, burst reads of a step's fragments, rolling or
+// unrolling the tile loop, giving neighbouring MFMAs different accumulators: each moved the pass by under 7 %.
+// PMC (profiles/r2_mlp_split_pmc_head.txt): matrix pipe 46 % busy; a wavefront spends 50 % of its cycles stalled
+// at issue behind its partner's MFMAs or its own chain, 29 % parked at waits and barriers, 21 % issuing -- the two
+// wavefronts of a SIMD run the same phase at the same time, so nothing fills the pipe while both split a tile.
 template <int D, int H1T, int H2T, int DT, int NT>
 __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const void* __restrict__ table,
                                                    uint32_t n_table_rows, const int32_t* ids, int n,
