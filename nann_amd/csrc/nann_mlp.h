@@ -61,7 +61,7 @@ struct MlpScratch {
 static_assert(sizeof(MlpScratch) <= kPhaseScratch, "phase scratch too small for the MLP");
 // split-f16 form: two slice buffers (slice s+1 lands in one while slice s feeds the MFMAs from the other)
 struct MlpSplitScratch {
-  uint4 buf[2][1024];
+  uint4 buf[4][1024];  // d <= 128: [tile parity][layer-1 slice, layer-2 slice]; d = 256: two of them, one slice each
   MlpVectors v;
 };
 
@@ -358,14 +358,37 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
     for (int kc = 0; kc < KC; ++kc) ev[kc] = src[2 * kc];
   };
   if (n > 0) load_row(row_of(0));
-  // slice pipeline: slice s sits in buf[s & 1]; slice s+1 (of this pass or the first of the next) travels
-  // L2 -> registers while s feeds the MFMAs, then registers -> the other buffer; ONE barrier per slice
-  uint4 pre0 = *slice_src(0, tid), pre1 = *slice_src(0, tid + NT);
+  // Slice pipeline.  A GROUP of G slices is handed over per barrier: group gi sits in buffer gi & 1 while the next
+  // group (of this pass or the first of the next) travels L2 -> registers, then registers -> the other buffer.
+  // G = 2 = a whole hidden tile when its two slices fit twice (d <= 128): with ONE barrier per TILE the two
+  // wavefronts of a SIMD no longer meet after every slice, and the one that lost the matrix pipe during layer 1
+  // runs its MFMAs under the other's PReLU / split arithmetic instead of beside it.  (Timing build: with a barrier
+  // per slice the older wavefront of a SIMD issues its chain at 32 cycles per MFMA, then waits 31 % of the pass at
+  // barriers for the younger one, whose chain could only start when the first had released the pipe.)
+  constexpr int G = SPT == 2 ? 2 : 1;
+  constexpr int NG = NSLICE / G;
+  static_assert(NSLICE % G == 0 && NG % 2 == 0, "group 0 of the next pass lands in buffer 0 again");
+  uint4 pre0, pre1, pre2, pre3;  // (scalars: an array here ends up in scratch memory)
+  auto fetch_group = [&](int gi) {
+    pre0 = *slice_src(gi * G, tid);
+    pre1 = *slice_src(gi * G, tid + NT);
+    if constexpr (G == 2) {
+      pre2 = *slice_src(gi * G + 1, tid);
+      pre3 = *slice_src(gi * G + 1, tid + NT);
+    }
+  };
+  auto write_group = [&](int b) {
+    buf[(b * G) * 1024 + tid] = pre0;
+    buf[(b * G) * 1024 + tid + NT] = pre1;
+    if constexpr (G == 2) {
+      buf[(b * G + 1) * 1024 + tid] = pre2;
+      buf[(b * G + 1) * 1024 + tid + NT] = pre3;
+    }
+  };
+  fetch_group(0);
   __syncthreads();  // the caller is done with the scratch (the vectors were staged before, behind a barrier)
-  buf[tid] = pre0;
-  buf[tid + NT] = pre1;
+  write_group(0);
   __syncthreads();
-  static_assert(NSLICE % 2 == 0, "slice 0 of the next pass lands in buffer 0 again");
 
   for (int i0 = 0; i0 < n; i0 += CPP) {
     const int i = i0 + wave * 32 + cand;
@@ -380,19 +403,16 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
       }
     f32x16 a1;
     f16x8 bh[2], bl[2];
-    // the hidden-tile loop is ROLLED: same speed as the unrolled form (27.3 us per pass, 4.75 ms per 1024 queries), an
-    // eighth of the code, and k_search keeps its registers (d = 256: 468 -> 68 B/lane of spills)
+    // the hidden-tile loop is ROLLED: same speed as the unrolled form, an eighth of the code, and k_search keeps its
+    // registers (d = 256: 468 -> 68 B/lane of spills)
 #pragma unroll 1
     for (int t = 0; t < H1T; ++t)
 #pragma unroll
     for (int ks = 0; ks < SPT; ++ks) {
       const int s = t * SPT + ks;
-      const uint4* A = buf + (s & 1) * 1024;
-      {  // next slice from L2 while this one feeds the MFMAs
-        const int sn = s + 1 < NSLICE ? s + 1 : 0;
-        pre0 = *slice_src(sn, tid);
-        pre1 = *slice_src(sn, tid + NT);
-      }
+      const int gi = s / G, gj = s % G;
+      const uint4* A = buf + ((gi & 1) * G + gj) * 1024;
+      if (gj == 0) fetch_group(gi + 1 < NG ? gi + 1 : 0);  // next group from L2 while this one feeds the MFMAs
       if (ks == 0) {  // the per-query part seeds the tile
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -442,10 +462,8 @@ __device__ __forceinline__ void wg_score_mlp_split(const MlpParams& P, const voi
             a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[(q * H2T + mt) * 2 + 1], bh[q], a2[mt], 0, 0, 0);
           }
       }
-      {  // hand the next slice over
-        uint4* nb = buf + ((s + 1) & 1) * 1024;
-        nb[tid] = pre0;
-        nb[tid + NT] = pre1;
+      if (gj == G - 1) {  // hand the next group over
+        write_group((gi + 1) & 1);
         __syncthreads();
       }
     }

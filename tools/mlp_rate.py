@@ -33,6 +33,11 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         ms = float(np.median(ts[1:]))
+        if os.environ.get("NANN_MLP_TIMING") and prec == "split":  # a timing build wrote shader cycles of a pass there
+            names = ["L1: burst reads landed", "L1: MFMAs issued", "L1: chain drained + PReLU/split", "L2: burst reads landed",
+                     "L2: step total before hand-over", "hand-over: LDS write issued (incl. wait for the fetched slice)",
+                     "barrier", "whole pass"]
+            print("cycles of the last pass of block 0:", dict(zip(names, [int(x) for x in out[:8].float().cpu()])), flush=True)
         passes_per_cu = n / 256 / 256
         print(f"d={d} {prec}: {ms:.3f} ms for {n} rows = {n / ms / 1e3:.1f} M rows/s; "
               f"{ms * 1e3 / passes_per_cu:.2f} us per 256-row pass per CU; checksum {float(out.float().sum()):.6g}",
