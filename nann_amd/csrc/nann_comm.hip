@@ -137,7 +137,7 @@ int nann_comm_create(int32_t world, int32_t rank, const void* id, nann_comm** ou
   c->world = world;
   c->rank = rank;
   c->loopback = world > 1 && !id;  // single-process test facility: every "shard" returns this rank's record
-  if (world > 1 && id) {
+  if (id) {  // (world == 1 with an id: a real one-rank communicator -- the whole RCCL path on a single GPU)
     int rc = load_rccl(&c->R);
     if (rc) { delete c; return rc; }
     ncclUniqueId uid;
@@ -183,13 +183,15 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
   unsigned char* recv = send + rb;
   const long long n = n_queries * k_in;
   hipLaunchKernelGGL(k_pack_record, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st,
-                     scores, ids, status, (long long)n_queries, (int)k_in, world > 1 ? send : recv);
+                     scores, ids, status, (long long)n_queries, (int)k_in, (world > 1 || c->comm) ? send : recv);
   NANN_HIP_TRY(hipGetLastError());
   if (world > 1 && c->loopback) {
     for (int r = 0; r < world; ++r)
       NANN_HIP_TRY(hipMemcpyAsync(recv + (size_t)r * rb, send, rb, hipMemcpyDeviceToDevice, st));
-  } else if (world > 1) {
+  } else if (c->comm) {
     RCCL_TRY(c->R, c->R->AllGather(send, recv, rb, ncclChar, c->comm, st));
+  } else if (world > 1) {
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_sharded_topk: communicator without RCCL state");
   }
   const size_t lds = (size_t)n_in * 4;
   if (lds > 48 * 1024)

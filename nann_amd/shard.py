@@ -80,8 +80,21 @@ class Comm:
                 raise RuntimeError("nann_comm_get_unique_id failed on rank 0 (RCCL not loadable?)")
             idb = np.frombuffer(box[0], np.uint8).copy()
         self.handle = C.c_void_p(0)
-        _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(rank), idb.ctypes.data_as(C.c_void_p),
+        _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(rank),
+                                      idb.ctypes.data_as(C.c_void_p) if world > 1 else None,
                                       C.byref(self.handle)), "comm create")
+
+    @classmethod
+    def single_rank_rccl(cls):
+        """A REAL one-rank RCCL communicator (ncclGetUniqueId, ncclCommInitRank, and ncclAllGather in
+        nann_sharded_topk): the library's whole RCCL binding exercised on a single GPU."""
+        self = cls.__new__(cls)
+        self.world, self.rank, self.handle = 1, 0, C.c_void_p(0)
+        idb = np.zeros(128, np.uint8)
+        _check(lib().nann_comm_get_unique_id(idb.ctypes.data_as(C.c_void_p)), "comm id")
+        _check(lib().nann_comm_create(C.c_int32(1), C.c_int32(0), idb.ctypes.data_as(C.c_void_p),
+                                      C.byref(self.handle)), "comm create")
+        return self
 
     @classmethod
     def loopback(cls, world):

@@ -467,6 +467,35 @@ def test_model_directory_forward(oracle, tmp_path, kind):
 
 
 # ---------------------------------------------------------------- 8(e): exchange + merge through the C ABI
+def test_rccl_binding_one_rank_communicator(oracle):
+    """The library's RCCL binding end to end on one GPU: nann_comm_get_unique_id (dlopen + ncclGetUniqueId),
+    nann_comm_create with that id (ncclCommInitRank, 1 rank), nann_sharded_topk through ncclAllGather on the
+    caller's stream, nann_comm_destroy -- same answer as the collective-free path.  (N > 1 ranks need N GPUs.)"""
+    from nann_amd import retrieval, shard
+    rng = np.random.default_rng(11)
+    nq, k, k_out = 300, 200, 150
+    scores = -np.sort(rng.integers(0, 900, size=(nq, k)).astype(np.float32) / 8, axis=1)
+    ids = rng.integers(1, 1 << 40, size=(nq, k)).astype(np.int64)
+    status = np.zeros(nq, np.int32)
+    status[3::29] = 6
+    local = retrieval.SearchResult(cuda(ids), cuda(scores), None, cuda(status), None)
+    comm = shard.Comm.single_rank_rccl()
+    ss = shard.ShardedSearch([0, 0, 0, 0, 0, k_out], 1, 0, transport="rccl", comm=comm)
+    for _ in range(3):  # (repeated: the collective is enqueued on the stream every call)
+        mi, ms = ss.merge(local)
+    torch.cuda.synchronize()
+    plain = shard.ShardedSearch([0, 0, 0, 0, 0, k_out], 1, 0, transport="rccl", comm=shard.Comm(1, 0))
+    pi, ps = plain.merge(local)
+    torch.cuda.synchronize()
+    assert (mi.cpu().numpy() == pi.cpu().numpy()).all() and (bits(ms.cpu().numpy()) == bits(ps.cpu().numpy())).all()
+    s_in = np.where((status == 0)[:, None], scores, -np.inf)
+    i_in = np.where((status == 0)[:, None], ids, 0)
+    for b in range(0, nq, 7):
+        rc, es, ei = oracle.merge_topk(s_in[b][None], i_in[b][None], k_out)
+        assert rc == 0 and (mi[b].cpu().numpy() == ei).all() and (bits(ms[b].cpu().numpy()) == bits(es)).all()
+    del ss, comm
+
+
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_sharded_topk_single_process(oracle, world):
     """nann_sharded_topk on one GPU: world == 1 (pack + merge, no RCCL) and loopback communicators
