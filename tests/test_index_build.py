@@ -66,3 +66,14 @@ def test_multithreaded_build_is_valid():
     ex = index_build.export_levels(raw, 2)
     lens = np.diff(ex["nb_row_splits"][0])
     assert lens.max() <= 64 and lens.min() >= 1 and ex["nb_values"][0].max() < 4000
+    # rows written under contention (a node's own list merged with the back-links that arrived first) keep the
+    # single-threaded invariants: ids in range, inside the level, no self link, no repeat
+    levels = raw["levels"]
+    for level, cap in ((0, 64), (1, 32)):
+        v, rs = ex["nb_values"][level], ex["nb_row_splits"][level]
+        rl = np.diff(rs)
+        assert rl.max() <= cap and v.min() >= 0 and v.max() < 4000 and (levels[v] > level).all()
+        assert (rl[levels <= level] == 0).all()
+        for i in np.nonzero(rl)[0]:
+            row = v[rs[i]:rs[i + 1]]
+            assert i not in row and len(set(row.tolist())) == len(row), (level, i)
