@@ -1,0 +1,314 @@
+// nann_serve -- a C++ serving host over the C ABI alone (include/nann_hip.h): no Python, no torch, no HIP
+// headers.  What the reference does with TF-Serving sessions x virtual GPUs x MPS behind blaze-benchmark's
+// closed-loop consumers (blaze-benchmark/benchmark/core/model.cc:192-235, predict_request_consumer.cc:17-53)
+// is, on this design, ONE resident index and a batching front end: concurrent single requests with the serving
+// signature (comm_seq f16[1, L*d] + level_topn -> top_k i64[1, k], build_opt_graph.py:151-159) are aggregated
+// into one nann_search launch.  The Python twin is nann_amd/serving.py; this program is the proof that a C++
+// host needs nothing but libnann_hip.so.
+//
+//   nann_serve <index_dir> <item_embs_dir> <dim> [--clients N] [--seconds S] [--max-batch B] [--max-wait-us U]
+//              [--ef E] [--topk K] [--seq-len L] [--model-dir DIR] [--probe-out FILE]
+// index_dir / item_embs_dir: the files build_hnsw_index.py writes (nann_amd.index_build writes the same).
+// Closed loop: every client thread sends a request, waits for its reply, sends the next.  Prints one JSON line.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nann_hip.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+[[noreturn]] void die(const char* what) {
+  std::fprintf(stderr, "nann_serve: %s: %s\n", what, nann_last_error());
+  std::exit(1);
+}
+#define CHECK(expr) do { if ((expr) != NANN_OK) die(#expr); } while (0)
+
+struct Request {
+  const uint16_t* comm_seq;  // f16 bits [L * d]
+  int64_t* top_k;            // [k]
+  int32_t status = -1;
+  bool done = false;
+  std::mutex mu;
+  std::condition_variable cv;
+};
+
+struct Queue {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Request*> pending;
+  bool closing = false;
+};
+
+uint16_t f32_to_f16_bits(float f) {  // round to nearest even; enough for a load generator
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t m = x & 0x7fffffu;
+  if (e <= 0) return (uint16_t)sign;  // flush tiny values
+  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  uint32_t h = sign | ((uint32_t)e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return (uint16_t)h;
+}
+
+float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) { x = sign; }
+    else {  // subnormal
+      int s = 0; uint32_t mm = m;
+      while (!(mm & 0x400u)) { mm <<= 1; ++s; }
+      x = sign | ((uint32_t)(127 - 15 - s + 1) << 23) | ((mm & 0x3ffu) << 13);
+    }
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e - 15 + 127) << 23) | (m << 13);
+  }
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+void* load(const std::string& path, int dtype, int64_t* count, int64_t elem_bytes) {
+  void* p = nullptr;
+  int64_t bytes = 0;
+  if (nann_huge_const_load(path.c_str(), dtype, nullptr, 0, /*allow_cast=*/1, &p, &bytes) != NANN_OK) die(path.c_str());
+  *count = bytes / elem_bytes;
+  return p;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: %s <index_dir> <item_embs_dir> <dim> [--clients N] [--seconds S] [--max-batch B] "
+                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--model-dir DIR]\n", argv[0]);
+    return 2;
+  }
+  const std::string index_dir = argv[1], embs_dir = argv[2];
+  const int d = std::atoi(argv[3]);
+  int clients = 64, max_batch = 256, max_wait_us = 200, ef = 128, topk = 200, L = 50;
+  double seconds = 3.0;
+  std::string model_dir, probe_out;
+  for (int i = 4; i + 1 < argc; i += 2) {
+    const std::string k = argv[i];
+    if (k == "--clients") clients = std::atoi(argv[i + 1]);
+    else if (k == "--seconds") seconds = std::atof(argv[i + 1]);
+    else if (k == "--max-batch") max_batch = std::atoi(argv[i + 1]);
+    else if (k == "--max-wait-us") max_wait_us = std::atoi(argv[i + 1]);
+    else if (k == "--ef") ef = std::atoi(argv[i + 1]);
+    else if (k == "--topk") topk = std::atoi(argv[i + 1]);
+    else if (k == "--seq-len") L = std::atoi(argv[i + 1]);
+    else if (k == "--model-dir") model_dir = argv[i + 1];
+    else if (k == "--probe-out") probe_out = argv[i + 1];  // after the run: one fixed request, its reply written as text
+    else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+  }
+  if (nann_device_count() < 1) { std::fprintf(stderr, "nann_serve: no HIP device\n"); return 1; }
+
+  // ---- the resident index: HugeConst loads with the casts build_model() asks for (build_opt_graph.py:70,83-90)
+  nann_index_desc desc = {};
+  int64_t n_rows = 0, n_ids = 0, cnt = 0;
+  desc.item_embs = load(embs_dir + "/item_embs.npy", NANN_F16, &n_rows, 2);
+  desc.item_ids = static_cast<const int64_t*>(load(embs_dir + "/item_ids.npy", NANN_I64, &n_ids, 8));
+  desc.n_items = n_ids;
+  desc.d = d;
+  desc.emb_dtype = NANN_F16;
+  if (n_rows != n_ids * d) { std::fprintf(stderr, "nann_serve: item_embs.npy is not [%lld, %d]\n", (long long)n_ids, d); return 1; }
+  for (int l = 0; l < 2; ++l) {
+    const std::string stem = index_dir + "/neighbors_level_" + std::to_string(l);
+    desc.nb_values[l] = static_cast<const int32_t*>(load(stem + "_values.npy", NANN_I32, &desc.nb_nnz[l], 4));
+    desc.nb_row_splits[l] = static_cast<const int64_t*>(load(stem + "_row_splits.npy", NANN_I64, &cnt, 8));
+    if (cnt != n_ids + 1) { std::fprintf(stderr, "nann_serve: level %d row_splits has %lld entries\n", l, (long long)cnt); return 1; }
+  }
+  desc.enter_points = static_cast<const int32_t*>(load(index_dir + "/enter_points.npy", NANN_I32, &desc.n_enter, 4));
+  desc.on_device = 1;
+  nann_index* ix = nullptr;
+  CHECK(nann_index_create(&desc, &ix));
+
+  nann_scorer* scorer = nullptr;
+  nann_model* model = nullptr;
+  if (model_dir.empty()) {
+    nann_scorer_desc sd = {};
+    sd.kind = NANN_SCORER_L2;
+    sd.d = d;
+    sd.emb_dtype = NANN_F16;
+    CHECK(nann_scorer_create(&sd, &scorer));
+  } else {
+    CHECK(nann_model_load(model_dir.c_str(), d, NANN_F16, L, &model));
+  }
+  const int seq_d = (model && nann_model_kind(model) == NANN_MODEL_ATTENTION) ? 64 : d;  // the attention model's sequence is [L, 64]
+  const size_t seq_elems = (size_t)L * seq_d;
+
+  // ---- device buffers of one launch
+  const int32_t level_topn[6] = {ef, ef, ef, ef, ef, topk};
+  int64_t ws_bytes = 0;
+  if (model) CHECK(nann_search_model_workspace_bytes(ix, model, level_topn, max_batch, &ws_bytes));
+  else CHECK(nann_search_workspace_bytes(ix, level_topn, max_batch, &ws_bytes));
+  void *ws = nullptr, *d_seq = nullptr, *d_q = nullptr, *d_topk = nullptr, *d_status = nullptr;
+  CHECK(nann_malloc(&ws, ws_bytes));
+  CHECK(nann_malloc(&d_seq, (int64_t)max_batch * seq_elems * 2));
+  CHECK(nann_malloc(&d_q, (int64_t)max_batch * d * 4));
+  CHECK(nann_malloc(&d_topk, (int64_t)max_batch * topk * 8));
+  CHECK(nann_malloc(&d_status, (int64_t)max_batch * 4));
+
+  // ---- request material: histories made of real item rows (a few thousand rows copied back once)
+  const int64_t pool_rows = std::min<int64_t>(n_ids, 4096);
+  std::vector<uint16_t> pool((size_t)pool_rows * d);
+  CHECK(nann_memcpy(pool.data(), desc.item_embs, (int64_t)pool.size() * 2, 1, nullptr));
+  CHECK(nann_stream_synchronize(nullptr));
+
+  Queue q;
+  std::atomic<long long> served{0}, failed{0}, launches{0}, batched{0};
+  std::vector<std::vector<float>> lat((size_t)clients);
+  const auto t_end = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
+
+  // ---- one launch for a batch of requests, replies handed back to their callers
+  std::vector<uint16_t> h_seq((size_t)max_batch * seq_elems);
+  std::vector<int64_t> h_topk((size_t)max_batch * topk);
+  std::vector<int32_t> h_status((size_t)max_batch);
+  auto run_batch = [&](const std::vector<Request*>& batch) {
+    const int b = (int)batch.size();
+    for (int i = 0; i < b; ++i) std::memcpy(&h_seq[(size_t)i * seq_elems], batch[i]->comm_seq, seq_elems * 2);
+    CHECK(nann_memcpy(d_seq, h_seq.data(), (int64_t)b * seq_elems * 2, 0, nullptr));
+    if (model) {
+      CHECK(nann_search_model(ix, model, d_seq, b, level_topn, ws, ws_bytes, static_cast<int64_t*>(d_topk), nullptr,
+                              nullptr, static_cast<int32_t*>(d_status), nullptr, nullptr));
+    } else {
+      CHECK(nann_user_seq_mean(d_seq, b, L, d, static_cast<float*>(d_q), nullptr));
+      CHECK(nann_search(ix, scorer, static_cast<const float*>(d_q), b, level_topn, ws, ws_bytes,
+                        static_cast<int64_t*>(d_topk), nullptr, nullptr, static_cast<int32_t*>(d_status), nullptr, nullptr));
+    }
+    CHECK(nann_memcpy(h_topk.data(), d_topk, (int64_t)b * topk * 8, 1, nullptr));
+    CHECK(nann_memcpy(h_status.data(), d_status, (int64_t)b * 4, 1, nullptr));
+    CHECK(nann_stream_synchronize(nullptr));
+    launches.fetch_add(1);
+    batched.fetch_add(b);
+    for (int i = 0; i < b; ++i) {
+      Request* r = batch[i];
+      std::memcpy(r->top_k, &h_topk[(size_t)i * topk], (size_t)topk * 8);
+      {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->status = h_status[(size_t)i];
+        r->done = true;
+      }
+      r->cv.notify_one();
+    }
+  };
+
+  // ---- the dispatcher: one launch per batch of whatever arrived within max_wait_us of the first request
+  std::thread dispatcher([&] {
+    std::vector<Request*> batch;
+    for (;;) {
+      batch.clear();
+      {
+        std::unique_lock<std::mutex> lk(q.mu);
+        q.cv.wait(lk, [&] { return !q.pending.empty() || q.closing; });
+        if (q.pending.empty() && q.closing) return;
+        const auto deadline = Clock::now() + std::chrono::microseconds(max_wait_us);
+        while ((int)q.pending.size() < max_batch && !q.closing &&
+               q.cv.wait_until(lk, deadline, [&] { return (int)q.pending.size() >= max_batch || q.closing; })) {
+        }
+        const size_t take = std::min<size_t>(q.pending.size(), (size_t)max_batch);
+        batch.assign(q.pending.begin(), q.pending.begin() + (long)take);
+        q.pending.erase(q.pending.begin(), q.pending.begin() + (long)take);
+      }
+      run_batch(batch);
+    }
+  });
+
+  // ---- closed-loop clients (predict_request_consumer.cc:17-53)
+  std::vector<std::thread> workers;
+  for (int c = 0; c < clients; ++c)
+    workers.emplace_back([&, c] {
+      std::mt19937 rng(1234u + (unsigned)c);
+      std::normal_distribution<float> noise(0.0f, 0.05f);
+      std::vector<uint16_t> seq(seq_elems);
+      std::vector<int64_t> out((size_t)topk);
+      while (Clock::now() < t_end) {
+        const int64_t row = (int64_t)(rng() % (uint64_t)pool_rows);
+        for (int l = 0; l < L; ++l)  // a user who looked at neighbours of one item (padding rows stay zero)
+          for (int k = 0; k < seq_d; ++k) {
+            const float v = l < L - 5 ? f16_bits_to_f32(pool[(size_t)row * d + (k % d)]) + noise(rng) : 0.0f;
+            seq[(size_t)l * seq_d + k] = f32_to_f16_bits(v);
+          }
+        Request r;
+        r.comm_seq = seq.data();
+        r.top_k = out.data();
+        const auto t0 = Clock::now();
+        {
+          std::lock_guard<std::mutex> lk(q.mu);
+          q.pending.push_back(&r);
+        }
+        q.cv.notify_all();
+        {
+          std::unique_lock<std::mutex> lk(r.mu);
+          r.cv.wait(lk, [&] { return r.done; });
+        }
+        lat[(size_t)c].push_back(std::chrono::duration<float, std::milli>(Clock::now() - t0).count());
+        if (r.status == 0) served.fetch_add(1); else failed.fetch_add(1);
+      }
+    });
+  const auto t_start = Clock::now();
+  for (auto& w : workers) w.join();
+  const double wall = std::chrono::duration<double>(Clock::now() - t_start).count();
+  {
+    std::lock_guard<std::mutex> lk(q.mu);
+    q.closing = true;
+  }
+  q.cv.notify_all();
+  dispatcher.join();
+
+  std::vector<float> all;
+  for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+  std::sort(all.begin(), all.end());
+  auto pct = [&](double p) { return all.empty() ? 0.0f : all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
+  const long long total = served.load() + failed.load();
+  std::printf("{\"host\": \"nann_serve (C++ over the C ABI)\", \"scorer\": \"%s\", \"items\": %lld, \"dim\": %d, \"ef\": %d, "
+              "\"topk\": %d, \"clients\": %d, \"max_batch\": %d, \"max_wait_us\": %d, \"seconds\": %.2f, \"requests\": %lld, "
+              "\"failed_requests\": %lld, \"qps\": %.1f, \"launches\": %lld, \"mean_batch\": %.1f, "
+              "\"latency_ms\": {\"p50\": %.3f, \"p90\": %.3f, \"p99\": %.3f, \"max\": %.3f}}\n",
+              model_dir.empty() ? "l2" : model_dir.c_str(), (long long)n_ids, d, ef, topk, clients, max_batch, max_wait_us,
+              wall, total, failed.load(), (double)total / wall, launches.load(),
+              launches.load() ? (double)batched.load() / (double)launches.load() : 0.0, pct(0.5), pct(0.9), pct(0.99),
+              all.empty() ? 0.0f : all.back());
+
+  if (!probe_out.empty()) {  // a fixed request through the same path: item row 0 as the whole history, no noise
+    std::vector<uint16_t> seq(seq_elems, 0);
+    for (int l = 0; l < L - 5; ++l)
+      for (int k = 0; k < seq_d; ++k) seq[(size_t)l * seq_d + k] = pool[(size_t)(k % d)];
+    std::vector<int64_t> out((size_t)topk);
+    Request r;
+    r.comm_seq = seq.data();
+    r.top_k = out.data();
+    run_batch({&r});
+    FILE* f = std::fopen(probe_out.c_str(), "w");
+    if (!f) { std::fprintf(stderr, "nann_serve: cannot write %s\n", probe_out.c_str()); return 1; }
+    std::fprintf(f, "%d\n", r.status);
+    for (int i = 0; i < topk; ++i) std::fprintf(f, "%lld\n", (long long)out[(size_t)i]);
+    std::fclose(f);
+  }
+
+  nann_free(ws); nann_free(d_seq); nann_free(d_q); nann_free(d_topk); nann_free(d_status);
+  if (scorer) nann_scorer_destroy(scorer);
+  if (model) nann_model_destroy(model);
+  nann_index_destroy(ix);
+  return 0;
+}

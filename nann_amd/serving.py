@@ -17,6 +17,7 @@ failed (TopKV2 with n < k, ...) raises the same InvalidArgument in its caller on
 The backend is any callable `(comm_seq f16[B, seq_len, d], level_topn) -> (top_k i64[B, k],
 status i32[B])`; `device_backend()` builds the real one.
 """
+import os
 import queue
 import threading
 import time
@@ -142,3 +143,41 @@ def closed_loop(server, make_request, n_clients, duration_s):
     return {"requests": len(lat), "failures": failures[0], "throughput_qps": len(lat) / wall,
             "latency_us": {"p50": pct(0.5), "p90": pct(0.9), "p99": pct(0.99), "max": float(a[-1])},
             "mean_batch": server.requests / max(server.batches, 1)}
+
+
+# ---------------------------------------------------------------------------------------------
+# the C++ twin: csrc/host/nann_serve.cpp, a serving host over the C ABI alone
+_SERVE_SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "host", "nann_serve.cpp")
+_SERVE_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "nann_serve")
+
+
+def build_serve_host(force=False):
+    """g++ the C++ serving host (no HIP headers: it only sees include/nann_hip.h) against the in-tree
+    libnann_hip.so -> nann_amd/_build/nann_serve."""
+    import subprocess
+    from . import build as _build
+    lib = _build.build()
+    if (force or not os.path.exists(_SERVE_BIN) or os.path.getmtime(_SERVE_SRC) > os.path.getmtime(_SERVE_BIN)
+            or os.path.getmtime(lib) > os.path.getmtime(_SERVE_BIN)):
+        inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", inc, _SERVE_SRC, "-o", _SERVE_BIN,
+                               "-L", os.path.dirname(lib), "-lnann_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
+                               "-Wl,--allow-shlib-undefined"])
+    return _SERVE_BIN
+
+
+def run_serve_host(index_dir, item_embs_dir, dim, clients=64, seconds=3.0, max_batch=256, max_wait_us=200, ef=128,
+                   topk=200, seq_len=50, model_dir=None, probe_out=None):
+    """Run the C++ host's closed-loop load test; returns its JSON line as a dict.  probe_out: file that receives
+    the reply to one fixed request (item row 0 as the history): status, then top_k ids, one per line."""
+    import json
+    import subprocess
+    cmd = [build_serve_host(), index_dir, item_embs_dir, str(dim), "--clients", str(clients), "--seconds", str(seconds),
+           "--max-batch", str(max_batch), "--max-wait-us", str(max_wait_us), "--ef", str(ef), "--topk", str(topk),
+           "--seq-len", str(seq_len)]
+    if model_dir:
+        cmd += ["--model-dir", model_dir]
+    if probe_out:
+        cmd += ["--probe-out", probe_out]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=120 + 2 * seconds).stdout
+    return json.loads(out.strip().splitlines()[-1])

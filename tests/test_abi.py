@@ -58,3 +58,20 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 for pat in banned:
                     assert not re.search(pat, text), (f, pat)
+
+
+def test_cpp_serving_host_builds_against_the_header_alone():
+    """nann_serve.cpp includes nothing but include/nann_hip.h and the C++ standard library, links against the in-tree
+    library, and fails loudly without a GPU."""
+    import subprocess
+    from nann_amd import serving
+    includes = [line.split()[1] for line in open(serving._SERVE_SRC) if line.startswith("#include")]
+    assert "\"nann_hip.h\"" in includes
+    assert all(i == "\"nann_hip.h\"" or (i.startswith("<") and "/" not in i and "." not in i) for i in includes), includes
+    exe = serving.build_serve_host()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "/nonexistent", "/nonexistent", "64"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr

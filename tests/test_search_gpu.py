@@ -230,6 +230,33 @@ def test_index_from_reference_files(oracle, tmp_path):
     _assert_same(_run(dix, q, topn), exp)
 
 
+def test_cpp_serving_host_over_the_c_abi(oracle, tmp_path):
+    """f4 in C++: csrc/host/nann_serve.cpp sees only include/nann_hip.h and libnann_hip.so -- it loads the index
+    files through nann_huge_const_load, batches the single requests of closed-loop client threads into
+    nann_search launches (the job of blaze-benchmark's consumers, predict_request_consumer.cc:17-53) and reports
+    throughput and latency.  Its reply to one fixed request equals the oracle's answer for that request."""
+    from nann_amd import serving, synth
+    g, oix, _ = synth_index(20000, 64, 32)
+    d = str(tmp_path)
+    disk = dict(g)
+    disk["item_embs"] = g["item_embs"].astype(np.float32)
+    disk["nb_values"] = [v.astype(np.int64) for v in g["nb_values"]]
+    synth.save_index(disk, d)
+    L, topn = 50, [32] * 5 + [20]
+    probe = os.path.join(d, "probe.txt")
+    stats = serving.run_serve_host(d, d, 64, clients=48, seconds=1.5, max_batch=64, max_wait_us=300, ef=32, topk=20,
+                                   seq_len=L, probe_out=probe)
+    assert stats["requests"] > 200 and stats["launches"] > 0 and stats["mean_batch"] > 1.5, stats
+    assert stats["latency_ms"]["p50"] > 0 and stats["latency_ms"]["p99"] >= stats["latency_ms"]["p50"]
+    seq = np.zeros((L, 64), np.float16)
+    seq[:L - 5] = g["item_embs"][0]
+    rc, eids, _, _, _ = oracle.search(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), oracle.user_seq_mean(seq), topn)
+    got = [int(x) for x in open(probe).read().split()]
+    assert got[0] == rc
+    if rc == 0:
+        assert got[1:] == eids.tolist()
+
+
 @pytest.mark.parametrize("mode", ["lds_hash", "lds_bitmap"])
 @pytest.mark.parametrize("d,dtype,ef,k", [(256, "bf16", 64, 40), (64, "f32", 32, 20), (256, "f16", 48, 30),
                                           (128, "bf16", 256, 200)])
