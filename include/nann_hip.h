@@ -70,6 +70,12 @@ int nann_free(void* dev_ptr);
 /* kind: 0 host->device, 1 device->host, 2 device->device; async on stream */
 int nann_memcpy(void* dst, const void* src, int64_t nbytes, int kind, nann_stream_t stream);
 int nann_stream_synchronize(nann_stream_t stream);
+/* a stream of the host's own (non-blocking with respect to the null stream) and page-locked staging memory: what a
+ * multi-lane C++ host needs to overlap one batch's copies with another's search (csrc/host/nann_serve.cpp) */
+int nann_stream_create(nann_stream_t* out);
+int nann_stream_destroy(nann_stream_t stream);
+int nann_host_malloc(void** host_ptr, int64_t nbytes);
+int nann_host_free(void* host_ptr);
 
 /* ---- a6: HugeConst (UO/huge_const_op/huge_const_op.cc:58-226) --------------
  * Loads a .npy (format 1.0/2.0, C order) into HBM once; the GPU kernel of the

@@ -29,7 +29,8 @@ PHASE_NAMES = ("zero", "walk", "expand", "score", "topk", "other", "tk_load", "t
 # every symbol include/nann_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nann_abi_version", "nann_last_error", "nann_device_count", "nann_malloc", "nann_free",
-    "nann_memcpy", "nann_stream_synchronize", "nann_huge_const_load", "nann_group_gather_count",
+    "nann_memcpy", "nann_stream_synchronize", "nann_stream_create", "nann_stream_destroy", "nann_host_malloc",
+    "nann_host_free", "nann_huge_const_load", "nann_group_gather_count",
     "nann_group_gather_fill", "nann_bitmap_ref_difference", "nann_bloom_filter_difference", "nann_gather_rows", "nann_topk",
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",

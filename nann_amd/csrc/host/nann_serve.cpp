@@ -3,11 +3,12 @@
 // closed-loop consumers (blaze-benchmark/benchmark/core/model.cc:192-235, predict_request_consumer.cc:17-53)
 // is, on this design, ONE resident index and a batching front end: concurrent single requests with the serving
 // signature (comm_seq f16[1, L*d] + level_topn -> top_k i64[1, k], build_opt_graph.py:151-159) are aggregated
-// into one nann_search launch.  The Python twin is nann_amd/serving.py; this program is the proof that a C++
+// into one nann_search launch, by --lanes dispatcher threads, each with a stream, a workspace and page-locked staging
+// of its own, so that one batch's copies run under another batch's search.  The Python twin is nann_amd/serving.py; this program is the proof that a C++
 // host needs nothing but libnann_hip.so.
 //
 //   nann_serve <index_dir> <item_embs_dir> <dim> [--clients N] [--seconds S] [--max-batch B] [--max-wait-us U]
-//              [--ef E] [--topk K] [--seq-len L] [--model-dir DIR] [--probe-out FILE]
+//              [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE]
 // index_dir / item_embs_dir: the files build_hnsw_index.py writes (nann_amd.index_build writes the same).
 // Closed loop: every client thread sends a request, waits for its reply, sends the next.  Prints one JSON line.
 #include <algorithm>
@@ -105,7 +106,7 @@ int main(int argc, char** argv) {
   }
   const std::string index_dir = argv[1], embs_dir = argv[2];
   const int d = std::atoi(argv[3]);
-  int clients = 64, max_batch = 256, max_wait_us = 200, ef = 128, topk = 200, L = 50;
+  int clients = 64, max_batch = 256, max_wait_us = 200, ef = 128, topk = 200, L = 50, lanes = 2;
   double seconds = 3.0;
   std::string model_dir, probe_out;
   for (int i = 4; i + 1 < argc; i += 2) {
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
     else if (k == "--ef") ef = std::atoi(argv[i + 1]);
     else if (k == "--topk") topk = std::atoi(argv[i + 1]);
     else if (k == "--seq-len") L = std::atoi(argv[i + 1]);
+    else if (k == "--lanes") lanes = std::max(1, std::atoi(argv[i + 1]));
     else if (k == "--model-dir") model_dir = argv[i + 1];
     else if (k == "--probe-out") probe_out = argv[i + 1];  // after the run: one fixed request, its reply written as text
     else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -157,17 +159,30 @@ int main(int argc, char** argv) {
   const int seq_d = (model && nann_model_kind(model) == NANN_MODEL_ATTENTION) ? 64 : d;  // the attention model's sequence is [L, 64]
   const size_t seq_elems = (size_t)L * seq_d;
 
-  // ---- device buffers of one launch
+  // ---- per lane: a stream, the device buffers of one launch, page-locked staging
   const int32_t level_topn[6] = {ef, ef, ef, ef, ef, topk};
   int64_t ws_bytes = 0;
   if (model) CHECK(nann_search_model_workspace_bytes(ix, model, level_topn, max_batch, &ws_bytes));
   else CHECK(nann_search_workspace_bytes(ix, level_topn, max_batch, &ws_bytes));
-  void *ws = nullptr, *d_seq = nullptr, *d_q = nullptr, *d_topk = nullptr, *d_status = nullptr;
-  CHECK(nann_malloc(&ws, ws_bytes));
-  CHECK(nann_malloc(&d_seq, (int64_t)max_batch * seq_elems * 2));
-  CHECK(nann_malloc(&d_q, (int64_t)max_batch * d * 4));
-  CHECK(nann_malloc(&d_topk, (int64_t)max_batch * topk * 8));
-  CHECK(nann_malloc(&d_status, (int64_t)max_batch * 4));
+  struct Lane {
+    nann_stream_t stream = nullptr;
+    void *ws = nullptr, *d_seq = nullptr, *d_q = nullptr, *d_topk = nullptr, *d_status = nullptr;
+    uint16_t* h_seq = nullptr;
+    int64_t* h_topk = nullptr;
+    int32_t* h_status = nullptr;
+  };
+  std::vector<Lane> lane((size_t)lanes);
+  for (Lane& ln : lane) {
+    CHECK(nann_stream_create(&ln.stream));
+    CHECK(nann_malloc(&ln.ws, ws_bytes));
+    CHECK(nann_malloc(&ln.d_seq, (int64_t)max_batch * seq_elems * 2));
+    CHECK(nann_malloc(&ln.d_q, (int64_t)max_batch * d * 4));
+    CHECK(nann_malloc(&ln.d_topk, (int64_t)max_batch * topk * 8));
+    CHECK(nann_malloc(&ln.d_status, (int64_t)max_batch * 4));
+    CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_seq), (int64_t)max_batch * seq_elems * 2));
+    CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_topk), (int64_t)max_batch * topk * 8));
+    CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_status), (int64_t)max_batch * 4));
+  }
 
   // ---- request material: histories made of real item rows (a few thousand rows copied back once)
   const int64_t pool_rows = std::min<int64_t>(n_ids, 4096);
@@ -180,59 +195,59 @@ int main(int argc, char** argv) {
   std::vector<std::vector<float>> lat((size_t)clients);
   const auto t_end = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
 
-  // ---- one launch for a batch of requests, replies handed back to their callers
-  std::vector<uint16_t> h_seq((size_t)max_batch * seq_elems);
-  std::vector<int64_t> h_topk((size_t)max_batch * topk);
-  std::vector<int32_t> h_status((size_t)max_batch);
-  auto run_batch = [&](const std::vector<Request*>& batch) {
+  // ---- one launch for a batch of requests on a lane, replies handed back to their callers
+  auto run_batch = [&](Lane& ln, const std::vector<Request*>& batch) {
     const int b = (int)batch.size();
-    for (int i = 0; i < b; ++i) std::memcpy(&h_seq[(size_t)i * seq_elems], batch[i]->comm_seq, seq_elems * 2);
-    CHECK(nann_memcpy(d_seq, h_seq.data(), (int64_t)b * seq_elems * 2, 0, nullptr));
+    for (int i = 0; i < b; ++i) std::memcpy(ln.h_seq + (size_t)i * seq_elems, batch[i]->comm_seq, seq_elems * 2);
+    CHECK(nann_memcpy(ln.d_seq, ln.h_seq, (int64_t)b * seq_elems * 2, 0, ln.stream));
     if (model) {
-      CHECK(nann_search_model(ix, model, d_seq, b, level_topn, ws, ws_bytes, static_cast<int64_t*>(d_topk), nullptr,
-                              nullptr, static_cast<int32_t*>(d_status), nullptr, nullptr));
+      CHECK(nann_search_model(ix, model, ln.d_seq, b, level_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk), nullptr,
+                              nullptr, static_cast<int32_t*>(ln.d_status), nullptr, ln.stream));
     } else {
-      CHECK(nann_user_seq_mean(d_seq, b, L, d, static_cast<float*>(d_q), nullptr));
-      CHECK(nann_search(ix, scorer, static_cast<const float*>(d_q), b, level_topn, ws, ws_bytes,
-                        static_cast<int64_t*>(d_topk), nullptr, nullptr, static_cast<int32_t*>(d_status), nullptr, nullptr));
+      CHECK(nann_user_seq_mean(ln.d_seq, b, L, d, static_cast<float*>(ln.d_q), ln.stream));
+      CHECK(nann_search(ix, scorer, static_cast<const float*>(ln.d_q), b, level_topn, ln.ws, ws_bytes,
+                        static_cast<int64_t*>(ln.d_topk), nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr,
+                        ln.stream));
     }
-    CHECK(nann_memcpy(h_topk.data(), d_topk, (int64_t)b * topk * 8, 1, nullptr));
-    CHECK(nann_memcpy(h_status.data(), d_status, (int64_t)b * 4, 1, nullptr));
-    CHECK(nann_stream_synchronize(nullptr));
+    CHECK(nann_memcpy(ln.h_topk, ln.d_topk, (int64_t)b * topk * 8, 1, ln.stream));
+    CHECK(nann_memcpy(ln.h_status, ln.d_status, (int64_t)b * 4, 1, ln.stream));
+    CHECK(nann_stream_synchronize(ln.stream));
     launches.fetch_add(1);
     batched.fetch_add(b);
     for (int i = 0; i < b; ++i) {
       Request* r = batch[i];
-      std::memcpy(r->top_k, &h_topk[(size_t)i * topk], (size_t)topk * 8);
+      std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)topk * 8);
       {
         std::lock_guard<std::mutex> lk(r->mu);
-        r->status = h_status[(size_t)i];
+        r->status = ln.h_status[(size_t)i];
         r->done = true;
       }
       r->cv.notify_one();
     }
   };
 
-  // ---- the dispatcher: one launch per batch of whatever arrived within max_wait_us of the first request
-  std::thread dispatcher([&] {
-    std::vector<Request*> batch;
-    for (;;) {
-      batch.clear();
-      {
-        std::unique_lock<std::mutex> lk(q.mu);
-        q.cv.wait(lk, [&] { return !q.pending.empty() || q.closing; });
-        if (q.pending.empty() && q.closing) return;
-        const auto deadline = Clock::now() + std::chrono::microseconds(max_wait_us);
-        while ((int)q.pending.size() < max_batch && !q.closing &&
-               q.cv.wait_until(lk, deadline, [&] { return (int)q.pending.size() >= max_batch || q.closing; })) {
+  // ---- the dispatchers: one launch per batch of whatever arrived within max_wait_us of the first request
+  std::vector<std::thread> dispatchers;
+  for (int li = 0; li < lanes; ++li)
+    dispatchers.emplace_back([&, li] {
+      std::vector<Request*> batch;
+      for (;;) {
+        batch.clear();
+        {
+          std::unique_lock<std::mutex> lk(q.mu);
+          q.cv.wait(lk, [&] { return !q.pending.empty() || q.closing; });
+          if (q.pending.empty() && q.closing) return;
+          const auto deadline = Clock::now() + std::chrono::microseconds(max_wait_us);
+          while ((int)q.pending.size() < max_batch && !q.closing &&
+                 q.cv.wait_until(lk, deadline, [&] { return (int)q.pending.size() >= max_batch || q.closing; })) {
+          }
+          const size_t take = std::min<size_t>(q.pending.size(), (size_t)max_batch);
+          batch.assign(q.pending.begin(), q.pending.begin() + (long)take);
+          q.pending.erase(q.pending.begin(), q.pending.begin() + (long)take);
         }
-        const size_t take = std::min<size_t>(q.pending.size(), (size_t)max_batch);
-        batch.assign(q.pending.begin(), q.pending.begin() + (long)take);
-        q.pending.erase(q.pending.begin(), q.pending.begin() + (long)take);
+        if (!batch.empty()) run_batch(lane[(size_t)li], batch);
       }
-      run_batch(batch);
-    }
-  });
+    });
 
   // ---- closed-loop clients (predict_request_consumer.cc:17-53)
   std::vector<std::thread> workers;
@@ -279,7 +294,7 @@ int main(int argc, char** argv) {
     q.closing = true;
   }
   q.cv.notify_all();
-  dispatcher.join();
+  for (auto& t : dispatchers) t.join();
 
   std::vector<float> all;
   for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
@@ -287,10 +302,10 @@ int main(int argc, char** argv) {
   auto pct = [&](double p) { return all.empty() ? 0.0f : all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
   const long long total = served.load() + failed.load();
   std::printf("{\"host\": \"nann_serve (C++ over the C ABI)\", \"scorer\": \"%s\", \"items\": %lld, \"dim\": %d, \"ef\": %d, "
-              "\"topk\": %d, \"clients\": %d, \"max_batch\": %d, \"max_wait_us\": %d, \"seconds\": %.2f, \"requests\": %lld, "
+              "\"topk\": %d, \"clients\": %d, \"max_batch\": %d, \"max_wait_us\": %d, \"lanes\": %d, \"seconds\": %.2f, \"requests\": %lld, "
               "\"failed_requests\": %lld, \"qps\": %.1f, \"launches\": %lld, \"mean_batch\": %.1f, "
               "\"latency_ms\": {\"p50\": %.3f, \"p90\": %.3f, \"p99\": %.3f, \"max\": %.3f}}\n",
-              model_dir.empty() ? "l2" : model_dir.c_str(), (long long)n_ids, d, ef, topk, clients, max_batch, max_wait_us,
+              model_dir.empty() ? "l2" : model_dir.c_str(), (long long)n_ids, d, ef, topk, clients, max_batch, max_wait_us, lanes,
               wall, total, failed.load(), (double)total / wall, launches.load(),
               launches.load() ? (double)batched.load() / (double)launches.load() : 0.0, pct(0.5), pct(0.9), pct(0.99),
               all.empty() ? 0.0f : all.back());
@@ -303,7 +318,7 @@ int main(int argc, char** argv) {
     Request r;
     r.comm_seq = seq.data();
     r.top_k = out.data();
-    run_batch({&r});
+    run_batch(lane[0], {&r});
     FILE* f = std::fopen(probe_out.c_str(), "w");
     if (!f) { std::fprintf(stderr, "nann_serve: cannot write %s\n", probe_out.c_str()); return 1; }
     std::fprintf(f, "%d\n", r.status);
@@ -311,7 +326,11 @@ int main(int argc, char** argv) {
     std::fclose(f);
   }
 
-  nann_free(ws); nann_free(d_seq); nann_free(d_q); nann_free(d_topk); nann_free(d_status);
+  for (Lane& ln : lane) {
+    nann_free(ln.ws); nann_free(ln.d_seq); nann_free(ln.d_q); nann_free(ln.d_topk); nann_free(ln.d_status);
+    nann_host_free(ln.h_seq); nann_host_free(ln.h_topk); nann_host_free(ln.h_status);
+    nann_stream_destroy(ln.stream);
+  }
   if (scorer) nann_scorer_destroy(scorer);
   if (model) nann_model_destroy(model);
   nann_index_destroy(ix);

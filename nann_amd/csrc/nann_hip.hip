@@ -548,6 +548,32 @@ int nann_stream_synchronize(nann_stream_t stream) {
   return NANN_OK;
 }
 
+int nann_stream_create(nann_stream_t* out) {
+  if (!out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_stream_create: null argument");
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = reinterpret_cast<nann_stream_t>(s);
+  return NANN_OK;
+}
+
+int nann_stream_destroy(nann_stream_t stream) {
+  if (!stream) return NANN_OK;
+  HIP_TRY(hipStreamDestroy(as_stream(stream)));
+  return NANN_OK;
+}
+
+int nann_host_malloc(void** host_ptr, int64_t nbytes) {
+  if (!host_ptr || nbytes < 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_host_malloc: bad argument");
+  HIP_TRY(hipHostMalloc(host_ptr, (size_t)std::max<int64_t>(nbytes, 1), hipHostMallocDefault));
+  return NANN_OK;
+}
+
+int nann_host_free(void* host_ptr) {
+  if (!host_ptr) return NANN_OK;
+  HIP_TRY(hipHostFree(host_ptr));
+  return NANN_OK;
+}
+
 // ---- HugeConst -------------------------------------------------------------
 static const char* npy_descr(int dtype) {
   switch (dtype) {

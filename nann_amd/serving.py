@@ -167,14 +167,14 @@ def build_serve_host(force=False):
 
 
 def run_serve_host(index_dir, item_embs_dir, dim, clients=64, seconds=3.0, max_batch=256, max_wait_us=200, ef=128,
-                   topk=200, seq_len=50, model_dir=None, probe_out=None):
+                   topk=200, seq_len=50, model_dir=None, probe_out=None, lanes=2):
     """Run the C++ host's closed-loop load test; returns its JSON line as a dict.  probe_out: file that receives
     the reply to one fixed request (item row 0 as the history): status, then top_k ids, one per line."""
     import json
     import subprocess
     cmd = [build_serve_host(), index_dir, item_embs_dir, str(dim), "--clients", str(clients), "--seconds", str(seconds),
            "--max-batch", str(max_batch), "--max-wait-us", str(max_wait_us), "--ef", str(ef), "--topk", str(topk),
-           "--seq-len", str(seq_len)]
+           "--seq-len", str(seq_len), "--lanes", str(lanes)]
     if model_dir:
         cmd += ["--model-dir", model_dir]
     if probe_out:

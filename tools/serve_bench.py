@@ -27,9 +27,11 @@ def main():
         synth.save_index(disk, d)
         del g, disk
         torch.cuda.empty_cache()
-        for c in clients:
-            r = serving.run_serve_host(d, d, 128, clients=c, seconds=4.0, max_batch=1024, max_wait_us=200, ef=128, topk=200)
-            print(json.dumps(r), flush=True)
+        for lanes in (1, 2, 4):
+            for c in clients:
+                r = serving.run_serve_host(d, d, 128, clients=c, seconds=3.0, max_batch=1024, max_wait_us=200, ef=128,
+                                           topk=200, lanes=lanes)
+                print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":
