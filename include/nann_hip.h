@@ -207,7 +207,8 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table,
  *   mlp          w1 [2d,256]  b1  alpha1  w2 [256,128]  b2  alpha2  w3 [128]     (nann_scorer_desc)
  *   attention    wq1 bq1 aq wq2 bq2 wk1 bk1 ak wk2 bk2  w0..w3  b0..b2  bn_scale0..2  bn_shift0..2
  *                alpha0..2                                                    (nann_attn_desc)
- *                optional precision.txt: "exact" (default) | "split" (nann_attn_desc.precision)
+ * mlp and attention directories may hold precision.txt: "exact" (default, f32-input MFMA) | "split" (split-f16 operands on
+ * the 16-bit MFMA: nann_scorer_desc.precision / nann_attn_desc.precision)
  * nann_model_forward is forward() of build_opt_graph.py:91-107 for ONE user: user_seq f16
  * [seq_len, d] (l2 / mlp: its non-pad mean is the query vector; attention: [seq_len, 64]),
  * item_emb [n, d] rows as BlazeXlaOp receives them (already gathered) -> f32 logits[n].

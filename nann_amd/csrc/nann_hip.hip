@@ -1369,6 +1369,21 @@ static int load_f32(const std::string& dir, const char* name, std::vector<std::v
   return NANN_OK;
 }
 
+}  // extern "C"
+
+// optional precision.txt of a weights directory: "exact" (f32-input MFMA, the default) | "split" (split-f16 operands)
+static int read_precision(const std::string& dir, int32_t* precision) {
+  std::ifstream pf(dir + "/precision.txt");
+  std::string prec;
+  if (!pf || !(pf >> prec)) return NANN_OK;
+  if (prec == "split") *precision = NANN_MLP_SPLIT_F16;
+  else if (prec == "exact") *precision = NANN_MLP_EXACT_F32;
+  else return fail(NANN_ERR_BAD_ARGUMENT, "precision.txt: expected exact or split, got '" + prec + "'");
+  return NANN_OK;
+}
+
+extern "C" {
+
 int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_len, nann_model** out) {
   if (!dir || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_load: null argument");
   const std::string D(dir);
@@ -1392,6 +1407,7 @@ int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_l
           {"b2", &sd.b2, 128}, {"alpha2", &sd.alpha2, 128}, {"w3", &sd.w3, 128}};
       for (const auto& e : w)
         if (!rc) rc = load_f32(D, e.n, &keep, e.p, e.cnt);
+      if (!rc) rc = read_precision(D, &sd.precision);
     }
     if (!rc) rc = nann_scorer_create(&sd, &m->scorer);
   } else if (kind == "attention") {
@@ -1408,14 +1424,7 @@ int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_l
         {"alpha0", &ad.alpha[0]}, {"alpha1", &ad.alpha[1]}, {"alpha2", &ad.alpha[2]}};
     for (const auto& e : w)
       if (!rc) rc = load_f32(D, e.n, &keep, e.p, -1);
-    {  // optional precision.txt: "exact" (f32 MFMA, the default) | "split" (split-f16 operands)
-      std::ifstream pf(D + "/precision.txt");
-      std::string prec;
-      if (pf && (pf >> prec)) {
-        if (prec == "split") ad.precision = NANN_MLP_SPLIT_F16;
-        else if (prec != "exact" && !rc) rc = fail(NANN_ERR_BAD_ARGUMENT, "precision.txt: expected exact or split, got '" + prec + "'");
-      }
-    }
+    if (!rc) rc = read_precision(D, &ad.precision);
     if (!rc) rc = nann_attn_scorer_create(&ad, &m->attn);
   } else {
     rc = fail(NANN_ERR_UNSUPPORTED, "scorer.txt: expected l2, mlp or attention, got '" + kind + "'");

@@ -356,7 +356,7 @@ def save_scorer_dir(path, kind, weights=None, precision=None):
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "scorer.txt"), "w") as f:
         f.write(kind + "\n")
-    if precision is not None:  # attention: "exact" | "split" (precision.txt, read by nann_model_load)
+    if precision is not None:  # mlp / attention: "exact" | "split" (precision.txt, read by nann_model_load)
         with open(os.path.join(path, "precision.txt"), "w") as f:
             f.write(precision + "\n")
     if kind == "mlp":
