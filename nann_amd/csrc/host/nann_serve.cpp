@@ -101,7 +101,7 @@ void* load(const std::string& path, int dtype, int64_t* count, int64_t elem_byte
 int main(int argc, char** argv) {
   if (argc < 4) {
     std::fprintf(stderr, "usage: %s <index_dir> <item_embs_dir> <dim> [--clients N] [--seconds S] [--max-batch B] "
-                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--model-dir DIR]\n", argv[0]);
+                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE]\n", argv[0]);
     return 2;
   }
   const std::string index_dir = argv[1], embs_dir = argv[2];
