@@ -93,21 +93,47 @@ def algorithmic_bytes(counters, d, emb_bytes, n_enter, k_out=200):
     return base + (G * 8).sum(axis=-1), base
 
 
-def load_pmc_traffic(tag):
-    """HBM bytes per k_search launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json,
-    written from the same bench command under rocprofv3): PMC counters cannot be read from inside the
-    timed process.  Only reported for the workload they were collected on."""
+def _pmc_entry(tag):
+    """profiles/pmc_latest.json: {"workloads": {tag: {...}}} (one entry per workload the rocprofv3 PMC passes were run on,
+    written by tools/pmc_to_json.py from the same bench command under rocprofv3; older files hold ONE entry at top level).
+    PMC counters cannot be read from inside the timed process, so the line carries the committed measurement -- only
+    for the workload (tag) it was collected on."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             p = json.load(f)
     except (OSError, ValueError):
         return None
-    if p.get("workload_tag") != tag:
+    if "workloads" in p:
+        return p["workloads"].get(tag)
+    return p if p.get("workload_tag") == tag else None
+
+
+def load_pmc_traffic(tag):
+    """HBM bytes per k_search launch (FETCH_SIZE / WRITE_SIZE passes)."""
+    p = _pmc_entry(tag)
+    if p is None or "FETCH_SIZE_KiB" not in p:
         return None
     # MI355X_MICROARCH.md (HBM / rocprofv3): KiB units; gfx950 FETCH_SIZE counts wide reads at half size
     b = (p["FETCH_SIZE_KiB"] * p.get("fetch_correction", 2.0) + p["WRITE_SIZE_KiB"]) * 1024.0
     return {"bytes_per_launch": b, "source": "profiles/pmc_latest.json (%s)" % p.get("kernel_version", "?")}
+
+
+def load_pmc_counters(tag):
+    """matrix-pipe counters of the fused MLP traversal (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES pass)."""
+    p = _pmc_entry(tag)
+    if p is None or "SQ_VALU_MFMA_BUSY_CYCLES" not in p:
+        return None
+    out = {"mfma_busy_source": "profiles/pmc_latest.json (%s)" % p.get("kernel_version", "?")}
+    # SQ_VALU_MFMA_BUSY_CYCLES sums, over the SIMDs, the cycles their matrix pipe was busy; SQ_BUSY_CYCLES the cycles
+    # an SQ (one per XCD ... summed over SEs) had waves: busy fraction = MFMA cycles / (4 SIMDs x CU-cycles the kernel ran)
+    if p.get("GRBM_GUI_ACTIVE"):
+        cu_cycles = p["GRBM_GUI_ACTIVE"] / 8.0 * 256  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        out["mfma_busy_frac"] = round(p["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu_cycles), 4)
+    for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
+        if k in p:
+            out[k] = p[k]
+    return out
 
 
 def usable_cores():
@@ -267,29 +293,32 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         roofline["traffic"] = pmc["bytes_per_launch"]
         roofline["traffic_source"] = pmc["source"]
     if scorer_kind == "mlp":
-        # SURVEY.md 8(d) charges 2*(2d*256 + 256*128 + 128) flop per scored row; the kernel computes the
-        # query half of layer 1 (W1q.q) once per query, so the MFMA work it ISSUES is d*256 + 256*128 MACs
-        # per row -- `frac` prices the issued work against the f32-input MFMA peak (157.3 TFLOP/s)
-        issued = rows * 2.0 * (dim * 256 + 256 * 128)
+        # 2*(2d*256 + 256*128 + 128) flop per scored row are the ALGORITHMIC flops `frac` prices, against
+        # the dense MFMA peak of the type the products run in.  What the kernel ISSUES differs and is reported beside it:
+        # the query half of layer 1 (W1q.q) is hoisted out (once per query); the split-f16 form spends 2 (layer 1) /
+        # 3 (layer 2) 16-bit MFMA products per f32 product; the exact form issues d*256 + 256*128 f32 MACs per row.
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
-        peak = F32_MFMA_PEAK_TF
-        flops_note = "issued f32-MFMA work (query half hoisted)"
         if precision == "split":
-            # split-f16: 2 (layer 1) / 3 (layer 2) 16-bit MFMA products per f32 product, priced against the
-            # dense f16 MFMA peak (2.5 PFLOP/s)
-            issued = rows * 2.0 * (2 * dim * 256 + 3 * 256 * 128)
-            peak = F16_MFMA_PEAK_TF
-            flops_note = "issued f16-MFMA work: 2 products per layer-1 MAC, 3 per layer-2 MAC (split-f16 operands)"
-        tf = issued / (kern_ms * 1e-3) / 1e12
+            issued, peak = rows * 2.0 * (2 * dim * 256 + 3 * 256 * 128), F16_MFMA_PEAK_TF
+            flops_note = "f16 MFMA (split-f16 operands: 2 products per layer-1 MAC, 3 per layer-2 MAC)"
+        else:
+            issued, peak = rows * 2.0 * (dim * 256 + 256 * 128), F32_MFMA_PEAK_TF
+            flops_note = "f32-input MFMA (query half of layer 1 hoisted)"
+        tf = nominal / (kern_ms * 1e-3) / 1e12
+        tf_issued = issued / (kern_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer, %s)" % precision, "achieved": round(tf, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                    "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": flops_note,
-                    "nominal_TFLOPs_incl_hoisted": round(nominal / (kern_ms * 1e-3) / 1e12, 2),
+                    "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": "SURVEY.md 8(d) algorithmic flops per scored row; " + flops_note,
+                    "algorithmic_flops_per_launch": nominal,
+                    "issued_TFLOPs": round(tf_issued, 2), "issued_frac_of_peak": round(tf_issued / peak, 4),
                     # tools/ubench_mfma.hip (profiles/r2_ubench_mfma.txt): a bare loop of this MFMA on every SIMD
                     # holds 1.6-1.9 PFLOP/s (f16) -- the chip clocks ~1.75 GHz under it, not 2.4
-                    "frac_of_measured_mfma_loop": (round(tf / 1830.0, 4) if precision == "split" else None),
+                    "issued_frac_of_measured_mfma_loop": (round(tf_issued / 1830.0, 4) if precision == "split" else None),
                     "hbm_algorithmic_GBps": round(achieved, 1),
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
+        pmc = load_pmc_counters(name)
+        if pmc is not None:
+            roofline.update(pmc)
 
     qps = batch * steps / elapsed
     res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
@@ -544,10 +573,11 @@ def main():
             + (f", sharded {world}-way as configs[3]" if world > 1 else ""))
     result = {
         "metric": "retrieval QPS @ recall@200 parity, 1M items/128-d",
-        # whole-job throughput: every rank searched every query on its own 1M-item shard, so the work done
-        # per second is queries/s x shards (weak scaling: the corpus grows with N); the rate at which
-        # complete answers over the N x 1M corpus leave the job is qps_end_to_end
-        "value": round(qps * world, 1), "unit": "queries/s x 1M-item shards searched",
+        # whole-job throughput = COMPLETE answers per second: with N ranks the corpus is N x 1M items (weak scaling:
+        # per-GPU work fixed, the corpus grows with N), every rank searches every query on its shard, and an answer
+        # is complete once the N per-shard lists are exchanged and merged.  Ideal weak scaling keeps `value` FLAT as N
+        # grows (efficiency = value(N) / value(1)); the shard-searches done per second are under `weak_scaling`.
+        "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": prim["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
@@ -558,6 +588,8 @@ def main():
                    "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
                    "exchange": (f"{args.transport} all-gather + {args.merge} merge" if world > 1 else None)},
         "qps_end_to_end": qps,
+        "weak_scaling": {"shard_searches_per_s": round(qps * world, 1), "unit": "queries/s x 1M-item shards searched",
+                         "efficiency_definition": "value(N) / value(1): answers/s over an N x larger corpus vs one shard"},
     }
     if world > 1 and exchange_note:
         result["exchange_note"] = exchange_note
@@ -586,7 +618,8 @@ def main():
             try:  # BASELINE configs[2]: same index, MLP scorer on the matrix cores
                 cfg = dict(primary_cfg, scorer="mlp", mlp_precision=prec, batch=min(args.batch, 1024),
                            steps=5 if prec == "split" else 3, warmup=1, _index=prim["_index"])
-                sec[key] = strip(run_workload(tag + "_mlp_" + prec, args, dev, rank, world, cfg, want_cpu=False,
+                sec[key] = strip(run_workload(tag + "_mlp_" + prec, args, dev, rank, world, cfg,
+                                              want_cpu=prec == "split" and not args.no_cpu_baseline,
                                               want_parity=True, want_recall=prec == "split"))
             except Exception as e:
                 sec[key] = {"error": repr(e)}

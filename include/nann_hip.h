@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NANN_ABI_VERSION 2
+#define NANN_ABI_VERSION 3
 
 /* status codes; 1..8 share the oracle's numbering (oracle/nann_oracle.h) and
  * map to the TF errors the reference raises at the cited lines */
@@ -172,12 +172,20 @@ typedef struct {
   int32_t precision;   /* MLP only: nann_mlp_precision */
 } nann_scorer_desc;
 /* How the MLP's contractions run on the matrix cores.
+ *   SPLIT_F16  every f32 operand as two f16 values (22 significant bits), products on
+ *              v_mfma_f32_32x32x16_f16 with f32 accumulation; scores within 1e-5 relative of the
+ *              fp32 chain (north_star's bound; ~3e-7 measured), ids equal up to near-ties.
+ *              Preconditions: 16-bit item rows; |w| <= 511 for the item half of W1 and for W2
+ *              (checked at creation: NANN_ERR_UNSUPPORTED); hidden activations |h1| <= 511
+ *              (f16 range after the x2^7 operand scale).  A larger activation SATURATES (the
+ *              hi plane is cut with round-toward-zero, which never produces inf): the score is
+ *              finite and wrong, so a model with such activations must use EXACT_F32.  The
+ *              reference's models are batch-normalised / PReLU nets with O(1) activations.
  *   EXACT_F32  v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, scores BIT-identical to the oracle's
  *              fp32 chain (and therefore identical top-k ids); 1/16 of the 16-bit MFMA rate.
- *   SPLIT_F16  every f32 operand as two f16 values (22 significant bits), products on
- *              v_mfma_f32_32x32x16_f16 with f32 accumulation: ~6x less matrix time; scores within
- *              1e-5 relative of the fp32 chain (north_star's bound), ids equal up to near-ties. */
-enum nann_mlp_precision { NANN_MLP_EXACT_F32 = 0, NANN_MLP_SPLIT_F16 = 1 };
+ *   DEFAULT    (0, what a zero-initialised descriptor asks for) SPLIT_F16 when the weights meet its
+ *              precondition, else EXACT_F32: 1e-5 is the contract, bit-exactness is opt-in. */
+enum nann_mlp_precision { NANN_MLP_PRECISION_DEFAULT = 0, NANN_MLP_SPLIT_F16 = 1, NANN_MLP_EXACT_F32 = 2 };
 int nann_scorer_create(const nann_scorer_desc* desc /*[host]*/, nann_scorer** out);
 void nann_scorer_destroy(nann_scorer* s);
 
@@ -198,17 +206,26 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table,
                int64_t* bad_i, nann_stream_t stream);
 
 /* ---- a4 (b): the scoring model a BlazeXlaOp node names ----------------------------------
- * The reference's op takes a frozen TensorFlow GraphDef in its `graph_def` attr and runs it in a
- * nested session (blaze_xla_kernel.cc:156-180, blaze_xla_predictor.cc:360-459).  This library has
- * no TensorFlow: the model is handed over as a DIRECTORY of .npy weight files exported once from
- * that graph / checkpoint (INTEGRATION.md shows the export), and the op shim passes the
- * directory named by its `graph_def` attr:
- *   scorer.txt   one word: l2 | mlp | attention
- *   mlp          w1 [2d,256]  b1  alpha1  w2 [256,128]  b2  alpha2  w3 [128]     (nann_scorer_desc)
- *   attention    wq1 bq1 aq wq2 bq2 wk1 bk1 ak wk2 bk2  w0..w3  b0..b2  bn_scale0..2  bn_shift0..2
- *                alpha0..2                                                    (nann_attn_desc)
- * mlp and attention directories may hold precision.txt: "exact" (default, f32-input MFMA) | "split" (split-f16 operands on
- * the 16-bit MFMA: nann_scorer_desc.precision / nann_attn_desc.precision)
+ * The reference's op takes the path of a frozen TensorFlow GraphDef in its `graph_def` attr and runs it in a
+ * nested session (blaze_xla_kernel.cc:156-180, blaze_xla_predictor.cc:360-459).  nann_model_load takes the
+ * same attr value:
+ *   a FILE       the frozen GraphDef itself, binary, as convert_meta.py:361-398 writes it (`frozen_graph.pb`:
+ *                Model.forward(training=False), model.py:189-233, frozen + fold_constants'ed or merely frozen).
+ *                No TensorFlow here and nothing of the graph is executed: the weights are pulled out of the
+ *                Const nodes by the names the reference's Python gives their consumers (csrc/host/
+ *                nann_graphdef.h), batch norm folded to scale / shift, and handed to the hand-written kernels
+ *                (nann_attn_desc).  A graph that is not that model -> NANN_ERR_UNSUPPORTED naming what is
+ *                missing; a text-format GraphDef -> NANN_ERR_IO.  An optional `<file>.precision` beside it
+ *                holds "split" | "exact".
+ *   a DIRECTORY  of .npy weight files, for scorers that have no frozen graph in the reference (BASELINE's L2
+ *                and MLP) and for hosts that hold the model as arrays:
+ *                  scorer.txt   one word: l2 | mlp | attention
+ *                  mlp          w1 [2d,256]  b1  alpha1  w2 [256,128]  b2  alpha2  w3 [128]     (nann_scorer_desc)
+ *                  attention    wq1 bq1 aq wq2 bq2 wk1 bk1 ak wk2 bk2  w0..w3  b0..b2  bn_scale0..2  bn_shift0..2
+ *                               alpha0..2                                                    (nann_attn_desc)
+ *                  precision.txt (optional, mlp / attention): "split" (default: split-f16 operands on the 16-bit
+ *                               MFMA) | "exact" (f32-input MFMA)
+ *                Every tensor is checked against the element count (d, seq_len) imply: NANN_ERR_SHAPE_MISMATCH.
  * nann_model_forward is forward() of build_opt_graph.py:91-107 for ONE user: user_seq f16
  * [seq_len, d] (l2 / mlp: its non-pad mean is the query vector; attention: [seq_len, 64]),
  * item_emb [n, d] rows as BlazeXlaOp receives them (already gathered) -> f32 logits[n].
@@ -386,7 +403,6 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
  * over the user's behaviour sequence u f16[L, 64] (comm_seq, build_opt_graph.py:76-79), then a DNN
  * 128-64-32-1 with batch norm (folded to scale/shift) and PReLU, last layer bias-free.  f32 logits,
  * rows scored independently.  This build: E = 64, L <= 64, d in {64, 128}, rows f16 or bf16.
- * STATUS: kernel written against the oracle restatement, not yet run on hardware.
  * All descriptor pointers are [host] f32; the scorer owns device copies. */
 typedef struct nann_attn_scorer nann_attn_scorer;
 typedef struct {
@@ -402,9 +418,9 @@ typedef struct {
   const float* bn_scale[3];
   const float* bn_shift[3];
   const float* alpha[3];
-  int32_t precision;  /* enum nann_mlp_precision: NANN_MLP_EXACT_F32 (0, f32-input MFMA) or NANN_MLP_SPLIT_F16
-                       * (every f32 operand as hi + lo f16 on the 16-bit MFMA, 3x fewer matrix cycles; logits
-                       * within ~1e-6 of the exact form) */
+  int32_t precision;  /* enum nann_mlp_precision: NANN_MLP_SPLIT_F16 (every f32 operand as hi + lo f16 on the
+                       * 16-bit MFMA, 3x fewer matrix cycles; logits within ~1e-6 of the exact form; the default),
+                       * NANN_MLP_EXACT_F32 (f32-input MFMA) */
 } nann_attn_desc;
 int nann_attn_scorer_create(const nann_attn_desc* desc /*[host]*/, nann_attn_scorer** out);
 void nann_attn_scorer_destroy(nann_attn_scorer* s);

@@ -19,7 +19,7 @@ STATUS_NAMES = {
 }
 F16, BF16, F32, I32, I64, F64 = 0, 1, 2, 3, 4, 5
 SCORER_L2, SCORER_MLP = 0, 1
-MLP_EXACT_F32, MLP_SPLIT_F16 = 0, 1
+MLP_DEFAULT, MLP_SPLIT_F16, MLP_EXACT_F32 = 0, 1, 2
 NUM_ROUNDS = 5
 NUM_PHASES = 19
 PHASE_NAMES = ("zero", "walk", "expand", "score", "topk", "other", "tk_load", "tk_search",

@@ -3,6 +3,7 @@
 // in nann_device.h.  Reference citations are relative to /root/reference/.
 #include "nann_eval.h"
 #include "nann_attn.h"
+#include "host/nann_graphdef.h"
 
 #include <algorithm>
 #include <atomic>
@@ -14,6 +15,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <sys/stat.h>
 
 using namespace nann;
 
@@ -1050,18 +1053,21 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
     s->mlp.w1 = w + o_w1; s->mlp.b1 = w + o_b1; s->mlp.alpha1 = w + o_a1;
     s->mlp.w2 = w + o_w2; s->mlp.b2 = w + o_b2; s->mlp.alpha2 = w + o_a2; s->mlp.w3 = w + o_w3;
     s->mlp.d = d; s->mlp.h1 = 256; s->mlp.h2 = 128;
-    if (desc->precision != NANN_MLP_EXACT_F32 && desc->precision != NANN_MLP_SPLIT_F16) {
+    if (desc->precision != NANN_MLP_PRECISION_DEFAULT && desc->precision != NANN_MLP_EXACT_F32 &&
+        desc->precision != NANN_MLP_SPLIT_F16) {
       nann_scorer_destroy(s);
       return fail(NANN_ERR_BAD_ARGUMENT, "MLP scorer: unknown precision");
     }
-    if (desc->precision == NANN_MLP_SPLIT_F16) {  // the pre-scaled weights must stay inside f16's range
+    if (desc->precision != NANN_MLP_EXACT_F32) {  // the pre-scaled weights must stay inside f16's range
       float wmax = 0.0f;
       for (size_t i2 = (size_t)d * h1; i2 < n_w1; ++i2) wmax = std::max(wmax, std::fabs(desc->w1[i2]));
       for (size_t i2 = 0; i2 < n_w2; ++i2) wmax = std::max(wmax, std::fabs(desc->w2[i2]));
-      if (!(wmax <= 511.0f)) {
+      const bool fits = wmax <= 511.0f;
+      if (!fits && desc->precision == NANN_MLP_SPLIT_F16) {
         nann_scorer_destroy(s);
         return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: split-f16 precision needs |w| <= 511; use NANN_MLP_EXACT_F32");
       }
+      s->desc.precision = fits ? NANN_MLP_SPLIT_F16 : NANN_MLP_EXACT_F32;  // DEFAULT resolved
     }
     {  // the split-f16 planes are small (256 KB): always built, used when precision says so
       std::vector<uint16_t> packed;
@@ -1238,11 +1244,12 @@ int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) 
   P.d = d;
   P.L = L;
   s->emb_dtype = desc->emb_dtype;
-  if (desc->precision != NANN_MLP_EXACT_F32 && desc->precision != NANN_MLP_SPLIT_F16) {
+  if (desc->precision != NANN_MLP_PRECISION_DEFAULT && desc->precision != NANN_MLP_EXACT_F32 &&
+      desc->precision != NANN_MLP_SPLIT_F16) {
     nann_attn_scorer_destroy(s);
     return fail(NANN_ERR_BAD_ARGUMENT, "attention scorer: unknown precision");
   }
-  s->precision = desc->precision;
+  s->precision = desc->precision;  // DEFAULT is resolved below, once the weights have been looked at
   {  // the split-f16 planes (~0.5 MB) are always built; `precision` picks the kernels
     std::vector<uint16_t> packed;
     bool ok = true;
@@ -1257,6 +1264,7 @@ int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) 
       nann_attn_scorer_destroy(s);
       return fail(NANN_ERR_UNSUPPORTED, "attention scorer, split-f16 form: |w| must be <= 511");
     }
+    if (s->precision == NANN_MLP_PRECISION_DEFAULT) s->precision = ok ? NANN_MLP_SPLIT_F16 : NANN_MLP_EXACT_F32;
     std::vector<float> pv(PV_COUNT, 0.0f);
     const float WS = kAttnWS, HS = kAttnHS;
     for (int j = 0; j < 128; ++j) {
@@ -1371,7 +1379,7 @@ static int load_f32(const std::string& dir, const char* name, std::vector<std::v
 
 }  // extern "C"
 
-// optional precision.txt of a weights directory: "exact" (f32-input MFMA, the default) | "split" (split-f16 operands)
+// optional precision.txt of a weights directory: "split" (split-f16 operands, the default) | "exact" (f32-input MFMA)
 static int read_precision(const std::string& dir, int32_t* precision) {
   std::ifstream pf(dir + "/precision.txt");
   std::string prec;
@@ -1384,15 +1392,71 @@ static int read_precision(const std::string& dir, int32_t* precision) {
 
 extern "C" {
 
+// BlazeXlaOp.graph_def as the reference writes it: a frozen GraphDef file (convert_meta.py:361-398).  The weights of
+// Model.forward (model.py:189-233) are pulled out of it by host/nann_graphdef.h; nothing of the graph is executed.
+static int model_from_graphdef(const std::string& path, int32_t d, int32_t emb_dtype, int32_t seq_len, nann_model* m) {
+  std::ifstream f(path, std::ifstream::binary);
+  if (!f) return fail(NANN_ERR_IO, "Fail to open file: " + path);
+  const std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  nann_gd::Graph g;
+  std::string msg;
+  if (!nann_gd::parse_graph(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &g, &msg))
+    return fail(NANN_ERR_IO, "parse proto from " + path + " failed: " + msg);  // blaze_xla_kernel.cc:169-175
+  nann_gd::AttnWeights w;
+  if (!nann_gd::extract_attention(g, &w, &msg))
+    return fail(NANN_ERR_UNSUPPORTED, path + ": not the reference's scorer model (model.py:189-233): " + msg);
+  if (w.d != d) return fail(NANN_ERR_SHAPE_MISMATCH, path + ": the model scores " + std::to_string(w.d) + "-d item rows, the request has " + std::to_string(d));
+  if (w.e != kAttnE) return fail(NANN_ERR_UNSUPPORTED, path + ": user sequence embedding dim " + std::to_string(w.e) + ", this build has 64");
+  const size_t hq = 2 * (size_t)kAttnE, hq2 = 4 * (size_t)kAttnE;
+  const size_t expect[] = {(size_t)d * hq, hq, hq, hq * hq2, hq2, (size_t)kAttnE * hq, hq, hq, hq * hq2, hq2};
+  const std::vector<float>* att[] = {&w.wq1, &w.bq1, &w.aq, &w.wq2, &w.bq2, &w.wk1, &w.bk1, &w.ak, &w.wk2, &w.bk2};
+  for (int i = 0; i < 10; ++i)
+    if (att[i]->size() != expect[i]) return fail(NANN_ERR_SHAPE_MISMATCH, path + ": attention tensor " + std::to_string(i) + " has an unexpected size");
+  const size_t widths[4] = {128, 64, 32, 1};
+  size_t n_in = (size_t)kAttnE + (size_t)d;
+  for (int l = 0; l < 4; ++l) {
+    if (w.w[l].size() != n_in * widths[l]) return fail(NANN_ERR_SHAPE_MISMATCH, path + ": DNN layer " + std::to_string(l + 1) + " is not the 128-64-32-1 tower this build has");
+    n_in = widths[l];
+  }
+  nann_attn_desc ad = {};
+  ad.d = d; ad.emb_dtype = emb_dtype; ad.seq_len = seq_len;
+  ad.wq1 = w.wq1.data(); ad.bq1 = w.bq1.data(); ad.aq = w.aq.data(); ad.wq2 = w.wq2.data(); ad.bq2 = w.bq2.data();
+  ad.wk1 = w.wk1.data(); ad.bk1 = w.bk1.data(); ad.ak = w.ak.data(); ad.wk2 = w.wk2.data(); ad.bk2 = w.bk2.data();
+  for (int l = 0; l < 4; ++l) ad.w[l] = w.w[l].data();
+  for (int l = 0; l < 3; ++l) {
+    ad.b[l] = w.b[l].data(); ad.bn_scale[l] = w.bn_scale[l].data(); ad.bn_shift[l] = w.bn_shift[l].data();
+    ad.alpha[l] = w.alpha[l].data();
+  }
+  ad.precision = NANN_MLP_PRECISION_DEFAULT;
+  {  // an optional <file>.precision beside the graph: "split" | "exact" (as precision.txt of the directory form)
+    std::ifstream pf(path + ".precision");
+    std::string prec;
+    if (pf && (pf >> prec)) {
+      if (prec == "split") ad.precision = NANN_MLP_SPLIT_F16;
+      else if (prec == "exact") ad.precision = NANN_MLP_EXACT_F32;
+      else return fail(NANN_ERR_BAD_ARGUMENT, path + ".precision: expected exact or split, got '" + prec + "'");
+    }
+  }
+  m->kind = NANN_MODEL_ATTENTION;
+  return nann_attn_scorer_create(&ad, &m->attn);
+}
+
 int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_len, nann_model** out) {
   if (!dir || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_load: null argument");
   const std::string D(dir);
-  std::ifstream kf(D + "/scorer.txt");
-  if (!kf) return fail(NANN_ERR_IO, "Fail to open file: " + D + "/scorer.txt");
-  std::string kind;
-  kf >> kind;
   nann_model* m = new nann_model();
   m->d = d; m->seq_len = seq_len; m->emb_dtype = emb_dtype;
+  struct stat sb;
+  if (::stat(dir, &sb) == 0 && S_ISREG(sb.st_mode)) {  // a frozen GraphDef file: what the reference's attr names
+    const int rc = model_from_graphdef(D, d, emb_dtype, seq_len, m);
+    if (rc) { nann_model_destroy(m); return rc; }
+    *out = m;
+    return NANN_OK;
+  }
+  std::ifstream kf(D + "/scorer.txt");
+  if (!kf) { nann_model_destroy(m); return fail(NANN_ERR_IO, "Fail to open file: " + D + "/scorer.txt"); }
+  std::string kind;
+  kf >> kind;
   std::vector<std::vector<char>> keep;
   int rc = NANN_OK;
   if (kind == "l2" || kind == "mlp") {
@@ -1414,16 +1478,19 @@ int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_l
     nann_attn_desc ad = {};
     ad.d = d; ad.emb_dtype = emb_dtype; ad.seq_len = seq_len;
     m->kind = NANN_MODEL_ATTENTION;
-    const struct { const char* n; const float** p; } w[] = {
-        {"wq1", &ad.wq1}, {"bq1", &ad.bq1}, {"aq", &ad.aq}, {"wq2", &ad.wq2}, {"bq2", &ad.bq2},
-        {"wk1", &ad.wk1}, {"bk1", &ad.bk1}, {"ak", &ad.ak}, {"wk2", &ad.wk2}, {"bk2", &ad.bk2},
-        {"w0", &ad.w[0]}, {"w1", &ad.w[1]}, {"w2", &ad.w[2]}, {"w3", &ad.w[3]},
-        {"b0", &ad.b[0]}, {"b1", &ad.b[1]}, {"b2", &ad.b[2]},
-        {"bn_scale0", &ad.bn_scale[0]}, {"bn_scale1", &ad.bn_scale[1]}, {"bn_scale2", &ad.bn_scale[2]},
-        {"bn_shift0", &ad.bn_shift[0]}, {"bn_shift1", &ad.bn_shift[1]}, {"bn_shift2", &ad.bn_shift[2]},
-        {"alpha0", &ad.alpha[0]}, {"alpha1", &ad.alpha[1]}, {"alpha2", &ad.alpha[2]}};
+    // every tensor with the element count nann_attn_scorer_create indexes it by: a directory exported for another d,
+    // or a truncated file, is refused instead of read out of bounds
+    const int64_t E = kAttnE, hq = 2 * E, hq2 = 4 * E;
+    const struct { const char* n; const float** p; int64_t cnt; } w[] = {
+        {"wq1", &ad.wq1, (int64_t)d * hq}, {"bq1", &ad.bq1, hq}, {"aq", &ad.aq, hq}, {"wq2", &ad.wq2, hq * hq2}, {"bq2", &ad.bq2, hq2},
+        {"wk1", &ad.wk1, E * hq}, {"bk1", &ad.bk1, hq}, {"ak", &ad.ak, hq}, {"wk2", &ad.wk2, hq * hq2}, {"bk2", &ad.bk2, hq2},
+        {"w0", &ad.w[0], (E + d) * 128}, {"w1", &ad.w[1], 128 * 64}, {"w2", &ad.w[2], 64 * 32}, {"w3", &ad.w[3], 32},
+        {"b0", &ad.b[0], 128}, {"b1", &ad.b[1], 64}, {"b2", &ad.b[2], 32},
+        {"bn_scale0", &ad.bn_scale[0], 128}, {"bn_scale1", &ad.bn_scale[1], 64}, {"bn_scale2", &ad.bn_scale[2], 32},
+        {"bn_shift0", &ad.bn_shift[0], 128}, {"bn_shift1", &ad.bn_shift[1], 64}, {"bn_shift2", &ad.bn_shift[2], 32},
+        {"alpha0", &ad.alpha[0], 128}, {"alpha1", &ad.alpha[1], 64}, {"alpha2", &ad.alpha[2], 32}};
     for (const auto& e : w)
-      if (!rc) rc = load_f32(D, e.n, &keep, e.p, -1);
+      if (!rc) rc = load_f32(D, e.n, &keep, e.p, e.cnt);
     if (!rc) rc = read_precision(D, &ad.precision);
     if (!rc) rc = nann_attn_scorer_create(&ad, &m->attn);
   } else {

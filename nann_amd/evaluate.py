@@ -41,8 +41,18 @@ class AverageMeter:
 
 
 def _query(scorer, seq):
-    """the per-user input of the scorer: mean of the non-pad history rows for l2 / mlp scorers"""
+    """the per-user input of an ops.Scorer (l2 / mlp): mean of the non-pad history rows"""
+    if isinstance(scorer, ops.Model):
+        raise NotImplementedError("an ops.Model takes the raw sequence (Model.forward); only ops.Scorer has a query vector")
     return ops.user_seq_mean(seq[None])[0]
+
+
+def _score_all(index, scorer, seq):
+    """logits of EVERY item for one user: ops.Model -> forward() on the raw sequence (the attention model's
+    input is [L, 64], not a mean); ops.Scorer -> blaze_score on the mean of the history rows"""
+    if isinstance(scorer, ops.Model):
+        return scorer.forward(seq[None], index.item_embs).reshape(-1)
+    return ops.blaze_score(scorer, _query(scorer, seq), item_emb=index.item_embs)
 
 
 def test(index, scorer, user_seqs, ground_truths, topk_eval=(200,), num_scoring_per_level=(3, 1, 1),
@@ -55,6 +65,9 @@ def test(index, scorer, user_seqs, ground_truths, topk_eval=(200,), num_scoring_
     prec, rec, f1m = defaultdict(AverageMeter), defaultdict(AverageMeter), defaultdict(AverageMeter)
     seqs = torch.as_tensor(np.asarray(user_seqs)).to(index.device)[:n]
     kmax = max(topk_eval)
+    if not fused and isinstance(scorer, ops.Model):
+        raise NotImplementedError("the op-by-op spelling scores through blaze_score (ops.Scorer); "
+                                  "an ops.Model runs on the fused kernel (fused=True)")
     if fused:
         q = seqs if isinstance(scorer, ops.Model) else ops.user_seq_mean(seqs)
         r = retrieval.search_eval(index, scorer, q, num_scoring_per_level, top_k_per_level, kmax)
@@ -83,7 +96,7 @@ def test_all(index, scorer, user_seqs, ground_truths, topk_eval=(200,), num_test
     prec, rec, f1m = defaultdict(AverageMeter), defaultdict(AverageMeter), defaultdict(AverageMeter)
     seqs = torch.as_tensor(np.asarray(user_seqs)).to(index.device)
     for u in range(n):
-        scores_all = ops.blaze_score(scorer, _query(scorer, seqs[u]), item_emb=index.item_embs)
+        scores_all = _score_all(index, scorer, seqs[u])
         _, idx = ops.top_k(scores_all, max(topk_eval))
         ids = index.item_ids[idx.long()].cpu().numpy()
         for k in topk_eval:

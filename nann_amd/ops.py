@@ -255,16 +255,31 @@ def top_k(values, k):
 _DT = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
 
 
+_PRECISION = {"split": _lib.MLP_SPLIT_F16, "exact": _lib.MLP_EXACT_F32}
+
+
+def _precision_code(precision):
+    """'split' | 'exact' -> nann_mlp_precision; anything else is an error (a typo must not silently select
+    the slower kernel)."""
+    try:
+        return _PRECISION[precision]
+    except KeyError:
+        raise ValueError(f"precision must be 'split' or 'exact', got {precision!r}") from None
+
+
 class Scorer:
     """What the frozen scoring GraphDef is to BlazeXlaOp (blaze_xla_kernel.cc:24-33):
     kind 'l2' (s = -||q - x||^2) or 'mlp' (weights dict as synth.make_mlp_weights)."""
 
-    def __init__(self, kind, d, emb_dtype=torch.float16, weights=None, precision="exact"):
-        """precision (mlp): "exact" = f32 MFMA, scores bit-identical to the oracle; "split" = split-f16
-        operands on the 16-bit MFMA, ~6x less matrix time, scores within 1e-5 (nann_mlp_precision)."""
+    def __init__(self, kind, d, emb_dtype=torch.float16, weights=None, precision="split"):
+        """precision (mlp): "split" (the default: north_star's contract is 1e-5) = split-f16 operands on the
+        16-bit MFMA, scores within 1e-5 of the fp32 chain; "exact" = f32-input MFMA, scores bit-identical to
+        the oracle, ~3x slower (nann_mlp_precision)."""
+        if kind not in ("l2", "mlp"):
+            raise ValueError(f"scorer kind must be 'l2' or 'mlp', got {kind!r}")
         self.kind, self.d, self.emb_dtype, self.precision = kind, d, emb_dtype, precision
         desc = _lib.ScorerDesc()
-        desc.precision = _lib.MLP_SPLIT_F16 if precision == "split" else _lib.MLP_EXACT_F32
+        desc.precision = _precision_code(precision)
         desc.kind = _lib.SCORER_L2 if kind == "l2" else _lib.SCORER_MLP
         desc.d = d
         desc.emb_dtype = _DT[emb_dtype]
@@ -290,13 +305,13 @@ class Scorer:
 class AttnScorer:
     """The reference's own scorer model behind the BlazeXlaOp contract (SURVEY.md 8 f2;
     model.py:189-233, model_util.py:70-97): weights dict as synth.make_attn_weights.
-    precision: "exact" (f32-input MFMA) | "split" (split-f16 operands on the 16-bit MFMA, nann_attn_split.h)."""
+    precision: "split" (default; split-f16 operands on the 16-bit MFMA, nann_attn_split.h) | "exact" (f32-input MFMA)."""
 
-    def __init__(self, d, seq_len, emb_dtype=torch.float16, weights=None, precision="exact"):
+    def __init__(self, d, seq_len, emb_dtype=torch.float16, weights=None, precision="split"):
         self.d, self.seq_len, self.emb_dtype, self.precision = d, seq_len, emb_dtype, precision
         desc = _lib.AttnDesc()
         desc.d, desc.seq_len, desc.emb_dtype = d, seq_len, _DT[emb_dtype]
-        desc.precision = {"exact": _lib.MLP_EXACT_F32, "split": _lib.MLP_SPLIT_F16}[precision]
+        desc.precision = _precision_code(precision)
         self._keep = []
 
         def hold(a):
@@ -373,8 +388,9 @@ def save_scorer_dir(path, kind, weights=None, precision=None):
 
 
 class Model:
-    """The scoring model a BlazeXlaOp node names, loaded from a weights directory
-    (nann_model_load; the reference loads a frozen GraphDef, blaze_xla_kernel.cc:156-180)."""
+    """The scoring model a BlazeXlaOp node names (nann_model_load): `path` is what the op's `graph_def` attr
+    holds -- the reference's frozen GraphDef FILE (convert_meta.py:361-398; blaze_xla_kernel.cc:156-180), read
+    without TensorFlow, or a weights DIRECTORY (save_scorer_dir) for the l2 / mlp scorers."""
 
     def __init__(self, path, d, seq_len=50, emb_dtype=torch.float16):
         self.d, self.seq_len = d, seq_len

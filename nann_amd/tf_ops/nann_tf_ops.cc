@@ -551,10 +551,22 @@ class BlazeXlaOpHip : public AsyncOpKernel {
     const int seq_len = (int)user.dim_size(1);
     {  // the model is loaded on first use: d and L come with the first request
       std::lock_guard<std::mutex> lk(mu_);
-      if (!model_)
+      if (!model_) {
         OP_REQUIRES_OK_ASYNC(ctx, ToStatus(nann_model_load(model_dir_.c_str(), (int32_t)d, NANN_F16, seq_len, &model_),
                                            "BlazeXlaOp"), done);
+        model_d_ = d;
+        model_seq_len_ = seq_len;
+      }
     }
+    // every later request must have the shapes the model was loaded for: the kernels size their reads from the
+    // model, not from the tensors (the reference fails such a request in PadToStatic, blaze_xla_predictor.cc:234-263)
+    const int64_t user_e = nann_model_kind(model_) == NANN_MODEL_ATTENTION ? 64 : model_d_;
+    OP_REQUIRES_ASYNC(ctx, user.dim_size(0) == 1 && user.dim_size(1) == model_seq_len_ && user.dim_size(2) == user_e,
+                      errors::InvalidArgument("BlazeXlaOp: user_seq_emb must be [1, ", model_seq_len_, ", ", user_e,
+                                              "] for this model, got ", user.shape().DebugString()), done);
+    OP_REQUIRES_ASYNC(ctx, d == model_d_,
+                      errors::InvalidArgument("BlazeXlaOp: item_emb must be [n, ", model_d_, "] for this model, got ",
+                                              item.shape().DebugString()), done);
     // zero candidates: the reference fails in PadToStatic (blaze_xla_predictor.cc:259-263)
     OP_REQUIRES_ASYNC(ctx, n > 0, errors::Internal("Error when getting input address or size"), done);
     int64_t ws_bytes = 0;
@@ -582,6 +594,7 @@ class BlazeXlaOpHip : public AsyncOpKernel {
   int user_in_ = -1, item_in_ = -1;
   std::mutex mu_;
   nann_model* model_ = nullptr;
+  int64_t model_d_ = 0, model_seq_len_ = 0;  // what the model was loaded for (first request)
 };
 
 REGISTER_KERNEL_BUILDER(Name("BlazeXlaOp").Device(DEVICE_CPU), BlazeXlaOpHip);

@@ -288,7 +288,7 @@ def test_mlp_score(oracle, d, dtype):
         host = dev.view(torch.int16).cpu().numpy().view(np.uint16)
         code, tdt = oracle.EMB_BF16, torch.bfloat16
     rc, exp = oracle.score_rows(oracle.Scorer("mlp", d, code, w), q, host[idx])
-    sc = ops.Scorer("mlp", d, tdt, w)
+    sc = ops.Scorer("mlp", d, tdt, w, precision="exact")
     got = ops.blaze_score(sc, cuda(q), table=dev, indices=idx).cpu().numpy()
     assert rc == 0
     np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-6)
@@ -378,7 +378,7 @@ def test_attn_scorer_matches_oracle(oracle, d, dtype):
         host, code, tdt = dev.view(torch.int16).cpu().numpy().view(np.uint16), oracle.EMB_BF16, torch.bfloat16
     m = oracle.AttnModel(d, E, L, code, w)
     rc, exp = oracle.attn_score_rows(m, u.astype(np.float32), host[idx])
-    sc = ops.AttnScorer(d, L, tdt, w)
+    sc = ops.AttnScorer(d, L, tdt, w, precision="exact")
     kt, upad = sc.prepare(cuda(u)[None])
     got = sc.score(kt[0], upad[0], table=dev, indices=idx).cpu().numpy()
     assert rc == 0
@@ -422,7 +422,7 @@ def test_attn_scorer_split_f16_matches_oracle(oracle, d, dtype):
         assert err <= 1e-5, (n, err)
         got2 = sc.score(kt[0], upad[0], item_emb=dev[torch.as_tensor(idx).long().cuda()]).cpu().numpy()
         assert (bits(got2) == bits(got)).all()
-    exact = ops.AttnScorer(d, L, tdt, w)  # and against the f32 form on the device
+    exact = ops.AttnScorer(d, L, tdt, w, precision="exact")  # and against the f32 form on the device
     kt2, upad2 = exact.prepare(cuda(u)[None])
     idx = np.arange(700, dtype=np.int32)
     a = sc.score(kt[0], upad[0], table=dev, indices=idx).cpu().numpy()
@@ -446,7 +446,7 @@ def test_model_directory_forward(oracle, tmp_path, kind):
     u[37:] = 0
     rows = (rng.standard_normal((n, d)) / 8).astype(np.float16)
     w = {"l2": None, "mlp": synth.make_mlp_weights(d), "attention": synth.make_attn_weights(d, 64)}[kind]
-    ops.save_scorer_dir(str(tmp_path), kind, w)
+    ops.save_scorer_dir(str(tmp_path), kind, w, precision=None if kind == "l2" else "exact")
     m = ops.Model(str(tmp_path), d, L)
     assert m.kind == kind
     got = m.forward(cuda(u)[None], cuda(rows))
@@ -464,6 +464,41 @@ def test_model_directory_forward(oracle, tmp_path, kind):
     assert e.value.status == 6
     with pytest.raises(ops.NotFoundError):
         ops.Model(str(tmp_path / "missing"), d, L)
+
+
+@pytest.mark.parametrize("folded", [True, False])
+def test_model_from_frozen_graphdef(oracle, tmp_path, folded):
+    """BlazeXlaOp.graph_def as the reference writes it (convert_meta.py:361-398): nann_model_load given a frozen
+    GraphDef FILE (written by nann_amd/frozen_graph.py with TF 1.15's node naming, frozen-only and constant-folded
+    forms) scores exactly like the same weights handed over as arrays -- logits bit-identical in both precisions --
+    and within 1e-5 of the oracle; a graph for another d, a non-model graph and a shorter request are refused."""
+    from nann_amd import frozen_graph, ops, synth
+    d, L, n = 128, 50, 900
+    rng = np.random.default_rng(11)
+    u = (rng.standard_normal((L, 64)) / 8).astype(np.float16)
+    u[40:] = 0
+    rows = (rng.standard_normal((n, d)) / 8).astype(np.float16)
+    w = synth.make_attn_weights(d, 64)
+    pb = tmp_path / "frozen_graph.pb"
+    frozen_graph.write_attention_graph(str(pb), w, seq_len=L, folded=folded)
+    rc, exp = oracle.attn_score_rows(oracle.AttnModel(d, 64, L, oracle.EMB_F16, w), u.astype(np.float32), rows)
+    assert rc == 0
+    for prec in ("split", "exact"):
+        (tmp_path / "frozen_graph.pb.precision").write_text(prec + "\n")
+        ops.save_scorer_dir(str(tmp_path / prec), "attention", w, precision=prec)
+        m_pb, m_dir = ops.Model(str(pb), d, L), ops.Model(str(tmp_path / prec), d, L)
+        assert m_pb.kind == "attention"
+        a = m_pb.forward(cuda(u)[None], cuda(rows)).cpu().numpy().ravel()
+        b = m_dir.forward(cuda(u)[None], cuda(rows)).cpu().numpy().ravel()
+        assert (bits(a) == bits(b)).all(), prec
+        assert np.abs(a - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max())
+    with pytest.raises(ops.NannError) as e:  # the file is a model for d = 128
+        ops.Model(str(pb), 64, L)
+    assert e.value.status == 106
+    (tmp_path / "other.pb").write_bytes(frozen_graph.const("x", np.zeros(4, np.float32)))
+    with pytest.raises(ops.NannError) as e:
+        ops.Model(str(tmp_path / "other.pb"), d, L)
+    assert e.value.status == 102 and "nonlinear_attention" in str(e.value)
 
 
 # ---------------------------------------------------------------- 8(e): exchange + merge through the C ABI

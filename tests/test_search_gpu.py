@@ -140,7 +140,7 @@ def test_mlp_search_matches_oracle(oracle):
     q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 48, seed=11)])
     topn = [32] * 5 + [20]
     exp = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q, topn, n_threads=8)
-    sc = ops.Scorer("mlp", 128, torch.float16, w)
+    sc = ops.Scorer("mlp", 128, torch.float16, w, precision="exact")
     r = retrieval.search(dix, sc, cuda(q), topn)
     torch.cuda.synchronize()
     got = (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
@@ -309,7 +309,7 @@ def test_mlp_traversal_in_hbm_bitmap_mode(oracle):
     topn = [32] * 5 + [20]
     exp = oracle.search_batch(oix, oracle.Scorer("mlp", 64, oracle.EMB_F16, w), q, topn, n_threads=8)
     with traversal_mode("hbm_bitmap"):
-        r = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w), cuda(q), topn)
+        r = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w, precision="exact"), cuda(q), topn)
         torch.cuda.synchronize()
     got = (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
            r.index.cpu().numpy(), r.counters.cpu().numpy())
@@ -324,7 +324,7 @@ def test_eval_graph_matches_oracle(oracle, kind):
     g, oix, dix = synth_index(20000, 64, 32)
     w = synth.make_mlp_weights(64) if kind == "mlp" else None
     osc = oracle.Scorer(kind, 64, oracle.EMB_F16, w)
-    sc = ops.Scorer(kind, 64, torch.float16, w)
+    sc = ops.Scorer(kind, 64, torch.float16, w, precision="exact")
     qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 6, seed=9)])
     n_ok = 0
     for cfg in [((3, 1, 1), (400, 200, 100), 200), ((2, 2, 1), (60, 40, 16), 30)]:
@@ -348,7 +348,7 @@ def test_fused_eval_graph_matches_oracle(oracle, kind):
     g, oix, dix = synth_index(20000, 64, 32)
     w = synth.make_mlp_weights(64) if kind == "mlp" else None
     osc = oracle.Scorer(kind, 64, oracle.EMB_F16, w)
-    sc = ops.Scorer(kind, 64, torch.float16, w)
+    sc = ops.Scorer(kind, 64, torch.float16, w, precision="exact")
     qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 40 if kind == "l2" else 12, seed=9)])
     for cfg in [((3, 1, 1), (400, 200, 100), 200), ((2, 2, 1), (60, 40, 16), 30), ((1, 0, 1), (50, 50, 8), 64),
                 ((3, 2, 1), (1024, 700, 300), 1024)]:
@@ -395,7 +395,7 @@ def test_fused_eval_graph_with_the_attention_model(oracle, tmp_path):
     d, L = 64, 50
     g, oix, dix = synth_index(20000, d, 32)
     w = synth.make_attn_weights(d, 64)
-    ops.save_scorer_dir(str(tmp_path), "attention", w)
+    ops.save_scorer_dir(str(tmp_path), "attention", w, precision="exact")
     model = ops.Model(str(tmp_path), d, L)
     seqs = queries_for(g, 8, seed=5)
     cfg = ((2, 1, 1), (100, 60, 30), 50)
@@ -459,7 +459,7 @@ def test_search_model_serving_signature(oracle, tmp_path, kind):
     seqs = queries_for(g, nq, seed=17)                      # f16 [nq, 50, 64]
     topn = [32] * 5 + [20]
     w = {"l2": None, "mlp": synth.make_mlp_weights(d), "attention": synth.make_attn_weights(d, 64)}[kind]
-    ops.save_scorer_dir(str(tmp_path), kind, w)
+    ops.save_scorer_dir(str(tmp_path), kind, w, precision=None if kind == "l2" else "exact")
     m = ops.Model(str(tmp_path), d, L)
     r = retrieval.search_model(dix, m, cuda(seqs), topn)
     torch.cuda.synchronize()

@@ -135,7 +135,7 @@ def test_config2_1m_mlp(oracle):
     topn = [128] * 5 + [200]
     q = _queries(128, 256, seed=99)
     w = synth.make_mlp_weights(128)
-    r = _search(dix, ops.Scorer("mlp", 128, torch.float16, w), q, topn)
+    r = _search(dix, ops.Scorer("mlp", 128, torch.float16, w, precision="exact"), q, topn)
     _properties(r, g, topn, len(g["enter_points"]))
     sel = slice(0, 32)
     exp = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q[sel].cpu().numpy(), topn, n_threads=16)
@@ -185,7 +185,7 @@ def test_config4_shard_shape_beyond_the_lds_bitmap(oracle, kind, mode):
     nq = 512 if kind == "l2" else 64
     q = _queries(256, nq, seed=5)
     w = synth.make_mlp_weights(256) if kind == "mlp" else None
-    r = _search(dix, ops.Scorer(kind, 256, torch.bfloat16, w), q, topn, mode)
+    r = _search(dix, ops.Scorer(kind, 256, torch.bfloat16, w, precision="exact"), q, topn, mode)
     _properties(r, g, topn, len(g["enter_points"]))
     sel = slice(0, 48 if kind == "l2" else 16)
     exp = oracle.search_batch(oix, oracle.Scorer(kind, 256, oracle.EMB_BF16, w), q[sel].cpu().numpy(), topn, n_threads=16)

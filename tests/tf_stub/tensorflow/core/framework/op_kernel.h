@@ -44,6 +44,7 @@ class TensorShape {
   TensorShape(std::initializer_list<int64> d) : dims_(d) {}
   int64 dim_size(int i) const { return dims_[i]; }
   int dims() const { return (int)dims_.size(); }
+  std::string DebugString() const { return "[...]"; }
  private:
   std::vector<int64> dims_;
 };
@@ -60,6 +61,7 @@ class Tensor {
   int64 NumElements() const { return n_; }
   int64 dim_size(int) const { return n_; }
   int dims() const { return shape_.dims(); }
+  const TensorShape& shape() const { return shape_; }
   DataType dtype() const { return dt_; }
   StringPieceStub tensor_data() const { return StringPieceStub{static_cast<const char*>(buf_)}; }
   template <typename T> FlatView<T> flat() const { return FlatView<T>{static_cast<T*>(buf_), n_}; }
