@@ -73,6 +73,9 @@ def parse():
                     help="l2 = BASELINE configs[1] (the headline metric); mlp = configs[2]: 256-128-1 MLP on MFMA")
     ap.add_argument("--mlp-precision", default="split", choices=["split", "exact"],
                     help="--scorer mlp: split = split-f16 operands on the 16-bit MFMA (scores within 1e-5); exact = f32 MFMA")
+    ap.add_argument("--mlp-weights", default="metric", choices=["metric", "random"],
+                    help="--scorer mlp: metric = layers constructed / fitted to rank like the index metric (recall means something); "
+                         "random = random-init weights of the architecture (rounds 1-2)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "lds_bitmap", "hbm_bitmap", "lds_hash", "lds_hash32"])
     ap.add_argument("--index-cache", default=None, help="directory to cache built indices in")
     ap.add_argument("--stress-items", type=int, default=2_000_000)
@@ -154,13 +157,25 @@ def to_bf16_bits(x_f32):
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
+def n_clusters_for(items, ef):
+    """Cluster count of the synthetic corpus.  SURVEY.md 8: "the generator must guarantee E >= ef and each round yields
+    >= ef new nodes, else the reference returns InvalidArgument" (TopKV2 k > n, topk_op.cc:67-71).  A beam of width ef
+    walks ~25-30 ef nodes of its neighbourhood; on HNSW(M=32, efConstruction=40) graphs -- mean level-0 degree ~17:
+    each node keeps the ~8.7 candidates the selection heuristic lets through plus as many back-links -- a cluster
+    smaller than that is exhausted before the third level-0 round (measured: 100k items in 256 clusters of 390,
+    ef = 64: 20 % of the requests valid; clusters of >= 30 ef items: 100 %).  256 clusters wherever they stay that
+    large (1M items / ef = 128 and up: the round-1/2 corpora unchanged), fewer for small corpora / wide beams."""
+    return int(min(256, max(1, items // (30 * ef))))
+
+
 def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_dir=None):
     """Seeded synthetic corpus + graph in the reference's array layout."""
     from nann_amd import index_build, synth
     cache = None
+    ncl = n_clusters_for(items, ef)
     if cache_dir:
         os.makedirs(cache_dir, exist_ok=True)
-        cache = os.path.join(cache_dir, f"idx_{items}_{dim}_{dtype}_{ef}_{graph}_{noise}_{rank}.npz")
+        cache = os.path.join(cache_dir, f"idx_{items}_{dim}_{dtype}_{ef}_{graph}_{noise}_{rank}_c{ncl}.npz")
         if os.path.exists(cache):
             z = np.load(cache)
             return {"item_embs": z["item_embs"], "item_ids": z["item_ids"],
@@ -168,7 +183,7 @@ def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_
                     "nb_row_splits": [z["nb_row_splits_0"], z["nb_row_splits_1"]],
                     "enter_points": z["enter_points"]}
     if graph == "hnsw":
-        embs, _ = synth.make_corpus(items, dim, noise=noise, seed=1234, item_seed=1234 + 100 + 1000 * rank)
+        embs, _ = synth.make_corpus(items, dim, n_clusters=ncl, noise=noise, seed=1234, item_seed=1234 + 100 + 1000 * rank)
         x32 = embs.astype(np.float32)  # the builder sees exactly the values the index stores (f16-exact)
         if dtype == "bf16":
             bits = to_bf16_bits(x32)
@@ -184,7 +199,7 @@ def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_
              "nb_row_splits": ex["nb_row_splits"], "enter_points": ex["enter_points"].astype(np.int32)}
     else:
         g = synth.make_index(items, dim, ef=ef, mode="hnsw" if graph == "synth" else "knn", noise=noise,
-                             device=str(dev), shard=rank)
+                             device=str(dev), shard=rank, n_clusters=ncl)
         if dtype == "bf16":
             g["item_embs"] = to_bf16_bits(g["item_embs"].astype(np.float32))
     if cache:
@@ -195,18 +210,18 @@ def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_
     return g
 
 
-def make_query_batches(dim, batch, n_batches, noise, dev, seed=4321):
+def make_query_batches(dim, batch, n_batches, noise, dev, seed=4321, n_clusters=256):
     """comm_seq f16[n_batches, B, 50, d] generated on the device (seeded): each history is 7..50 draws
-    around one of the corpus' 256 cluster centres, zero-padded tail (convert_UB_to_tfrecord.py:121-137)."""
+    around one of the corpus' cluster centres, zero-padded tail (convert_UB_to_tfrecord.py:121-137)."""
     import torch
     from nann_amd import synth
-    centres = torch.as_tensor(synth.make_centres(dim, 256, 1234)).to(dev)
+    centres = torch.as_tensor(synth.make_centres(dim, n_clusters, 1234)).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     out = []
     for _ in range(n_batches):
         lens = torch.randint(7, 51, (batch,), generator=gen, device=dev)
-        cl = torch.randint(0, 256, (batch,), generator=gen, device=dev)
+        cl = torch.randint(0, n_clusters, (batch,), generator=gen, device=dev)
         x = centres[cl][:, None, :] + noise * torch.randn((batch, 50, dim), generator=gen, device=dev)
         x = x * (1.0 / np.sqrt(dim))
         mask = torch.arange(50, device=dev)[None, :] < lens[:, None]
@@ -228,11 +243,20 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                                         max(1, cores // world), args.index_cache)
     index = retrieval.Index.from_dict(g, device=dev)
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
-    mlp_w = synth.make_mlp_weights(dim) if scorer_kind == "mlp" else None
+    # the MLP's weights: constructed + last layer fitted so that it ranks like the index metric (what the reference's
+    # training produces; synth.make_mlp_weights_metric) -- with random-init weights (--mlp-weights random) recall against
+    # brute force under the same scorer is ~0.4 and "QPS @ recall parity" says nothing
+    mlp_w = None
+    if scorer_kind == "mlp":
+        rows = g["item_embs"][:: max(1, items // 65536)]
+        if dtype == "bf16":
+            rows = (rows.astype(np.uint32) << 16).view(np.float32)
+        mlp_w = (synth.make_mlp_weights(dim) if args.mlp_weights == "random"
+                 else synth.make_mlp_weights_metric(dim, rows))
     precision = cfg.get("mlp_precision", "exact") if scorer_kind == "mlp" else "exact"
     scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w, precision=precision)
     n_batches = min(steps + warmup, 24)
-    seqs = make_query_batches(dim, batch, n_batches, args.noise, dev)
+    seqs = make_query_batches(dim, batch, n_batches, args.noise, dev, n_clusters=n_clusters_for(items, ef))
     setup_s = time.time() - t0
     retrieval.set_traversal_mode(cfg.get("traversal", "auto"))
 
@@ -326,6 +350,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
            "n_enter": int(len(g["enter_points"])),
            "mean_degree_l0": round(float(len(g["nb_values"][0])) / items, 2),
            "traversal": cfg.get("traversal", "auto"), "roofline": roofline,
+           **({"mlp_weights": args.mlp_weights} if scorer_kind == "mlp" else {}),
            "batch_latency_ms": {"batch": batch, "p50": round(float(np.percentile(kern_all, 50)), 4),
                                 "p99": round(float(np.percentile(kern_all, 99)), 4),
                                 "max": round(float(kern_all.max()), 4)}}

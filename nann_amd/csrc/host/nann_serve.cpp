@@ -7,10 +7,21 @@
 // of its own, so that one batch's copies run under another batch's search.  The Python twin is nann_amd/serving.py; this program is the proof that a C++
 // host needs nothing but libnann_hip.so.
 //
-//   nann_serve <index_dir> <item_embs_dir> <dim> [--clients N] [--seconds S] [--max-batch B] [--max-wait-us U]
-//              [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE]
+// Round 3: (1) for the l2 / mlp scorers the request is REDUCED ON THE THREAD THAT SUBMITS IT (the RPC handler of a real
+// server): the mean of the non-pad history rows -- bit for bit what nann_user_seq_mean computes on the device -- so a
+// dispatcher stages d floats per request instead of the L x d halves of comm_seq (512 B instead of 12.8 KB) and the
+// per-batch host work drops 25x; the attention model still receives the raw sequence.  (2) The load generator keeps
+// its CLOSED LOOP per logical client (one request in flight each, predict_request_consumer.cc:17-53) but multiplexes
+// the clients over --client-threads OS threads, each sleeping on ONE completion counter: the dispatcher wakes a thread
+// at most once per batch instead of once per request, and no condition variable lives on a client's stack (the
+// round-2 version could notify a Request its client had already destroyed).  (3) Dispatcher and client threads are
+// pinned to disjoint cores.
+//
+//   nann_serve <index_dir> <item_embs_dir> <dim> [--clients N] [--client-threads T] [--seconds S] [--max-batch B]
+//              [--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE]
+//              [--no-pin 1]
 // index_dir / item_embs_dir: the files build_hnsw_index.py writes (nann_amd.index_build writes the same).
-// Closed loop: every client thread sends a request, waits for its reply, sends the next.  Prints one JSON line.
+// Closed loop: every logical client sends a request, waits for its reply, sends the next.  Prints one JSON line.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -25,6 +36,12 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+#if defined(__F16C__) && defined(__AVX2__)
+#include <immintrin.h>
+#endif
+
 #include "nann_hip.h"
 
 namespace {
@@ -37,19 +54,30 @@ using Clock = std::chrono::steady_clock;
 }
 #define CHECK(expr) do { if ((expr) != NANN_OK) die(#expr); } while (0)
 
+struct ClientThread;
+
 struct Request {
-  const uint16_t* comm_seq;  // f16 bits [L * d]
-  int64_t* top_k;            // [k]
+  const uint16_t* comm_seq = nullptr;  // f16 bits [L * d]: the request as the caller sent it (attention model: staged as it is)
+  const float* q = nullptr;            // l2 / mlp: the query vector the submitting thread reduced it to (f32 [d])
+  int64_t* top_k = nullptr;            // [k]
   int32_t status = -1;
-  bool done = false;
+  std::atomic<int> done{0};
+  ClientThread* owner = nullptr;       // whose completion counter the reply bumps
+};
+
+// one OS thread of the load generator: its logical clients' replies arrive on ONE counter
+struct ClientThread {
   std::mutex mu;
   std::condition_variable cv;
+  std::atomic<long long> completed{0};
+  std::atomic<int> sleeping{0};
 };
 
 struct Queue {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Request*> pending;
+  int waiting = 0;  // dispatchers blocked in cv.wait (submitters notify only then)
   bool closing = false;
 };
 
@@ -88,6 +116,61 @@ float f16_bits_to_f32(uint16_t h) {
   return f;
 }
 
+// comm_seq f16[L, d] -> q f32[d]: mean over the rows that are not all-zero (padding), accumulated row by row in f32 and
+// divided once -- the operation order of nann_user_seq_mean's kernel (k_user_seq_mean) and of the oracle, so the
+// device sees the same bits whichever side reduces the request.
+void seq_mean_host(const uint16_t* seq, int L, int d, float* q) {
+  int count = 0;
+#if defined(__F16C__) && defined(__AVX2__)
+  if (d % 8 == 0 && d <= 512) {
+    __m256 acc[64];
+    for (int v = 0; v < d / 8; ++v) acc[v] = _mm256_setzero_ps();
+    const __m128i absmask = _mm_set1_epi16(0x7fff);
+    for (int r = 0; r < L; ++r) {
+      const __m128i* row = reinterpret_cast<const __m128i*>(seq + (size_t)r * d);
+      __m128i nz = _mm_setzero_si128();
+      for (int v = 0; v < d / 8; ++v) {
+        const __m128i h = _mm_loadu_si128(row + v);
+        nz = _mm_or_si128(nz, _mm_and_si128(h, absmask));
+        acc[v] = _mm256_add_ps(acc[v], _mm256_cvtph_ps(h));  // exact conversion, one rounded add per row: the device's order
+      }
+      count += !_mm_testz_si128(nz, nz);
+    }
+    const __m256 cnt = _mm256_set1_ps((float)count);
+    for (int v = 0; v < d / 8; ++v)
+      _mm256_storeu_ps(q + 8 * v, count ? _mm256_div_ps(acc[v], cnt) : _mm256_setzero_ps());
+    return;
+  }
+#endif
+  for (int r = 0; r < L; ++r) {
+    uint16_t nz = 0;
+    for (int k = 0; k < d; ++k) nz |= (uint16_t)(seq[(size_t)r * d + k] & 0x7fffu);
+    count += nz != 0;
+  }
+  for (int k = 0; k < d; ++k) q[k] = 0.0f;
+  for (int r = 0; r < L; ++r)
+    for (int k = 0; k < d; ++k) q[k] = q[k] + f16_bits_to_f32(seq[(size_t)r * d + k]);
+  for (int k = 0; k < d; ++k) q[k] = count ? q[k] / (float)count : 0.0f;
+}
+
+void pin_to_core(int core) {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET(core, &set);
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+
+std::vector<int> allowed_cores() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  std::vector<int> out;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0)
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &set)) out.push_back(c);
+  if (out.empty()) out.push_back(0);
+  return out;
+}
+
 void* load(const std::string& path, int dtype, int64_t* count, int64_t elem_bytes) {
   void* p = nullptr;
   int64_t bytes = 0;
@@ -100,18 +183,19 @@ void* load(const std::string& path, int dtype, int64_t* count, int64_t elem_byte
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s <index_dir> <item_embs_dir> <dim> [--clients N] [--seconds S] [--max-batch B] "
-                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <index_dir> <item_embs_dir> <dim> [--clients N] [--client-threads T] [--seconds S] [--max-batch B] "
+                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE] [--no-pin 1]\n", argv[0]);
     return 2;
   }
   const std::string index_dir = argv[1], embs_dir = argv[2];
   const int d = std::atoi(argv[3]);
-  int clients = 64, max_batch = 256, max_wait_us = 200, ef = 128, topk = 200, L = 50, lanes = 2;
+  int clients = 64, client_threads = 0, max_batch = 256, max_wait_us = 200, ef = 128, topk = 200, L = 50, lanes = 2, no_pin = 0;
   double seconds = 3.0;
   std::string model_dir, probe_out;
   for (int i = 4; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     if (k == "--clients") clients = std::atoi(argv[i + 1]);
+    else if (k == "--client-threads") client_threads = std::atoi(argv[i + 1]);
     else if (k == "--seconds") seconds = std::atof(argv[i + 1]);
     else if (k == "--max-batch") max_batch = std::atoi(argv[i + 1]);
     else if (k == "--max-wait-us") max_wait_us = std::atoi(argv[i + 1]);
@@ -121,9 +205,14 @@ int main(int argc, char** argv) {
     else if (k == "--lanes") lanes = std::max(1, std::atoi(argv[i + 1]));
     else if (k == "--model-dir") model_dir = argv[i + 1];
     else if (k == "--probe-out") probe_out = argv[i + 1];  // after the run: one fixed request, its reply written as text
+    else if (k == "--no-pin") no_pin = std::atoi(argv[i + 1]);
     else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
   }
   if (nann_device_count() < 1) { std::fprintf(stderr, "nann_serve: no HIP device\n"); return 1; }
+  const std::vector<int> cores = allowed_cores();
+  if (client_threads <= 0)  // the cores the dispatchers leave, at most one thread per logical client
+    client_threads = std::max(1, std::min(clients, std::max(1, (int)cores.size() - lanes)));
+  client_threads = std::min(client_threads, clients);
 
   // ---- the resident index: HugeConst loads with the casts build_model() asks for (build_opt_graph.py:70,83-90)
   nann_index_desc desc = {};
@@ -145,29 +234,33 @@ int main(int argc, char** argv) {
   nann_index* ix = nullptr;
   CHECK(nann_index_create(&desc, &ix));
 
-  nann_scorer* scorer = nullptr;
+  nann_scorer* own_scorer = nullptr;
   nann_model* model = nullptr;
   if (model_dir.empty()) {
     nann_scorer_desc sd = {};
     sd.kind = NANN_SCORER_L2;
     sd.d = d;
     sd.emb_dtype = NANN_F16;
-    CHECK(nann_scorer_create(&sd, &scorer));
+    CHECK(nann_scorer_create(&sd, &own_scorer));
   } else {
     CHECK(nann_model_load(model_dir.c_str(), d, NANN_F16, L, &model));
   }
-  const int seq_d = (model && nann_model_kind(model) == NANN_MODEL_ATTENTION) ? 64 : d;  // the attention model's sequence is [L, 64]
+  const bool attention = model && nann_model_kind(model) == NANN_MODEL_ATTENTION;
+  // l2 / mlp: the scorer nann_search takes; requests arrive reduced to their query vector
+  const nann_scorer* scorer = attention ? nullptr : (model ? nann_model_scorer(model) : own_scorer);
+  const int seq_d = attention ? 64 : d;  // the attention model's sequence is [L, 64]
   const size_t seq_elems = (size_t)L * seq_d;
 
   // ---- per lane: a stream, the device buffers of one launch, page-locked staging
   const int32_t level_topn[6] = {ef, ef, ef, ef, ef, topk};
   int64_t ws_bytes = 0;
-  if (model) CHECK(nann_search_model_workspace_bytes(ix, model, level_topn, max_batch, &ws_bytes));
+  if (attention) CHECK(nann_search_model_workspace_bytes(ix, model, level_topn, max_batch, &ws_bytes));
   else CHECK(nann_search_workspace_bytes(ix, level_topn, max_batch, &ws_bytes));
+  const int64_t in_bytes = attention ? (int64_t)seq_elems * 2 : (int64_t)d * 4;  // staged per request
   struct Lane {
     nann_stream_t stream = nullptr;
-    void *ws = nullptr, *d_seq = nullptr, *d_q = nullptr, *d_topk = nullptr, *d_status = nullptr;
-    uint16_t* h_seq = nullptr;
+    void *ws = nullptr, *d_in = nullptr, *d_topk = nullptr, *d_status = nullptr;
+    unsigned char* h_in = nullptr;
     int64_t* h_topk = nullptr;
     int32_t* h_status = nullptr;
   };
@@ -175,11 +268,10 @@ int main(int argc, char** argv) {
   for (Lane& ln : lane) {
     CHECK(nann_stream_create(&ln.stream));
     CHECK(nann_malloc(&ln.ws, ws_bytes));
-    CHECK(nann_malloc(&ln.d_seq, (int64_t)max_batch * seq_elems * 2));
-    CHECK(nann_malloc(&ln.d_q, (int64_t)max_batch * d * 4));
+    CHECK(nann_malloc(&ln.d_in, (int64_t)max_batch * in_bytes));
     CHECK(nann_malloc(&ln.d_topk, (int64_t)max_batch * topk * 8));
     CHECK(nann_malloc(&ln.d_status, (int64_t)max_batch * 4));
-    CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_seq), (int64_t)max_batch * seq_elems * 2));
+    CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_in), (int64_t)max_batch * in_bytes));
     CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_topk), (int64_t)max_batch * topk * 8));
     CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_status), (int64_t)max_batch * 4));
   }
@@ -192,20 +284,22 @@ int main(int argc, char** argv) {
 
   Queue q;
   std::atomic<long long> served{0}, failed{0}, launches{0}, batched{0};
-  std::vector<std::vector<float>> lat((size_t)clients);
+  std::vector<ClientThread> cthreads((size_t)client_threads);
+  std::vector<std::vector<float>> lat((size_t)client_threads);
   const auto t_end = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
 
   // ---- one launch for a batch of requests on a lane, replies handed back to their callers
   auto run_batch = [&](Lane& ln, const std::vector<Request*>& batch) {
     const int b = (int)batch.size();
-    for (int i = 0; i < b; ++i) std::memcpy(ln.h_seq + (size_t)i * seq_elems, batch[i]->comm_seq, seq_elems * 2);
-    CHECK(nann_memcpy(ln.d_seq, ln.h_seq, (int64_t)b * seq_elems * 2, 0, ln.stream));
-    if (model) {
-      CHECK(nann_search_model(ix, model, ln.d_seq, b, level_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk), nullptr,
+    for (int i = 0; i < b; ++i)
+      std::memcpy(ln.h_in + (size_t)i * in_bytes, attention ? static_cast<const void*>(batch[i]->comm_seq) : static_cast<const void*>(batch[i]->q),
+                  (size_t)in_bytes);
+    CHECK(nann_memcpy(ln.d_in, ln.h_in, (int64_t)b * in_bytes, 0, ln.stream));
+    if (attention) {
+      CHECK(nann_search_model(ix, model, ln.d_in, b, level_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk), nullptr,
                               nullptr, static_cast<int32_t*>(ln.d_status), nullptr, ln.stream));
     } else {
-      CHECK(nann_user_seq_mean(ln.d_seq, b, L, d, static_cast<float*>(ln.d_q), ln.stream));
-      CHECK(nann_search(ix, scorer, static_cast<const float*>(ln.d_q), b, level_topn, ln.ws, ws_bytes,
+      CHECK(nann_search(ix, scorer, static_cast<const float*>(ln.d_in), b, level_topn, ln.ws, ws_bytes,
                         static_cast<int64_t*>(ln.d_topk), nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr,
                         ln.stream));
     }
@@ -214,33 +308,46 @@ int main(int argc, char** argv) {
     CHECK(nann_stream_synchronize(ln.stream));
     launches.fetch_add(1);
     batched.fetch_add(b);
+    ClientThread* touched[64];
+    int n_touched = 0;
     for (int i = 0; i < b; ++i) {
       Request* r = batch[i];
       std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)topk * 8);
-      {
-        std::lock_guard<std::mutex> lk(r->mu);
-        r->status = ln.h_status[(size_t)i];
-        r->done = true;
+      r->status = ln.h_status[(size_t)i];
+      ClientThread* owner = r->owner;  // (read before the release: the request may be reused the moment `done` is seen)
+      r->done.store(1, std::memory_order_release);
+      if (owner) {
+        owner->completed.fetch_add(1, std::memory_order_release);
+        bool seen = false;
+        for (int t = 0; t < n_touched; ++t) seen |= touched[t] == owner;
+        if (!seen && n_touched < 64) touched[n_touched++] = owner;
       }
-      r->cv.notify_one();
     }
+    for (int t = 0; t < n_touched; ++t)  // one wake-up per client THREAD per batch, and only if it sleeps
+      if (touched[t]->sleeping.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(touched[t]->mu);
+        touched[t]->cv.notify_one();
+      }
   };
 
   // ---- the dispatchers: one launch per batch of whatever arrived within max_wait_us of the first request
   std::vector<std::thread> dispatchers;
   for (int li = 0; li < lanes; ++li)
     dispatchers.emplace_back([&, li] {
+      if (!no_pin) pin_to_core(cores[(size_t)li % cores.size()]);
       std::vector<Request*> batch;
       for (;;) {
         batch.clear();
         {
           std::unique_lock<std::mutex> lk(q.mu);
+          ++q.waiting;
           q.cv.wait(lk, [&] { return !q.pending.empty() || q.closing; });
-          if (q.pending.empty() && q.closing) return;
+          if (q.pending.empty() && q.closing) { --q.waiting; return; }
           const auto deadline = Clock::now() + std::chrono::microseconds(max_wait_us);
           while ((int)q.pending.size() < max_batch && !q.closing &&
                  q.cv.wait_until(lk, deadline, [&] { return (int)q.pending.size() >= max_batch || q.closing; })) {
           }
+          --q.waiting;
           const size_t take = std::min<size_t>(q.pending.size(), (size_t)max_batch);
           batch.assign(q.pending.begin(), q.pending.begin() + (long)take);
           q.pending.erase(q.pending.begin(), q.pending.begin() + (long)take);
@@ -249,13 +356,26 @@ int main(int argc, char** argv) {
       }
     });
 
-  // ---- closed-loop clients (predict_request_consumer.cc:17-53)
+  // what a server's request handler does before queueing: reduce the history to the query vector (l2 / mlp)
+  auto submit = [&](Request* const* reqs, int n) {
+    {
+      std::lock_guard<std::mutex> lk(q.mu);
+      for (int i = 0; i < n; ++i) q.pending.push_back(reqs[i]);
+      if (!q.waiting) return;
+    }
+    q.cv.notify_all();
+  };
+
+  // ---- closed-loop clients (predict_request_consumer.cc:17-53), `clients` of them over `client_threads` OS threads
   std::vector<std::thread> workers;
-  for (int c = 0; c < clients; ++c)
+  for (int c = 0; c < client_threads; ++c)
     workers.emplace_back([&, c] {
+      if (!no_pin) pin_to_core(cores[(size_t)(lanes + c) % cores.size()]);
+      const int mine = clients / client_threads + (c < clients % client_threads ? 1 : 0);  // logical clients of this thread
+      ClientThread& me = cthreads[(size_t)c];
       std::mt19937 rng(1234u + (unsigned)c);
       std::normal_distribution<float> noise(0.0f, 0.05f);
-      // a few histories per client, made up front: the generator must not be what the test measures
+      // a few histories per thread, made up front: the generator must not be what the test measures
       constexpr int kVariants = 16;
       std::vector<uint16_t> seqs((size_t)kVariants * seq_elems, 0);
       for (int v = 0; v < kVariants; ++v) {
@@ -265,25 +385,53 @@ int main(int argc, char** argv) {
             seqs[(size_t)v * seq_elems + (size_t)l * seq_d + k] =
                 f32_to_f16_bits(f16_bits_to_f32(pool[(size_t)row * d + (k % d)]) + noise(rng));
       }
-      std::vector<int64_t> out((size_t)topk);
+      std::vector<Request> reqs((size_t)mine);
+      std::vector<int64_t> outs((size_t)mine * topk);
+      std::vector<float> qs((size_t)mine * d);
+      std::vector<Clock::time_point> t0((size_t)mine);
+      std::vector<Request*> ready;
       unsigned turn = 0;
-      while (Clock::now() < t_end) {
-        const uint16_t* seq_ptr = &seqs[(size_t)(turn++ % kVariants) * seq_elems];
-        Request r;
-        r.comm_seq = seq_ptr;
-        r.top_k = out.data();
-        const auto t0 = Clock::now();
-        {
-          std::lock_guard<std::mutex> lk(q.mu);
-          q.pending.push_back(&r);
+      auto arm = [&](int i) {  // logical client i sends its next request
+        Request& r = reqs[(size_t)i];
+        r.comm_seq = &seqs[(size_t)(turn++ % kVariants) * seq_elems];
+        r.top_k = &outs[(size_t)i * topk];
+        r.owner = &me;
+        r.status = -1;
+        r.done.store(0, std::memory_order_relaxed);
+        t0[(size_t)i] = Clock::now();
+        if (!attention) {  // the handler's share of the request: comm_seq -> query vector
+          seq_mean_host(r.comm_seq, L, d, &qs[(size_t)i * d]);
+          r.q = &qs[(size_t)i * d];
         }
-        q.cv.notify_all();
-        {
-          std::unique_lock<std::mutex> lk(r.mu);
-          r.cv.wait(lk, [&] { return r.done; });
+        ready.push_back(&r);
+      };
+      for (int i = 0; i < mine; ++i) arm(i);
+      submit(ready.data(), (int)ready.size());
+      ready.clear();
+      long long seen = 0;
+      int in_flight = mine;
+      bool stop = false;
+      while (in_flight > 0) {
+        // sleep until at least one reply is in (spin briefly first: a batch takes ~0.5 ms)
+        if (me.completed.load(std::memory_order_acquire) == seen) {
+          std::unique_lock<std::mutex> lk(me.mu);
+          me.sleeping.store(1, std::memory_order_release);
+          me.cv.wait(lk, [&] { return me.completed.load(std::memory_order_acquire) != seen; });
+          me.sleeping.store(0, std::memory_order_release);
         }
-        lat[(size_t)c].push_back(std::chrono::duration<float, std::milli>(Clock::now() - t0).count());
-        if (r.status == 0) served.fetch_add(1); else failed.fetch_add(1);
+        const auto now = Clock::now();
+        stop = stop || now >= t_end;
+        for (int i = 0; i < mine; ++i) {
+          Request& r = reqs[(size_t)i];
+          if (r.owner == nullptr || !r.done.load(std::memory_order_acquire)) continue;
+          ++seen;
+          --in_flight;
+          lat[(size_t)c].push_back(std::chrono::duration<float, std::milli>(now - t0[(size_t)i]).count());
+          if (r.status == 0) served.fetch_add(1); else failed.fetch_add(1);
+          r.owner = nullptr;  // retired
+          if (!stop) { arm(i); ++in_flight; }
+        }
+        if (!ready.empty()) { submit(ready.data(), (int)ready.size()); ready.clear(); }
       }
     });
   const auto t_start = Clock::now();
@@ -302,11 +450,12 @@ int main(int argc, char** argv) {
   auto pct = [&](double p) { return all.empty() ? 0.0f : all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
   const long long total = served.load() + failed.load();
   std::printf("{\"host\": \"nann_serve (C++ over the C ABI)\", \"scorer\": \"%s\", \"items\": %lld, \"dim\": %d, \"ef\": %d, "
-              "\"topk\": %d, \"clients\": %d, \"max_batch\": %d, \"max_wait_us\": %d, \"lanes\": %d, \"seconds\": %.2f, \"requests\": %lld, "
+              "\"topk\": %d, \"clients\": %d, \"client_threads\": %d, \"max_batch\": %d, \"max_wait_us\": %d, \"lanes\": %d, \"pinned\": %s, "
+              "\"staged_bytes_per_request\": %lld, \"seconds\": %.2f, \"requests\": %lld, "
               "\"failed_requests\": %lld, \"qps\": %.1f, \"launches\": %lld, \"mean_batch\": %.1f, "
               "\"latency_ms\": {\"p50\": %.3f, \"p90\": %.3f, \"p99\": %.3f, \"max\": %.3f}}\n",
-              model_dir.empty() ? "l2" : model_dir.c_str(), (long long)n_ids, d, ef, topk, clients, max_batch, max_wait_us, lanes,
-              wall, total, failed.load(), (double)total / wall, launches.load(),
+              model_dir.empty() ? "l2" : model_dir.c_str(), (long long)n_ids, d, ef, topk, clients, client_threads, max_batch, max_wait_us,
+              lanes, no_pin ? "false" : "true", (long long)in_bytes, wall, total, failed.load(), (double)total / wall, launches.load(),
               launches.load() ? (double)batched.load() / (double)launches.load() : 0.0, pct(0.5), pct(0.9), pct(0.99),
               all.empty() ? 0.0f : all.back());
 
@@ -315,9 +464,11 @@ int main(int argc, char** argv) {
     for (int l = 0; l < L - 5; ++l)
       for (int k = 0; k < seq_d; ++k) seq[(size_t)l * seq_d + k] = pool[(size_t)(k % d)];
     std::vector<int64_t> out((size_t)topk);
+    std::vector<float> qv((size_t)d);
     Request r;
     r.comm_seq = seq.data();
     r.top_k = out.data();
+    if (!attention) { seq_mean_host(seq.data(), L, d, qv.data()); r.q = qv.data(); }
     run_batch(lane[0], {&r});
     FILE* f = std::fopen(probe_out.c_str(), "w");
     if (!f) { std::fprintf(stderr, "nann_serve: cannot write %s\n", probe_out.c_str()); return 1; }
@@ -327,11 +478,11 @@ int main(int argc, char** argv) {
   }
 
   for (Lane& ln : lane) {
-    nann_free(ln.ws); nann_free(ln.d_seq); nann_free(ln.d_q); nann_free(ln.d_topk); nann_free(ln.d_status);
-    nann_host_free(ln.h_seq); nann_host_free(ln.h_topk); nann_host_free(ln.h_status);
+    nann_free(ln.ws); nann_free(ln.d_in); nann_free(ln.d_topk); nann_free(ln.d_status);
+    nann_host_free(ln.h_in); nann_host_free(ln.h_topk); nann_host_free(ln.h_status);
     nann_stream_destroy(ln.stream);
   }
-  if (scorer) nann_scorer_destroy(scorer);
+  if (own_scorer) nann_scorer_destroy(own_scorer);
   if (model) nann_model_destroy(model);
   nann_index_destroy(ix);
   return 0;

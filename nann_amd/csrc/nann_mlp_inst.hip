@@ -1,6 +1,8 @@
 // nann_mlp_inst.hip -- MLP-scorer instantiations of the fused traversal and of the
 // stand-alone scorer for ONE embedding dim (-DNANN_MLP_D=64|128|256), so that the three
 // heavy objects (1024 unrolled MFMAs each) compile in parallel.
+#include <cstdlib>
+
 #include "nann_eval.h"
 
 #ifndef NANN_MLP_D
@@ -11,13 +13,30 @@
 
 namespace nann {
 
+// NANN_MLP_MAPPING=1 in the environment: run the split-f16 scorer in its first mapping (8 wavefronts x 32 rows) where
+// the second one (nann_mlp2.h) would be chosen -- A/B measurements on one build (tools/gpu_r3.sh), not a product knob
+static bool first_mapping_forced() {
+  static const bool forced = [] { const char* e = std::getenv("NANN_MLP_MAPPING"); return e && e[0] == '1'; }();
+  return forced;
+}
+
 int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int slots, size_t lds_bytes,
                                               const SearchArgs& a, hipStream_t st) {
   constexpr int LPR = NANN_MLP_D / 8;
   if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
-  if (split && vis == VIS_LDS_HASH) {  // one 512-thread workgroup per CU: 16K-slot set + two weight-slice buffers
+  if (split && vis == VIS_LDS_HASH) {  // one workgroup per CU: 16K-slot set + the weight-slice buffers
+#if NANN_MLP_D <= 128
+    // second mapping (nann_mlp2.h): 256 threads, 64 rows per wavefront at one wavefront per SIMD
+    if (!first_mapping_forced()) {
+      if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlp2NT>(slots, lds_bytes, a, st);
+      return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlp2NT>(slots, lds_bytes, a, st);
+    }
     if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
     return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
+#else
+    if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
+    return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
+#endif
   }
   if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: no kernel for this plan");
   if (split) {
@@ -43,6 +62,15 @@ int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int dt, int split, unsigned blocks,
 #define NANN_LAUNCH_SCORE(DT_, SPLIT_)                                                                       \
   hipLaunchKernelGGL((k_score_mlp<NANN_MLP_D, DT_, SPLIT_>), dim3(blocks), dim3(kMlpNT), 0, st, P, table, \
                      n_table_rows, indices, n, q, out, res)
+#if NANN_MLP_D <= 128
+#define NANN_LAUNCH_SCORE2(DT_)                                                                               \
+  hipLaunchKernelGGL((k_score_mlp2<NANN_MLP_D, DT_>), dim3(blocks), dim3(kMlp2NT), 0, st, P, table, n_table_rows, \
+                     indices, n, q, out, res)
+  if (split && !first_mapping_forced() && dt == NANN_F16) NANN_LAUNCH_SCORE2(DT_F16);
+  else if (split && !first_mapping_forced() && dt == NANN_BF16) NANN_LAUNCH_SCORE2(DT_BF16);
+  else
+#undef NANN_LAUNCH_SCORE2
+#endif
   if (dt == NANN_F16 && split) NANN_LAUNCH_SCORE(DT_F16, true);
   else if (dt == NANN_F16) NANN_LAUNCH_SCORE(DT_F16, false);
   else if (dt == NANN_BF16 && split) NANN_LAUNCH_SCORE(DT_BF16, true);

@@ -6,6 +6,7 @@
 #include "../../include/nann_hip.h"
 #include "nann_device.h"
 #include "nann_mlp.h"
+#include "nann_mlp2.h"
 #include "nann_attn_kernels.h"
 #include "nann_attn_split.h"
 
@@ -61,6 +62,33 @@ __global__ __launch_bounds__(kMlpNT) void k_score_mlp(MlpParams P, const void* t
     const int32_t* idx = indices ? indices + c0 : nullptr;
     if constexpr (SPLIT) wg_score_mlp_split<D, 8, 4, DT, kMlpNT>(P, tab, n_tab, idx, cnt, S, scores + c0);
     else wg_score_mlp<D, 8, 4, DT, kMlpNT>(P, tab, n_tab, idx, cnt, S, scores + c0);
+  }
+}
+
+// the split-f16 scorer's second mapping (nann_mlp2.h: 4 wavefronts x 64 rows, d <= 128) as the stand-alone op
+template <int D, int DT>
+__global__ __launch_bounds__(kMlp2NT, 1) void k_score_mlp2(MlpParams P, const void* table, long long n_table_rows,
+                                                          const int32_t* indices, long long n, const float* qv,
+                                                          float* scores, OpResult* res) {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(Mlp2Scratch<D>)];
+  Mlp2Scratch<D>* S = reinterpret_cast<Mlp2Scratch<D>*>(scratch);
+  constexpr int CPP = kMlp2NT;  // 4 wavefronts x 64 rows
+  if (indices) {  // bounds first (gather_op.cc:170-175)
+    for (long long i = (long long)blockIdx.x * kMlp2NT + threadIdx.x; i < n; i += (long long)gridDim.x * kMlp2NT) {
+      const long long r = indices[i];
+      if (r < 0 || r >= n_table_rows)
+        atomicMin(reinterpret_cast<unsigned long long*>(&res->bad_i), (unsigned long long)i);
+    }
+  }
+  wg_mlp2_stage_setup<kMlp2NT>(P, wg_mlp_query_u<kMlp2NT>(P, qv), &S->v);
+  // each workgroup takes ONE contiguous run of passes: the slice pipeline and the row prefetch stay primed
+  const long long passes = (n + CPP - 1) / CPP, per = (passes + gridDim.x - 1) / gridDim.x;
+  const long long c0 = (long long)blockIdx.x * per * CPP;
+  if (c0 < n) {
+    const int cnt = (int)((n - c0) < per * CPP ? (n - c0) : per * CPP);
+    const void* tab = indices ? table : static_cast<const char*>(table) + (size_t)c0 * D * 2;
+    const uint32_t n_tab = indices ? (uint32_t)n_table_rows : (uint32_t)(n_table_rows - c0);
+    wg_score_mlp_split2<D, DT>(P, tab, n_tab, indices ? indices + c0 : nullptr, cnt, S, scores + c0);
   }
 }
 
@@ -148,6 +176,7 @@ constexpr int hash_phase_scratch() {
 // phase scratch of a traversal kernel: the attention scorer stages 32 KB weight slices
 constexpr int kAttnScratch = (kAttnSlice + kAttnVecFloats) * 4;
 constexpr int kMlpSplitScratch = (int)((sizeof(MlpSplitScratch) + 255) & ~(size_t)255);  // two slice buffers + the vectors
+static_assert(sizeof(Mlp2Scratch<128>) <= sizeof(MlpSplitScratch), "the second mapping's tile buffers fit the same phase scratch");
 template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
@@ -311,7 +340,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                              reinterpret_cast<float*>(scratch), sc_out);
       } else {
         // (the phase scratch was reused since the last stage)
-        if constexpr (SC == kScorerMlpSplit) {
+        if constexpr (SC == kScorerMlpSplit && NT == kMlp2NT) {  // second mapping: 4 wavefronts x 64 rows (nann_mlp2.h)
+          Mlp2Scratch<LPR * 8>* M = reinterpret_cast<Mlp2Scratch<LPR * 8>*>(scratch);
+          wg_mlp2_stage_setup<NT>(a.mlp, mlp_u, &M->v);
+          wg_score_mlp_split2<LPR * 8, DT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
+        } else if constexpr (SC == kScorerMlpSplit) {
           MlpSplitScratch* M = reinterpret_cast<MlpSplitScratch*>(scratch);
           wg_mlp_stage_setup<NT>(a.mlp, mlp_u, &M->v, kSplitWScale, kSplitWScale * kSplitHScale, kSplitHScale / kSplitWScale);
           wg_score_mlp_split<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);

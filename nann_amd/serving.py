@@ -160,21 +160,21 @@ def build_serve_host(force=False):
     if (force or not os.path.exists(_SERVE_BIN) or os.path.getmtime(_SERVE_SRC) > os.path.getmtime(_SERVE_BIN)
             or os.path.getmtime(lib) > os.path.getmtime(_SERVE_BIN)):
         inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", inc, _SERVE_SRC, "-o", _SERVE_BIN,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-mavx2", "-mf16c", "-I", inc, _SERVE_SRC, "-o", _SERVE_BIN,
                                "-L", os.path.dirname(lib), "-lnann_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
                                "-Wl,--allow-shlib-undefined"])
     return _SERVE_BIN
 
 
 def run_serve_host(index_dir, item_embs_dir, dim, clients=64, seconds=3.0, max_batch=256, max_wait_us=200, ef=128,
-                   topk=200, seq_len=50, model_dir=None, probe_out=None, lanes=2):
+                   topk=200, seq_len=50, model_dir=None, probe_out=None, lanes=2, client_threads=0):
     """Run the C++ host's closed-loop load test; returns its JSON line as a dict.  probe_out: file that receives
     the reply to one fixed request (item row 0 as the history): status, then top_k ids, one per line."""
     import json
     import subprocess
     cmd = [build_serve_host(), index_dir, item_embs_dir, str(dim), "--clients", str(clients), "--seconds", str(seconds),
            "--max-batch", str(max_batch), "--max-wait-us", str(max_wait_us), "--ef", str(ef), "--topk", str(topk),
-           "--seq-len", str(seq_len), "--lanes", str(lanes)]
+           "--seq-len", str(seq_len), "--lanes", str(lanes), "--client-threads", str(client_threads)]
     if model_dir:
         cmd += ["--model-dir", model_dir]
     if probe_out:

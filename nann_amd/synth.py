@@ -254,6 +254,56 @@ def make_mlp_weights(d, h1=256, h2=128, seed=777):
     }
 
 
+def mlp_forward(w, q, rows):
+    """The 2d-256-128-1 PReLU MLP on f32 arrays (numpy, BLAS order -- a workload generator's view of the scorer, not a
+    parity reference): q f32[d], rows [n, d] -> scores f32[n]."""
+    q = np.asarray(q, np.float32)
+    x = np.asarray(rows, np.float32)
+    d = q.shape[0]
+    h = x @ w["w1"][d:] + (q @ w["w1"][:d] + w["b1"])
+    h = np.maximum(h, 0) + w["alpha1"] * np.minimum(h, 0)
+    o = h @ w["w2"] + w["b2"]
+    o = np.maximum(o, 0) + w["alpha2"] * np.minimum(o, 0)
+    return (o @ w["w3"]).astype(np.float32)
+
+
+def make_mlp_weights_metric(d, item_embs=None, h1=256, h2=128, seed=779, n_fit=4096):
+    """An MLP scorer that RANKS LIKE THE INDEX METRIC -- what the reference's training produces (model.py:94-149 trains
+    the scorer on the corpus the HNSW graph is later built over, so that graph neighbourhoods are score
+    neighbourhoods; with random-init weights the traversal's recall against brute force under the same scorer is
+    ~0.4 and the "QPS @ recall parity" metric is vacuous).  No training here: the first two layers are CONSTRUCTED,
+    the last one FITTED in closed form:
+      layer 1   unit j < 128: +r_j . (q - e), unit j + 128: -r_j . (q - e)  (r_j random directions, b1 = 0):
+                PReLU(z) + PReLU(-z) = (1 - alpha) |z|
+      layer 2   o = M (h[:128] + h[128:]) with M = I + a small positive dense matrix: every o_k >= 0 (PReLU = identity),
+                a dense mixture of the |r_j . (q - e)|
+      layer 3   w3 = least squares of -||q - e|| on o over (query, item) pairs sampled from the corpus
+    so score(q, e) ~ -sum_j |r_j . (q - e)|, a norm of the projected difference that orders items nearly as L2 does.
+    item_embs: rows to sample the fitting pairs from (f16 / f32 [n, d]); None: unit-scale Gaussian rows."""
+    assert h1 == 256 and h2 == 128
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    r = rng.standard_normal((d, h2)).astype(f32) / f32(math.sqrt(d))            # 128 directions in R^d
+    w1 = np.zeros((2 * d, h1), f32)
+    w1[:d, :h2], w1[:d, h2:] = r, -r                                             # rows of q
+    w1[d:, :h2], w1[d:, h2:] = -r, r                                             # rows of e
+    m = np.eye(h2, dtype=f32) + (rng.random((h2, h2)).astype(f32) * f32(0.2 / h2))
+    w2 = np.concatenate([m.T, m.T], axis=0).astype(f32)                          # o = (h_plus + h_minus) @ m.T
+    w = {"w1": w1, "b1": np.zeros(h1, f32), "alpha1": np.full(h1, 0.25, f32), "w2": w2, "b2": np.zeros(h2, f32),
+         "alpha2": np.full(h2, 0.25, f32), "w3": np.zeros(h2, f32)}
+    if item_embs is None:
+        x = rng.standard_normal((n_fit, d)).astype(f32) / f32(math.sqrt(d))
+    else:
+        x = np.asarray(item_embs[rng.integers(0, len(item_embs), size=n_fit)], f32)
+    qs = x[rng.permutation(n_fit)] + (rng.standard_normal((n_fit, d)).astype(f32) * f32(0.05))
+    z = qs - x
+    h = z @ r
+    feats = (f32(0.75) * np.abs(h)) @ m.T                                        # what layer 2 outputs for these pairs
+    target = -np.sqrt((z * z).sum(1))
+    w["w3"] = np.linalg.lstsq(feats.astype(np.float64), target.astype(np.float64), rcond=None)[0].astype(f32)
+    return w
+
+
 def make_attn_weights(d, E=64, h=(128, 64, 32), seed=778):
     """Seeded weights of the reference's scorer model (model.py:189-233, model_util.py:70-97) with
     the reference's initialisers' scales: attention dense layers glorot-uniform with zero bias

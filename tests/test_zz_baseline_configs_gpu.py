@@ -45,10 +45,12 @@ def _index(items, dim, ef, dtype="f16", rank=0):
     return _IDX[key]
 
 
-def _queries(dim, n, seed=4321):
+def _queries(dim, n, seed=4321, items=1_000_000, ef=128):
+    """queries around the centres of the (items, ef) corpus (bench.n_clusters_for: same centres as the index)"""
     import bench
     from nann_amd import ops
-    seq = bench.make_query_batches(dim, n, 1, 1.0, torch.device("cuda"), seed=seed)[0]
+    seq = bench.make_query_batches(dim, n, 1, 1.0, torch.device("cuda"), seed=seed,
+                                   n_clusters=bench.n_clusters_for(items, ef))[0]
     return ops.user_seq_mean(seq)
 
 
@@ -75,10 +77,9 @@ def _properties(r, g, topn, E):
     per-round counters inside SURVEY.md 8's bounds."""
     st = r.status.cpu().numpy()
     ok = st == 0
-    # (a workload precondition, not the property under test: on the clustered synthetic corpus a few per cent of the
-    #  requests run out of new nodes in some round -- TopKV2's k > n, which the reference fails too -- and the share
-    #  moves with the multithreaded builder's graph: 0.92-0.94 at config 4's shape, seen below 0.9 once)
-    assert ok.mean() > 0.75, np.bincount(st)
+    # the generator's contract (SURVEY.md 8: every round must yield >= ef new nodes, else the reference itself fails
+    # the request in TopKV2): clusters of >= 30 ef items (bench.n_clusters_for) keep the workload valid
+    assert ok.mean() >= 0.95, np.bincount(st)
     idx = r.index.cpu().numpy()[ok]
     n = g["item_embs"].shape[0]
     assert idx.min() >= 0 and idx.max() < n
@@ -97,14 +98,15 @@ def _properties(r, g, topn, E):
 def test_config0_100k_64d_ef64(oracle):
     from nann_amd import ops
     g, oix, dix = _index(100_000, 64, 64)
-    q = _queries(64, 256)
+    q = _queries(64, 256, items=100_000, ef=64)
     topn = [64] * 5 + [200]
     r = _search(dix, ops.Scorer("l2", 64), q, topn)
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q.cpu().numpy(), topn, n_threads=16)
-    # 100k items in 256 clusters = ~390 per cluster: an ef=64 beam runs out of unvisited nodes in the later
-    # level-0 rounds for most queries, and TopKV2 then rejects k > n exactly as the reference would
-    # (topk_op.cc:67-71) -- those requests must fail with the same code; the rest must match bit for bit
-    assert 0.05 < (exp[0] == 0).mean() and set(np.unique(exp[0])) <= {0, 4}
+    # a valid workload (round 2 ran this shape on 256 clusters of 390 items, where most requests ran out of unvisited
+    # nodes and failed in TopKV2 like the reference would): >= 95 % of the requests succeed, a failing one must fail
+    # with the reference's code, the rest match bit for bit
+    assert (exp[0] == 0).mean() >= 0.95 and set(np.unique(exp[0])) <= {0, 4}
+    _properties(r, g, topn, len(g["enter_points"]))
     _assert_equals_oracle(r, exp)
 
 
@@ -142,6 +144,33 @@ def test_config2_1m_mlp(oracle):
     _assert_equals_oracle(r, exp, sel)
 
 
+def test_config2_metric_scorer_recall(oracle):
+    """configs[2] with a scorer whose recall means something: the MLP constructed / fitted to rank like the index
+    metric (synth.make_mlp_weights_metric -- what training against the index metric gives the reference), split-f16
+    form.  The traversal's top-200 against brute force under the SAME scorer: >= 0.8 (random-init weights: ~0.4);
+    a sample against the oracle's traversal, tie-aware."""
+    from nann_amd import ops, synth
+    g, oix, dix = _index(1_000_000, 128, 128)
+    topn = [128] * 5 + [200]
+    q = _queries(128, 128, seed=23)
+    w = synth.make_mlp_weights_metric(128, g["item_embs"][::16])
+    sc = ops.Scorer("mlp", 128, torch.float16, w, precision="split")
+    r = _search(dix, sc, q, topn)
+    _properties(r, g, topn, len(g["enter_points"]))
+    hits = 0
+    for b in range(8):
+        s_all = ops.blaze_score(sc, q[b], item_emb=dix.item_embs)
+        _, bi = ops.top_k(s_all, 200)
+        hits += len(set(bi.cpu().tolist()) & set(r.index[b].cpu().tolist()))
+    assert hits / (8 * 200) >= 0.8, hits / 1600
+    sel = slice(0, 16)
+    est, eids, esc, eidx, ectr = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q[sel].cpu().numpy(),
+                                                     topn, n_threads=16)
+    gx, gs = r.index.cpu().numpy()[sel], r.scores.cpu().numpy()[sel]
+    kinds = [oracle.tolerant_parity(gx[b], gs[b], eidx[b], esc[b]) for b in range(16) if est[b] == 0]
+    assert kinds.count("diverged") <= 1, kinds
+
+
 def test_config3_two_shards_exchange_and_merge(oracle):
     """configs[3]'s structure on one GPU: two 200k-item shards of the corpus searched one after the other,
     their top-200 lists merged by the library (records laid out as the all-gather delivers them) -- against
@@ -150,7 +179,7 @@ def test_config3_two_shards_exchange_and_merge(oracle):
     from nann_amd import ops
     from nann_amd._lib import lib
     topn = [128] * 5 + [200]
-    q = _queries(128, 64, seed=7)
+    q = _queries(128, 64, seed=7, items=200_000, ef=128)
     sc = ops.Scorer("l2", 128)
     parts, oparts = [], []
     for rank in (0, 1):
@@ -183,10 +212,55 @@ def test_config4_shard_shape_beyond_the_lds_bitmap(oracle, kind, mode):
     assert dix.bitmap_words * 4 + 27648 + 2304 > 160 * 1024  # the LDS bitmap cannot be chosen
     topn = [256] * 5 + [200]
     nq = 512 if kind == "l2" else 64
-    q = _queries(256, nq, seed=5)
+    q = _queries(256, nq, seed=5, items=1_200_000, ef=256)
     w = synth.make_mlp_weights(256) if kind == "mlp" else None
     r = _search(dix, ops.Scorer(kind, 256, torch.bfloat16, w, precision="exact"), q, topn, mode)
     _properties(r, g, topn, len(g["enter_points"]))
     sel = slice(0, 48 if kind == "l2" else 16)
     exp = oracle.search_batch(oix, oracle.Scorer(kind, 256, oracle.EMB_BF16, w), q[sel].cpu().numpy(), topn, n_threads=16)
     _assert_equals_oracle(r, exp, sel)
+
+
+def test_config3_real_shard_1m_mlp_split_through_sharded_topk(oracle):
+    """configs[3] at its own shard size: ONE 1M x 128-d shard searched with the split-f16 MLP scorer (the matrix-core
+    form the config names), its top-200 lists sent through nann_sharded_topk on an 8-shard loopback communicator
+    (every shard returns this rank's record: the record layout, the strided merge, cross-shard tie order) --
+    per-shard lists against the oracle's traversal (scores within 1e-5, ids tie-aware), the merged lists bit for
+    bit against the oracle's merge of the same eight lists."""
+    from nann_amd import ops, retrieval, shard, synth
+    g, oix, dix = _index(1_000_000, 128, 128)
+    topn = [128] * 5 + [200]
+    q = _queries(128, 256, seed=31)
+    w = synth.make_mlp_weights(128)
+    r = _search(dix, ops.Scorer("mlp", 128, torch.float16, w, precision="split"), q, topn)
+    _properties(r, g, topn, len(g["enter_points"]))
+    sel = slice(0, 24)
+    est, eids, esc, eidx, ectr = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q[sel].cpu().numpy(),
+                                                     topn, n_threads=16)
+    st, gx, gs = r.status.cpu().numpy()[sel], r.index.cpu().numpy()[sel], r.scores.cpu().numpy()[sel]
+    assert (st == est).all() and (est == 0).all()
+    kinds = [oracle.tolerant_parity(gx[b], gs[b], eidx[b], esc[b]) for b in range(len(est))]
+    assert kinds.count("diverged") <= 1 and kinds.count("exact") >= 18, kinds  # (a near-tie inside the beam may fork a traversal)
+    ss = shard.ShardedSearch(topn, 8, 0, transport="rccl", comm=shard.Comm.loopback(8))
+    mi, ms = ss.merge(r)
+    torch.cuda.synchronize()
+    ids_h, sc_h = r.item_ids.cpu().numpy(), r.scores.cpu().numpy()
+    for b in range(0, 256, 5):
+        rc, es, ei = oracle.merge_topk(np.repeat(sc_h[b][None], 8, 0), np.repeat(ids_h[b][None], 8, 0), 200)
+        assert rc == 0 and (mi[b].cpu().numpy() == ei).all() and (bits(ms[b].cpu().numpy()) == bits(es)).all(), b
+
+
+def test_config4_full_shard_4m_256d_bf16_ef256(oracle):
+    """configs[4]'s shard at its own size: 4M x 256-d bf16 (2 GB table, 8x the Infinity Cache), ef = 256, top-200, L2 --
+    properties on 2048 queries, the planner's kernel for it (32K-slot hash set, 10 position bits at 22-bit ids) and
+    an oracle-exact sample; collected last: the host-side builder takes a few minutes for this graph."""
+    from nann_amd import ops
+    g, oix, dix = _index(4_000_000, 256, 256, dtype="bf16")
+    topn = [256] * 5 + [200]
+    q = _queries(256, 2048, seed=17, items=4_000_000, ef=256)
+    r = _search(dix, ops.Scorer("l2", 256, torch.bfloat16), q, topn)
+    _properties(r, g, topn, len(g["enter_points"]))
+    sel = slice(0, 32)
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 256, oracle.EMB_BF16), q[sel].cpu().numpy(), topn, n_threads=16)
+    _assert_equals_oracle(r, exp, sel)
+    del _IDX[(4_000_000, 256, 256, "bf16", 0)]  # 4 GB of host + device arrays: not kept for the session

@@ -1,0 +1,110 @@
+#!/bin/bash
+# Round-3 GPU session runner (through gpurun): named steps, each skipped once the deadline has passed.
+# usage: tools/gpu_r3.sh <tag> <deadline_s> <step> [<step> ...]
+#   steps: tests_mlp tests_full smoke rate_mlp bench_mlp bench_mlp_ab bench_full bench_l2 prof_mlp prof_l2 prof_stress serve coop
+set -u
+TAG=$1; DEADLINE=$2; shift 2
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+T0=$(date +%s)
+left() { echo $(( DEADLINE - ($(date +%s) - T0) )); }
+mkdir -p $OUT /tmp/idx /tmp/prof
+cd $R
+export TMPDIR=/tmp NANN_TEST_INDEX_CACHE=/tmp/idx
+BENCH="python $R/bench.py --index-cache /tmp/idx"
+show() {  # file label
+python - <<PY
+import json
+try:
+    d = json.loads(open('$1').read().strip().splitlines()[-1])
+    r = d['roofline']
+    print('$2', 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'issued', r.get('issued_frac_of_peak'),
+          'valid', d.get('valid_queries'), 'cpu', d.get('cpu_baseline', {}).get('value'), 'parity', d.get('parity'),
+          'recall', d.get('recall_at_k_vs_bruteforce'), 'setup_s', d.get('setup_s'), 'rows/q', r.get('rows_scored_per_query'))
+    if 'phase_breakdown' in d:
+        print('   ticks', {k: round(v) for k, v in d['phase_breakdown']['ticks_per_query'].items() if v})
+    for k, v in d.get('secondary', {}).items():
+        if isinstance(v, dict) and 'roofline' in v:
+            print('   SEC', k, 'qps', v['qps_end_to_end'], 'kernel_ms', v['roofline']['kernel_ms'], 'frac', v['roofline']['frac'],
+                  'valid', v.get('valid_queries'), 'parity', v.get('parity'), 'recall', v.get('recall_at_k_vs_bruteforce'),
+                  'cpu', v.get('cpu_baseline', {}).get('value'), 'setup_s', v.get('setup_s'))
+        else:
+            print('   SEC', k, v)
+except Exception as e:
+    print('$2 parse failed', e)
+PY
+}
+pmc() {  # name, kernel substring, counters..., then -- command
+  local NAME=$1 KSUB=$2; shift 2
+  local CTRS=""
+  while [ "$1" != "--" ]; do CTRS="$CTRS $1"; shift; done
+  shift
+  rm -rf /tmp/prof/pmc_$NAME
+  ( cd /tmp && timeout 240 rocprofv3 --pmc $CTRS --output-format csv -d /tmp/prof/pmc_$NAME -o pmc -- "$@" > $OUT/prof_pmc_${NAME}_$TAG.log 2>&1 )
+  python - <<PY >> $OUT/pmc_$TAG.txt 2>&1
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob('/tmp/prof/pmc_$NAME/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if '$KSUB' in r.get('Kernel_Name', ''):
+            acc[(r['Kernel_Name'][:64], r.get('Counter_Name'))].append(float(r['Counter_Value']))
+for (k, c), v in sorted(acc.items()):
+    print('$NAME', c, k, 'dispatches', len(v), 'mean', sum(v) / len(v), 'min', min(v), 'max', max(v))
+PY
+}
+kstats() {  # name -- command
+  local NAME=$1; shift 2
+  rm -rf /tmp/prof/kt_$NAME
+  ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt_$NAME -o kt -- "$@" > $OUT/prof_kt_${NAME}_$TAG.log 2>&1 )
+  find /tmp/prof/kt_$NAME -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_${NAME}_$TAG.csv \;
+  grep -E "k_search|k_score|k_hnsw" $OUT/kernel_stats_${NAME}_$TAG.csv | head -4
+}
+: > $OUT/pmc_$TAG.txt
+for STEP in "$@"; do
+  if [ $(left) -lt 45 ]; then echo "SKIP $STEP (deadline)"; continue; fi
+  echo "=== $STEP (left $(left) s)"
+  case $STEP in
+    tests_mlp)
+      timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_search_gpu.py -m gpu -q --timeout 300 -x \
+          -k "mlp or frozen or model_directory or serving_signature or batch_size" > $OUT/pytest_mlp_$TAG.log 2>&1
+      tail -4 $OUT/pytest_mlp_$TAG.log; grep -E "^(E  |FAILED|ERROR)" $OUT/pytest_mlp_$TAG.log | head -20 ;;
+    tests_full)
+      timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_$TAG.log 2>&1
+      tail -4 $OUT/pytest_$TAG.log; grep -E "^(E  |FAILED|ERROR)" $OUT/pytest_$TAG.log | head -30 ;;
+    smoke)
+      timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -1 $OUT/smoke_$TAG.log ;;
+    rate_mlp)
+      timeout 200 python tools/mlp_rate.py 128 3145728 split > $OUT/rate_mlp_$TAG.txt 2>&1
+      NANN_MLP_MAPPING=1 timeout 200 python tools/mlp_rate.py 128 3145728 split >> $OUT/rate_mlp_$TAG.txt 2>&1
+      timeout 200 python tools/mlp_rate.py 64 3145728 split >> $OUT/rate_mlp_$TAG.txt 2>&1
+      cat $OUT/rate_mlp_$TAG.txt ;;
+    bench_mlp)
+      timeout 400 $BENCH --scorer mlp --batch 1024 --steps 5 --warmup 2 --no-secondary --phase-ticks --cpu-seconds 6 > $OUT/bench_mlp_$TAG.json 2> $OUT/bench_mlp_$TAG.err
+      show $OUT/bench_mlp_$TAG.json MLP; tail -2 $OUT/bench_mlp_$TAG.err ;;
+    bench_mlp_ab)
+      NANN_MLP_MAPPING=1 timeout 300 $BENCH --scorer mlp --batch 1024 --steps 5 --warmup 2 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_mlp_map1_$TAG.json 2> $OUT/bench_mlp_map1_$TAG.err
+      show $OUT/bench_mlp_map1_$TAG.json MLP_FIRST_MAPPING ;;
+    bench_l2)
+      timeout 300 $BENCH --no-secondary --phase-ticks --no-cpu-baseline --steps 10 > $OUT/bench_l2_$TAG.json 2> $OUT/bench_l2_$TAG.err
+      show $OUT/bench_l2_$TAG.json L2; tail -2 $OUT/bench_l2_$TAG.err ;;
+    bench_full)
+      timeout 900 $BENCH --phase-ticks --cpu-seconds 8 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?"
+      show $OUT/bench_$TAG.json DEFAULT; tail -3 $OUT/bench_$TAG.err ;;
+    prof_mlp)
+      kstats mlp -- $BENCH --scorer mlp --batch 1024 --steps 5 --warmup 1 --no-secondary --no-cpu-baseline
+      pmc mlp_a k_search SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -- $BENCH --scorer mlp --batch 1024 --steps 3 --warmup 1 --no-secondary --no-cpu-baseline
+      pmc mlp_b k_search GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $BENCH --scorer mlp --batch 1024 --steps 3 --warmup 1 --no-secondary --no-cpu-baseline ;;
+    prof_l2)
+      kstats l2 -- $BENCH --steps 10 --warmup 2 --no-secondary --no-cpu-baseline
+      pmc l2_fetch k_search FETCH_SIZE -- $BENCH --steps 3 --warmup 1 --no-secondary --no-cpu-baseline
+      pmc l2_write k_search WRITE_SIZE -- $BENCH --steps 3 --warmup 1 --no-secondary --no-cpu-baseline ;;
+    prof_stress)
+      S="--items 2000000 --dim 256 --dtype bf16 --ef 256 --batch 2048 --no-secondary --no-cpu-baseline"
+      kstats stress -- $BENCH $S --steps 5 --warmup 2
+      pmc stress_fetch k_search FETCH_SIZE -- $BENCH $S --steps 3 --warmup 1
+      pmc stress_write k_search WRITE_SIZE -- $BENCH $S --steps 3 --warmup 1 ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+done
+cat $OUT/pmc_$TAG.txt
+echo "done left=$(left)"

@@ -18,7 +18,7 @@ from nann_amd import serving, synth  # noqa: E402
 
 def main():
     items = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    clients = [int(x) for x in sys.argv[2:]] or [64, 1024]
+    clients = [int(x) for x in sys.argv[2:]] or [64, 512, 2048]
     g = bench.make_index(items, 128, 128, "hnsw", 1.0, "f16", 0, torch.device("cuda"), bench.usable_cores())
     with tempfile.TemporaryDirectory() as d:
         disk = dict(g)
@@ -32,6 +32,11 @@ def main():
                 r = serving.run_serve_host(d, d, 128, clients=c, seconds=3.0, max_batch=1024, max_wait_us=200, ef=128,
                                            topk=200, lanes=lanes)
                 print(json.dumps(r), flush=True)
+        # the batch size a lane settles at follows the client count; a larger cap for the many-client points
+        for lanes, c in ((1, 4096), (2, 4096)):
+            r = serving.run_serve_host(d, d, 128, clients=c, seconds=3.0, max_batch=2048, max_wait_us=200, ef=128,
+                                       topk=200, lanes=lanes)
+            print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":
