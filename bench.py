@@ -13,8 +13,9 @@ when the timed region starts; every step sees a DIFFERENT batch of queries.
 
 Primary workload (BASELINE.json configs[1]): 1M items x 128-d f16, M=32, ef_search=128
 (level_topn = [128]*5 + [200]), L2 scoring, on each GPU; the graph comes from the shipped
-index builder (nann_amd/csrc/host/hnsw_build.cpp: HNSW M=32, efConstruction=40 -- what the
-reference gets from faiss.IndexHNSWFlat, build_hnsw_index.py:33-35).  With N > 1 ranks the
+index builder (nann_amd/csrc/nann_hnsw_build.hip, on the device: HNSW M=32, efConstruction=40 -- what
+the reference gets from faiss.IndexHNSWFlat, build_hnsw_index.py:33-35; --graph hnsw_cpu: the same
+algorithm by the host-side builder of rounds 1-2).  With N > 1 ranks the
 corpus is N shards of 1M items (configs[3] shape: item-id sharding); every rank searches
 every query on its shard, the per-shard top-200 lists are exchanged with one ncclAllGather
 issued by the C ABI (nann_sharded_topk) and merged on the device.
@@ -56,9 +57,10 @@ def parse():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
-    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "synth", "knn"],
-                    help="hnsw = the shipped C++ HNSW builder (default); synth = exact-search insertion graph "
-                         "built with torch (round-1 default, ~2 min at 1M); knn = full-degree exact k-NN rows")
+    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "hnsw_cpu", "synth", "knn"],
+                    help="hnsw = the shipped HNSW builder ON THE DEVICE (default since round 3: 1M x 128-d in ~0.6 s); "
+                         "hnsw_cpu = the same algorithm by the host-side C++ builder (rounds 1-2: 16-30 s); synth = exact-search "
+                         "insertion graph built with torch (round-1 default, ~2 min at 1M); knn = full-degree exact k-NN rows")
     ap.add_argument("--noise", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,15 +184,24 @@ def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_
                     "nb_values": [z["nb_values_0"], z["nb_values_1"]],
                     "nb_row_splits": [z["nb_row_splits_0"], z["nb_row_splits_1"]],
                     "enter_points": z["enter_points"]}
-    if graph == "hnsw":
+    if graph in ("hnsw", "hnsw_cpu"):
+        import torch
         embs, _ = synth.make_corpus(items, dim, n_clusters=ncl, noise=noise, seed=1234, item_seed=1234 + 100 + 1000 * rank)
         x32 = embs.astype(np.float32)  # the builder sees exactly the values the index stores (f16-exact)
         if dtype == "bf16":
             bits = to_bf16_bits(x32)
             x32 = (bits.astype(np.uint32) << 16).view(np.float32)
-        raw = index_build.build_hnsw(x32, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank,
-                                     n_threads=n_threads)
-        ex = index_build.export_levels(raw, start_level=2)
+        if graph == "hnsw":  # HNSW construction on the device (csrc/nann_hnsw_build.hip): 1M x 128-d in ~0.6 s
+            with torch.cuda.device(dev):
+                rows = (torch.as_tensor(bits.view(np.int16)).to(dev).view(torch.bfloat16) if dtype == "bf16"
+                        else torch.as_tensor(embs).to(dev))
+                ex = index_build.build_hnsw_gpu(rows, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank)
+                del rows
+        else:  # the host-side builder (csrc/host/hnsw_build.cpp), multi-threaded
+            raw = index_build.build_hnsw(x32, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank,
+                                         n_threads=n_threads)
+            ex = index_build.export_levels(raw, start_level=2)
+        del x32
         if len(ex["enter_points"]) < ef:
             raise RuntimeError(f"only {len(ex['enter_points'])} enter points for ef={ef}: corpus too small")
         g = {"item_embs": bits if dtype == "bf16" else embs,
@@ -589,7 +600,8 @@ def main():
 
     qps = prim["qps_end_to_end"]
     desc = (f"{args.items} items/GPU x {args.dim}-d {args.dtype}, M=32 graph from "
-            + {"hnsw": "the shipped HNSW builder (efConstruction=40)", "synth": "synth.py (exact-search insertion)",
+            + {"hnsw": "the shipped HNSW builder on the device (efConstruction=40)",
+               "hnsw_cpu": "the shipped host-side HNSW builder (efConstruction=40)", "synth": "synth.py (exact-search insertion)",
                "knn": "exact k-NN rows"}[args.graph]
             + f", ef_search={args.ef}, top-{args.topk}, "
             + ("L2 scoring" if args.scorer == "l2" else "3-layer MLP 256-128-1 scorer on MFMA")

@@ -398,6 +398,27 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
                       int64_t n_queries, int32_t k_in, int32_t k_out, void* workspace,
                       int64_t workspace_bytes, float* out_scores, int64_t* out_ids, nann_stream_t stream);
 
+/* ---- 8(f1): HNSW index construction on the device -------------------------------------------------
+ * What the reference does on the host with faiss.IndexHNSWFlat(d, M).add(embeddings)
+ * (NANN_impls/nann/delivery/build_hnsw_index.py:33-35): the HNSW insertion algorithm (Malkov & Yashunin alg. 1-4
+ * with Faiss' conventions: L2, M links above level 0 and 2M at level 0, efConstruction = 40, selection heuristic
+ * without keepPrunedConnections), batched -- nodes go in by descending level in batches of at most a quarter of
+ * the graph built so far (<= 16384), every node of a batch searches the graph of the earlier batches with one
+ * wavefront, back-links are applied per target in a deterministic order (csrc/nann_hnsw_build.hip).  Index
+ * contents are not a parity target (Faiss' own are thread-schedule dependent); layout, invariants and recall are.
+ *   nann_hnsw_draw_levels   [host] levels[i] = number of levels of node i (Faiss convention, P(levels > l) = M^-l),
+ *                           same draw as the CPU builder's; *n_up_rows = sum(levels - 1) = rows of adj_up
+ *   nann_hnsw_build_device  item_embs device [n, d] f16 | bf16 (d in 64 | 128 | 256), levels [host];
+ *                           outputs (device, caller-allocated): adj0 i32[n, 2M] (-1 = empty slot), up_row i32[n]
+ *                           (first row of node i in adj_up, -1 if it has one level), adj_up i32[n_up_rows, M]
+ *                           (level l >= 1 of node i: row up_row[i] + l - 1).  Synchronous (returns when built).
+ * nann_amd/index_build.py exports these as build_hnsw_index.py:41-66 does (enter points = levels > start_level,
+ * per-level CSR over all items with the -1 slots dropped). */
+int nann_hnsw_draw_levels(int64_t n_items, int32_t M, uint64_t seed, int32_t* levels /*[host]*/, int64_t* n_up_rows);
+int nann_hnsw_build_device(const void* item_embs, int64_t n_items, int32_t d, int32_t emb_dtype, int32_t M,
+                           int32_t ef_construction, const int32_t* levels /*[host]*/, int32_t* adj0, int32_t* up_row,
+                           int32_t* adj_up, nann_stream_t stream);
+
 /* ---- 8(f2): the reference's own scorer model behind the BlazeXlaOp contract -------------
  * NANN_impls/nann/model/model.py:189-233 + model_util.py:70-97: softmax attention of the candidate
  * over the user's behaviour sequence u f16[L, 64] (comm_seq, build_opt_graph.py:76-79), then a DNN

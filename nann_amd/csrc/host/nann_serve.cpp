@@ -160,6 +160,8 @@ void pin_to_core(int core) {
   (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
 }
 
+// the cores this process may run on: the affinity mask, cut to the cgroup's CPU quota when there is one (a container
+// that sees 128 cores in its mask may own 16 of them)
 std::vector<int> allowed_cores() {
   cpu_set_t set;
   CPU_ZERO(&set);
@@ -168,6 +170,15 @@ std::vector<int> allowed_cores() {
     for (int c = 0; c < CPU_SETSIZE; ++c)
       if (CPU_ISSET(c, &set)) out.push_back(c);
   if (out.empty()) out.push_back(0);
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[64];
+    long long period = 0;
+    if (std::fscanf(f, "%63s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+      const long long n = std::max(1ll, std::atoll(quota) / period);
+      if ((long long)out.size() > n) out.resize((size_t)n);
+    }
+    std::fclose(f);
+  }
   return out;
 }
 
@@ -263,6 +274,7 @@ int main(int argc, char** argv) {
     unsigned char* h_in = nullptr;
     int64_t* h_topk = nullptr;
     int32_t* h_status = nullptr;
+    std::vector<ClientThread*> touched;
   };
   std::vector<Lane> lane((size_t)lanes);
   for (Lane& ln : lane) {
@@ -308,8 +320,8 @@ int main(int argc, char** argv) {
     CHECK(nann_stream_synchronize(ln.stream));
     launches.fetch_add(1);
     batched.fetch_add(b);
-    ClientThread* touched[64];
-    int n_touched = 0;
+    std::vector<ClientThread*>& touched = ln.touched;  // the client threads with a reply in this batch, each once
+    touched.clear();
     for (int i = 0; i < b; ++i) {
       Request* r = batch[i];
       std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)topk * 8);
@@ -318,15 +330,13 @@ int main(int argc, char** argv) {
       r->done.store(1, std::memory_order_release);
       if (owner) {
         owner->completed.fetch_add(1, std::memory_order_release);
-        bool seen = false;
-        for (int t = 0; t < n_touched; ++t) seen |= touched[t] == owner;
-        if (!seen && n_touched < 64) touched[n_touched++] = owner;
+        if (std::find(touched.begin(), touched.end(), owner) == touched.end()) touched.push_back(owner);
       }
     }
-    for (int t = 0; t < n_touched; ++t)  // one wake-up per client THREAD per batch, and only if it sleeps
-      if (touched[t]->sleeping.load(std::memory_order_acquire)) {
-        std::lock_guard<std::mutex> lk(touched[t]->mu);
-        touched[t]->cv.notify_one();
+    for (ClientThread* t : touched)  // one wake-up per client THREAD per batch, and only if it sleeps
+      if (t->sleeping.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(t->mu);
+        t->cv.notify_one();
       }
   };
 

@@ -1682,6 +1682,10 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   else if (mode == NANN_TRAVERSAL_AUTO && (kind == NANN_SCORER_L2 || kind < 0)) {
     if (worst_visited <= 16320.0 || est_visited <= 11000.0) hash_vis = VIS_LDS_HASH;
     else if (worst_visited <= 32704.0 || est_visited <= 24000.0) hash_vis = VIS_LDS_HASH32;
+    // small batches: with at most one query per CU the second 512-thread workgroup of the 16K-slot plan has nothing to
+    // overlap with, and a query is served faster by ONE 1024-thread workgroup owning the CU (measured at configs[1]:
+    // B = 1 0.196 -> 0.160 ms, B = 64 0.206 -> 0.165 ms; profiles/r3d_*)
+    if (hash_vis == VIS_LDS_HASH && kind == NANN_SCORER_L2 && n_queries <= (int64_t)di.cus) hash_vis = VIS_LDS_HASH32;
   }
   const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && pos_bits >= 10;  // 16K slots, one workgroup per CU
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&

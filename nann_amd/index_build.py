@@ -97,3 +97,57 @@ def build_and_save_index(embeddings, start_level, num_neighbors, output_dir, see
         np.save(os.path.join(output_dir, f"neighbors_level_{level}_values.npy"), ex["nb_values"][level])
         np.save(os.path.join(output_dir, f"neighbors_level_{level}_row_splits.npy"), ex["nb_row_splits"][level])
     return raw, ex
+
+
+# ---- construction on the device (csrc/nann_hnsw_build.hip) -----------------------------------------------------
+def build_hnsw_gpu(item_embs, num_neighbors=32, ef_construction=40, seed=0, start_level=2, want_raw=False):
+    """HNSW(M) over the rows of `item_embs` (CUDA tensor f16 | bf16 [N, d], or a numpy f16 array) built ON THE GPU
+    (nann_hnsw_build_device).  Returns the export of build_hnsw_index.py:41-66 -- {"enter_points", "nb_values"
+    [start_level], "nb_row_splits"[start_level], "levels"} as numpy arrays (values int64 on disk) -- assembled with
+    torch on the device; with want_raw also the Faiss-shaped raw arrays of build_hnsw()."""
+    import torch
+    from . import _lib
+    from .ops import _check, _ptr, _stream, _DT
+    L = _lib.lib()
+    x = item_embs if isinstance(item_embs, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(item_embs))
+    x = x.cuda().contiguous()
+    n, d = x.shape
+    m = int(num_neighbors)
+    levels = np.zeros(n, np.int32)
+    n_up = C.c_int64(0)
+    _check(L.nann_hnsw_draw_levels(C.c_int64(n), C.c_int32(m), C.c_uint64(seed), levels.ctypes.data_as(C.c_void_p),
+                                   C.byref(n_up)), "hnsw levels")
+    adj0 = torch.empty((n, 2 * m), dtype=torch.int32, device=x.device)
+    up_row = torch.empty(n, dtype=torch.int32, device=x.device)
+    adj_up = torch.empty((max(n_up.value, 1), m), dtype=torch.int32, device=x.device)
+    torch.cuda.synchronize()
+    _check(L.nann_hnsw_build_device(_ptr(x), C.c_int64(n), C.c_int32(d), C.c_int32(_DT[x.dtype]), C.c_int32(m),
+                                    C.c_int32(ef_construction), levels.ctypes.data_as(C.c_void_p), _ptr(adj0), _ptr(up_row),
+                                    _ptr(adj_up), _stream()), "hnsw build")
+    lev = torch.as_tensor(levels, device=x.device)
+    out = {"levels": levels, "enter_points": np.nonzero(levels > start_level)[0],  # build_hnsw_index.py:45
+           "nb_values": [], "nb_row_splits": []}
+    for level in range(start_level):                                              # :49
+        if level == 0:
+            rows = adj0
+        else:  # row of node i on level l >= 1: up_row[i] + l - 1 (absent: an empty row, :53)
+            rows = torch.full((n, m), -1, dtype=torch.int32, device=x.device)
+            has = lev > level
+            rows[has] = adj_up[(up_row[has] + (level - 1)).long()]
+        keep = rows >= 0                                                          # :59 drop the -1 slots
+        rs = torch.zeros(n + 1, dtype=torch.int64, device=x.device)
+        torch.cumsum(keep.sum(1), 0, out=rs[1:])
+        out["nb_values"].append(rows[keep].to(torch.int64).cpu().numpy())         # :66 int64 on disk
+        out["nb_row_splits"].append(rs.cpu().numpy())
+    if want_raw:
+        cum = np.concatenate([[0], 2 * m + m * np.arange(int(levels.max()))]).astype(np.int32)
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(2 * m + (levels.astype(np.int64) - 1) * m, out=offsets[1:])
+        nb = np.full(int(offsets[-1]), -1, np.int32)
+        a0, au, ur = adj0.cpu().numpy(), adj_up.cpu().numpy(), up_row.cpu().numpy()
+        nb[(offsets[:-1, None] + np.arange(2 * m)[None, :]).ravel()] = a0.ravel()
+        for i in np.nonzero(levels > 1)[0]:
+            for l in range(1, levels[i]):
+                nb[offsets[i] + cum[l]: offsets[i] + cum[l] + m] = au[ur[i] + l - 1]
+        out["raw"] = {"levels": levels, "offsets": offsets, "neighbors": nb, "cum_nneighbor_per_level": cum}
+    return out

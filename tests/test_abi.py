@@ -61,13 +61,17 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_cpp_serving_host_builds_against_the_header_alone():
-    """nann_serve.cpp includes nothing but include/nann_hip.h and the C++ standard library, links against the in-tree
-    library, and fails loudly without a GPU."""
+    """nann_serve.cpp includes nothing but include/nann_hip.h, the C++ standard library and three system headers (no HIP,
+    no torch), links against the in-tree library, and fails loudly without a GPU."""
     import subprocess
     from nann_amd import serving
     includes = [line.split()[1] for line in open(serving._SERVE_SRC) if line.startswith("#include")]
     assert "\"nann_hip.h\"" in includes
-    assert all(i == "\"nann_hip.h\"" or (i.startswith("<") and "/" not in i and "." not in i) for i in includes), includes
+    # besides the ABI header: the C++ standard library, and the system headers for thread pinning / F16C conversion
+    system = {"<pthread.h>", "<sched.h>", "<immintrin.h>"}
+    assert all(i == "\"nann_hip.h\"" or i in system or (i.startswith("<") and "/" not in i and "." not in i)
+               for i in includes), includes
+    assert not any(w in i for i in includes for w in ("hip/", "torch", "rocm")), includes
     exe = serving.build_serve_host()
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr

@@ -71,6 +71,22 @@ for STEP in "$@"; do
     tests_full)
       timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_$TAG.log 2>&1
       tail -4 $OUT/pytest_$TAG.log; grep -E "^(E  |FAILED|ERROR)" $OUT/pytest_$TAG.log | head -30 ;;
+    tests_new)
+      timeout 900 python -m pytest tests/test_index_build_gpu.py tests/test_zz_baseline_configs_gpu.py tests/test_search_gpu.py -m gpu -q --timeout 600 \
+          -k "device_builder or metric or config0 or config3_real or cpp_serving or serving_front" > $OUT/pytest_new_$TAG.log 2>&1
+      tail -4 $OUT/pytest_new_$TAG.log; grep -E "^(E  |FAILED|ERROR)" $OUT/pytest_new_$TAG.log | head -20 ;;
+    serve)
+      timeout 400 python tools/serve_bench.py 1000000 64 512 2048 2> $OUT/serve_$TAG.err | tee $OUT/serve_$TAG.txt; tail -2 $OUT/serve_$TAG.err ;;
+    b1)
+      for B in 1 64; do
+        timeout 200 $BENCH --batch $B --steps 20 --warmup 3 --no-secondary --no-cpu-baseline --phase-ticks > $OUT/bench_b${B}_$TAG.json 2> $OUT/bench_b${B}_$TAG.err
+        show $OUT/bench_b${B}_$TAG.json "B=$B"
+      done ;;
+    b1modes)
+      for M in lds_hash32 lds_bitmap; do for B in 1 64; do
+        timeout 200 $BENCH --batch $B --steps 20 --warmup 3 --no-secondary --no-cpu-baseline --phase-ticks --traversal $M > $OUT/bench_b${B}_${M}_$TAG.json 2> $OUT/bench_b${B}_${M}_$TAG.err
+        show $OUT/bench_b${B}_${M}_$TAG.json "B=$B $M"
+      done; done ;;
     smoke)
       timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; tail -1 $OUT/smoke_$TAG.log ;;
     rate_mlp)
