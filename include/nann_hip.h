@@ -181,6 +181,12 @@ typedef struct {
  *              hi plane is cut with round-toward-zero, which never produces inf): the score is
  *              finite and wrong, so a model with such activations must use EXACT_F32.  The
  *              reference's models are batch-normalised / PReLU nets with O(1) activations.
+ *              In nann_search the split form runs with the ITEM HALF OF LAYER 1 PRE-PROJECTED: W1e^T e_i is the same
+ *              vector whoever scores item i, so the first search of a (scorer, index) pair computes it for every item
+ *              once -- a resident f32 [n_items, 256] table owned by the scorer, 1 GB per million items, built in
+ *              ~10 ms per million -- and the traversal gathers that row instead of running layer 1 (csrc/nann_mlp3.h).
+ *              A scorer keeps the tables of the two indices it searched last.  nann_score (stand-alone rows, no
+ *              index) runs all three layers on the matrix cores.
  *   EXACT_F32  v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, scores BIT-identical to the oracle's
  *              fp32 chain (and therefore identical top-k ids); 1/16 of the 16-bit MFMA rate.
  *   DEFAULT    (0, what a zero-initialised descriptor asks for) SPLIT_F16 when the weights meet its

@@ -497,6 +497,11 @@ struct nann_scorer {
   float* dev_weights = nullptr;  // MLP weights block in HBM
   uint4* dev_packed = nullptr;   // split-f16 planes in MFMA A-fragment order
   MlpParams mlp = {};
+  // split-f16 MLP: the item half of layer 1 pre-projected for the indices this scorer has searched (nann_mlp3.h):
+  // f32 [n_items, 256] per index, built at the first nann_search of the pair, at most two kept (the older one goes)
+  struct Proj { uint64_t index_uid = 0; float* table = nullptr; };
+  mutable std::mutex proj_mu;
+  mutable Proj proj[2];
 };
 
 struct nann_attn_scorer {
@@ -509,6 +514,7 @@ struct nann_attn_scorer {
 
 struct nann_index {
   nann_index_desc desc;  // device pointers
+  uint64_t uid = 0;      // process-unique (a scorer keys its per-index tables by it; a pointer could be reused)
   bool owns = false;
   std::vector<void*> owned;
   int64_t max_deg[2] = {0, 0};
@@ -1091,6 +1097,7 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
 
 void nann_scorer_destroy(nann_scorer* s) {
   if (!s) return;
+  for (auto& p : s->proj) if (p.table) (void)hipFree(p.table);
   if (s->dev_weights) (void)hipFree(s->dev_weights);
   if (s->dev_packed) (void)hipFree(s->dev_packed);
   delete s;
@@ -1550,6 +1557,10 @@ int nann_index_create(const nann_index_desc* desc, nann_index** out) {
       return fail(NANN_ERR_UNSUPPORTED, "a level holds more than 2^32-1 links");
   nann_index* ix = new nann_index();
   ix->desc = h;
+  {
+    static std::atomic<uint64_t> next_uid{1};
+    ix->uid = next_uid.fetch_add(1);
+  }
   const int64_t N = h.n_items;
   // host copies of the small arrays for validation
   std::vector<int64_t> rs_host[2];
@@ -1742,6 +1753,45 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
 
 }  // extern "C"
 
+namespace nann {
+int mlp_mapping_choice() {
+  static const int choice = [] {
+    const char* e = std::getenv("NANN_MLP_MAPPING");
+    return (e && e[0] >= '1' && e[0] <= '4' && e[1] == 0) ? e[0] - '0' : 3;
+  }();
+  return choice;
+}
+}  // namespace nann
+
+// the pre-projected item half of layer 1 for (scorer, index): built on `st` at the pair's first search
+static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, const float** out) {
+  std::lock_guard<std::mutex> lk(sc->proj_mu);
+  for (auto& p : sc->proj)
+    if (p.table && p.index_uid == ix->uid) { *out = p.table; return NANN_OK; }
+  nann_scorer::Proj& slot = sc->proj[0].table == nullptr ? sc->proj[0] : sc->proj[1];
+  if (slot.table) {  // evict (stream-ordered free would need the owner's stream: synchronise the device once)
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(slot.table);
+    slot.table = nullptr;
+  }
+  float* t = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t), (size_t)ix->desc.n_items * kMlpProjWidth * 4));
+  const int rc = launch_mlp_preproject(ix->desc.emb_dtype, ix->desc.item_embs, (long long)ix->desc.n_items, ix->desc.d, sc->mlp.w1, t, st);
+  if (rc) { (void)hipFree(t); return rc; }
+  // the table becomes visible to searches on OTHER streams when this function returns: it must be complete by then
+  // (a one-time wait per (scorer, index) pair, ~10 ms per million items)
+  {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(t); return fail(NANN_ERR_HIP, std::string("pre-projection: ") + hipGetErrorString(e)); }
+  }
+  if (&slot == &sc->proj[0] && sc->proj[1].table) std::swap(sc->proj[0], sc->proj[1]);  // keep [1] the most recent
+  nann_scorer::Proj& dst = sc->proj[0].table == nullptr ? sc->proj[0] : sc->proj[1];
+  dst.index_uid = ix->uid;
+  dst.table = t;
+  *out = t;
+  return NANN_OK;
+}
+
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
 // nann_mlp_inst.hip (one per embedding dim): the heavy kernels compile in parallel.
 static int launch_search_any(int lpr, int dt, int kind, int split, int vis, int nt, int slots, size_t lds_bytes,
@@ -1804,6 +1854,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
   a.pos_bits = p.pos_bits;
   a.redo = 0;
+  a.proj = nullptr;
   a.mlp = MlpParams{};
   a.attn = AttnParams{};
   a.kt = kt; a.upad = upad;
@@ -1819,8 +1870,16 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
     return launch(ix->desc.d, dt, p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
   }
   a.mlp = scorer->mlp;
+  a.proj = nullptr;
   const int split = kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
-  rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
+  if (split && p.vis == VIS_LDS_HASH && mlp_mapping_choice() >= 3) {
+    // the default form: item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h)
+    rc = mlp_projection(scorer, ix, st, &a.proj);
+    if (rc) return rc;
+    rc = launch_search_mlp_proj(p.slots, p.lds_bytes, a, st);
+  } else {
+    rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
+  }
   if (rc || !hashed) return rc;
   // queries whose visited set could have overflowed the hash set are rerun on the bitmap kernel (its
   // workgroups leave at once when there is none)

@@ -13,12 +13,25 @@
 
 namespace nann {
 
-// NANN_MLP_MAPPING=1 in the environment: run the split-f16 scorer in its first mapping (8 wavefronts x 32 rows) where
-// the second one (nann_mlp2.h) would be chosen -- A/B measurements on one build (tools/gpu_r3.sh), not a product knob
-static bool first_mapping_forced() {
-  static const bool forced = [] { const char* e = std::getenv("NANN_MLP_MAPPING"); return e && e[0] == '1'; }();
-  return forced;
+static bool first_mapping_forced() { return mlp_mapping_choice() == 1; }
+
+#if NANN_MLP_D == 128
+int launch_search_mlp_proj(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  // 512 threads: one 32-row block per wavefront, two wavefronts per SIMD; NANN_MLP_MAPPING=4: the 256-thread form
+  if (mlp_mapping_choice() == 4) return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, kMlp2NT>(slots, lds_bytes, a, st);
+  return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, 512>(slots, lds_bytes, a, st);
 }
+
+int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st) {
+  if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
+  if (d > 256 || d % 4) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256");
+  const unsigned blocks = (unsigned)((n_rows + 31) / 32);
+  if (dt == NANN_F16) hipLaunchKernelGGL((k_mlp_preproject<DT_F16>), dim3(blocks), dim3(256), 0, st, emb, n_rows, d, w1, proj);
+  else hipLaunchKernelGGL((k_mlp_preproject<DT_BF16>), dim3(blocks), dim3(256), 0, st, emb, n_rows, d, w1, proj);
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+#endif
 
 int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int slots, size_t lds_bytes,
                                               const SearchArgs& a, hipStream_t st) {

@@ -7,6 +7,7 @@
 #include "nann_device.h"
 #include "nann_mlp.h"
 #include "nann_mlp2.h"
+#include "nann_mlp3.h"
 #include "nann_attn_kernels.h"
 #include "nann_attn_split.h"
 
@@ -117,6 +118,7 @@ struct SearchArgs {
   int32_t* counters;
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
+  const float* proj;       // kScorerMlpProj: the pre-projected item half of layer 1, f32 [n_items, 256] (nann_mlp3.h)
   AttnParams attn;         // kScorerAttn only
   const float* kt;         //   per-query projected keys f32 [n_queries, 256, 64] (k_attn_prepare)
   const float* upad;       //   per-query padded sequence f32 [n_queries, 64, 64]
@@ -156,6 +158,7 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
 constexpr int kScorerMlpSplit = 2;
 constexpr int kScorerAttn = 3;  // the reference's attention + DNN model (nann_attn.h); "query" = kt / upad of the user
 constexpr int kScorerAttnSplit = 4;  //   the same on the 16-bit MFMA with split operands (nann_attn_split.h)
+constexpr int kScorerMlpProj = 5;    // split-f16 MLP with the item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h)
 constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit; }
 
 // where a query's visited set lives
@@ -182,7 +185,7 @@ constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int base = hash ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
   if (is_attn(SC) && base < kAttnScratch) return kAttnScratch;
-  if (SC == kScorerMlpSplit && base < kMlpSplitScratch) return kMlpSplitScratch;
+  if ((SC == kScorerMlpSplit || SC == kScorerMlpProj) && base < kMlpSplitScratch) return kMlpSplitScratch;
   return base;
 }
 
@@ -209,7 +212,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   __syncthreads();
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
   float mlp_u = 0.0f;              // MLP: thread j's per-query part of hidden unit j, once per query
-  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
+  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit || SC == kScorerMlpProj) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
 
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
@@ -340,7 +343,13 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                              reinterpret_cast<float*>(scratch), sc_out);
       } else {
         // (the phase scratch was reused since the last stage)
-        if constexpr (SC == kScorerMlpSplit && NT == kMlp2NT) {  // second mapping: 4 wavefronts x 64 rows (nann_mlp2.h)
+        if constexpr (SC == kScorerMlpProj) {  // item half of layer 1 pre-projected: gather P rows, layer 2 on the matrix cores
+          static_assert(NT == kMlp2NT || NT == 512, "the pre-projected scorer: 256 threads (two blocks per wavefront) or 512 (one)");
+          Mlp3Scratch* M = reinterpret_cast<Mlp3Scratch*>(scratch);
+          wg_mlp2_stage_setup<NT>(a.mlp, mlp_u, &M->v);
+          if constexpr (NT == 512) wg_score_mlp_proj1(a.mlp, a.proj, a.n_items, sc_ids, sc_n, M, sc_out);
+          else wg_score_mlp_proj(a.mlp, a.proj, a.n_items, sc_ids, sc_n, M, sc_out);
+        } else if constexpr (SC == kScorerMlpSplit && NT == kMlp2NT) {  // second mapping: 4 wavefronts x 64 rows (nann_mlp2.h)
           Mlp2Scratch<LPR * 8>* M = reinterpret_cast<Mlp2Scratch<LPR * 8>*>(scratch);
           wg_mlp2_stage_setup<NT>(a.mlp, mlp_u, &M->v);
           wg_score_mlp_split2<LPR * 8, DT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
@@ -515,6 +524,13 @@ int launch_search_l2_f32(int lpr, int vis, int nt, int slots, size_t lds_bytes, 
 int launch_search_mlp_d64(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d128(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+// the pre-projected form (nann_mlp3.h): ONE instantiation for every d / row dtype (it never reads the embedding table);
+// lives in the d = 128 object.  launch_mlp_preproject fills the table.
+int launch_search_mlp_proj(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
+// which form of the split-f16 MLP the traversal runs: 3 = pre-projected (default), 2 = second mapping, 1 = first
+// (NANN_MLP_MAPPING in the environment: A/B measurements on one build, not a product knob)
+int mlp_mapping_choice();
 // attention-scorer instantiations live in nann_attn_inst.hip: (vis, 512 threads) for vis in
 // {VIS_LDS_HASH (one workgroup per CU), VIS_LDS_BITMAP, VIS_HBM_BITMAP}
 int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);

@@ -97,6 +97,11 @@ for STEP in "$@"; do
     bench_mlp)
       timeout 400 $BENCH --scorer mlp --batch 1024 --steps 5 --warmup 2 --no-secondary --phase-ticks --cpu-seconds 6 > $OUT/bench_mlp_$TAG.json 2> $OUT/bench_mlp_$TAG.err
       show $OUT/bench_mlp_$TAG.json MLP; tail -2 $OUT/bench_mlp_$TAG.err ;;
+    bench_mlp_maps)
+      for M in 2 4; do
+        NANN_MLP_MAPPING=$M timeout 300 $BENCH --scorer mlp --batch 1024 --steps 5 --warmup 2 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_mlp_map${M}_$TAG.json 2> $OUT/bench_mlp_map${M}_$TAG.err
+        show $OUT/bench_mlp_map${M}_$TAG.json "MLP_MAPPING_$M"
+      done ;;
     bench_mlp_ab)
       NANN_MLP_MAPPING=1 timeout 300 $BENCH --scorer mlp --batch 1024 --steps 5 --warmup 2 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_mlp_map1_$TAG.json 2> $OUT/bench_mlp_map1_$TAG.err
       show $OUT/bench_mlp_map1_$TAG.json MLP_FIRST_MAPPING ;;
@@ -119,6 +124,13 @@ for STEP in "$@"; do
       kstats stress -- $BENCH $S --steps 5 --warmup 2
       pmc stress_fetch k_search FETCH_SIZE -- $BENCH $S --steps 3 --warmup 1
       pmc stress_write k_search WRITE_SIZE -- $BENCH $S --steps 3 --warmup 1 ;;
+    prof_4m)
+      S="--items 4000000 --dim 256 --dtype bf16 --ef 256 --batch 2048 --no-secondary"
+      timeout 400 $BENCH $S --steps 5 --warmup 2 --cpu-seconds 6 > $OUT/bench_4m_$TAG.json 2> $OUT/bench_4m_$TAG.err
+      show $OUT/bench_4m_$TAG.json SHARD_4M
+      kstats shard4m -- $BENCH $S --steps 5 --warmup 2 --no-cpu-baseline
+      pmc shard4m_fetch k_search FETCH_SIZE -- $BENCH $S --steps 3 --warmup 1 --no-cpu-baseline
+      pmc shard4m_write k_search WRITE_SIZE -- $BENCH $S --steps 3 --warmup 1 --no-cpu-baseline ;;
     *) echo "unknown step $STEP" ;;
   esac
 done

@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../nann_amd/csrc/nann_mlp2.h"
+#include "../nann_amd/csrc/nann_mlp3.h"
 
 using namespace nann;
 
@@ -24,6 +24,19 @@ __global__ __launch_bounds__(kMlp2NT, 1) void k_var(MlpParams P, const void* tab
   const long long t0 = __builtin_readcyclecounter();
   wg_score_mlp_split2<D, DT_F16, VAR>(P, table, n_rows, ids + (size_t)blockIdx.x * per_block, per_block, S,
                                       scores + (size_t)blockIdx.x * per_block);
+  const long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
+// the pre-projected form (nann_mlp3.h): rows of the f32 [rows, 256] table; `row_mask` bounds the rows touched (a small
+// table stays in L2: instruction-bound time; the full one comes from HBM)
+__global__ __launch_bounds__(kMlp2NT, 1) void k_proj(MlpParams P, const float* proj, uint32_t n_rows, const int32_t* ids,
+                                                    int per_block, const float* qv, float* scores, long long* ticks) {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[sizeof(Mlp3Scratch)];
+  Mlp3Scratch* S = reinterpret_cast<Mlp3Scratch*>(scratch);
+  wg_mlp2_stage_setup<kMlp2NT>(P, wg_mlp_query_u<kMlp2NT>(P, qv), &S->v);
+  const long long t0 = __builtin_readcyclecounter();
+  wg_score_mlp_proj(P, proj, n_rows, ids + (size_t)blockIdx.x * per_block, per_block, S, scores + (size_t)blockIdx.x * per_block);
   const long long t1 = __builtin_readcyclecounter();
   if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
@@ -94,6 +107,28 @@ int main() {
   std::vector<float> q(D);
   for (auto& v : q) v = 0.3f * gauss();
   hipMalloc(&d.q, D * 4); hipMemcpy(d.q, q.data(), D * 4, hipMemcpyHostToDevice);
+  {  // pre-projected form: 1M x 256 f32 table (1 GB), random rows; then rows folded into 4096 (L2-resident)
+    float* proj; hipMalloc(&proj, (size_t)n_tab * 256 * 4);
+    hipMemset(proj, 0, (size_t)n_tab * 256 * 4);
+    int32_t* ids_small; hipMalloc(&ids_small, (size_t)n * 4);
+    std::vector<int32_t> sm(ids); for (auto& v : sm) v &= 4095;
+    hipMemcpy(ids_small, sm.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+    for (int which = 0; which < 2; ++which) {
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e30f;
+      for (int it = 0; it < 4; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_proj, dim3(256), dim3(kMlp2NT), 0, 0, d.P, proj, (uint32_t)n_tab, which ? ids_small : d.ids, passes * 256, d.q, d.scores, d.ticks);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        if (it > 0 && ms < best) best = ms;
+      }
+      long long h[256]; hipMemcpy(h, d.ticks, sizeof(h), hipMemcpyDeviceToHost);
+      double mean = 0; for (int i = 0; i < 256; ++i) mean += (double)h[i]; mean /= 256;
+      printf("pre-projected form, %-44s %.2f us/pass/CU  %.0f ticks/pass  tick rate %.2f GHz\n", which ? "rows from a 4 MB window (L2)" : "rows from the 1 GB table (HBM)",
+             best * 1e3 / passes, mean / passes, mean / (best * 1e6));
+    }
+  }
   run<128, 0>("full", d, passes);
   run<128, 1>("no PReLU / split arithmetic", d, passes);
   run<128, 2>("no weight staging (no fetch / LDS store / barrier)", d, passes);
