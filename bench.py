@@ -284,6 +284,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
             return sharded.merge(r), r, q
         return (r.item_ids, r.scores), r, q
 
+    import gc
+    gc.collect()  # handles of an earlier workload (hipFree of GBs synchronises the device) go now, not inside the timed loop
     for j in range(warmup):
         out, r, q = step(j)
     torch.cuda.synchronize()
@@ -291,13 +293,16 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
+    host_marks = []
     for i in range(steps):
         out, r, q = step(warmup + i, i)
+        host_marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    host_enqueue_ms = [round((b - a) * 1e3, 3) for a, b in zip([t_start] + host_marks[:-1], host_marks)]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -358,6 +363,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     qps = batch * steps / elapsed
     res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
            "batch": batch, "steps": steps, "valid_queries": n_valid, "setup_s": round(setup_s, 1),
+           # host time to ENQUEUE each step (no sync inside the loop): a value near ms_per_step = the host blocked
+           "host_enqueue_ms": host_enqueue_ms[:8],
            "n_enter": int(len(g["enter_points"])),
            "mean_degree_l0": round(float(len(g["nb_values"][0])) / items, 2),
            "traversal": cfg.get("traversal", "auto"), "roofline": roofline,
