@@ -638,7 +638,7 @@ def main():
     if world > 1 and exchange_note:
         result["exchange_note"] = exchange_note
     for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "roofline", "batch_latency_ms",
-              "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown"):
+              "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown", "host_enqueue_ms"):
         if k in prim:
             result[k] = prim[k]
 

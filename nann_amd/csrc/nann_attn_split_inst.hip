@@ -1,6 +1,7 @@
 // nann_attn_split_inst.hip -- kernels of the reference scorer model in its split-f16 form (nann_attn_split.h)
 // and their launchers: per-user packing, the stand-alone scorer, the fused traversal.
 #define NANN_ATTN_SPLIT_TU 1
+#include <algorithm>
 #include "nann_search.h"
 
 namespace nann {
@@ -74,6 +75,26 @@ int launch_search_attn_split(int d, int dt, int vis, int slots, size_t lds_bytes
   if (d == 128 && dt == NANN_F16) return launch_attn_split_vis<128, DT_F16>(vis, slots, lds_bytes, a, st);
   if (d == 128 && dt == NANN_BF16) return launch_attn_split_vis<128, DT_BF16>(vis, slots, lds_bytes, a, st);
   return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d in {64, 128}, rows f16 or bf16");
+}
+
+int launch_search_attn_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  // the scorer never reads the embedding table: the <16, f16> instance serves every d and row dtype
+  if (vis == VIS_LDS_HASH) return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerAttnProj, kAttnNT>(slots, lds_bytes, a, st);
+  if (vis == VIS_LDS_BITMAP || vis == VIS_HBM_BITMAP)
+    return launch_search_bitmap<16, DT_F16, kScorerAttnProj, kAttnNT>(vis, slots, lds_bytes, a, st);
+  return fail(NANN_ERR_UNSUPPORTED, "attention traversal: no kernel for this plan");
+}
+
+int launch_attn_preproject(int dt, const AttnParams& P, const void* emb, long long n_rows, float* proj, hipStream_t st) {
+  if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "attention scorer: rows f16 or bf16");
+  if (P.d <= 0 || P.d > 128) return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d <= 128");
+  const long long steps = (n_rows + 15) / 16;
+  const unsigned blocks = (unsigned)std::min<long long>(steps, 256 * 8);
+  if (blocks == 0) return NANN_OK;
+  if (dt == NANN_F16) hipLaunchKernelGGL((k_attn_preproject<DT_F16>), dim3(blocks), dim3(256), 0, st, P, emb, n_rows, proj);
+  else hipLaunchKernelGGL((k_attn_preproject<DT_BF16>), dim3(blocks), dim3(256), 0, st, P, emb, n_rows, proj);
+  NANN_HIP_TRY(hipGetLastError());
+  return NANN_OK;
 }
 
 }  // namespace nann

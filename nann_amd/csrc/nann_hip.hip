@@ -492,24 +492,31 @@ __global__ __launch_bounds__(256) void k_score_l2(const void* table, long long n
 // ===========================================================================
 // C ABI
 // ===========================================================================
+// The item-only part of a split-f16 scorer, pre-projected for the indices the scorer has searched (nann_mlp3.h: the item
+// half of the MLP's layer 1, f32 [n_items, 256]; nann_attn_proj.h: q_ and the e rows of DNN layer 1, f32 [n_items, 384]):
+// built at the first nann_search of the (scorer, index) pair, at most two kept per scorer (the older one goes).
+struct ProjCache {
+  struct Entry { uint64_t index_uid = 0; float* table = nullptr; };
+  std::mutex mu;
+  Entry e[2];
+  ~ProjCache() { for (auto& x : e) if (x.table) (void)hipFree(x.table); }
+};
+
 struct nann_scorer {
   nann_scorer_desc desc;
   float* dev_weights = nullptr;  // MLP weights block in HBM
   uint4* dev_packed = nullptr;   // split-f16 planes in MFMA A-fragment order
   MlpParams mlp = {};
-  // split-f16 MLP: the item half of layer 1 pre-projected for the indices this scorer has searched (nann_mlp3.h):
-  // f32 [n_items, 256] per index, built at the first nann_search of the pair, at most two kept (the older one goes)
-  struct Proj { uint64_t index_uid = 0; float* table = nullptr; };
-  mutable std::mutex proj_mu;
-  mutable Proj proj[2];
+  mutable ProjCache proj;
 };
 
 struct nann_attn_scorer {
   AttnParams P = {};
   int emb_dtype = 0;
-  int precision = NANN_MLP_EXACT_F32;  // NANN_MLP_SPLIT_F16: the split-f16 kernels (nann_attn_split.h)
+  int precision = NANN_MLP_EXACT_F32;  // NANN_MLP_SPLIT_F16: the split-f16 kernels (nann_attn_split.h, nann_attn_proj.h)
   float* dev_weights = nullptr;
   uint4* dev_packed = nullptr;         // split form: A fragments + pre-scaled vectors
+  mutable ProjCache proj;
 };
 
 struct nann_index {
@@ -1097,7 +1104,6 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
 
 void nann_scorer_destroy(nann_scorer* s) {
   if (!s) return;
-  for (auto& p : s->proj) if (p.table) (void)hipFree(p.table);
   if (s->dev_weights) (void)hipFree(s->dev_weights);
   if (s->dev_packed) (void)hipFree(s->dev_packed);
   delete s;
@@ -1698,7 +1704,10 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     // B = 1 0.196 -> 0.160 ms, B = 64 0.206 -> 0.165 ms; profiles/r3d_*)
     if (hash_vis == VIS_LDS_HASH && kind == NANN_SCORER_L2 && n_queries <= (int64_t)di.cus) hash_vis = VIS_LDS_HASH32;
   }
-  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && pos_bits >= 10;  // 16K slots, one workgroup per CU
+  // attention model / split-f16 MLP: 16K slots, one workgroup per CU -- when the level's visited ids are expected to fit
+  // (a beam too wide for the set would send nearly every query through both kernels)
+  const bool fits16 = worst_visited <= 16320.0 || est_visited <= 11000.0 || mode == NANN_TRAVERSAL_LDS_HASH;
+  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && pos_bits >= 10 && fits16;
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
       !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
     return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards below 4M items; the 32K-slot set: L2 scorer only");
@@ -1763,33 +1772,46 @@ int mlp_mapping_choice() {
 }
 }  // namespace nann
 
-// the pre-projected item half of layer 1 for (scorer, index): built on `st` at the pair's first search
-static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, const float** out) {
-  std::lock_guard<std::mutex> lk(sc->proj_mu);
-  for (auto& p : sc->proj)
+// the pre-projected table of (scorer, index): built on `st` at the pair's first search by `build(table)`
+template <typename Build>
+static int projection_for(ProjCache& c, const nann_index* ix, int width, hipStream_t st, Build build, const float** out) {
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (auto& p : c.e)
     if (p.table && p.index_uid == ix->uid) { *out = p.table; return NANN_OK; }
-  nann_scorer::Proj& slot = sc->proj[0].table == nullptr ? sc->proj[0] : sc->proj[1];
+  ProjCache::Entry& slot = c.e[0].table == nullptr ? c.e[0] : c.e[1];
   if (slot.table) {  // evict (stream-ordered free would need the owner's stream: synchronise the device once)
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(slot.table);
     slot.table = nullptr;
   }
   float* t = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t), (size_t)ix->desc.n_items * kMlpProjWidth * 4));
-  const int rc = launch_mlp_preproject(ix->desc.emb_dtype, ix->desc.item_embs, (long long)ix->desc.n_items, ix->desc.d, sc->mlp.w1, t, st);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t), (size_t)ix->desc.n_items * (size_t)width * 4));
+  const int rc = build(t);
   if (rc) { (void)hipFree(t); return rc; }
   // the table becomes visible to searches on OTHER streams when this function returns: it must be complete by then
-  // (a one-time wait per (scorer, index) pair, ~10 ms per million items)
+  // (a one-time wait per (scorer, index) pair, ~10-20 ms per million items)
   {
     const hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(t); return fail(NANN_ERR_HIP, std::string("pre-projection: ") + hipGetErrorString(e)); }
   }
-  if (&slot == &sc->proj[0] && sc->proj[1].table) std::swap(sc->proj[0], sc->proj[1]);  // keep [1] the most recent
-  nann_scorer::Proj& dst = sc->proj[0].table == nullptr ? sc->proj[0] : sc->proj[1];
+  if (&slot == &c.e[0] && c.e[1].table) std::swap(c.e[0], c.e[1]);  // keep [1] the most recent
+  ProjCache::Entry& dst = c.e[0].table == nullptr ? c.e[0] : c.e[1];
   dst.index_uid = ix->uid;
   dst.table = t;
   *out = t;
   return NANN_OK;
+}
+
+static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, const float** out) {
+  return projection_for(sc->proj, ix, kMlpProjWidth, st, [&](float* t) {
+    return launch_mlp_preproject(ix->desc.emb_dtype, ix->desc.item_embs, (long long)ix->desc.n_items, ix->desc.d, sc->mlp.w1, t, st);
+  }, out);
+}
+
+static int attn_projection(const nann_attn_scorer* sc, const nann_index* ix, hipStream_t st, const float** out) {
+  return projection_for(sc->proj, ix, kAttnProjWidth, st, [&](float* t) {
+    return launch_attn_preproject(ix->desc.emb_dtype, sc->P, ix->desc.item_embs, (long long)ix->desc.n_items, t, st);
+  }, out);
 }
 
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
@@ -1863,6 +1885,15 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   const bool hashed = p.vis == VIS_LDS_HASH || p.vis == VIS_LDS_HASH32;
   if (attn) {
     a.attn = attn->P;
+    if (attn->precision == NANN_MLP_SPLIT_F16 && mlp_mapping_choice() >= 3) {
+      // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
+      rc = attn_projection(attn, ix, st, &a.proj);
+      if (rc) return rc;
+      rc = launch_search_attn_proj(p.vis, p.slots, p.lds_bytes, a, st);
+      if (rc || !hashed) return rc;
+      a.redo = 1;
+      return launch_search_attn_proj(p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
+    }
     auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_split : launch_search_attn;
     rc = launch(ix->desc.d, dt, p.vis, p.slots, p.lds_bytes, a, st);
     if (rc || !hashed) return rc;
@@ -1872,14 +1903,17 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   a.mlp = scorer->mlp;
   a.proj = nullptr;
   const int split = kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
-  if (split && p.vis == VIS_LDS_HASH && mlp_mapping_choice() >= 3) {
-    // the default form: item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h)
+  if (split && mlp_mapping_choice() >= 3) {
+    // the default form: item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h) -- on every plan, so that a
+    // query scores with the same arithmetic whether the hash set held its visited ids or the bitmap kernel reran it
     rc = mlp_projection(scorer, ix, st, &a.proj);
     if (rc) return rc;
-    rc = launch_search_mlp_proj(p.slots, p.lds_bytes, a, st);
-  } else {
-    rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
+    rc = launch_search_mlp_proj(p.vis, p.slots, p.lds_bytes, a, st);
+    if (rc || !hashed) return rc;
+    a.redo = 1;
+    return launch_search_mlp_proj(p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
   }
+  rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
   if (rc || !hashed) return rc;
   // queries whose visited set could have overflowed the hash set are rerun on the bitmap kernel (its
   // workgroups leave at once when there is none)

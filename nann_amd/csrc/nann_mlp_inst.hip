@@ -16,10 +16,16 @@ namespace nann {
 static bool first_mapping_forced() { return mlp_mapping_choice() == 1; }
 
 #if NANN_MLP_D == 128
-int launch_search_mlp_proj(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
-  // 512 threads: one 32-row block per wavefront, two wavefronts per SIMD; NANN_MLP_MAPPING=4: the 256-thread form
-  if (mlp_mapping_choice() == 4) return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, kMlp2NT>(slots, lds_bytes, a, st);
-  return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, 512>(slots, lds_bytes, a, st);
+int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  // 512 threads: one 32-row block per wavefront, two wavefronts per SIMD; NANN_MLP_MAPPING=4: the 256-thread form.
+  // The scorer never reads the embedding table, so the <16, f16> instance serves every d and row dtype.
+  if (vis == VIS_LDS_HASH) {
+    if (mlp_mapping_choice() == 4) return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, kMlp2NT>(slots, lds_bytes, a, st);
+    return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, 512>(slots, lds_bytes, a, st);
+  }
+  // wide beams (the 16K-slot set would overflow), forced bitmap modes, and the rerun of queries the set handed back
+  if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: no kernel for this plan");
+  return launch_search_bitmap<16, DT_F16, kScorerMlpProj, 512>(vis, slots, lds_bytes, a, st);
 }
 
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st) {

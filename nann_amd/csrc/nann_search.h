@@ -10,6 +10,7 @@
 #include "nann_mlp3.h"
 #include "nann_attn_kernels.h"
 #include "nann_attn_split.h"
+#include "nann_attn_proj.h"
 
 #include <string>
 
@@ -118,7 +119,8 @@ struct SearchArgs {
   int32_t* counters;
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
-  const float* proj;       // kScorerMlpProj: the pre-projected item half of layer 1, f32 [n_items, 256] (nann_mlp3.h)
+  const float* proj;       // kScorerMlpProj: the pre-projected item half of layer 1, f32 [n_items, 256] (nann_mlp3.h);
+                           // kScorerAttnProj: the item-only layers of the attention model, f32 [n_items, 384] (nann_attn_proj.h)
   AttnParams attn;         // kScorerAttn only
   const float* kt;         //   per-query projected keys f32 [n_queries, 256, 64] (k_attn_prepare)
   const float* upad;       //   per-query padded sequence f32 [n_queries, 64, 64]
@@ -159,7 +161,8 @@ constexpr int kScorerMlpSplit = 2;
 constexpr int kScorerAttn = 3;  // the reference's attention + DNN model (nann_attn.h); "query" = kt / upad of the user
 constexpr int kScorerAttnSplit = 4;  //   the same on the 16-bit MFMA with split operands (nann_attn_split.h)
 constexpr int kScorerMlpProj = 5;    // split-f16 MLP with the item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h)
-constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit; }
+constexpr int kScorerAttnProj = 6;   // split-f16 attention model with its item-only layers pre-projected per (model, index) (nann_attn_proj.h)
+constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj; }
 
 // where a query's visited set lives
 enum : int {
@@ -341,6 +344,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                              reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
                                              a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
                                              reinterpret_cast<float*>(scratch), sc_out);
+      } else if constexpr (SC == kScorerAttnProj) {
+        wg_score_attn_proj<NT>(a.attn, reinterpret_cast<const uint4*>(a.kt + (size_t)qi * 256 * kAttnLP),
+                               reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
+                               a.proj, (long long)a.n_items, sc_ids, (long long)sc_n,
+                               reinterpret_cast<float*>(scratch), sc_out);
       } else {
         // (the phase scratch was reused since the last stage)
         if constexpr (SC == kScorerMlpProj) {  // item half of layer 1 pre-projected: gather P rows, layer 2 on the matrix cores
@@ -526,7 +534,7 @@ int launch_search_mlp_d128(int dt, int split, int vis, int slots, size_t lds_byt
 int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 // the pre-projected form (nann_mlp3.h): ONE instantiation for every d / row dtype (it never reads the embedding table);
 // lives in the d = 128 object.  launch_mlp_preproject fills the table.
-int launch_search_mlp_proj(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
 // which form of the split-f16 MLP the traversal runs: 3 = pre-projected (default), 2 = second mapping, 1 = first
 // (NANN_MLP_MAPPING in the environment: A/B measurements on one build, not a product knob)
@@ -535,6 +543,10 @@ int mlp_mapping_choice();
 // {VIS_LDS_HASH (one workgroup per CU), VIS_LDS_BITMAP, VIS_HBM_BITMAP}
 int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_attn_split(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);  // nann_attn_split_inst.hip
+// the pre-projected form (nann_attn_proj.h): one instantiation per plan for every d / row dtype (it never reads the
+// embedding table); launch_attn_preproject fills the f32 [n_rows, kAttnProjWidth] table.  nann_attn_split_inst.hip
+int launch_search_attn_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_attn_preproject(int dt, const AttnParams& P, const void* emb, long long n_rows, float* proj, hipStream_t st);
 int launch_score_mlp_d64(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,
                          float* out, OpResult* res);

@@ -483,21 +483,24 @@ def test_search_model_serving_signature(oracle, tmp_path, kind):
     assert kinds.count("diverged") <= 2, kinds
 
 
-def test_search_model_attention_split_f16(oracle, tmp_path):
-    """The serving signature with the attention model in its split-f16 form (precision.txt = split): the fused
-    traversal against the oracle's traversal with the fp32 model, tie-aware at 1e-5; and against the device's
-    own f32 form."""
+@pytest.mark.parametrize("d,mode", [(64, "auto"), (128, "auto"), (128, "hbm_bitmap"), (64, "lds_bitmap")])
+def test_search_model_attention_split_f16(oracle, tmp_path, d, mode):
+    """The serving signature with the attention model in its split-f16 form (precision.txt = split; since round 3 the
+    traversal runs it with the item-only layers pre-projected per (model, index), nann_attn_proj.h, on every plan):
+    the fused traversal against the oracle's traversal with the fp32 model, tie-aware at 1e-5; and against the
+    device's own f32 form."""
     from nann_amd import ops, retrieval, synth
-    d, L, nq = 64, 50, 40
+    L, nq = 50, 40
     g, oix, dix = synth_index(20000, d, 32)
     seqs = queries_for(g, nq, seed=17)
     topn = [32] * 5 + [20]
     w = synth.make_attn_weights(d, 64)
     ops.save_scorer_dir(str(tmp_path / "split"), "attention", w, precision="split")
     ops.save_scorer_dir(str(tmp_path / "exact"), "attention", w, precision="exact")
-    r = retrieval.search_model(dix, ops.Model(str(tmp_path / "split"), d, L), cuda(seqs), topn)
-    r2 = retrieval.search_model(dix, ops.Model(str(tmp_path / "exact"), d, L), cuda(seqs), topn)
-    torch.cuda.synchronize()
+    with traversal_mode(mode):
+        r = retrieval.search_model(dix, ops.Model(str(tmp_path / "split"), d, L), cuda(seqs), topn)
+        r2 = retrieval.search_model(dix, ops.Model(str(tmp_path / "exact"), d, L), cuda(seqs), topn)
+        torch.cuda.synchronize()
     st, idx, sc = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
     osc = oracle.Scorer("attention", d, oracle.EMB_F16, attn_model=oracle.AttnModel(d, 64, L, oracle.EMB_F16, w))
     est, eids, esc, eidx, _ = oracle.search_batch(oix, osc, seqs.astype(np.float32).reshape(nq, -1), topn, n_threads=8)
@@ -505,6 +508,9 @@ def test_search_model_attention_split_f16(oracle, tmp_path):
     assert (st == est).sum() >= nq - 2 and ok.mean() > 0.5
     kinds = [tolerant_parity(idx[b], sc[b], eidx[b], esc[b]) for b in np.nonzero(ok)[0]]
     assert kinds.count("exact") >= 0.8 * len(kinds) and kinds.count("diverged") <= 2, kinds
+    for b in np.nonzero(ok)[0]:  # where the lists agree the logits are the fp32 model's within 1e-5
+        same = idx[b] == eidx[b]
+        assert (np.abs(sc[b][same] - esc[b][same]) <= 1e-5 * np.maximum(1.0, np.abs(esc[b][same]))).all()
     st2, idx2, sc2 = r2.status.cpu().numpy(), r2.index.cpu().numpy(), r2.scores.cpu().numpy()
     both = (st == 0) & (st2 == 0)
     kinds2 = [tolerant_parity(idx[b], sc[b], idx2[b], sc2[b]) for b in np.nonzero(both)[0]]

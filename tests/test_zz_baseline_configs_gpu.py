@@ -250,6 +250,53 @@ def test_config3_real_shard_1m_mlp_split_through_sharded_topk(oracle):
         assert rc == 0 and (mi[b].cpu().numpy() == ei).all() and (bits(ms[b].cpu().numpy()) == bits(es)).all(), b
 
 
+def _assert_within_tolerance(oracle, r, exp, sel, max_diverged=1, min_exact_frac=0.75):
+    """split-f16 scorers: status codes equal, id lists identical or different only where scores tie within 1e-5"""
+    est, eids, esc, eidx, ectr = exp
+    st, gx, gs = r.status.cpu().numpy()[sel], r.index.cpu().numpy()[sel], r.scores.cpu().numpy()[sel]
+    assert (st == est).all(), (st, est)
+    ok = np.nonzero(est == 0)[0]
+    kinds = [oracle.tolerant_parity(gx[b], gs[b], eidx[b], esc[b]) for b in ok]
+    assert kinds.count("diverged") <= max_diverged and kinds.count("exact") >= min_exact_frac * len(kinds), kinds
+    for b in ok:
+        same = gx[b] == eidx[b]
+        assert (np.abs(gs[b][same] - esc[b][same]) <= 1e-5 * np.maximum(1.0, np.abs(esc[b][same]))).all()
+
+
+@pytest.mark.parametrize("items,dim,ef,dtype,mode", [(100_000, 64, 64, "f16", "auto"), (80_000, 256, 64, "bf16", "auto"),
+                                                     (80_000, 256, 64, "bf16", "hbm_bitmap")])
+def test_mlp_split_other_row_shapes(oracle, items, dim, ef, dtype, mode):
+    """The default (split-f16, item half of layer 1 pre-projected) MLP traversal never reads the embedding table, so ONE
+    kernel instance serves every d and row dtype: 64-d f16 and 256-d bf16 rows against the oracle's fp32 chain."""
+    from nann_amd import ops, synth
+    g, oix, dix = _index(items, dim, ef, dtype=dtype)
+    topn = [ef] * 5 + [50]
+    q = _queries(dim, 96, seed=23, items=items, ef=ef)
+    w = synth.make_mlp_weights(dim)
+    tdt, code = (torch.float16, oracle.EMB_F16) if dtype == "f16" else (torch.bfloat16, oracle.EMB_BF16)
+    r = _search(dix, ops.Scorer("mlp", dim, tdt, w, precision="split"), q, topn, mode)
+    assert (r.status.cpu().numpy() == 0).mean() >= 0.95
+    sel = slice(0, 48)
+    exp = oracle.search_batch(oix, oracle.Scorer("mlp", dim, code, w), q[sel].cpu().numpy(), topn, n_threads=16)
+    _assert_within_tolerance(oracle, r, exp, sel, max_diverged=2)
+
+
+def test_config4_shard_shape_mlp_split_wide_beam(oracle):
+    """1.2M x 256-d bf16, ef = 256 with the split-f16 MLP: a level's visited ids do not fit the 16K-slot set, so the planner
+    must go straight to the bitmap kernel (HBM bitmap at this size) with the same pre-projected scorer -- not through
+    the hash-set kernel and its rerun."""
+    from nann_amd import ops, synth
+    g, oix, dix = _index(1_200_000, 256, 256, dtype="bf16")
+    topn = [256] * 5 + [200]
+    q = _queries(256, 96, seed=7, items=1_200_000, ef=256)
+    w = synth.make_mlp_weights(256)
+    r = _search(dix, ops.Scorer("mlp", 256, torch.bfloat16, w, precision="split"), q, topn)
+    _properties(r, g, topn, len(g["enter_points"]))
+    sel = slice(0, 16)
+    exp = oracle.search_batch(oix, oracle.Scorer("mlp", 256, oracle.EMB_BF16, w), q[sel].cpu().numpy(), topn, n_threads=16)
+    _assert_within_tolerance(oracle, r, exp, sel)
+
+
 def test_config4_full_shard_4m_256d_bf16_ef256(oracle):
     """configs[4]'s shard at its own size: 4M x 256-d bf16 (2 GB table, 8x the Infinity Cache), ef = 256, top-200, L2 --
     properties on 2048 queries, the planner's kernel for it (32K-slot hash set, 10 position bits at 22-bit ids) and

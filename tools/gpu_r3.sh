@@ -131,6 +131,23 @@ for STEP in "$@"; do
       kstats shard4m -- $BENCH $S --steps 5 --warmup 2 --no-cpu-baseline
       pmc shard4m_fetch k_search FETCH_SIZE -- $BENCH $S --steps 3 --warmup 1 --no-cpu-baseline
       pmc shard4m_write k_search WRITE_SIZE -- $BENCH $S --steps 3 --warmup 1 --no-cpu-baseline ;;
+    tests_k)  # TESTS_K='<-k expression>' tools/gpu_r3.sh ...
+      timeout 1200 python -m pytest tests -m gpu -q --timeout 600 -k "${TESTS_K:-mlp}" > $OUT/pytest_k_$TAG.log 2>&1
+      tail -4 $OUT/pytest_k_$TAG.log; grep -E "^(E  |FAILED|ERROR)" $OUT/pytest_k_$TAG.log | head -30 ;;
+    bench_mlp_wide)  # split-f16 MLP on config 5's row shape and beam: 1.2M x 256-d bf16, ef=256 (bitmap plan + pre-projected scorer)
+      S="--items 1200000 --dim 256 --dtype bf16 --ef 256 --scorer mlp --batch 1024 --steps 4 --warmup 1 --no-secondary --no-cpu-baseline"
+      timeout 400 $BENCH $S > $OUT/bench_mlp_wide_$TAG.json 2> $OUT/bench_mlp_wide_$TAG.err
+      show $OUT/bench_mlp_wide_$TAG.json MLP_WIDE; tail -2 $OUT/bench_mlp_wide_$TAG.err
+      NANN_MLP_MAPPING=1 timeout 400 $BENCH $S > $OUT/bench_mlp_wide_map1_$TAG.json 2> $OUT/bench_mlp_wide_map1_$TAG.err
+      show $OUT/bench_mlp_wide_map1_$TAG.json MLP_WIDE_FIRST_MAPPING ;;
+    mlp_exact_diag)
+      timeout 300 $BENCH --scorer mlp --mlp-precision exact --batch 1024 --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > $OUT/bench_mlp_exact_$TAG.json 2> $OUT/bench_mlp_exact_$TAG.err
+      show $OUT/bench_mlp_exact_$TAG.json MLP_EXACT
+      python -c "import json;d=json.loads(open('$OUT/bench_mlp_exact_$TAG.json').read().strip().splitlines()[-1]);print('host_enqueue_ms',d.get('host_enqueue_ms'))" ;;
+    bench_attn)
+      timeout 300 python tools/attn_bench.py /tmp/idx 512 1024 > $OUT/bench_attn_$TAG.txt 2> $OUT/bench_attn_$TAG.err
+      NANN_MLP_MAPPING=1 timeout 300 python tools/attn_bench.py /tmp/idx 512 >> $OUT/bench_attn_$TAG.txt 2>> $OUT/bench_attn_$TAG.err
+      cat $OUT/bench_attn_$TAG.txt; tail -2 $OUT/bench_attn_$TAG.err ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
