@@ -10,7 +10,7 @@
 // attention logits: a lane gathers the four 16-byte pieces of its row of T that hold its 16 units of q_ tile t in the
 // C/D layout (the tile arrives where q2's accumulators would have been), splits it and multiplies it with the keys;
 // DNN layer 1 seeds its accumulators with b1 + the row's W1e part and runs the attention half only.
-// Per 32 candidates: 220 MFMAs, 16 slices of at most 16 KB (keys x 8, the sequence, W1a x 4, W2 x 2, W3).
+// Per 32 candidates: 220 MFMAs, 12 slices of at most 16 KB (keys 4 x two tiles, the sequence, W1a x 4, W2 x 2, W3).
 // Scores agree with the f32 form within the same 1e-5 every attention test holds (the table is an f32 chain; what is
 // split into f16 planes afterwards is what the split form splits at the same place).
 #pragma once
@@ -97,7 +97,8 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
                                                    float* slice_f, float* scores) {
   static_assert(NT == 512, "two uint4 per thread per 16 KB slice");
   constexpr int CPP = (NT / 64) * 32;
-  constexpr int S_SEQ = 8, S_W1 = 9, S_W2 = 13, S_W3 = 15, NS = 16;  // slices per pass
+  // slices per pass: the keys travel two tiles per 16 KB slice (one barrier per pair)
+  constexpr int S_SEQ = 4, S_W1 = 5, S_W2 = 9, S_W3 = 11, NS = 12;
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, g = lane >> 5;
   uint4* buf = reinterpret_cast<uint4*>(slice_f);  // [2][1024]
@@ -109,7 +110,7 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
   const float att_scale = (1.0f / sqrtf(256.0f)) / (kAttnWS * kAttnHS);  // model_util.py:89-91, and the operand scales
 
   auto slice_src = [&](int s, int* cnt) -> const uint4* {
-    if (s < S_SEQ) { *cnt = 512; return kt + (size_t)s * 512; }                       // keys for q_ tile s
+    if (s < S_SEQ) { *cnt = 1024; return kt + (size_t)s * 1024; }                     // keys for q_ tiles 2s, 2s + 1
     if (s == S_SEQ) { *cnt = 512; return ua; }                                        // the sequence
     if (s < S_W2) { *cnt = 512; return P.pw1a + (size_t)(s - S_W1) * 512; }           // W1 rows of a, tile m
     if (s < S_W3) { *cnt = 1024; return P.pw2 + (size_t)(s - S_W2) * 1024; }
@@ -122,17 +123,18 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
     pre0 = src[min(tid, cnt - 1)];
     pre1 = src[min(tid + NT, cnt - 1)];
   };
+  // the slices of a pass form a ring: the last step of a pass brings in slice 0 of the next one (the same keys -- one
+  // call scores one user's candidates), so only the first pass waits for its first slice
+  static_assert(NS % 2 == 0, "slice s lives in buffer s & 1 in every pass");
   auto step_begin = [&](int s) -> const uint4* {
-    if (s + 1 < NS) fetch(s + 1);
+    fetch(s + 1 < NS ? s + 1 : 0);
     return buf + (s & 1) * 1024;
   };
   auto step_end = [&](int s) {
-    if (s + 1 < NS) {
-      uint4* nb = buf + ((s + 1) & 1) * 1024;
-      nb[tid] = pre0;
-      nb[tid + NT] = pre1;
-      __syncthreads();
-    }
+    uint4* nb = buf + ((s + 1) & 1) * 1024;
+    nb[tid] = pre0;
+    nb[tid + NT] = pre1;
+    __syncthreads();
   };
   // the lane's 16 values of a 32-unit tile of its row: four runs of 4 consecutive floats (load_tile_vec's pattern)
   auto gather_tile = [&](const float* tile, float4 (&x)[4]) {
@@ -144,19 +146,26 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
     for (int rr = 0; rr < 4; ++rr) { v[4 * rr] = x[rr].x; v[4 * rr + 1] = x[rr].y; v[4 * rr + 2] = x[rr].z; v[4 * rr + 3] = x[rr].w; }
   };
 
+  auto row_id = [&](long long i) -> long long {
+    const long long ic = i < n ? i : n - 1;
+    return indices ? (long long)indices[ic] : ic;
+  };
+  auto row_of = [&](long long rid) -> const float* {
+    return proj + ((rid >= 0 && rid < n_table_rows) ? (size_t)rid : 0u) * kAttnProjWidth;
+  };
+  if (n <= 0) return;
+  float4 qa[4], qb[4];  // q_ tiles in flight: two tiles ahead of their use (four: spills, slower)
+  fetch(0);
+  __syncthreads();  // the caller is done with both buffers
+  buf[tid] = pre0;
+  buf[tid + NT] = pre1;
+  __syncthreads();
+
   for (long long c0 = 0; c0 < n; c0 += CPP) {
     const long long i = c0 + wave * 32 + cand;
-    const long long ic = i < n ? i : n - 1;
-    const long long rid = indices ? (long long)indices[ic] : ic;
-    const float* T = proj + ((rid >= 0 && rid < n_table_rows) ? (size_t)rid : 0u) * kAttnProjWidth;
-    float4 qa[4], qb[4];  // q_ tiles in flight: two tiles ahead of their use
+    const float* T = row_of(row_id(i));
     gather_tile(T, qa);
     gather_tile(T + 32, qb);
-    fetch(0);
-    __syncthreads();  // the previous pass (or the caller) is done with both buffers
-    buf[tid] = pre0;
-    buf[tid + NT] = pre1;
-    __syncthreads();
 
     f32x16 acc;
     // ---- attention logits, q_ tile by q_ tile: att[l] += sum_{j in tile} q_[j] k_l[j]
@@ -165,12 +174,11 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) att[p][r] = 0.0f;
-    auto keys_step = [&](int t, float4 (&x)[4]) {
-      const uint4* A = step_begin(t);
+    auto keys_tile = [&](const uint4* A, float4 (&x)[4], int refill) {  // refill: the tile x holds next, or < 0
       f16x8 qh[2], ql[2];
       as_tile(x, acc);
       split_tile(acc, qh, ql);
-      gather_tile(T + 32 * min(t + 2, 7), x);  // refill: tile t + 2 (the last two refills reload tile 7, unused)
+      if (refill >= 0) gather_tile(T + 32 * refill, x);
       f16x8 K[8];
       load_frags(A, lane, K);
 #pragma unroll
@@ -185,17 +193,18 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int p = 0; p < 2; ++p) att[p] = NANN_MFMA16(K[(p * 2 + q) * 2 + 1], qh[q], att[p]);
-      step_end(t);
     };
 #pragma unroll 1
-    for (int t = 0; t < 8; t += 2) {
-      keys_step(t, qa);
-      keys_step(t + 1, qb);
+    for (int tp = 0; tp < 4; ++tp) {  // tiles 2 tp, 2 tp + 1
+      const uint4* A = step_begin(tp);
+      keys_tile(A, qa, tp < 3 ? 2 * tp + 2 : -1);
+      keys_tile(A + 512, qb, tp < 3 ? 2 * tp + 3 : -1);
+      step_end(tp);
     }
     // the row's part of DNN layer 1: in flight under the softmax
-    float4 de[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) gather_tile(T + 256 + 32 * m, de[m]);
+    float4 dA[4], dB[4];  // tiles 0 and 1 now, 2 and 3 when these have been used
+    gather_tile(T + 256, dA);
+    gather_tile(T + 256 + 32, dB);
     // ---- softmax over the L positions (:93); positions >= L are padding of the layout
     f16x8 ph[2][2], pl[2][2];  // softmax weights x 2^4, split
     {
@@ -255,9 +264,10 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
       float seed[16];
       load_tile_vec(pv + PV_B1 + 32 * m, g, seed);
       f32x16 dv;
-      as_tile(de[m], dv);
+      as_tile((m & 1) ? dB : dA, dv);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = seed[r] + dv[r];
+      if (m < 2) gather_tile(T + 256 + 32 * (m + 2), (m & 1) ? dB : dA);
       f16x8 W[8];
       load_frags(A, lane, W);
 #pragma unroll

@@ -101,16 +101,30 @@ __global__ __launch_bounds__(256) void k_attn_prepare_split(AttnParams P, const 
 }
 #endif  // NANN_ATTN_SPLIT_TU
 
-// hi / lo split of 16 f32 values (x already carries the activation scale) into the two 8-wide B fragments
-// of a finished tile.  hi is cut toward zero (one packed conversion per pair), lo = x - hi is exact in f32.
+// hi / lo split of 16 f32 values (x already carries the activation scale) into the two 8-wide B fragments of a finished
+// tile, 1.5 instructions per value: hi cut toward zero by one packed conversion per pair, lo = f16(x - hi) by ONE
+// v_fma_mix{lo,hi}_f16 per value, which converts its f16 operand itself (nann_mlp2.h prelu_split_pair; the first form,
+// cvt + sub + cvt, cost ~3 per value and twice the registers: 123 -> 8 spilled registers in the traversal kernels).
 __device__ __forceinline__ void split_tile(const f32x16& x, f16x8 (&h)[2], f16x8 (&l)[2]) {
   typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const h2_t hi = __builtin_amdgcn_cvt_pkrtz(x[r], x[r + 1]);
-    const h2_t lo = __builtin_amdgcn_cvt_pkrtz(x[r] - (float)hi[0], x[r + 1] - (float)hi[1]);
-    h[r >> 3][r & 7] = (_Float16)hi[0]; h[r >> 3][(r & 7) + 1] = (_Float16)hi[1];
-    l[r >> 3][r & 7] = (_Float16)lo[0]; l[r >> 3][(r & 7) + 1] = (_Float16)lo[1];
+  for (int q = 0; q < 2; ++q) {
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float x0 = x[8 * q + 2 * k], x1 = x[8 * q + 2 * k + 1];
+      const h2_t hv = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+      hw[k] = __builtin_bit_cast(uint32_t, hv);
+      uint32_t lo;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hw[k]), "v"(x0));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hw[k]), "v"(x1));
+      lw[k] = lo;
+    }
+    uint4 hh, ll;
+    hh.x = hw[0]; hh.y = hw[1]; hh.z = hw[2]; hh.w = hw[3];
+    ll.x = lw[0]; ll.y = lw[1]; ll.z = lw[2]; ll.w = lw[3];
+    h[q] = as_f16x8(hh);
+    l[q] = as_f16x8(ll);
   }
 }
 
