@@ -384,7 +384,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
             "fraction": {n: round(float(tk[:, i].sum() / tot), 4) for i, n in enumerate(_lib.PHASE_NAMES)}}
 
     # ---- checker legs: oracle = test infrastructure, never inside the timed region
-    n_check = min(64, batch)
+    n_check = min(cfg.get("parity_queries", 64), batch)
     if want_parity or want_cpu:
         from oracle import oracle as O
         code = O.EMB_F16 if dtype == "f16" else O.EMB_BF16
@@ -535,8 +535,14 @@ def attention_model_rate(handles, dim, topn, precision, n_users=512):
         if it >= 1:
             ts.append(e0.elapsed_time(e1))
     ms = float(np.median(ts))
-    return {"users": n_users, "precision": precision, "ms": round(ms, 3),
-            "queries_per_s": round(n_users / (ms * 1e-3), 1), "failed": int((r.status != 0).sum())}
+    out = {"users": n_users, "precision": precision, "ms": round(ms, 3),
+           "queries_per_s": round(n_users / (ms * 1e-3), 1), "failed": int((r.status != 0).sum())}
+    if precision == "split":
+        out["form"] = "item-only layers pre-projected per (model, index): nann_attn_proj.h"
+        pmc = load_pmc_counters("attention_model_f2_split")
+        if pmc is not None:
+            out["counters"] = pmc
+    return out
 
 
 def strip(res):
@@ -673,9 +679,18 @@ def main():
         try:  # HBM-honest: config 5's shard shape (256-d bf16, ef=256) at a size whose table is 4x the Infinity Cache
             cfg = {"items": args.stress_items, "dim": 256, "ef": 256, "topk": 200, "batch": 2048, "steps": 5,
                    "warmup": 2, "scorer": "l2", "dtype": "bf16", "graph": "hnsw", "traversal": "auto"}
-            sec["hbm_stress_config5_shape"] = strip(run_workload(
-                f"{args.stress_items}x256bf16_ef256", args, dev, rank, world, cfg, want_cpu=False,
-                want_parity=True, want_recall=False))
+            stress = run_workload(f"{args.stress_items}x256bf16_ef256", args, dev, rank, world, cfg, want_cpu=False,
+                                  want_parity=True, want_recall=False)
+            sec["hbm_stress_config5_shape"] = strip(stress)
+            try:  # the same rows and beam under the MLP scorer: wide beams take the bitmap plan + pre-projected scorer
+                cfg = dict(cfg, scorer="mlp", mlp_precision="split", batch=1024, steps=3, warmup=1,
+                           parity_queries=32, _index=stress["_index"])
+                stress.pop("_handles", None)
+                sec["mlp_config5_shape_split_f16"] = strip(run_workload(
+                    f"{args.stress_items}x256bf16_ef256_mlp_split", args, dev, rank, world, cfg, want_cpu=False,
+                    want_parity=True, want_recall=False))
+            except Exception as e:
+                sec["mlp_config5_shape_split_f16"] = {"error": repr(e)}
         except Exception as e:
             sec["hbm_stress_config5_shape"] = {"error": repr(e)}
         result["secondary"] = sec

@@ -148,6 +148,14 @@ for STEP in "$@"; do
       timeout 300 python tools/attn_bench.py /tmp/idx 512 1024 > $OUT/bench_attn_$TAG.txt 2> $OUT/bench_attn_$TAG.err
       NANN_MLP_MAPPING=1 timeout 300 python tools/attn_bench.py /tmp/idx 512 >> $OUT/bench_attn_$TAG.txt 2>> $OUT/bench_attn_$TAG.err
       cat $OUT/bench_attn_$TAG.txt; tail -2 $OUT/bench_attn_$TAG.err ;;
+    prof_attn)
+      kstats attn -- python $R/tools/attn_bench.py /tmp/idx 512
+      pmc attn_a k_search SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -- python $R/tools/attn_bench.py /tmp/idx 512
+      pmc attn_b k_search GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- python $R/tools/attn_bench.py /tmp/idx 512 ;;
+    phase_4m)
+      S="--items 4000000 --dim 256 --dtype bf16 --ef 256 --batch 2048 --no-secondary --no-cpu-baseline --phase-ticks"
+      timeout 400 $BENCH $S --steps 3 --warmup 1 > $OUT/bench_4m_phase_$TAG.json 2> $OUT/bench_4m_phase_$TAG.err
+      show $OUT/bench_4m_phase_$TAG.json SHARD_4M_PHASES ;;
     *) echo "unknown step $STEP" ;;
   esac
 done

@@ -59,6 +59,19 @@ def main():
                     e[c] = mean
         for t in ("1000000x128f16_ef128_k200_b1024_mlp_hnsw", "1000000x128f16_ef128_k200_b4096_l2_hnsw_mlp_split"):
             out["workloads"].setdefault(t, {}).update(e)
+    # the attention model's fused traversal (tools/attn_bench.py): split-f16 form = the instance with the most MFMAs
+    attn_kernel, most = None, 0.0
+    for (c, k), (mean, n) in rows.get("attn_a", {}).items():
+        if c == "SQ_INSTS_MFMA" and "k_search" in k and ", 6, 512>" in k and mean > most:
+            attn_kernel, most = k, mean
+    if attn_kernel:
+        e = {"kernel": attn_kernel, "kernel_version": note,
+             "workload": "f2: attention + DNN model, split-f16, pre-projected, 512 users on configs[1]'s index"}
+        for g in ("attn_a", "attn_b"):
+            for (c, k), (mean, n) in rows.get(g, {}).items():
+                if k == attn_kernel:
+                    e[c] = mean
+        out["workloads"].setdefault("attention_model_f2_split", {}).update(e)
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         old = json.load(open(path))

@@ -37,6 +37,18 @@ def main():
             r = serving.run_serve_host(d, d, 128, clients=c, seconds=3.0, max_batch=2048, max_wait_us=200, ef=128,
                                        topk=200, lanes=lanes)
             print(json.dumps(r), flush=True)
+        # the model-scoring configs behind the same front end: the 256-128-1 MLP (weights directory, split-f16) and the
+        # reference's attention + DNN model read from a frozen GraphDef, as BlazeXlaOp.graph_def names it
+        from nann_amd import frozen_graph, ops
+        mlp_dir = os.path.join(d, "mlp_model")
+        ops.save_scorer_dir(mlp_dir, "mlp", synth.make_mlp_weights(128), precision="split")
+        pb = os.path.join(d, "frozen_graph.pb")
+        frozen_graph.write_attention_graph(pb, synth.make_attn_weights(128, 64), seq_len=50)
+        for model in (mlp_dir, pb):
+            for lanes, c in ((1, 512), (1, 2048), (2, 2048)):
+                r = serving.run_serve_host(d, d, 128, clients=c, seconds=3.0, max_batch=1024, max_wait_us=200, ef=128,
+                                           topk=200, lanes=lanes, model_dir=model)
+                print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":
