@@ -170,9 +170,10 @@ def test_mlp_split_f16_search_within_tolerance(oracle, mode):
     assert ok.mean() > 0.5
     kinds = [tolerant_parity(idx[b], sc[b], eidx[b], esc[b]) for b in np.nonzero(ok & (st == 0))[0]]
     n_div = kinds.count("diverged")
-    assert (st == est).sum() >= len(st) - n_div - 1
-    assert kinds.count("exact") >= 0.85 * len(kinds), kinds
-    assert n_div <= max(1, len(kinds) // 20), kinds
+    print("split-f16 MLP traversal vs oracle:", {k: kinds.count(k) for k in ("exact", "near-tie", "diverged")})
+    assert (st == est).sum() >= len(st) - n_div
+    assert kinds.count("exact") >= 0.9 * len(kinds), kinds
+    assert n_div <= 1, kinds  # (round 2 allowed 5 %; measured on every plan: none)
     for b in np.nonzero(ok & (st == 0))[0]:
         assert len(set(idx[b].tolist()) & set(eidx[b].tolist())) >= 0.9 * topn[5]
 
