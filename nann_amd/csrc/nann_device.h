@@ -605,9 +605,9 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
 // instead of the 1-bit-per-item bitmap (125 KB at 1M items), so the memory phases of one query
 // overlap the LDS/VALU phases of the other.
 //
-// A slot holds (id << PB) | pos.  pos = 0 marks an id visited before the current piece;
+// A slot holds (tag << 12) | pos.  pos = 0 marks an id visited before the current piece;
 // the copies of an id inside the current piece meet in ONE slot (claimed by CAS on the empty
-// value, joined by id match) and ds_min_u32 leaves the SMALLEST position there -- the copy the
+// value, joined by tag match) and ds_min_u32 leaves the SMALLEST position there -- the copy the
 // reference's serial scan keeps (bitmap_ops.cc:224-232).  After one barrier a position is kept
 // iff its own value survived in its slot, and the keeper resets pos to 0.  The virtual list
 // (CSR rows of the frontier, concatenated) is never staged: thread t owns positions
@@ -619,10 +619,21 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
 // themselves: wave w's j-th ballot IS the keep-mask of positions [j * NT + 64 w, +64).  Two
 // barriers per piece of up to 4095 ids (five per 2048 in wg_filter_chunk), no per-piece table.
 //
-// PB = position bits = min(12, 32 - bits(n_items)): 1M-item shards get pieces of 4095 ids, 4M-item
-// shards 1023.  Capacity: the set must stay below SLOTS - 64 entries; a piece that could
-// exceed it returns -2 and the host reruns that query on the bitmap kernel.
+// Up to 2^20 items the tag IS the id (id << 12 | pos).  Beyond, it is not (rounds 1-2 stored the id anyway: 22-bit ids
+// of a 4M-item shard left 10 position bits, i.e. pieces of 1023 ids -- four times the barriers and latency chains of a
+// 1M-item shard, 34 % of a query at 4M x 256-d; and the tag form costs configs[1] 3 %, so small shards keep the id).  With
+// B = bits(n_items), p = id * odd mod 2^B is a bijection of the id space; its top HB bits are the home slot h0, its
+// low 14 bits t cover the remainder (B - HB <= 14 bits) and drive the probe stride.  An id that settles k steps down
+// its sequence is stored as tag = (t << 6) | k: from (slot, t, k) follow stride(t), h0 = slot - k stride, p, and the
+// id -- the set stays EXACT with 20 tag bits whatever the shard size, and every shard gets 12 position bits.
+// Every copy of an id walks the same sequence and slots are never vacated, so a copy finds its id at the same k.
+// A sequence longer than 62 steps hands the query to the bitmap kernel like a full set (probability ~load^63; step
+// 63 is never stored, so no entry equals the empty value 0xffffffff).
+// Capacity: the set must stay below SLOTS - 64 entries; a piece that could exceed it returns -2 and the host reruns
+// that query on the bitmap kernel.
 constexpr uint32_t kVisEmpty = 0xffffffffu;
+constexpr int kVisPosBits = 12;   // position in the piece + 1 (0 = visited before the piece)
+constexpr int kVisStepBits = 6;   // probe steps an entry may sit from its home slot
 template <int NT, int SLOTS>
 struct ExpandHashScratch {
   static constexpr int PER = 4096 / NT;        // positions per thread and piece
@@ -633,24 +644,43 @@ struct ExpandHashScratch {
   unsigned short maskprefix[kMaskWords];   // rows that start before word w
   unsigned long long kept[64];             // keep-masks of the piece: word j * (NT/64) + wave
   uint32_t wave_tot[2 * kNW];
-  int flags[4];                            // [0] bad id, [1] duplicate in a mark list
+  int flags[4];                            // [0] bad id, [1] duplicate in a mark list, [2] probe sequence too long
 };
 
 // SLOTS = 16384 (64 KB: two 512-thread workgroups per CU) or 32768 (128 KB: one 1024-thread
-// workgroup per CU, for beams whose visited set outgrows the small table)
-template <int SLOTS>
-__device__ __forceinline__ uint32_t vis_hash(int32_t x) {
+// workgroup per CU, for beams whose visited set outgrows the small table).
+// vis_key: home slot h0 and the 14 low bits t of id x's image p in a B-bit id space (HB < B <= HB + 14).  Three
+// bijections of [0, 2^B) in a row -- multiply by an odd constant, fold the high half onto the low half, multiply
+// again -- so that both halves of p depend on every bit of the id.
+constexpr int kVisTagBits = 14;
+constexpr int kVisDirectBits = 32 - kVisPosBits;  // id spaces of up to 20 bits: the entry holds the id itself (rounds 1-2)
+// -> home slot h0 and the entry's high part `hi` (everything but step and position)
+template <int SLOTS, bool TAG>
+__device__ __forceinline__ void vis_key(int32_t x, int id_bits, uint32_t& h0, uint32_t& hi) {
   static_assert(SLOTS == 16384 || SLOTS == 32768, "14 or 15 hash bits");
-  return ((uint32_t)x * 2654435761u) >> (SLOTS == 16384 ? 18 : 17);
+  constexpr int HB = SLOTS == 16384 ? 14 : 15;
+  if constexpr (!TAG) {
+    h0 = ((uint32_t)x * 2654435761u) >> (32 - HB);
+    hi = (uint32_t)x << kVisPosBits;
+    return;
+  }
+  const uint32_t mask = (1u << id_bits) - 1u;
+  uint32_t p = ((uint32_t)x * 2654435761u) & mask;
+  p ^= p >> (id_bits >> 1);
+  p = (p * 0x85ebca6bu) & mask;
+  h0 = p >> (id_bits - HB);
+  hi = (p & ((1u << kVisTagBits) - 1u)) << (kVisStepBits + kVisPosBits);
 }
-// Double hashing: the probe sequence of id x is h, h + s, h + 2s, ... with an odd stride s(x) (odd:
+// Double hashing: the probe sequence of an id is h0, h0 + s, h0 + 2s, ... with an odd stride s(t) (odd:
 // the sequence visits every slot of the power-of-two table).  A wavefront probes until its SLOWEST
 // lane is done, i.e. for the longest of 512 probe sequences; with linear probing that tail is the
-// longest cluster (measured: 14 k cycles per 4095-id piece), with a per-id stride it is ~log(512) /
-// log(1 / load) steps.  Every copy of an id walks the same sequence, which is all the set needs.
+// longest cluster (measured: 14 k cycles per 4095-id piece), with 2^13 strides it is ~log(512) / log(1 / load)
+// steps.  The stride may only depend on bits the slot stores -- that is what lets (slot, tag) name the id --, and
+// it needs all 14 of them: strides from the 6 remainder bits of a 1M-item shard (64 strides) or key-independent
+// triangular steps cluster (measured at configs[1]: insert 69 k -> 98 k / 111 k cycles per query).
 template <int SLOTS>
-__device__ __forceinline__ uint32_t vis_stride(int32_t x) {
-  return (((uint32_t)x * 0x85ebca6bu) >> (SLOTS == 16384 ? 18 : 17)) | 1u;
+__device__ __forceinline__ uint32_t vis_stride(uint32_t t) {  // t = the entry's id (direct) or its 14 stored bits
+  return ((t * 0x85ebca6bu) >> (SLOTS == 16384 ? 18 : 17)) | 1u;
 }
 
 template <int SLOTS>
@@ -663,26 +693,34 @@ __device__ __forceinline__ void wg_vis_clear(uint32_t* vis) {
 // The "mark" calls (build_opt_graph.py:119-120,132-133) on the hash set: the list is a TopKV2 output
 // over distinct nodes and the set is empty, so BitmapRefDifference returns the list unchanged and
 // every id goes in with position 0 ("visited before").  One CAS per probe step.  Returns n, or -1
-// on an out-of-range id, or -4 if an id occurs twice (premise violated: the caller clears the set
-// and runs the ordered filter instead).  All NT threads; ends with barriers.
+// on an out-of-range id, -2 when a probe sequence is too long for its tag (the bitmap kernel reruns the query),
+// or -4 if an id occurs twice (premise violated: the caller clears the set and runs the ordered
+// filter instead).  All NT threads; ends with barriers.
 template <int NT, int SLOTS>
 __device__ __forceinline__ int wg_mark_hash(const int32_t* list, int n, uint32_t n_items, uint32_t* vis,
-                                            int pos_bits, int32_t* out, unsigned char* scratch) {
+                                            int id_bits, int32_t* out, unsigned char* scratch) {
   auto* S = reinterpret_cast<ExpandHashScratch<NT, SLOTS>*>(scratch);
   const int tid = local_tid();
-  if (tid < 2) S->flags[tid] = 0;
+  if (tid < 3) S->flags[tid] = 0;
   __syncthreads();
+  constexpr uint32_t kStepOne = 1u << kVisPosBits, kStepEnd = ((1u << kVisStepBits) - 2u) << kVisPosBits;
+  const bool direct = id_bits <= kVisDirectBits;  // uniform
+  const uint32_t step_inc = direct ? 0u : kStepOne;
+  const int tag_shift = direct ? kVisPosBits : kVisStepBits + kVisPosBits;
   for (int i = tid; i < n; i += NT) {
     const int32_t id = list[i];
     if ((uint32_t)id < n_items) {
-      const uint32_t val = (uint32_t)id << pos_bits;
-      uint32_t h = vis_hash<SLOTS>(id);
-      const uint32_t step = vis_stride<SLOTS>(id);
+      uint32_t h, val;
+      if (direct) vis_key<SLOTS, false>(id, id_bits, h, val);
+      else vis_key<SLOTS, true>(id, id_bits, h, val);
+      const uint32_t step = vis_stride<SLOTS>(val >> tag_shift);
       for (;;) {
         const uint32_t c = atomicCAS(&vis[h], kVisEmpty, val);
         if (c == kVisEmpty) break;
-        if ((c >> pos_bits) == (uint32_t)id) { S->flags[1] = 1; break; }
+        if ((c ^ val) < kStepOne) { S->flags[1] = 1; break; }
+        if (step_inc && (val & kStepEnd) == kStepEnd) { S->flags[2] = 1; break; }
         h = (h + step) & (SLOTS - 1);
+        val += step_inc;
       }
       out[i] = id;
     } else {
@@ -690,19 +728,19 @@ __device__ __forceinline__ int wg_mark_hash(const int32_t* list, int n, uint32_t
     }
   }
   __syncthreads();
-  const int bad = S->flags[0], dup = S->flags[1];
+  const int bad = S->flags[0], dup = S->flags[1], far = S->flags[2];
   __syncthreads();
-  return bad ? -1 : dup ? -4 : n;
+  return bad ? -1 : far ? -2 : dup ? -4 : n;
 }
 
 // All NT threads.  Contract as wg_expand_walk; vis_count (uniform, in/out) = ids in the set.
 // Returns ids kept (appended to out[0..)), -1 on an out-of-range id, -2 when the set could overflow
 // (or the round's list is longer than the start-bit mask).
-template <int NT, int SLOTS>
-__device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_frontier,
+template <int NT, int SLOTS, bool TAG>
+__device__ __forceinline__ int wg_expand_hash_impl(const int32_t* frontier, int n_frontier,
                                               const int32_t* __restrict__ values,
                                               const int64_t* __restrict__ row_splits, uint32_t n_items,
-                                              uint32_t* vis, int pos_bits, int& vis_count, int32_t* out,
+                                              uint32_t* vis, int id_bits, int& vis_count, int32_t* out,
                                               unsigned char* scratch, int* gathered, SubTimer pt) {
   using Scratch = ExpandHashScratch<NT, SLOTS>;
   constexpr int PER = Scratch::PER;
@@ -784,8 +822,12 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
   }
   pt.sub(PH_EX_PASS1, tsub);
   // ---- pass 2: pieces of PL positions; the ids of piece c+1 are fetched underneath piece c
-  const int PL = min((1 << pos_bits) - 1, NT * PER - 1);
-  const uint32_t pmask = (1u << pos_bits) - 1u;
+  constexpr int PL = NT * PER - 1;  // 4095 positions (+1: 12 bits)
+  static_assert(PL < (1 << kVisPosBits), "a piece's positions fit the position field");
+  constexpr uint32_t pmask = (1u << kVisPosBits) - 1u;
+  constexpr uint32_t kStepOne = 1u << kVisPosBits;
+  constexpr uint32_t step_inc = TAG ? kStepOne : 0u;  // !TAG: the entry holds the id itself, no step field
+  constexpr int tag_shift = TAG ? kVisStepBits + kVisPosBits : kVisPosBits;
   auto fetch = [&](int c0, int n_c, int32_t (&xx)[PER]) {
     uint32_t src[PER];
 #pragma unroll
@@ -811,9 +853,9 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
     long long tw = pt.now();
     if (c0 + PL < G) fetch(c0 + PL, min(PL, G - c0 - PL), xn);
     pt.sub(PH_EX_LOOKUP, tw);
-    // 1. test-and-insert: (id << PB) | (position in piece + 1).  One CAS per probe step: an empty
-    //    slot is claimed, a slot of the same id is joined with ds_min (the smallest position of an
-    //    id stays), anything else sends the lane to the next slot.
+    // 1. test-and-insert: (tag << 12) | (position in piece + 1), tag = (t << 6) | probe step.  One CAS per
+    //    probe step: an empty slot is claimed, a slot with the same tag (= the same id) is joined with ds_min (the
+    //    smallest position of an id stays), anything else sends the lane to the next slot of its sequence.
     uint32_t val[PER], h[PER];
     bool act[PER], in_set[PER];
 #pragma unroll
@@ -822,12 +864,13 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
       const bool inr = (uint32_t)x[j] < n_items;
       bad |= valid && !inr;
       act[j] = in_set[j] = valid && inr;
-      val[j] = ((uint32_t)x[j] << pos_bits) | (uint32_t)(j * NT + tid + 1);
-      h[j] = vis_hash<SLOTS>(x[j]);
+      uint32_t hi;
+      vis_key<SLOTS, TAG>(x[j], id_bits, h[j], hi);
+      val[j] = hi | (uint32_t)(j * NT + tid + 1);
     }
     if (pt.on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pt.sub(PH_EX_LOAD, tw);
-    for (;;) {
+    for (int it = 0;; ++it) {
       uint32_t c[PER];
 #pragma unroll
       for (int j = 0; j < PER; ++j) c[j] = act[j] ? atomicCAS(&vis[h[j]], kVisEmpty, val[j]) : 0u;
@@ -837,16 +880,24 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
         if (act[j]) {
           if (c[j] == kVisEmpty) {
             act[j] = false;  // claimed the slot
-          } else if ((c[j] >> pos_bits) == (uint32_t)x[j]) {
+          } else if ((c[j] >> kVisPosBits) == (val[j] >> kVisPosBits)) {  // the same tag: the same id
             atomicMin(&vis[h[j]], val[j]);
             act[j] = false;
           } else {
-            h[j] = (h[j] + vis_stride<SLOTS>(x[j])) & (SLOTS - 1);
+            h[j] = (h[j] + vis_stride<SLOTS>(TAG ? val[j] >> tag_shift : (uint32_t)x[j])) & (SLOTS - 1);
+            if constexpr (TAG) val[j] += step_inc;
             any = true;
           }
         }
       }
       if (__ballot(any) == 0ull) break;
+      if constexpr (TAG) {
+        // every probing lane is `it + 1` steps from home: at 62 its tag cannot name the next slot (uniform test)
+        if (it + 1 == (1 << kVisStepBits) - 2) {
+          if (any) S->flags[2] = 1;
+          break;
+        }
+      }
     }
     pt.sub(PH_EX_INSERT, tw);
     __syncthreads();
@@ -861,6 +912,9 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
       if (lane == 0) S->kept[j * NWV + wave] = km[j];
     }
     __syncthreads();
+    // a probe sequence outran its tag: the piece's result is void, the bitmap kernel reruns the query (uniform: the flag
+    // is only set before the barrier above; read here, behind the check's own LDS traffic, not on the barrier's heels)
+    if (TAG && S->flags[2]) return -2;
     pt.sub(PH_EX_CHECK, tw);
     // 3. ordered compaction: exclusive prefix over the 64 mask words (every wavefront on its own)
     const uint32_t cnt = (uint32_t)popc64(S->kept[lane]);
@@ -884,6 +938,19 @@ __device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_fro
   const int any_bad = S->flags[0];
   __syncthreads();
   return any_bad ? -1 : base;
+}
+
+template <int NT, int SLOTS>
+__device__ __forceinline__ int wg_expand_hash(const int32_t* frontier, int n_frontier,
+                                              const int32_t* __restrict__ values,
+                                              const int64_t* __restrict__ row_splits, uint32_t n_items,
+                                              uint32_t* vis, int id_bits, int& vis_count, int32_t* out,
+                                              unsigned char* scratch, int* gathered, SubTimer pt) {
+  if (id_bits <= kVisDirectBits)  // uniform: entries hold the id (two loop bodies: the tag form costs configs[1] 2 %)
+    return wg_expand_hash_impl<NT, SLOTS, false>(frontier, n_frontier, values, row_splits, n_items, vis, id_bits,
+                                                 vis_count, out, scratch, gathered, pt);
+  return wg_expand_hash_impl<NT, SLOTS, true>(frontier, n_frontier, values, row_splits, n_items, vis, id_bits,
+                                              vis_count, out, scratch, gathered, pt);
 }
 
 // ---------------------------------------------------------------------------

@@ -1684,14 +1684,17 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // gathered ids are new.  16K slots (two queries per CU) when that estimate leaves headroom, 32K
   // slots (one query per CU) for wider beams; beyond that the bitmap.  A wrong guess costs speed,
   // not correctness: overflowing queries are rerun on the bitmap kernel.
-  const int pos_bits = std::min(12, 32 - bit_length((uint64_t)ix->desc.n_items));
+  // set entries are (remainder, probe step) tags cut from a bijection of the id space (nann_device.h, vis_key): any
+  // shard up to 2^27 items gets 12 position bits (rounds 1-2 stored the id: 10 position bits at 4M items)
+  const int id_bits = std::max(16, bit_length((uint64_t)std::max<int64_t>(ix->desc.n_items - 1, 1)));
+  const bool tag_fits = id_bits <= 27;
   const double mean_deg0 = (double)ix->desc.nb_nnz[0] / (double)std::max<int64_t>(ix->desc.n_items, 1);
   const double walk_deg = std::min<double>((double)ix->max_deg[0], 2.75 * mean_deg0);
   const double est_visited = t[1] + 0.45 * walk_deg * ((double)t[1] + t[2] + t[3]);
   const double worst_visited = t[1] + (double)ix->max_deg[0] * ((double)t[1] + t[2] + t[3]);
   const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512, 16384>() + tail;
   const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT, 32768>() + tail;
-  const bool hash_ok = (kind == NANN_SCORER_L2 || kind < 0) && pos_bits >= 10 && 2 * hash16_lds <= di.lds_max &&
+  const bool hash_ok = (kind == NANN_SCORER_L2 || kind < 0) && tag_fits && 2 * hash16_lds <= di.lds_max &&
                        hash32_lds <= di.lds_max;
   int hash_vis = -1;
   if (mode == NANN_TRAVERSAL_LDS_HASH) hash_vis = VIS_LDS_HASH;
@@ -1707,13 +1710,13 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // attention model / split-f16 MLP: 16K slots, one workgroup per CU -- when the level's visited ids are expected to fit
   // (a beam too wide for the set would send nearly every query through both kernels)
   const bool fits16 = worst_visited <= 16320.0 || est_visited <= 11000.0 || mode == NANN_TRAVERSAL_LDS_HASH;
-  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && pos_bits >= 10 && fits16;
+  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && tag_fits && fits16;
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
       !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
     return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards below 4M items; the 32K-slot set: L2 scorer only");
   unsigned long long off[8];
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u, off);
-  p->pos_bits = pos_bits;
+  p->id_bits = id_bits;
   p->fb_vis = bm_vis;
   p->fb_lds_bytes = bm_lds;
   p->fb_slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * bm_per_cu));
@@ -1874,7 +1877,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index;
   a.status = status; a.counters = counters;
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
-  a.pos_bits = p.pos_bits;
+  a.id_bits = p.id_bits;
   a.redo = 0;
   a.proj = nullptr;
   a.mlp = MlpParams{};

@@ -124,7 +124,7 @@ struct SearchArgs {
   AttnParams attn;         // kScorerAttn only
   const float* kt;         //   per-query projected keys f32 [n_queries, 256, 64] (k_attn_prepare)
   const float* upad;       //   per-query padded sequence f32 [n_queries, 64, 64]
-  int pos_bits;            // VIS_LDS_HASH: position bits of a set entry
+  int id_bits;             // VIS_LDS_HASH*: bits of the shard's id space (set entries are (remainder, step) tags: vis_key)
   int redo;                // 1: fallback launch, only queries with status NANN_ERR_CAPACITY
 };
 
@@ -293,12 +293,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                              scratch, &gathered, ss == 0 ? no_timer() : pt);
         } else {
           if (ss == 0) {  // distinct ids into an empty set: one CAS each; a duplicate redoes it in order
-            kept = wg_mark_hash<NT, SLOTS>(src, n_in, a.n_items, bm, a.pos_bits, dst, scratch);
+            kept = wg_mark_hash<NT, SLOTS>(src, n_in, a.n_items, bm, a.id_bits, dst, scratch);
             if (kept == -4) { wg_vis_clear<SLOTS>(bm); __syncthreads(); kept = -3; }
             else if (kept >= 0) vis_count = kept;
           }
           if (kept == -3)
-            kept = wg_expand_hash<NT, SLOTS>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, a.pos_bits,
+            kept = wg_expand_hash<NT, SLOTS>(ss == 0 ? nullptr : frontier, n_in, src, rs, a.n_items, bm, a.id_bits,
                                              vis_count, dst, scratch, &gathered, ss == 0 ? no_timer() : pt);
         }
         mark(ss == 0 ? PH_WALK : PH_EXPAND);
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
 struct SearchPlan {
   int max_cand, max_raw, pool_cap;
   int vis;             // VIS_*
-  int pos_bits;        // VIS_LDS_HASH: position bits of a set entry
+  int id_bits;         // VIS_LDS_HASH*: bits of the id space the set's tags are cut from
   size_t lds_bytes;
   unsigned long long slot_bytes;
   int slots;

@@ -167,22 +167,49 @@ def test_min_subtraction_spreads_the_leading_digit():
 # ---- wg_expand_hash: the visited set as a positional open-addressing table ---------------------
 class PosHashSet:
     """Model of the LDS table: every LDS operation of an insert (read, CAS, min) is one atomic step;
-    the inserts of a piece are interleaved at that granularity in random order."""
+    the inserts of a piece are interleaved at that granularity in random order.
 
-    def __init__(self, slots, pos_bits):
+    A slot holds (tag << pos_bits) | pos with tag = (remainder << step_bits) | probe step (nann_device.h, vis_key):
+    a bijection p of the id space (odd multiply, fold, odd multiply), its top bits the home slot, its low 14 bits
+    stored (they cover the remainder and drive the probe stride) -- so (slot, tag) names exactly one id (`decode`)."""
+    ODD, ODD2 = 2654435761, 0x85EBCA6B
+
+    def __init__(self, slots, pos_bits, id_bits, step_bits=6, tag_bits=14):
         self.v = [EMPTY] * slots
-        self.slots, self.pb = slots, pos_bits
+        self.slots, self.pb, self.ib, self.sb, self.tb = slots, pos_bits, id_bits, step_bits, tag_bits
+        self.hb = slots.bit_length() - 1
+        assert self.hb < self.ib <= self.hb + tag_bits and tag_bits + step_bits + pos_bits <= 32
 
-    def hash(self, x):
-        return ((x * 2654435761) & 0xFFFFFFFF) % self.slots
+    def key(self, x):
+        m = (1 << self.ib) - 1
+        p = (x * self.ODD) & m
+        p ^= p >> (self.ib >> 1)
+        p = (p * self.ODD2) & m
+        return p >> (self.ib - self.hb), p & ((1 << self.tb) - 1)
 
-    def stride(self, x):  # odd: the probe sequence h, h + s, h + 2s, ... visits every slot of the 2^n table
-        return (((x * 0x85EBCA6B) & 0xFFFFFFFF) % self.slots) | 1
+    def stride(self, t):  # odd: the probe sequence h, h + s, h + 2s, ... visits every slot of the 2^n table
+        return (((t * 0x85EBCA6B) & 0xFFFFFFFF) >> (32 - self.hb)) | 1
+
+    def decode(self, slot, value):
+        """the id an entry stands for: undo the probe steps (the stride is a function of stored bits), then the
+        three bijections"""
+        tag = value >> self.pb
+        tt, k = tag >> self.sb, tag & ((1 << self.sb) - 1)
+        h0 = (slot - k * self.stride(tt)) % self.slots
+        m = (1 << self.ib) - 1
+        rb = self.ib - self.hb
+        p = (((h0 << rb) | (tt & ((1 << rb) - 1))) * pow(self.ODD2, -1, 1 << self.ib)) & m
+        q, sh = p, self.ib >> 1
+        for _ in range(4):                                    # y = x ^ (x >> sh)  ->  x
+            q = p ^ (q >> sh)
+        return (q * pow(self.ODD, -1, 1 << self.ib)) & m
 
     def insert_steps(self, x, pos, slot_out, key):
-        val = (x << self.pb) | pos
-        h = self.hash(x)
+        h, r = self.key(x)
+        st = self.stride(r)
+        k = 0
         while True:
+            val = (((r << self.sb) | k) << self.pb) | pos
             cur = self.v[h]                                   # ds_read
             yield
             if cur == EMPTY:
@@ -190,13 +217,15 @@ class PosHashSet:
                 if cur == EMPTY:
                     self.v[h] = val
                 yield
-            if cur == EMPTY or (cur >> self.pb) == x:
+            if cur == EMPTY or (cur >> self.pb) == (val >> self.pb):
                 if cur != EMPTY:
                     self.v[h] = min(self.v[h], val)           # ds_min_u32
                     yield
-                slot_out[key] = h
+                slot_out[key] = (h, val)
                 return
-            h = (h + self.stride(x)) % self.slots
+            assert k + 2 < (1 << self.sb), "probe sequence longer than the tag can name (the kernel hands the query back)"
+            h = (h + st) % self.slots
+            k += 1
 
     def filter_piece(self, xs, rng):
         """One piece (len(xs) <= 2^pb - 1): insert all, barrier, keep iff own value survived; the
@@ -212,21 +241,21 @@ class PosHashSet:
                 live.remove(i)
         keep = []
         for p in rng.permutation(len(xs)):                    # check + reset race freely after the barrier
-            val = (int(xs[p]) << self.pb) | (p + 1)
-            if self.v[slot[p]] == val:
-                self.v[slot[p]] = val & ~((1 << self.pb) - 1)
+            h, val = slot[p]
+            if self.v[h] == val:
+                self.v[h] = val & ~((1 << self.pb) - 1)
                 keep.append(p)
         return [int(xs[p]) for p in sorted(keep)]             # ordered compaction by position
 
 
-@pytest.mark.parametrize("pos_bits,slots", [(12, 16384), (6, 128)])
-def test_positional_hash_set_equals_serial_scan(pos_bits, slots):
+@pytest.mark.parametrize("pos_bits,slots,id_bits", [(12, 16384, 21), (12, 16384, 22), (12, 32768, 27), (6, 128, 12)])
+def test_positional_hash_set_equals_serial_scan(pos_bits, slots, id_bits):
     rng = np.random.default_rng(21)
     piece = (1 << pos_bits) - 1
-    for trial in range(60 if pos_bits == 6 else 12):
-        hi = int(rng.choice([8, 40, 3000, 1_000_000]))
-        hi = min(hi, 1 << (32 - pos_bits))
-        table, visited, expect_all, got_all = PosHashSet(slots, pos_bits), set(), [], []
+    for trial in range(60 if pos_bits == 6 else 8):
+        hi = int(rng.choice([8, 40, 3000, 1_000_000, 1 << 27]))
+        hi = min(hi, 1 << id_bits)
+        table, visited, expect_all, got_all = PosHashSet(slots, pos_bits, id_bits, tag_bits=14 if slots > 128 else 8), set(), [], []
         cap = slots - 64 if slots > 128 else slots // 2
         for _ in range(int(rng.integers(1, 5))):              # several pieces (rounds) against one set
             n = int(rng.integers(1, piece + 1))
@@ -236,6 +265,19 @@ def test_positional_hash_set_equals_serial_scan(pos_bits, slots):
             expect_all += serial_scan(xs, visited)
             got_all += table.filter_piece(xs, rng)
         assert got_all == expect_all
-        stored = [v >> pos_bits for v in table.v if v != EMPTY]
-        assert sorted(stored) == sorted(visited)               # every id once, position fields reset
+        stored = [table.decode(i, v) for i, v in enumerate(table.v) if v != EMPTY]
+        assert sorted(stored) == sorted(visited)               # every id once (decoded from slot + tag), positions reset
         assert all((v & ((1 << pos_bits) - 1)) == 0 for v in table.v if v != EMPTY)
+
+
+def test_hash_set_tag_is_a_bijection():
+    """(home slot, remainder) <-> id for every id of a small id space, and distinct strides keep sequences apart."""
+    t = PosHashSet(128, 6, 12, tag_bits=8)
+    seen = set()
+    for x in range(1 << 12):
+        h, r = t.key(x)
+        assert (h, r) not in seen
+        seen.add((h, r))
+        for k in (0, 1, 5, 62):
+            slot = (h + k * t.stride(r)) % t.slots
+            assert t.decode(slot, (((r << t.sb) | k) << t.pb) | 3) == x
