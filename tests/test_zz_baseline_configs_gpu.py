@@ -299,7 +299,7 @@ def test_config4_shard_shape_mlp_split_wide_beam(oracle):
 
 def test_config4_full_shard_4m_256d_bf16_ef256(oracle):
     """configs[4]'s shard at its own size: 4M x 256-d bf16 (2 GB table, 8x the Infinity Cache), ef = 256, top-200, L2 --
-    properties on 2048 queries, the planner's kernel for it (32K-slot hash set, 10 position bits at 22-bit ids) and
+    properties on 2048 queries, the planner's kernel for it (32K-slot hash set with (stored bits, step) tags: 22-bit ids) and
     an oracle-exact sample; collected last: the host-side builder takes a few minutes for this graph."""
     from nann_amd import ops
     g, oix, dix = _index(4_000_000, 256, 256, dtype="bf16")
