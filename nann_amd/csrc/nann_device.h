@@ -870,25 +870,25 @@ __device__ __forceinline__ int wg_expand_hash_impl(const int32_t* frontier, int 
     }
     if (pt.on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pt.sub(PH_EX_LOAD, tw);
+    // (The loop is written as selects around ONE predicated ds_min: as an if / else-if / else chain the compiler
+    //  nests three exec-mask regions with branches per id -- ~45 instructions each, 8 ids per lane and step -- and the
+    //  insert phase is bound by that, not by the LDS: `profiles/r4d_*`.)
     for (int it = 0;; ++it) {
       uint32_t c[PER];
 #pragma unroll
-      for (int j = 0; j < PER; ++j) c[j] = act[j] ? atomicCAS(&vis[h[j]], kVisEmpty, val[j]) : 0u;
+      for (int j = 0; j < PER; ++j) c[j] = act[j] ? atomicCAS(&vis[h[j]], kVisEmpty, val[j]) : kVisEmpty;
       bool any = false;
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
-        if (act[j]) {
-          if (c[j] == kVisEmpty) {
-            act[j] = false;  // claimed the slot
-          } else if ((c[j] >> kVisPosBits) == (val[j] >> kVisPosBits)) {  // the same tag: the same id
-            atomicMin(&vis[h[j]], val[j]);
-            act[j] = false;
-          } else {
-            h[j] = (h[j] + vis_stride<SLOTS>(TAG ? val[j] >> tag_shift : (uint32_t)x[j])) & (SLOTS - 1);
-            if constexpr (TAG) val[j] += step_inc;
-            any = true;
-          }
-        }
+        const bool occupied = c[j] != kVisEmpty;  // (an idle lane and a lane that just claimed its slot: false)
+        const bool same = (c[j] >> kVisPosBits) == (val[j] >> kVisPosBits);  // the same tag: the same id
+        if (occupied && same) atomicMin(&vis[h[j]], val[j]);
+        const bool adv = occupied && !same;
+        const uint32_t hn = (h[j] + vis_stride<SLOTS>(TAG ? val[j] >> tag_shift : (uint32_t)x[j])) & (SLOTS - 1);
+        h[j] = adv ? hn : h[j];
+        if constexpr (TAG) val[j] += adv ? step_inc : 0u;
+        act[j] = adv;
+        any |= adv;
       }
       if (__ballot(any) == 0ull) break;
       if constexpr (TAG) {
