@@ -274,13 +274,14 @@ int nann_index_info(const nann_index* ix, int64_t out[6]);
 
 #define NANN_NUM_ROUNDS 5
 /* Where a query's visited set lives (the reference: a TemporaryVariable bitmap of N/32 words,
- * build_opt_graph.py:115-118).  AUTO picks per call: L2 scorer and shards below 4M items ->
- * an exact hash set of visited ids in LDS -- LDS_HASH (16K slots, 64 KB, two queries per CU) or,
- * for beams whose visited set is expected to outgrow it, LDS_HASH32 (32K slots, one query per
- * CU); a query whose set could overflow is rerun on a bitmap kernel inside the same call.
- * Otherwise LDS_BITMAP when ceil(N/32) words fit the CU's LDS next to the phase buffers
- * (N <= ~1.07M), else HBM_BITMAP.  Results are identical in every mode (tested); the knob exists
- * for tests and tuning.  Process-wide, thread-safe. */
+ * build_opt_graph.py:115-118).  AUTO picks per call: shards of up to 2^27 items -> an exact hash
+ * set of visited ids in LDS -- LDS_HASH (16K slots, 64 KB: two queries per CU with the L2 scorer,
+ * one with the matrix-core scorers) or, L2 scorer only, for beams whose visited set is expected to
+ * outgrow it and for batches of at most one query per CU, LDS_HASH32 (32K slots, one query per CU);
+ * a query whose set could overflow is rerun on a bitmap kernel inside the same call.  Otherwise
+ * (matrix-core scorers with wide beams, larger shards) LDS_BITMAP when ceil(N/32) words fit the CU's
+ * LDS next to the phase buffers, else HBM_BITMAP.  Results are identical in every mode (tested);
+ * the knob exists for tests and tuning.  Process-wide, thread-safe. */
 enum nann_traversal_mode { NANN_TRAVERSAL_AUTO = 0, NANN_TRAVERSAL_LDS_BITMAP = 1,
                            NANN_TRAVERSAL_HBM_BITMAP = 2, NANN_TRAVERSAL_LDS_HASH = 3,
                            NANN_TRAVERSAL_LDS_HASH32 = 4 };

@@ -1678,7 +1678,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   const int bm_vis = (bitmap_fits && mode != NANN_TRAVERSAL_HBM_BITMAP) ? VIS_LDS_BITMAP : VIS_HBM_BITMAP;
   const size_t bm_lds = bm_scratch + tail + (bm_vis == VIS_LDS_BITMAP ? bm_bytes : 0);
   const int bm_per_cu = bm_vis == VIS_LDS_BITMAP ? 1 : 2;
-  // the hash-set plans: L2 scorer, ids + a useful number of position bits in 32 bits.  Which table:
+  // the hash-set plans.  Which table:
   // the visited set of a level holds its marks plus every id the level's rounds keep.  Measured on
   // HNSW(M=32) graphs (profiles/): the rows a beam walks are ~2.75x the mean degree and ~45% of the
   // gathered ids are new.  16K slots (two queries per CU) when that estimate leaves headroom, 32K
@@ -1713,7 +1713,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && tag_fits && fits16;
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
       !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
-    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards below 4M items; the 32K-slot set: L2 scorer only");
+    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards of up to 2^27 items; the 32K-slot set: L2 scorer only");
   unsigned long long off[8];
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u, off);
   p->id_bits = id_bits;
