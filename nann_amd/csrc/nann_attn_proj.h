@@ -223,7 +223,7 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          att[p][r] = expf(att[p][r] - mx);
+          att[p][r] = exp_nonpos(att[p][r] - mx);
           sum += att[p][r];
         }
       sum += __shfl_xor(sum, 32);
@@ -282,8 +282,8 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
       load_tile_vec(pv + PV_A1 + 32 * m, g, al_);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = __fmaf_rn(acc[r], sc[r], sh[r]);  // bn(x W + b)
-        acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
+        const float w = __fmaf_rn(acc[r], sc[r], sh[r]);  // bn(x W + b) x 2^4
+        acc[r] = __fmaf_rn(neg_part(w), al_[r], w);  // prelu: w + (alpha - 1) min(w, 0)
       }
       split_tile(acc, h1h[m], h1l[m]);
       step_end(S_W1 + m);
@@ -311,8 +311,8 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
       load_tile_vec(pv + PV_A2 + 32 * m, g, al_);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
-        acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
+        const float w = __fmaf_rn(acc[r], sc[r], sh[r]);
+        acc[r] = __fmaf_rn(neg_part(w), al_[r], w);
       }
       split_tile(acc, h2h[m], h2l[m]);
       step_end(S_W2 + m);

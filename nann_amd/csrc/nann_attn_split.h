@@ -33,10 +33,10 @@ enum : int {
   PV_AQ = 128,           // aq * HS / WS                    [128]
   PV_BQ2 = 256,          // bq2 * WS * HS                   [256]
   PV_B1 = 512,           // b1 * WS * HS                    [128]
-  PV_S1 = 640,           // bn_scale1 / (WS * HS)           [128]
-  PV_T1 = 768,           // bn_shift1                       [128]
-  PV_A1 = 896,           // alpha1 * HS                     [128]
-  PV_B2 = 1024, PV_S2 = 1088, PV_T2 = 1152, PV_A2 = 1216,  // [64] each
+  PV_S1 = 640,           // bn_scale1 / WS  (bn output x 2^4) [128]
+  PV_T1 = 768,           // bn_shift1 * HS                  [128]
+  PV_A1 = 896,           // alpha1 - 1  (prelu: w + A min(w, 0)) [128]
+  PV_B2 = 1024, PV_S2 = 1088, PV_T2 = 1152, PV_A2 = 1216,  // [64] each, scaled like layer 1's
   PV_B3 = 1280, PV_S3 = 1312, PV_T3 = 1344, PV_A3 = 1376,  // [32] each; A3 = alpha3 (unscaled)
   PV_W4 = 1408,          // w4                              [32]
   PV_COUNT = 1440
@@ -126,6 +126,19 @@ __device__ __forceinline__ void split_tile(const f32x16& x, f16x8 (&h)[2], f16x8
     h[q] = as_f16x8(hh);
     l[q] = as_f16x8(ll);
   }
+}
+
+// exp(x) for the softmax's x <= 0 in six instructions (expf() is ~10): 2^(x log2 e) with the product carried in two
+// floats -- t = x * L, e = the multiply's rounding error plus x * (log2 e - L) -- and 2^(t + e) = 2^t (1 + e ln 2);
+// v_exp_f32 is good to ~1 ulp, the result to ~2 ulp (the logits are held to 1e-5)
+__device__ __forceinline__ float exp_nonpos(float x) {
+  x = fmaxf(x, -128.0f);  // the padding positions carry -inf (inf - inf below would be NaN); 2^-184 flushes to 0 like exp(-inf)
+  constexpr float L = 1.44269502162933349609375f;       // float(log2 e)
+  constexpr float L_lo = 1.92596299112661746e-08f;      // log2 e - L
+  const float t = x * L;
+  const float e = __builtin_fmaf(x, L_lo, __builtin_fmaf(x, L, -t));
+  const float r = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(r * 0.693147182464599609375f, e, r);
 }
 
 // the lane's 16 rows of a 32-unit vector tile: four runs of 4 consecutive floats
@@ -332,7 +345,7 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          att[p][r] = expf(att[p][r] - mx);
+          att[p][r] = exp_nonpos(att[p][r] - mx);
           sum += att[p][r];
         }
       sum += __shfl_xor(sum, 32);
@@ -408,8 +421,8 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
         load_tile_vec(pv + PV_A1 + 32 * m, g, al_);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = __fmaf_rn(__fmaf_rn(acc_e[r], kAttnHS, acc[r]), sc[r], sh[r]);  // bn(x W + b)
-          acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
+          const float w = __fmaf_rn(__fmaf_rn(acc_e[r], kAttnHS, acc[r]), sc[r], sh[r]);  // bn(x W + b) x 2^4
+          acc[r] = __fmaf_rn(neg_part(w), al_[r], w);  // prelu: w + (alpha - 1) min(w, 0)
         }
         split_tile(acc, h1h[m], h1l[m]);
         step_end(22 + 2 * m);
@@ -441,8 +454,8 @@ __device__ __forceinline__ void wg_score_attn_split(const AttnParams& P, const u
       load_tile_vec(pv + PV_A2 + 32 * m, g, al_);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
-        acc[r] = v * (v > 0.0f ? kAttnHS : al_[r]);
+        const float w = __fmaf_rn(acc[r], sc[r], sh[r]);
+        acc[r] = __fmaf_rn(neg_part(w), al_[r], w);
       }
       split_tile(acc, h2h[m], h2l[m]);
       step_end(29 + m);

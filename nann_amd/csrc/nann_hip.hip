@@ -1284,16 +1284,18 @@ int nann_attn_scorer_create(const nann_attn_desc* desc, nann_attn_scorer** out) 
       pv[PV_BQ1 + j] = desc->bq1[j] * WS;
       pv[PV_AQ + j] = desc->aq[j] * (HS / WS);
       pv[PV_B1 + j] = desc->b[0][j] * (WS * HS);
-      pv[PV_S1 + j] = desc->bn_scale[0][j] / (WS * HS);
-      pv[PV_T1 + j] = desc->bn_shift[0][j];
-      pv[PV_A1 + j] = desc->alpha[0][j] * HS;
+      // bn + prelu of a hidden layer as w = fma(acc, S, T) (= 2^4 x the normalised value: power-of-two scales are exact)
+      // and w + A min(w, 0): S = scale / 2^7, T = shift x 2^4, A = alpha - 1
+      pv[PV_S1 + j] = desc->bn_scale[0][j] / WS;
+      pv[PV_T1 + j] = desc->bn_shift[0][j] * HS;
+      pv[PV_A1 + j] = desc->alpha[0][j] - 1.0f;
     }
     for (int j = 0; j < 256; ++j) pv[PV_BQ2 + j] = desc->bq2[j] * (WS * HS);
     for (int j = 0; j < 64; ++j) {
       pv[PV_B2 + j] = desc->b[1][j] * (WS * HS);
-      pv[PV_S2 + j] = desc->bn_scale[1][j] / (WS * HS);
-      pv[PV_T2 + j] = desc->bn_shift[1][j];
-      pv[PV_A2 + j] = desc->alpha[1][j] * HS;
+      pv[PV_S2 + j] = desc->bn_scale[1][j] / WS;
+      pv[PV_T2 + j] = desc->bn_shift[1][j] * HS;
+      pv[PV_A2 + j] = desc->alpha[1][j] - 1.0f;
     }
     for (int j = 0; j < 32; ++j) {
       pv[PV_B3 + j] = desc->b[2][j] * (WS * HS);

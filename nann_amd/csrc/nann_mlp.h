@@ -280,6 +280,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kSplitWScale = 128.0f;  // weights x 2^7 (|w| <= 511 or the scorer is refused)
 constexpr float kSplitHScale = 16.0f;   // hidden activations x 2^4 (|h| <= 4094)
 
+// min(x, 0) as ONE v_min_f32 (fminf() costs a second instruction: the compiler canonicalises its operand first; the
+// accumulators hold no signalling NaNs to quiet)
+__device__ __forceinline__ float neg_part(float x) {
+  float r;
+  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 __device__ __forceinline__ f16x8 as_f16x8(const uint4& v) {
   union { uint4 u; f16x8 h; } c;
   c.u = v;

@@ -62,14 +62,6 @@ __device__ __forceinline__ void wg_mlp2_stage_setup(const MlpParams& P, float u,
   __syncthreads();
 }
 
-// min(x, 0) as ONE v_min_f32 (fminf() costs a second instruction: the compiler canonicalises its operand first; the
-// accumulators hold no signalling NaNs to quiet)
-__device__ __forceinline__ float neg_part(float x) {
-  float r;
-  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-
 // h = x + beta min(x, 0) for a pair of accumulator values, split into f16 hi (round toward zero) and lo = f16(h - hi):
 // 2 v_min + 2 v_fma + cvt_pkrtz + v_fma_mixlo_f16 + v_fma_mixhi_f16
 __device__ __forceinline__ void prelu_split_pair(float x0, float x1, float b0, float b1, uint32_t& hi, uint32_t& lo) {
