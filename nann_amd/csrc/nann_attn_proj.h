@@ -10,7 +10,7 @@
 // attention logits: a lane gathers the four 16-byte pieces of its row of T that hold its 16 units of q_ tile t in the
 // C/D layout (the tile arrives where q2's accumulators would have been), splits it and multiplies it with the keys;
 // DNN layer 1 seeds its accumulators with b1 + the row's W1e part and runs the attention half only.
-// Per 32 candidates: 220 MFMAs, 12 slices of at most 16 KB (keys 4 x two tiles, the sequence, W1a x 4, W2 x 2, W3).
+// Per 32 candidates: 220 MFMAs, 6 slices of 16 KB per pass (keys 4 x two tiles, W2 x 2); the sequence, W1a and W3 stay in LDS.
 // Scores agree with the f32 form within the same 1e-5 every attention test holds (the table is an f32 chain; what is
 // split into f16 planes afterwards is what the split form splits at the same place).
 #pragma once
@@ -19,6 +19,11 @@
 namespace nann {
 
 constexpr int kAttnProjWidth = 384;  // floats per item: q_ x 2^4 [256] ; (e W1e) x 2^11 [128]
+// A fragments that stay in LDS for a whole scoring call instead of travelling once per pass: the user's sequence
+// (512 uint4), W1a (4 tiles x 512) and W3 (512) -- 48 KB behind the slice buffers and the vectors; the keys (64 KB)
+// and W2 (32 KB) keep streaming
+constexpr int kAttnResidentU4 = 512 + 2048 + 512;
+constexpr int kAttnResidentBytes = kAttnResidentU4 * 16;
 
 #ifdef NANN_ATTN_SPLIT_TU
 // 16 rows per step of a 256-thread workgroup; weights stream from L2 (they are re-read once per 16 rows: 256 KB).
@@ -97,24 +102,26 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
                                                    float* slice_f, float* scores) {
   static_assert(NT == 512, "two uint4 per thread per 16 KB slice");
   constexpr int CPP = (NT / 64) * 32;
-  // slices per pass: the keys travel two tiles per 16 KB slice (one barrier per pair)
-  constexpr int S_SEQ = 4, S_W1 = 5, S_W2 = 9, S_W3 = 11, NS = 12;
+  // slices per pass: the keys, two tiles per 16 KB slice (one barrier per pair), and W2; the rest is resident
+  constexpr int S_W2 = 4, NS = 6;
+  constexpr int R_SEQ = 0, R_W1 = 512, R_W3 = 2560;  // uint4 offsets in the resident block
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, g = lane >> 5;
   uint4* buf = reinterpret_cast<uint4*>(slice_f);  // [2][1024]
   float* pv = slice_f + kAttnSlice;                // the small vectors, in LDS
+  uint4* res = reinterpret_cast<uint4*>(slice_f + kAttnSlice + kAttnVecFloats);  // [kAttnResidentU4]
   __syncthreads();
   for (int k = tid; k < PV_COUNT / 4; k += NT)
     reinterpret_cast<float4*>(pv)[k] = reinterpret_cast<const float4*>(P.pvec)[k];
+  for (int k = tid; k < kAttnResidentU4; k += NT)
+    res[k] = k < R_W1 ? ua[k] : k < R_W3 ? P.pw1a[k - R_W1] : P.pw3[k - R_W3];
   // (visible after the barriers that open the first pass)
   const float att_scale = (1.0f / sqrtf(256.0f)) / (kAttnWS * kAttnHS);  // model_util.py:89-91, and the operand scales
 
   auto slice_src = [&](int s, int* cnt) -> const uint4* {
-    if (s < S_SEQ) { *cnt = 1024; return kt + (size_t)s * 1024; }                     // keys for q_ tiles 2s, 2s + 1
-    if (s == S_SEQ) { *cnt = 512; return ua; }                                        // the sequence
-    if (s < S_W2) { *cnt = 512; return P.pw1a + (size_t)(s - S_W1) * 512; }           // W1 rows of a, tile m
-    if (s < S_W3) { *cnt = 1024; return P.pw2 + (size_t)(s - S_W2) * 1024; }
-    *cnt = 512; return P.pw3;
+    *cnt = 1024;
+    if (s < S_W2) return kt + (size_t)s * 1024;                                       // keys for q_ tiles 2s, 2s + 1
+    return P.pw2 + (size_t)(s - S_W2) * 1024;
   };
   uint4 pre0, pre1;
   auto fetch = [&](int s) {
@@ -238,9 +245,8 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
     // ---- a = sum_l p_l u_l (:95, model.py:204-206): u is exact f16
     f16x8 ah[2][2], al[2][2];  // a x 2^4, split
     {
-      const uint4* A = step_begin(S_SEQ);
       f16x8 U[8];
-      load_frags(A, lane, U);
+      load_frags(res + R_SEQ, lane, U);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -254,13 +260,12 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
           }
         split_tile(acc, ah[m], al[m]);
       }
-      step_end(S_SEQ);
     }
     // ---- DNN layer 1 on [a ; e] (model.py:211-214): the e rows come from the table
     f16x8 h1h[4][2], h1l[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const uint4* A = step_begin(S_W1 + m);
+      const uint4* A = res + R_W1 + 512 * m;
       float seed[16];
       load_tile_vec(pv + PV_B1 + 32 * m, g, seed);
       f32x16 dv;
@@ -286,7 +291,6 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
         acc[r] = __fmaf_rn(neg_part(w), al_[r], w);  // prelu: w + (alpha - 1) min(w, 0)
       }
       split_tile(acc, h1h[m], h1l[m]);
-      step_end(S_W1 + m);
     }
     // ---- layer 2
     f16x8 h2h[2][2], h2l[2][2];
@@ -320,7 +324,7 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
     // ---- layer 3 and the bias-free output (:218-219)
     float logit = 0.0f;
     {
-      const uint4* A = step_begin(S_W3);
+      const uint4* A = res + R_W3;
       float seed[16];
       load_tile_vec(pv + PV_B3, g, seed);
 #pragma unroll
@@ -343,7 +347,6 @@ __device__ __forceinline__ void wg_score_attn_proj(const AttnParams& P, const ui
         const float v = __fmaf_rn(acc[r], sc[r], sh[r]);
         logit = __fmaf_rn(v > 0.0f ? v : al_[r] * v, w4[r], logit);
       }
-      step_end(S_W3);
     }
     logit += __shfl_xor(logit, 32);
     if (g == 0 && i < n) scores[i] = logit;

@@ -180,7 +180,7 @@ constexpr int hash_phase_scratch() {
   return ((a > b ? a : b) + 255) & ~255;
 }
 // phase scratch of a traversal kernel: the attention scorer stages 32 KB weight slices
-constexpr int kAttnScratch = (kAttnSlice + kAttnVecFloats) * 4;
+constexpr int kAttnScratch = (kAttnSlice + kAttnVecFloats) * 4 + kAttnResidentBytes;  // slice buffers, vectors, resident fragments (nann_attn_proj.h)
 constexpr int kMlpSplitScratch = (int)((sizeof(MlpSplitScratch) + 255) & ~(size_t)255);  // two slice buffers + the vectors
 static_assert(sizeof(Mlp2Scratch<128>) <= sizeof(MlpSplitScratch), "the second mapping's tile buffers fit the same phase scratch");
 template <int VIS, int SC, int NT>
