@@ -484,8 +484,9 @@ def test_search_model_serving_signature(oracle, tmp_path, kind):
     assert kinds.count("diverged") <= 2, kinds
 
 
-@pytest.mark.parametrize("d,mode", [(64, "auto"), (128, "auto"), (128, "hbm_bitmap"), (64, "lds_bitmap")])
-def test_search_model_attention_split_f16(oracle, tmp_path, d, mode):
+@pytest.mark.parametrize("d,mode,rows", [(64, "auto", "f16"), (128, "auto", "f16"), (128, "hbm_bitmap", "f16"),
+                                         (64, "lds_bitmap", "f16"), (64, "auto", "bf16")])
+def test_search_model_attention_split_f16(oracle, tmp_path, d, mode, rows):
     """The serving signature with the attention model in its split-f16 form (precision.txt = split; since round 3 the
     traversal runs it with the item-only layers pre-projected per (model, index), nann_attn_proj.h, on every plan):
     the fused traversal against the oracle's traversal with the fp32 model, tie-aware at 1e-5; and against the
@@ -493,17 +494,24 @@ def test_search_model_attention_split_f16(oracle, tmp_path, d, mode):
     from nann_amd import ops, retrieval, synth
     L, nq = 50, 40
     g, oix, dix = synth_index(20000, d, 32)
+    code, tdt = oracle.EMB_F16, torch.float16
+    if rows == "bf16":  # the same graph over bf16 rows (the pre-projection reads them through its own conversion)
+        dev = cuda(g["item_embs"].astype(np.float32)).to(torch.bfloat16)
+        host = dev.view(torch.int16).cpu().numpy().view(np.uint16)
+        oix = oracle.Index(host, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+        dix = retrieval.Index(dev, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+        code, tdt = oracle.EMB_BF16, torch.bfloat16
     seqs = queries_for(g, nq, seed=17)
     topn = [32] * 5 + [20]
     w = synth.make_attn_weights(d, 64)
     ops.save_scorer_dir(str(tmp_path / "split"), "attention", w, precision="split")
     ops.save_scorer_dir(str(tmp_path / "exact"), "attention", w, precision="exact")
     with traversal_mode(mode):
-        r = retrieval.search_model(dix, ops.Model(str(tmp_path / "split"), d, L), cuda(seqs), topn)
-        r2 = retrieval.search_model(dix, ops.Model(str(tmp_path / "exact"), d, L), cuda(seqs), topn)
+        r = retrieval.search_model(dix, ops.Model(str(tmp_path / "split"), d, L, emb_dtype=tdt), cuda(seqs), topn)
+        r2 = retrieval.search_model(dix, ops.Model(str(tmp_path / "exact"), d, L, emb_dtype=tdt), cuda(seqs), topn)
         torch.cuda.synchronize()
     st, idx, sc = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
-    osc = oracle.Scorer("attention", d, oracle.EMB_F16, attn_model=oracle.AttnModel(d, 64, L, oracle.EMB_F16, w))
+    osc = oracle.Scorer("attention", d, code, attn_model=oracle.AttnModel(d, 64, L, code, w))
     est, eids, esc, eidx, _ = oracle.search_batch(oix, osc, seqs.astype(np.float32).reshape(nq, -1), topn, n_threads=8)
     ok = (est == 0) & (st == 0)
     assert (st == est).sum() >= nq - 2 and ok.mean() > 0.5
