@@ -71,6 +71,9 @@ def parse():
                          "dry run of the multi-rank flow with every rank on cuda:0, exchange staged through the host)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: rccl = ncclAllGather issued by the C ABI; torch = torch.distributed collectives")
+    ap.add_argument("--no-overlap-exchange", action="store_true",
+                    help="N > 1, rccl transport: run each batch's all-gather + merge on the search stream instead of "
+                         "a stream of its own underneath the next batch's search")
     ap.add_argument("--scorer", default="l2", choices=["l2", "mlp"],
                     help="l2 = BASELINE configs[1] (the headline metric); mlp = configs[2]: 256-128-1 MLP on MFMA")
     ap.add_argument("--mlp-precision", default="split", choices=["split", "exact"],
@@ -281,7 +284,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         if i is not None:
             ev[i][1].record()
         if sharded is not None:
-            return sharded.merge(r), r, q
+            return sharded.merge(r, overlap=cfg.get("overlap_exchange", False)), r, q
         return (r.item_ids, r.scores), r, q
 
     import gc
@@ -297,6 +300,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     for i in range(steps):
         out, r, q = step(warmup + i, i)
         host_marks.append(time.perf_counter())
+    if sharded is not None:
+        sharded.wait()  # overlapped exchanges: all of them belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -604,7 +609,8 @@ def main():
 
     primary_cfg = {"items": args.items, "dim": args.dim, "ef": args.ef, "topk": args.topk, "batch": args.batch,
                    "steps": args.steps, "warmup": args.warmup, "scorer": args.scorer, "dtype": args.dtype,
-                   "graph": args.graph, "traversal": args.traversal, "mlp_precision": args.mlp_precision}
+                   "graph": args.graph, "traversal": args.traversal, "mlp_precision": args.mlp_precision,
+                   "overlap_exchange": world > 1 and args.transport == "rccl" and not args.no_overlap_exchange}
     is_headline = (args.items == 1_000_000 and args.dim == 128 and args.ef == 128 and args.topk == 200
                    and args.dtype == "f16")
     tag = f"{args.items}x{args.dim}{args.dtype}_ef{args.ef}_k{args.topk}_b{args.batch}_{args.scorer}_{args.graph}"
@@ -636,6 +642,7 @@ def main():
         "config": {"workload": desc, "level_topn": [args.ef] * 5 + [args.topk], "batch": args.batch,
                    "items_total": args.items * world,
                    "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
+                   **({"exchange_overlapped_with_next_search": primary_cfg["overlap_exchange"]} if world > 1 else {}),
                    "exchange": (f"{args.transport} all-gather + {args.merge} merge" if world > 1 else None)},
         "qps_end_to_end": qps,
         "weak_scaling": {"shard_searches_per_s": round(qps * world, 1), "unit": "queries/s x 1M-item shards searched",

@@ -121,27 +121,50 @@ class ShardedSearch:
         self.transport = transport
         self.comm = comm if comm is not None else (Comm(world, rank, group) if transport == "rccl" else None)
         self._ws = None
+        self._comm_stream = None
 
-    def merge(self, result):
+    def _exchange(self, result):
+        """pack + ncclAllGather + merge on the CURRENT stream (nann_sharded_topk)"""
+        nq, k = result.scores.shape
+        dev = result.scores.device
+        nbytes = C.c_int64(0)
+        _check(lib().nann_sharded_topk_workspace_bytes(C.c_int32(self.world), C.c_int64(nq), C.c_int32(k),
+                                                      C.byref(nbytes)))
+        if self._ws is None or self._ws.numel() < nbytes.value:
+            self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+        out_s = torch.empty((nq, self.k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((nq, self.k), dtype=torch.int64, device=dev)
+        _check(lib().nann_sharded_topk(self.comm.handle, _ptr(result.scores), _ptr(result.item_ids),
+                                       _ptr(result.status), C.c_int64(nq), C.c_int32(k), C.c_int32(self.k),
+                                       _ptr(self._ws), C.c_int64(self._ws.numel()), _ptr(out_s), _ptr(out_i),
+                                       _stream()), "sharded top-k")
+        return out_i, out_s
+
+    def merge(self, result, overlap=False):
         """result: this rank's retrieval.SearchResult -> (item_ids i64[nq,k], scores f32[nq,k]) of
         the whole corpus, identical on every rank.  A query that failed on a shard (status != 0)
         contributes -inf scores / id 0 from that shard: never selected while another shard holds
-        real candidates."""
+        real candidates.
+
+        overlap (rccl transport): the exchange of this batch runs on a stream of its own behind the search that
+        produced it, so the NEXT batch's search (enqueued on the caller's stream right after this call) overlaps it --
+        per step the device then costs max(search, exchange + merge) instead of their sum.  Exchanges still execute
+        in call order (one communicator, one stream, one workspace).  The returned tensors belong to that stream:
+        call wait() before reading them on the caller's stream."""
         if self.transport == "rccl":
-            nq, k = result.scores.shape
+            if not overlap:
+                return self._exchange(result)
             dev = result.scores.device
-            nbytes = C.c_int64(0)
-            _check(lib().nann_sharded_topk_workspace_bytes(C.c_int32(self.world), C.c_int64(nq), C.c_int32(k),
-                                                          C.byref(nbytes)))
-            if self._ws is None or self._ws.numel() < nbytes.value:
-                self._ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
-            out_s = torch.empty((nq, self.k), dtype=torch.float32, device=dev)
-            out_i = torch.empty((nq, self.k), dtype=torch.int64, device=dev)
-            _check(lib().nann_sharded_topk(self.comm.handle, _ptr(result.scores), _ptr(result.item_ids),
-                                           _ptr(result.status), C.c_int64(nq), C.c_int32(k), C.c_int32(self.k),
-                                           _ptr(self._ws), C.c_int64(self._ws.numel()), _ptr(out_s), _ptr(out_i),
-                                           _stream()), "sharded top-k")
-            return out_i, out_s
+            cur = torch.cuda.current_stream(dev)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            cs = self._comm_stream
+            cs.wait_stream(cur)  # the search that wrote `result`
+            with torch.cuda.stream(cs):
+                out = self._exchange(result)
+            for t in (result.scores, result.item_ids, result.status):
+                t.record_stream(cs)  # the caching allocator must not hand these out again before the exchange read them
+            return out
         scores = result.scores
         bad = (result.status != 0)[:, None]
         scores = torch.where(bad, torch.full_like(scores, float("-inf")), scores)
@@ -152,3 +175,8 @@ class ShardedSearch:
             return torch.as_tensor(i), torch.as_tensor(s)
         s, i = merge_device(gs, gi, self.k)
         return i, s
+
+    def wait(self):
+        """make the caller's current stream wait for every overlapped exchange issued so far"""
+        if self._comm_stream is not None:
+            torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)

@@ -554,3 +554,39 @@ def test_sharded_topk_single_process(oracle, world):
         rc, es, ei = oracle.merge_topk(np.repeat(s_in[b][None], world, 0), np.repeat(i_in[b][None], world, 0), k_out)
         assert rc == 0
         assert (mi[b].cpu().numpy() == ei).all() and (bits(ms[b].cpu().numpy()) == bits(es)).all(), b
+
+
+def test_sharded_topk_overlapped_with_the_next_search(oracle):
+    """ShardedSearch.merge(overlap=True): each batch's exchange + merge runs on a stream of its own behind the search
+    that produced it while the caller's stream goes on to the next batch.  Six batches back to back on an 8-shard
+    loopback communicator, inputs dropped by the caller at once (the allocator may hand their memory to the next
+    batch): every merged list equals the sequential path's, and wait() orders the caller's stream behind them."""
+    from nann_amd import retrieval, shard
+    rng = np.random.default_rng(5)
+    nq, k = 512, 200
+    seq = shard.ShardedSearch([0, 0, 0, 0, 0, k], 8, 0, transport="rccl", comm=shard.Comm.loopback(8))
+    ovl = shard.ShardedSearch([0, 0, 0, 0, 0, k], 8, 0, transport="rccl", comm=shard.Comm.loopback(8))
+    batches = []
+    for b in range(6):
+        scores = -np.sort(rng.integers(0, 5000, size=(nq, k)).astype(np.float32) / 8, axis=1)
+        ids = rng.integers(1, 1 << 40, size=(nq, k)).astype(np.int64)
+        status = np.zeros(nq, np.int32)
+        status[b::19] = 4
+        batches.append((ids, scores, status))
+    expect = []
+    for ids, scores, status in batches:
+        mi, ms = seq.merge(retrieval.SearchResult(cuda(ids), cuda(scores), None, cuda(status), None))
+        torch.cuda.synchronize()
+        expect.append((mi.cpu().numpy(), ms.cpu().numpy()))
+    outs = []
+    filler = torch.empty(1 << 22, device="cuda")
+    for ids, scores, status in batches:
+        local = retrieval.SearchResult(cuda(ids), cuda(scores), None, cuda(status), None)
+        filler.normal_()  # work on the caller's stream between the batches
+        outs.append(ovl.merge(local, overlap=True))
+        del local
+    ovl.wait()
+    got = [(mi.clone(), ms.clone()) for mi, ms in outs]  # on the caller's stream, behind wait()
+    torch.cuda.synchronize()
+    for (mi, ms), (ei, es) in zip(got, expect):
+        assert (mi.cpu().numpy() == ei).all() and (bits(ms.cpu().numpy()) == bits(es)).all()
