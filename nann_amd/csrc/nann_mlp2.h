@@ -76,6 +76,26 @@ __device__ __forceinline__ void prelu_split_pair(float x0, float x1, float b0, f
   lo = l;
 }
 
+// The same for h = (x + u) + beta min(x + u, 0) with the add and the fma as PACKED f32 instructions (v_pk_add_f32,
+// v_pk_fma_f32: two values per instruction at the scalar ones' issue cost -- a wavefront's vector instruction holds its
+// SIMD for four cycles, and this scorer's time is two thirds issue): 3.5 instructions per value instead of 4.5.
+// Element for element the same IEEE operations as prelu_split_pair(x0 + u0, x1 + u1, ...): bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void prelu_split_pair_pk(f32x2 x, f32x2 u, f32x2 b, uint32_t& hi, uint32_t& lo) {
+  typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+  const f32x2 xs = x + u;
+  // (plain min, not neg_part's asm: an add's result needs no canonicalising, and asm outputs land in unrelated
+  //  registers, which would scalarise the packed fma that consumes them)
+  const f32x2 m = __builtin_elementwise_min(xs, f32x2{0.0f, 0.0f});
+  const f32x2 h = __builtin_elementwise_fma(m, b, xs);
+  const h2_t hv = __builtin_amdgcn_cvt_pkrtz(h.x, h.y);
+  hi = __builtin_bit_cast(uint32_t, hv);
+  uint32_t l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(h.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(h.y));
+  lo = l;
+}
+
 // the finished layer-1 tile of one block -> the B fragments of its two 16-deep layer-2 steps (bh / bl [q]);
 // beta[r] = (alpha1 - 1) of the hidden unit register r holds
 __device__ __forceinline__ void split_tile(const f32x16& a1, const float (&beta)[16], f16x8 (&bh)[2], f16x8 (&bl)[2]) {

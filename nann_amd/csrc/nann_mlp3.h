@@ -286,8 +286,8 @@ __device__ __forceinline__ void wg_score_mlp_proj1(const MlpParams& P, const flo
           const float4 u = *reinterpret_cast<const float4*>(&V->u[32 * t + 8 * rr + 4 * g]);
           const float4 be = *reinterpret_cast<const float4*>(&V->beta1[32 * t + 8 * rr + 4 * g]);
           uint32_t h0, l0, h1, l1;
-          prelu_split_pair(x[rr].x + u.x, x[rr].y + u.y, be.x, be.y, h0, l0);
-          prelu_split_pair(x[rr].z + u.z, x[rr].w + u.w, be.z, be.w, h1, l1);
+          prelu_split_pair_pk(f32x2{x[rr].x, x[rr].y}, f32x2{u.x, u.y}, f32x2{be.x, be.y}, h0, l0);
+          prelu_split_pair_pk(f32x2{x[rr].z, x[rr].w}, f32x2{u.z, u.w}, f32x2{be.z, be.w}, h1, l1);
           if (half == 0) { h.x = h0; h.y = h1; l.x = l0; l.y = l1; } else { h.z = h0; h.w = h1; l.z = l0; l.w = l1; }
         }
         bh[q] = as_f16x8(h); bl[q] = as_f16x8(l);
