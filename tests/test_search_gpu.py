@@ -598,3 +598,27 @@ def test_recall_harness_test_and_test_all(oracle):
     q0 = oracle.user_seq_mean(seqs[0])
     rc, eids, _, _ = oracle.search_eval(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q0, (2, 1, 1), (100, 60, 30), 50)
     assert rc == 0 and (truths[0] in eids[:50].tolist()) == (evaluate.calc_pr(truths[0], eids[:50])[1] == 1.0)
+
+
+def test_projection_tables_follow_the_index(oracle):
+    """A split-f16 MLP scorer keeps the pre-projected tables of the two indices it searched last: searched against
+    three indices in turn (A, B, C, A -- C evicts A's table, A's comes back rebuilt) it must answer each one exactly
+    as a scorer that has only ever seen that index."""
+    from nann_amd import ops, retrieval, synth
+    w = synth.make_mlp_weights(64)
+    topn = [32] * 5 + [20]
+    shared = ops.Scorer("mlp", 64, torch.float16, w, precision="split")
+    cases = []
+    for seed in (1234, 77, 901):
+        g, _, dix = synth_index(20000, 64, 32, seed=seed)
+        q = cuda(np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 24, seed=seed + 1)]))
+        fresh = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w, precision="split"), q, topn)
+        torch.cuda.synchronize()
+        cases.append((dix, q, fresh.status.cpu().numpy(), fresh.index.cpu().numpy(), fresh.scores.cpu().numpy()))
+    for k in (0, 1, 2, 0, 2, 1):
+        dix, q, st, idx, sc = cases[k]
+        r = retrieval.search(dix, shared, q, topn)
+        torch.cuda.synchronize()
+        assert (r.status.cpu().numpy() == st).all()
+        ok = st == 0
+        assert (r.index.cpu().numpy()[ok] == idx[ok]).all() and (bits(r.scores.cpu().numpy()[ok]) == bits(sc[ok])).all(), k
