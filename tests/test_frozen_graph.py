@@ -100,3 +100,41 @@ def test_errors_name_what_is_missing(tmp_path):
     (tmp_path / "cut.pb").write_bytes(blob[: len(blob) // 2])
     with pytest.raises(ValueError):
         read_attention(tmp_path / "cut.pb")
+
+
+def test_reader_survives_corrupted_files(tmp_path):
+    """Truncations, flipped bytes and inserted garbage: the reader either reports an error or (when only weight bytes
+    were hit) returns tensors -- it never crashes or over-reads (this runs inside the test process)."""
+    lib = C.CDLL(index_build.build_host_lib())
+    blob = frozen_graph.write_attention_graph(str(tmp_path / "ok.pb"), synth.make_attn_weights(64, 64))
+    rng = np.random.default_rng(0)
+    path = tmp_path / "fuzz.pb"
+    outcomes = set()
+    for i in range(160):
+        b = bytearray(blob)
+        kind = i % 4
+        if kind == 0:
+            b = b[: int(rng.integers(1, len(b)))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 2:  # among the first 4 KB: node headers, names, varints
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, 4096))] = int(rng.integers(0, 256))
+        else:
+            pos = int(rng.integers(0, len(b)))
+            b[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 64))).astype(np.uint8))
+        path.write_bytes(bytes(b))
+        counts = (C.c_int64 * 26)()
+        d, e = C.c_int32(0), C.c_int32(0)
+        err = C.create_string_buffer(512)
+        rc = lib.nann_graphdef_attention(str(path).encode(), counts, None, C.byref(d), C.byref(e), err, 512)
+        if rc == 0:
+            assert 0 < sum(counts) < 10_000_000
+            flat = np.zeros(sum(counts), np.float32)
+            rc = lib.nann_graphdef_attention(str(path).encode(), counts, flat.ctypes.data_as(C.c_void_p), C.byref(d), C.byref(e),
+                                             err, 512)
+        else:
+            assert err.value  # an error always says what failed
+        outcomes.add(rc)
+    assert outcomes <= {0, 1} and 1 in outcomes
