@@ -401,7 +401,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         if want_cpu and rank == 0 and world == 1:
             # bounded sample: grow the chunk until the time budget is used
             n_done, t_cpu, chunk = 0, 0.0, min(batch, max(n_check, 4 * cores))
-            while t_cpu < args.cpu_seconds and n_done < 50 * batch:
+            while t_cpu < cfg.get("cpu_seconds", args.cpu_seconds) and n_done < 50 * batch:
                 sel = np.arange(n_done, n_done + chunk) % batch
                 t1 = time.perf_counter()
                 ores = O.search_batch(oix, osc, qh[sel], topn, n_threads=cores)
@@ -686,8 +686,9 @@ def main():
         try:  # HBM-honest: config 5's shard shape (256-d bf16, ef=256) at a size whose table is 4x the Infinity Cache
             cfg = {"items": args.stress_items, "dim": 256, "ef": 256, "topk": 200, "batch": 2048, "steps": 5,
                    "warmup": 2, "scorer": "l2", "dtype": "bf16", "graph": "hnsw", "traversal": "auto"}
-            stress = run_workload(f"{args.stress_items}x256bf16_ef256", args, dev, rank, world, cfg, want_cpu=False,
-                                  want_parity=True, want_recall=False)
+            cfg["cpu_seconds"] = min(args.cpu_seconds, 5.0)
+            stress = run_workload(f"{args.stress_items}x256bf16_ef256", args, dev, rank, world, cfg,
+                                  want_cpu=not args.no_cpu_baseline, want_parity=True, want_recall=False)
             sec["hbm_stress_config5_shape"] = strip(stress)
             try:  # the same rows and beam under the MLP scorer: wide beams take the bitmap plan + pre-projected scorer
                 cfg = dict(cfg, scorer="mlp", mlp_precision="split", batch=1024, steps=3, warmup=1,
