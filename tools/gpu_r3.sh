@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-3 GPU session runner (through gpurun): named steps, each skipped once the deadline has passed.
 # usage: tools/gpu_r3.sh <tag> <deadline_s> <step> [<step> ...]
-#   steps: tests_mlp tests_full smoke rate_mlp bench_mlp bench_mlp_ab bench_full bench_l2 prof_mlp prof_l2 prof_stress serve coop
+#   steps: tests_full tests_mlp tests_new tests_k (TESTS_K='<-k expr>') smoke bench_full bench_l2 bench_mlp bench_mlp_ab bench_mlp_maps
+#          bench_mlp_wide mlp_exact_diag bench_attn b1 b1modes phase_4m rate_mlp serve prof_l2 prof_mlp prof_attn prof_stress prof_4m
 set -u
 TAG=$1; DEADLINE=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
