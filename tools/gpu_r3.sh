@@ -157,6 +157,15 @@ for STEP in "$@"; do
       S="--items 4000000 --dim 256 --dtype bf16 --ef 256 --batch 2048 --no-secondary --no-cpu-baseline --phase-ticks"
       timeout 400 $BENCH $S --steps 3 --warmup 1 > $OUT/bench_4m_phase_$TAG.json 2> $OUT/bench_4m_phase_$TAG.err
       show $OUT/bench_4m_phase_$TAG.json SHARD_4M_PHASES ;;
+    prof_small)  # one launch of 1 and of 64 queries: kernel time by rocprofv3 next to the HIP-event numbers of the batch sweep
+      for B in 1 64; do
+        kstats b$B -- $BENCH --batch $B --steps 30 --warmup 5 --no-secondary --no-cpu-baseline
+      done ;;
+    prof_mlp_wide)
+      S="--items 2000000 --dim 256 --dtype bf16 --ef 256 --scorer mlp --batch 1024 --steps 4 --warmup 1 --no-secondary --no-cpu-baseline"
+      kstats mlpwide -- $BENCH $S
+      pmc mlpwide_a k_search SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_MFMA SQ_INSTS_VALU -- $BENCH $S
+      pmc mlpwide_b k_search GRBM_GUI_ACTIVE -- $BENCH $S ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
