@@ -138,7 +138,8 @@ def load_pmc_counters(tag):
     if p.get("GRBM_GUI_ACTIVE"):
         cu_cycles = p["GRBM_GUI_ACTIVE"] / 8.0 * 256  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         out["mfma_busy_frac"] = round(p["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu_cycles), 4)
-    for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
+    for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE",
+              "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
         if k in p:
             out[k] = p[k]
     return out
@@ -338,32 +339,61 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         roofline["traffic"] = pmc["bytes_per_launch"]
         roofline["traffic_source"] = pmc["source"]
     if scorer_kind == "mlp":
-        # 2*(2d*256 + 256*128 + 128) flop per scored row are the ALGORITHMIC flops `frac` prices, against
-        # the dense MFMA peak of the type the products run in.  What the kernel ISSUES differs and is reported beside it:
-        # the query half of layer 1 (W1q.q) is hoisted out (once per query); the split-f16 form spends 2 (layer 1) /
-        # 3 (layer 2) 16-bit MFMA products per f32 product; the exact form issues d*256 + 256*128 f32 MACs per row.
+        # What the traversal EXECUTES on the matrix cores per scored row (round 4: both precisions run on the table of
+        # pre-projected item halves with layer 2 resident in LDS, nann_mlp5.h; NANN_MLP_MAPPING / NANN_PREPROJECT=0
+        # select the older forms, priced by their own counts):
+        #   split-f16  layer 2 only, 3 f16 products per f32 MAC: 3 * 2*256*128 = 196 608 flop = 6 MFMAs of 32x32x16 per
+        #              (32 rows x 32 outputs x 16 k); forms that still run layer 1 add 2 * 2*d*256
+        #   exact f32  layer 2 only: 2*256*128 = 65 536 flop = 16 MFMAs of 32x32x2 per (32 rows x 32 outputs x 32 k); the
+        #              form that runs layer 1 adds 2*d*256
+        # `frac` prices THOSE (never more than the pipe can do); SURVEY.md 8(d)'s nominal 2*(2d*256 + 256*128 + 128) per
+        # row -- which counts the hoisted query half and the looked-up item half of layer 1 as if they were computed per
+        # candidate -- is the second figure.  The issued count is cross-checked against SQ_INSTS_MFMA of the committed
+        # rocprofv3 pass (profiles/pmc_latest.json).
+        mapping = os.environ.get("NANN_MLP_MAPPING", "5")
+        table_form = os.environ.get("NANN_PREPROJECT", "1") != "0" and (mapping == "5" or (precision == "split" and mapping in "34"))
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
         if precision == "split":
-            issued, peak = rows * 2.0 * (2 * dim * 256 + 3 * 256 * 128), F16_MFMA_PEAK_TF
-            flops_note = "f16 MFMA (split-f16 operands: 2 products per layer-1 MAC, 3 per layer-2 MAC)"
+            per_row = 3 * 2.0 * 256 * 128 + (0 if table_form else 2 * 2.0 * dim * 256)
+            peak, flop_per_mfma = F16_MFMA_PEAK_TF, 32 * 32 * 16 * 2
+            flops_note = "v_mfma_f32_32x32x16_f16 on split-f16 operands (3 products per layer-2 MAC%s)" % (
+                "; layer 1: item half from the pre-projected table, query half hoisted" if table_form else ", 2 per layer-1 MAC")
         else:
-            issued, peak = rows * 2.0 * (dim * 256 + 256 * 128), F32_MFMA_PEAK_TF
-            flops_note = "f32-input MFMA (query half of layer 1 hoisted)"
-        tf = nominal / (kern_ms * 1e-3) / 1e12
-        tf_issued = issued / (kern_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer, %s)" % precision, "achieved": round(tf, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                    "traffic": None, "kernel_ms": round(kern_ms, 4), "flops": "SURVEY.md 8(d) algorithmic flops per scored row; " + flops_note,
-                    "algorithmic_flops_per_launch": nominal,
-                    "issued_TFLOPs": round(tf_issued, 2), "issued_frac_of_peak": round(tf_issued / peak, 4),
+            per_row = 2.0 * 256 * 128 + (0 if table_form else 2.0 * dim * 256)
+            peak, flop_per_mfma = F32_MFMA_PEAK_TF, 32 * 32 * 2 * 2
+            flops_note = "v_mfma_f32_32x32x2_f32 (%s)" % ("layer 2 only: item half of layer 1 from the pre-projected table, query half hoisted"
+                                                        if table_form else "query half of layer 1 hoisted")
+        executed = rows * per_row
+        tf = executed / (kern_ms * 1e-3) / 1e12
+        tf_nominal = nominal / (kern_ms * 1e-3) / 1e12
+        # bytes the scorer gathers per row: the 1 KB row of the table (f32 x 256) instead of the d x 2 B embedding row
+        row_bytes = 1024 if table_form else dim * 2
+        tot_b2, _ = algorithmic_bytes(counters[ok], row_bytes // 2, 2, len(g["enter_points"]), topk)
+        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form and mapping == "5" else ""),
+                    "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                    "traffic": None, "kernel_ms": round(kern_ms, 4),
+                    "flops": "EXECUTED matrix-core flops per scored row x rows scored: " + flops_note,
+                    "executed_flops_per_row": per_row, "executed_flops_per_launch": executed,
+                    "mfma_instructions_per_launch": executed / flop_per_mfma,
+                    # SURVEY.md 8(d)'s figure beside it (includes work that is hoisted / looked up, not executed):
+                    "nominal_8d_flops_per_launch": nominal, "nominal_8d_TFLOPs": round(tf_nominal, 2),
+                    "nominal_8d_over_peak": round(tf_nominal / peak, 4),
                     # tools/ubench_mfma.hip (profiles/r2_ubench_mfma.txt): a bare loop of this MFMA on every SIMD
                     # holds 1.6-1.9 PFLOP/s (f16) -- the chip clocks ~1.75 GHz under it, not 2.4
-                    "issued_frac_of_measured_mfma_loop": (round(tf_issued / 1830.0, 4) if precision == "split" else None),
-                    "hbm_algorithmic_GBps": round(achieved, 1),
+                    "frac_of_measured_mfma_loop": (round(tf / 1830.0, 4) if precision == "split" else None),
+                    "hbm_algorithmic_GBps": round(float(tot_b2.sum()) / (kern_ms * 1e-3) / 1e9, 1),
+                    "hbm_bytes_gathered_per_row": row_bytes,
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
         pmc = load_pmc_counters(name)
         if pmc is not None:
             roofline.update(pmc)
+            if pmc.get("SQ_INSTS_MFMA"):
+                roofline["mfma_instructions_per_launch_pmc"] = pmc["SQ_INSTS_MFMA"]
+                roofline["executed_over_pmc_instructions"] = round(executed / flop_per_mfma / pmc["SQ_INSTS_MFMA"], 4)
+        pmc = load_pmc_traffic(name)
+        if pmc is not None:
+            roofline["traffic"] = pmc["bytes_per_launch"]
+            roofline["traffic_source"] = pmc["source"]
 
     qps = batch * steps / elapsed
     res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NANN_ABI_VERSION 3
+#define NANN_ABI_VERSION 4
 
 /* status codes; 1..8 share the oracle's numbering (oracle/nann_oracle.h) and
  * map to the TF errors the reference raises at the cited lines */
@@ -157,6 +157,7 @@ int nann_topk(const float* values, int64_t n_rows, int64_t n_cols, int32_t k,
  * L2: s = -||q - x||^2.  MLP: x=[q;e] -> h1 -> PReLU -> h2 -> PReLU -> 1
  * (weights f32; [host] pointers, copied to HBM at creation). */
 typedef struct nann_scorer nann_scorer;
+typedef struct nann_index nann_index;
 typedef struct {
   int32_t kind;      /* nann_scorer_kind */
   int32_t d;         /* embedding dim: 64, 128, 256 or 512 */
@@ -181,19 +182,43 @@ typedef struct {
  *              hi plane is cut with round-toward-zero, which never produces inf): the score is
  *              finite and wrong, so a model with such activations must use EXACT_F32.  The
  *              reference's models are batch-normalised / PReLU nets with O(1) activations.
- *              In nann_search the split form runs with the ITEM HALF OF LAYER 1 PRE-PROJECTED: W1e^T e_i is the same
- *              vector whoever scores item i, so the first search of a (scorer, index) pair computes it for every item
- *              once -- a resident f32 [n_items, 256] table owned by the scorer, 1 GB per million items, built in
- *              ~10 ms per million -- and the traversal gathers that row instead of running layer 1 (csrc/nann_mlp3.h).
- *              A scorer keeps the tables of the two indices it searched last.  nann_score (stand-alone rows, no
- *              index) runs all three layers on the matrix cores.
  *   EXACT_F32  v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, scores BIT-identical to the oracle's
  *              fp32 chain (and therefore identical top-k ids); 1/16 of the 16-bit MFMA rate.
+ *   In nann_search BOTH forms run with the ITEM HALF OF LAYER 1 PRE-PROJECTED: P_i = W1e^T e_i is the same vector
+ *   whoever scores item i (the canonical order of layer 1 is a1 = u + P with P a chain of its own, oracle/
+ *   nann_oracle.c), so it is computed for every item once per (scorer, index) pair -- a resident f32 [n_items, 256]
+ *   table owned by the scorer, 1 GB per million items, ~10 ms per million to build: at the pair's first search, or
+ *   ahead of traffic by nann_scorer_prepare (below) -- and the traversal gathers that row instead of running layer 1,
+ *   with all of layer 2 resident in LDS (csrc/nann_mlp5.h).  Without room for the table (or with pre-projection
+ *   switched off) the kernels that read the embedding rows run instead: same results for EXACT_F32, same tolerance for
+ *   SPLIT_F16.  nann_score (stand-alone rows, no index) runs all three layers on the matrix cores.
  *   DEFAULT    (0, what a zero-initialised descriptor asks for) SPLIT_F16 when the weights meet its
  *              precondition, else EXACT_F32: 1e-5 is the contract, bit-exactness is opt-in. */
 enum nann_mlp_precision { NANN_MLP_PRECISION_DEFAULT = 0, NANN_MLP_SPLIT_F16 = 1, NANN_MLP_EXACT_F32 = 2 };
 int nann_scorer_create(const nann_scorer_desc* desc /*[host]*/, nann_scorer** out);
 void nann_scorer_destroy(nann_scorer* s);
+
+/* Lifecycle of the pre-projected tables (MLP scorers; attention models in split precision: nann_model_* below).
+ *   nann_scorer_prepare      builds the table of (scorer, index) on `stream` NOW (or finds it), waits for it, and PINS
+ *                            it: a pinned table is never evicted.  A serving host calls this at start-up, so that no
+ *                            request pays the build (a hipMalloc + ~10-20 ms per million items + one stream wait).
+ *                            NANN_ERR_CAPACITY when HBM has no room for it (searches of the pair still work: they read
+ *                            the embedding rows).  Counts: n prepare calls need n releases.
+ *   nann_scorer_release      drops one pin; at zero the table is retired at once.
+ *   nann_scorer_table_bytes  *table_bytes = HBM bytes the table of this pair takes (ix may be NULL: 0), *resident_bytes
+ *                            = bytes the scorer holds right now, all indices (either may be NULL).  This memory is NOT
+ *                            part of nann_search_workspace_bytes.
+ * Without prepare, the first nann_search of a pair builds the table inside the call (one stream wait) and the scorer
+ * keeps the unpinned tables of the two indices it searched last (least recently used goes).  Eviction, release and
+ * nann_index_destroy only RETIRE a table: it is freed by a later call once every launch that reads it has completed
+ * (an event per stream behind each search), so no call synchronises the device and a concurrent search on another
+ * thread never loses its table.  Thread-safe.
+ * nann_set_preprojection(0) switches the tables off process-wide (NANN_PREPROJECT=0 in the environment: the same). */
+int nann_scorer_prepare(const nann_scorer* scorer, const nann_index* ix, nann_stream_t stream);
+int nann_scorer_release(const nann_scorer* scorer, const nann_index* ix);
+int nann_scorer_table_bytes(const nann_scorer* scorer, const nann_index* ix, int64_t* table_bytes,
+                            int64_t* resident_bytes);
+int nann_set_preprojection(int32_t enabled);
 
 /* comm_seq f16[n_queries, seq_len, d] -> q f32[n_queries, d]: mean over
  * non-pad (not all-zero) rows; the user side of forward()
@@ -252,7 +277,6 @@ int nann_model_forward(const nann_model* m, const void* user_seq_f16, const void
  * (build_opt_graph.py:83-90, 70): item_embs [N,d], item_ids i64[N], per level
  * CSR (values i32, row_splits i64[N+1]) for levels 0 and 1, enter_points
  * i32[E] (ascending, unique). */
-typedef struct nann_index nann_index;
 typedef struct {
   int64_t n_items;
   int32_t d;
@@ -274,7 +298,7 @@ int nann_index_info(const nann_index* ix, int64_t out[6]);
 
 #define NANN_NUM_ROUNDS 5
 /* Where a query's visited set lives (the reference: a TemporaryVariable bitmap of N/32 words,
- * build_opt_graph.py:115-118).  AUTO picks per call: shards of up to 2^27 items -> an exact hash
+ * build_opt_graph.py:115-118).  AUTO picks per call: shards below 2^27 items -> an exact hash
  * set of visited ids in LDS -- LDS_HASH (16K slots, 64 KB: two queries per CU with the L2 scorer,
  * one with the matrix-core scorers) or, L2 scorer only, for beams whose visited set is expected to
  * outgrow it and for batches of at most one query per CU, LDS_HASH32 (32K slots, one query per CU);
@@ -313,7 +337,20 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
                 int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
                 int32_t* out_index, int32_t* status, int32_t* counters, nann_stream_t stream);
 
-/* Same, plus per-query time attribution for tuning: phase_ticks
+/* The same with level_topn PER QUERY, as the reference feeds it per request (build_opt_graph.py:75,151-159: `level_topn`
+ * is a placeholder of the serving signature, so two requests of one batch may ask for different beams).
+ *   level_topn_max [host] i32[6]  per-launch maxima: they size the workspace (nann_search_workspace_bytes) and the
+ *                                 plan, and level_topn_max[5] is the ROW STRIDE of out_item_ids / out_scores / out_index
+ *   level_topn     device i32[n_queries, 6] (NULL: every query takes level_topn_max -- nann_search's fast path)
+ * Query i returns its level_topn[i][5] results at the head of row i, zeros behind.  An entry outside
+ * [0, level_topn_max[j]] fails THAT query with NANN_ERR_BAD_ARGUMENT in status[i]; k > n and the other failures of
+ * the reference are per query as before.  Each query's result is bit-identical to a uniform launch with its values. */
+int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                  const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
+                  int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                  int32_t* status, int32_t* counters, nann_stream_t stream);
+
+/* Same as nann_search, plus per-query time attribution for tuning: phase_ticks
  * i64[n_queries, NANN_NUM_PHASES] receives shader-clock ticks spent in
  * {bitmap zeroing, mark walks, CSR expand+walk, gather+score, top-k, other} followed by
  * sub-phases {top-k: load, search, collect, sort; expand: pass 1, pipeline loop, filter; hash-set
@@ -338,6 +375,15 @@ int nann_search_model(const nann_index* ix, const nann_model* m, const void* com
                       const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
                       int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                       int32_t* counters, nann_stream_t stream);
+
+/* per-query level_topn (nann_search_v) and the table lifecycle (nann_scorer_prepare ...) for a model */
+int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                        const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
+                        int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                        int32_t* status, int32_t* counters, nann_stream_t stream);
+int nann_model_prepare(const nann_model* m, const nann_index* ix, nann_stream_t stream);
+int nann_model_release(const nann_model* m, const nann_index* ix);
+int nann_model_table_bytes(const nann_model* m, const nann_index* ix, int64_t* table_bytes, int64_t* resident_bytes);
 
 /* ---- 8(f3): the evaluation graph's traversal, one kernel per batch of users ---------------
  * Model.retrieval + search_level (NANN_impls/nann/model.py:299-362), the traversal behind

@@ -4,6 +4,7 @@
 #include "nann_eval.h"
 #include "nann_attn.h"
 #include "host/nann_graphdef.h"
+#include "host/nann_projcache.h"
 
 #include <algorithm>
 #include <atomic>
@@ -12,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -495,17 +497,51 @@ __global__ __launch_bounds__(256) void k_score_l2(const void* table, long long n
 // The item-only part of a split-f16 scorer, pre-projected for the indices the scorer has searched (nann_mlp3.h: the item
 // half of the MLP's layer 1, f32 [n_items, 256]; nann_attn_proj.h: q_ and the e rows of DNN layer 1, f32 [n_items, 384]):
 // built at the first nann_search of the (scorer, index) pair, at most two kept per scorer (the older one goes).
-struct ProjCache {
-  struct Entry { uint64_t index_uid = 0; float* table = nullptr; };
-  std::mutex mu;
-  Entry e[2];
-  ~ProjCache() { for (auto& x : e) if (x.table) (void)hipFree(x.table); }
+// Lifecycle (round 4): host/nann_projcache.h -- ref-counted tables, LRU among the unpinned ones, retirement instead of
+// freeing (an event per stream behind every launch that reads a table), pinning by nann_*_prepare.
+struct HipProjBackend {
+  typedef hipStream_t Stream;
+  typedef hipEvent_t Event;
+  static bool malloc(void** p, size_t bytes) {
+    if (hipMalloc(p, bytes) == hipSuccess) return true;
+    (void)hipGetLastError();  // not sticky: the search goes on without a table
+    return false;
+  }
+  static void free(void* p) { (void)hipFree(p); }
+  static bool mem_info(size_t* free_b) {
+    size_t total = 0;
+    if (hipMemGetInfo(free_b, &total) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+  }
+  static bool event_create(Event* e) {
+    if (hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+  }
+  static void event_destroy(Event e) { (void)hipEventDestroy(e); }
+  static void event_record(Event e, Stream s) { (void)hipEventRecord(e, s); }
+  static bool event_done(Event e) { return hipEventQuery(e) != hipErrorNotReady; }
+  static void event_wait(Event e) { (void)hipEventSynchronize(e); }
 };
+typedef nann::ProjCacheT<HipProjBackend> ProjCache;
+typedef nann::ProjTableT<HipProjBackend> ProjTable;
+static std::atomic<int> g_preproject{-1};  // -1: NANN_PREPROJECT from the environment (default on), 0 off, 1 on
+static bool preproject_enabled() {
+  int v = g_preproject.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("NANN_PREPROJECT");
+    v = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
+    g_preproject.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
 
 struct nann_scorer {
   nann_scorer_desc desc;
   float* dev_weights = nullptr;  // MLP weights block in HBM
   uint4* dev_packed = nullptr;   // split-f16 planes in MFMA A-fragment order
+  float4* dev_packed_x = nullptr;  // W2 as f32 A fragments (exact form, layer 2 resident in LDS)
   MlpParams mlp = {};
   mutable ProjCache proj;
 };
@@ -1095,6 +1131,24 @@ int nann_scorer_create(const nann_scorer_desc* desc, nann_scorer** out) {
       s->mlp.p1 = s->dev_packed;
       s->mlp.p2 = s->dev_packed + p2_off / 8;
     }
+    {  // W2 as f32 A fragments of the exact form's resident layer 2 (nann_mlp5.h): p2x[t][mt][j][lane][i] =
+       // W2[32 t + i + 8 j + 4 (lane >> 5)][32 mt + (lane & 31)] -- step r = 4 j + i of tile t in ORDER_H
+      std::vector<float> px((size_t)256 * 128);
+      for (int t = 0; t < 8; ++t)
+        for (int mt = 0; mt < 4; ++mt)
+          for (int j = 0; j < 4; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int i = 0; i < 4; ++i)
+                px[((((size_t)t * 4 + mt) * 4 + j) * 64 + lane) * 4 + i] =
+                    desc->w2[(size_t)(32 * t + i + 8 * j + 4 * (lane >> 5)) * 128 + 32 * mt + (lane & 31)];
+      e = hipMalloc(reinterpret_cast<void**>(&s->dev_packed_x), px.size() * 4);
+      if (e == hipSuccess) e = hipMemcpy(s->dev_packed_x, px.data(), px.size() * 4, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        nann_scorer_destroy(s);
+        return fail(NANN_ERR_HIP, std::string("scorer weights: ") + hipGetErrorString(e));
+      }
+      s->mlp.p2x = s->dev_packed_x;
+    }
     // the host pointers of the descriptor are not kept
     s->desc.w1 = s->desc.b1 = s->desc.alpha1 = s->desc.w2 = s->desc.b2 = s->desc.alpha2 = s->desc.w3 = nullptr;
   }
@@ -1106,6 +1160,7 @@ void nann_scorer_destroy(nann_scorer* s) {
   if (!s) return;
   if (s->dev_weights) (void)hipFree(s->dev_weights);
   if (s->dev_packed) (void)hipFree(s->dev_packed);
+  if (s->dev_packed_x) (void)hipFree(s->dev_packed_x);
   delete s;
 }
 
@@ -1632,6 +1687,7 @@ int nann_index_create(const nann_index_desc* desc, nann_index** out) {
 
 void nann_index_destroy(nann_index* ix) {
   if (!ix) return;
+  ProjCache::drop_index(ix->uid);  // the scorers' pre-projected tables of this index go with it (retired, then freed)
   for (void* p : ix->owned) (void)hipFree(p);
   delete ix;
 }
@@ -1650,6 +1706,8 @@ static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } retur
 
 constexpr int kKindAttn = 2;      // plan_search: the attention model (NANN_MODEL_ATTENTION); 0 / 1 = nann_scorer_kind
 constexpr int kKindMlpSplit = 3;  //   the MLP scorer in split-f16 form (two slice buffers: the scratch of an attention plan)
+constexpr int kKindMlpRes = 4;    //   the MLP scorer, either precision, on the pre-projected table with layer 2 resident in LDS
+                                  //   (nann_mlp5.h): 16K-slot set under the weights, or the HBM bitmap
 // kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
 static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p) {
   for (int i = 0; i < 6; ++i)
@@ -1671,15 +1729,17 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // scratch behind the visited set: "any" (workspace sizing) assumes the largest, so that its slots can hold the HBM
   // bitmap of whatever plan the call ends up with
   const size_t big_scratch = (size_t)std::max(kAttnScratch, kMlpSplitScratch);
+  const bool res = kind == kKindMlpRes;
   const size_t bm_scratch = kind == kKindAttn ? (size_t)kAttnScratch
                             : kind == kKindMlpSplit ? (size_t)kMlpSplitScratch
+                            : res ? (size_t)kMlpResBytes
                             : kind < 0 ? big_scratch : (size_t)kPhaseScratch;
-  const bool bitmap_fits = bm_bytes + bm_scratch + tail <= di.lds_max;
+  const bool bitmap_fits = !res && bm_bytes + bm_scratch + tail <= di.lds_max;  // resident layer 2 owns the LDS: HBM bitmap
   const int mode = g_traversal_mode.load(std::memory_order_relaxed);
   // the bitmap plan: what MLP traversals run, what oversized shards run, and the fallback of the hash plan
   const int bm_vis = (bitmap_fits && mode != NANN_TRAVERSAL_HBM_BITMAP) ? VIS_LDS_BITMAP : VIS_HBM_BITMAP;
   const size_t bm_lds = bm_scratch + tail + (bm_vis == VIS_LDS_BITMAP ? bm_bytes : 0);
-  const int bm_per_cu = bm_vis == VIS_LDS_BITMAP ? 1 : 2;
+  const int bm_per_cu = (bm_vis == VIS_LDS_BITMAP || res) ? 1 : 2;
   // the hash-set plans.  Which table:
   // the visited set of a level holds its marks plus every id the level's rounds keep.  Measured on
   // HNSW(M=32) graphs (profiles/): the rows a beam walks are ~2.75x the mean degree and ~45% of the
@@ -1687,8 +1747,10 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // slots (one query per CU) for wider beams; beyond that the bitmap.  A wrong guess costs speed,
   // not correctness: overflowing queries are rerun on the bitmap kernel.
   // set entries are (remainder, probe step) tags cut from a bijection of the id space (nann_device.h, vis_key): any
-  // shard up to 2^27 items gets 12 position bits (rounds 1-2 stored the id: 10 position bits at 4M items)
-  const int id_bits = std::max(16, bit_length((uint64_t)std::max<int64_t>(ix->desc.n_items - 1, 1)));
+  // shard below 2^27 items gets 12 position bits (rounds 1-2 stored the id: 10 position bits at 4M items)
+  // bit_length(n_items), not (n_items - 1): a shard of exactly 2^20 items would otherwise take the direct form, where
+  // id 2^20 - 1 at position 4095 encodes as the empty value 0xffffffff
+  const int id_bits = std::max(16, bit_length((uint64_t)std::max<int64_t>(ix->desc.n_items, 1)));
   const bool tag_fits = id_bits <= 27;
   const double mean_deg0 = (double)ix->desc.nb_nnz[0] / (double)std::max<int64_t>(ix->desc.n_items, 1);
   const double walk_deg = std::min<double>((double)ix->max_deg[0], 2.75 * mean_deg0);
@@ -1712,12 +1774,16 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // attention model / split-f16 MLP: 16K slots, one workgroup per CU -- when the level's visited ids are expected to fit
   // (a beam too wide for the set would send nearly every query through both kernels)
   const bool fits16 = worst_visited <= 16320.0 || est_visited <= 11000.0 || mode == NANN_TRAVERSAL_LDS_HASH;
-  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit) && tag_fits && fits16;
+  const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit || res) && tag_fits && fits16;
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
       !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
-    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards of up to 2^27 items; the 32K-slot set: L2 scorer only");
+    return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards below 2^27 items; the 32K-slot set: L2 scorer only");
   unsigned long long off[8];
-  p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u, off);
+  // the slot's last region: the HBM bitmap of a bitmap plan, and where a resident-layer-2 traversal parks its 16K-slot
+  // set while it scores (nann_mlp5.h); "any" sizes for both
+  uint32_t gbm_words = bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u;
+  if (res || kind < 0) gbm_words = std::max<uint32_t>(std::max<uint32_t>(gbm_words, ix->bm_words), (uint32_t)vis_slots(VIS_LDS_HASH));
+  p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
   p->id_bits = id_bits;
   p->fb_vis = bm_vis;
   p->fb_lds_bytes = bm_lds;
@@ -1726,7 +1792,8 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     // attention model / split-f16 MLP: 16K-slot set + two weight-slice buffers, one 512-thread workgroup per CU
     p->vis = VIS_LDS_HASH;
     p->nt = 512;
-    p->lds_bytes = (size_t)vis_slots(VIS_LDS_HASH) * 4 + bm_scratch + tail;
+    p->lds_bytes = res ? bm_scratch + tail  // the weights lie over [set | scratch]: the same bytes as the bitmap plan
+                       : (size_t)vis_slots(VIS_LDS_HASH) * 4 + bm_scratch + tail;
     p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus));
   } else if (hash_ok && hash_vis == VIS_LDS_HASH) {
     p->vis = VIS_LDS_HASH;
@@ -1771,52 +1838,47 @@ namespace nann {
 int mlp_mapping_choice() {
   static const int choice = [] {
     const char* e = std::getenv("NANN_MLP_MAPPING");
-    return (e && e[0] >= '1' && e[0] <= '4' && e[1] == 0) ? e[0] - '0' : 3;
+    return (e && e[0] >= '1' && e[0] <= '5' && e[1] == 0) ? e[0] - '0' : 5;
   }();
   return choice;
 }
 }  // namespace nann
 
-// the pre-projected table of (scorer, index): built on `st` at the pair's first search by `build(table)`
+// The pre-projected table of (scorer, index): found, or built on `st` by `build(table)` (a one-time wait per pair,
+// ~10-20 ms per million items: nann_*_prepare moves it ahead of traffic).  *out stays null -- with NANN_OK -- when there
+// is to be no table: pre-projection switched off, or no room for it in HBM (the caller then runs the kernels that
+// read the embedding rows; ADVICE r3: a failed hipMalloc must not fail the search).  pin: count a prepare call.
 template <typename Build>
-static int projection_for(ProjCache& c, const nann_index* ix, int width, hipStream_t st, Build build, const float** out) {
-  std::lock_guard<std::mutex> lk(c.mu);
-  for (auto& p : c.e)
-    if (p.table && p.index_uid == ix->uid) { *out = p.table; return NANN_OK; }
-  ProjCache::Entry& slot = c.e[0].table == nullptr ? c.e[0] : c.e[1];
-  if (slot.table) {  // evict (stream-ordered free would need the owner's stream: synchronise the device once)
-    HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(slot.table);
-    slot.table = nullptr;
-  }
-  float* t = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t), (size_t)ix->desc.n_items * (size_t)width * 4));
-  const int rc = build(t);
-  if (rc) { (void)hipFree(t); return rc; }
-  // the table becomes visible to searches on OTHER streams when this function returns: it must be complete by then
-  // (a one-time wait per (scorer, index) pair, ~10-20 ms per million items)
-  {
+static int projection_for(ProjCache& c, const nann_index* ix, int width, hipStream_t st, Build build, bool pin,
+                          std::shared_ptr<ProjTable>* out) {
+  const size_t bytes = (size_t)ix->desc.n_items * (size_t)width * 4;
+  return c.acquire(ix->uid, bytes, preproject_enabled(), pin, [&](float* t) -> int {
+    const int rc = build(t);
+    if (rc) return rc;
+    // the table becomes visible to searches on OTHER streams when acquire() returns: it must be complete by then
     const hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(t); return fail(NANN_ERR_HIP, std::string("pre-projection: ") + hipGetErrorString(e)); }
-  }
-  if (&slot == &c.e[0] && c.e[1].table) std::swap(c.e[0], c.e[1]);  // keep [1] the most recent
-  ProjCache::Entry& dst = c.e[0].table == nullptr ? c.e[0] : c.e[1];
-  dst.index_uid = ix->uid;
-  dst.table = t;
-  *out = t;
-  return NANN_OK;
+    if (e != hipSuccess) return fail(NANN_ERR_HIP, std::string("pre-projection: ") + hipGetErrorString(e));
+    return NANN_OK;
+  }, out);
 }
 
-static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, const float** out) {
+static void projection_used(ProjCache& c, const std::shared_ptr<ProjTable>& tab, hipStream_t st) { c.used(tab, st); }
+
+static int projection_release(ProjCache& c, const nann_index* ix) {
+  if (c.release(ix->uid)) return NANN_OK;
+  return fail(NANN_ERR_BAD_ARGUMENT, "release: no pre-projected table of this index");
+}
+
+static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, bool pin, std::shared_ptr<ProjTable>* out) {
   return projection_for(sc->proj, ix, kMlpProjWidth, st, [&](float* t) {
     return launch_mlp_preproject(ix->desc.emb_dtype, ix->desc.item_embs, (long long)ix->desc.n_items, ix->desc.d, sc->mlp.w1, t, st);
-  }, out);
+  }, pin, out);
 }
 
-static int attn_projection(const nann_attn_scorer* sc, const nann_index* ix, hipStream_t st, const float** out) {
+static int attn_projection(const nann_attn_scorer* sc, const nann_index* ix, hipStream_t st, bool pin, std::shared_ptr<ProjTable>* out) {
   return projection_for(sc->proj, ix, kAttnProjWidth, st, [&](float* t) {
     return launch_attn_preproject(ix->desc.emb_dtype, sc->P, ix->desc.item_embs, (long long)ix->desc.n_items, t, st);
-  }, out);
+  }, pin, out);
 }
 
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
@@ -1847,17 +1909,34 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
 }  // extern "C"
 
 // the traversal for (index, scorer | attention model): plan, fill the arguments, launch (+ the
-// fallback launch of the hash-set plans)
+// fallback launch of the hash-set plans).  tq: optional device i32[n_queries, 6], level_topn per query (level_topn then
+// holds the per-launch maxima).
 static int search_impl(const nann_index* ix, const nann_scorer* scorer, const nann_attn_scorer* attn,
                        const float* q, const float* kt, const float* upad, int64_t n_queries,
-                       const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                       const int32_t level_topn[6], const int32_t* tq, void* workspace, int64_t workspace_bytes,
                        int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                        int32_t* counters, int64_t* phase_ticks, hipStream_t st) {
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
   const int kind = attn ? kKindAttn : scorer->desc.kind;
-  const bool mlp_split = !attn && kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
+  const bool mlp = !attn && kind == NANN_SCORER_MLP;
+  const bool mlp_split = mlp && scorer->desc.precision == NANN_MLP_SPLIT_F16;
+  const int mapping = mlp_mapping_choice();
+  // the item-only part of the scorer, pre-projected per (scorer, index): found or built here (nann_*_prepare does it
+  // ahead of traffic); without a table -- switched off, or no room in HBM -- the kernels that read the embedding rows run
+  std::shared_ptr<ProjTable> tab;
+  ProjCache* cache = nullptr;
+  int rc = NANN_OK;
+  if (attn && attn->precision == NANN_MLP_SPLIT_F16 && mapping >= 3) {
+    cache = &attn->proj;
+    rc = attn_projection(attn, ix, st, false, &tab);
+  } else if (mlp && (mapping >= 5 || (mlp_split && mapping >= 3))) {
+    cache = &scorer->proj;
+    rc = mlp_projection(scorer, ix, st, false, &tab);
+  }
+  if (rc) return rc;
+  const bool mlp_res = mlp && tab && mapping >= 5;  // layer 2 resident in LDS, either precision (nann_mlp5.h)
   SearchPlan p;
-  int rc = plan_search(ix, level_topn, n_queries, mlp_split ? kKindMlpSplit : kind, &p);
+  rc = plan_search(ix, level_topn, n_queries, mlp_res ? kKindMlpRes : mlp_split ? kKindMlpSplit : kind, &p);
   if (rc) return rc;
   if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots)))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");
@@ -1872,6 +1951,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   a.q = q;
   a.n_queries = (int)n_queries;
   for (int i = 0; i < 6; ++i) a.t[i] = level_topn[i];
+  a.tq = tq;
   a.ws = static_cast<unsigned char*>(workspace);
   a.slot_bytes = p.slot_bytes;
   a.bm_words = ix->bm_words;
@@ -1881,49 +1961,41 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
   a.id_bits = p.id_bits;
   a.redo = 0;
-  a.proj = nullptr;
+  a.proj = tab ? tab->table : nullptr;
   a.mlp = MlpParams{};
   a.attn = AttnParams{};
   a.kt = kt; a.upad = upad;
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));  // WsHeader: query queues, hand-back counter
   const int dt = ix->desc.emb_dtype;
   const bool hashed = p.vis == VIS_LDS_HASH || p.vis == VIS_LDS_HASH32;
+  // main launch, then -- hash-set plans -- the rerun of the queries whose set could have overflowed on the bitmap
+  // kernel (its workgroups leave at once when there is none)
+  auto both = [&](auto&& launch_on) -> int {
+    int r2 = launch_on(p.vis, p.nt, p.slots, p.lds_bytes);
+    if (!r2 && hashed) {
+      a.redo = 1;
+      r2 = launch_on(p.fb_vis, kNT, p.fb_slots, p.fb_lds_bytes);
+    }
+    if (cache) projection_used(*cache, tab, st);
+    return r2;
+  };
   if (attn) {
     a.attn = attn->P;
-    if (attn->precision == NANN_MLP_SPLIT_F16 && mlp_mapping_choice() >= 3) {
-      // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
-      rc = attn_projection(attn, ix, st, &a.proj);
-      if (rc) return rc;
-      rc = launch_search_attn_proj(p.vis, p.slots, p.lds_bytes, a, st);
-      if (rc || !hashed) return rc;
-      a.redo = 1;
-      return launch_search_attn_proj(p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
-    }
+    if (tab)  // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
+      return both([&](int vis, int, int slots, size_t lds) { return launch_search_attn_proj(vis, slots, lds, a, st); });
     auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_split : launch_search_attn;
-    rc = launch(ix->desc.d, dt, p.vis, p.slots, p.lds_bytes, a, st);
-    if (rc || !hashed) return rc;
-    a.redo = 1;
-    return launch(ix->desc.d, dt, p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
+    return both([&](int vis, int, int slots, size_t lds) { return launch(ix->desc.d, dt, vis, slots, lds, a, st); });
   }
   a.mlp = scorer->mlp;
-  a.proj = nullptr;
-  const int split = kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_SPLIT_F16;
-  if (split && mlp_mapping_choice() >= 3) {
-    // the default form: item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h) -- on every plan, so that a
-    // query scores with the same arithmetic whether the hash set held its visited ids or the bitmap kernel reran it
-    rc = mlp_projection(scorer, ix, st, &a.proj);
-    if (rc) return rc;
-    rc = launch_search_mlp_proj(p.vis, p.slots, p.lds_bytes, a, st);
-    if (rc || !hashed) return rc;
-    a.redo = 1;
-    return launch_search_mlp_proj(p.fb_vis, p.fb_slots, p.fb_lds_bytes, a, st);
-  }
-  rc = launch_search_any(ix->desc.d / 8, dt, kind, split, p.vis, p.nt, p.slots, p.lds_bytes, a, st);
-  if (rc || !hashed) return rc;
-  // queries whose visited set could have overflowed the hash set are rerun on the bitmap kernel (its
-  // workgroups leave at once when there is none)
-  a.redo = 1;
-  return launch_search_any(ix->desc.d / 8, dt, kind, split, p.fb_vis, kNT, p.fb_slots, p.fb_lds_bytes, a, st);
+  if (mlp_res)  // the default form of both precisions: item half of layer 1 from the table, layer 2 resident in LDS
+    return both([&](int vis, int, int slots, size_t lds) {
+      return launch_search_mlp_res(scorer->desc.precision == NANN_MLP_EXACT_F32, vis, slots, lds, a, st);
+    });
+  if (mlp_split && tab)  // round 3's form (NANN_MLP_MAPPING=3|4): the table, layer-2 slices streamed per pass (nann_mlp3.h)
+    return both([&](int vis, int, int slots, size_t lds) { return launch_search_mlp_proj(vis, slots, lds, a, st); });
+  return both([&](int vis, int nt, int slots, size_t lds) {
+    return launch_search_any(ix->desc.d / 8, dt, kind, mlp_split, vis, nt, slots, lds, a, st);
+  });
 }
 
 extern "C" {
@@ -1937,8 +2009,67 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   if (n_queries <= 0) return NANN_OK;
   if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
     return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
-  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, workspace, workspace_bytes,
+  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, nullptr, workspace, workspace_bytes,
                      out_item_ids, out_scores, out_index, status, counters, phase_ticks, as_stream(stream));
+}
+
+int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                  const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
+                  int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                  int32_t* status, int32_t* counters, nann_stream_t stream) {
+  if (!ix || !scorer || !level_topn_max || !out_item_ids || !status)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_v: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn_max, level_topn, workspace,
+                     workspace_bytes, out_item_ids, out_scores, out_index, status, counters, nullptr, as_stream(stream));
+}
+
+// ---- lifecycle of the pre-projected tables (ProjCache) -------------------------------------------------------
+int nann_set_preprojection(int32_t enabled) {
+  g_preproject.store(enabled ? 1 : 0, std::memory_order_relaxed);
+  return NANN_OK;
+}
+
+static int table_width(const nann_scorer* s, const nann_attn_scorer* at) {
+  if (at) return at->precision == NANN_MLP_SPLIT_F16 ? kAttnProjWidth : 0;
+  return (s && s->desc.kind == NANN_SCORER_MLP) ? kMlpProjWidth : 0;
+}
+static int prepare_impl(const nann_scorer* s, const nann_attn_scorer* at, const nann_index* ix, hipStream_t st) {
+  if (table_width(s, at) == 0) return NANN_OK;  // L2 / f32-form attention: nothing to pre-project
+  const int d = at ? at->P.d : s->desc.d, dt = at ? at->emb_dtype : s->desc.emb_dtype;
+  if (d != ix->desc.d || dt != ix->desc.emb_dtype) return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  std::shared_ptr<ProjTable> tab;
+  const int rc = at ? attn_projection(at, ix, st, true, &tab) : mlp_projection(s, ix, st, true, &tab);
+  if (rc) return rc;
+  if (!tab) return fail(NANN_ERR_CAPACITY, "no room in HBM for the pre-projected table (or pre-projection is switched off): "
+                                           "searches of this pair will read the embedding table");
+  return NANN_OK;
+}
+static int table_bytes_impl(const nann_scorer* s, const nann_attn_scorer* at, const nann_index* ix, int64_t* table_bytes,
+                            int64_t* resident_bytes) {
+  if (table_bytes) *table_bytes = ix ? (int64_t)ix->desc.n_items * table_width(s, at) * 4 : 0;
+  if (resident_bytes) {
+    *resident_bytes = 0;
+    ProjCache* c = at ? &at->proj : s ? &s->proj : nullptr;
+    if (c) *resident_bytes = (int64_t)c->resident();
+  }
+  return NANN_OK;
+}
+
+int nann_scorer_prepare(const nann_scorer* scorer, const nann_index* ix, nann_stream_t stream) {
+  if (!scorer || !ix) return fail(NANN_ERR_BAD_ARGUMENT, "nann_scorer_prepare: null argument");
+  return prepare_impl(scorer, nullptr, ix, as_stream(stream));
+}
+int nann_scorer_release(const nann_scorer* scorer, const nann_index* ix) {
+  if (!scorer || !ix) return fail(NANN_ERR_BAD_ARGUMENT, "nann_scorer_release: null argument");
+  if (table_width(scorer, nullptr) == 0) return NANN_OK;
+  return projection_release(scorer->proj, ix);
+}
+int nann_scorer_table_bytes(const nann_scorer* scorer, const nann_index* ix, int64_t* table_bytes, int64_t* resident_bytes) {
+  if (!scorer) return fail(NANN_ERR_BAD_ARGUMENT, "nann_scorer_table_bytes: null scorer");
+  return table_bytes_impl(scorer, nullptr, ix, table_bytes, resident_bytes);
 }
 
 // ---- the serving signature: comm_seq + level_topn -> top_k, for whatever model the node names ----
@@ -1958,10 +2089,10 @@ int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m,
   return NANN_OK;
 }
 
-int nann_search_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
-                      const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
-                      int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
-                      int32_t* counters, nann_stream_t stream) {
+static int search_model_impl(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                             const int32_t level_topn[6], const int32_t* tq, void* workspace, int64_t workspace_bytes,
+                             int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                             int32_t* counters, nann_stream_t stream) {
   if (!ix || !m || !comm_seq_f16 || !level_topn || !out_item_ids || !status || !workspace)
     return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_model: null argument");
   if (n_queries <= 0) return NANN_OK;
@@ -1980,14 +2111,45 @@ int nann_search_model(const nann_index* ix, const nann_model* m, const void* com
     float* upad = kt + (size_t)n_queries * 256 * 64;
     rc = nann_attn_prepare(m->attn, comm_seq_f16, n_queries, kt, upad, stream);
     if (rc) return rc;
-    return search_impl(ix, nullptr, m->attn, nullptr, kt, upad, n_queries, level_topn, workspace, search_bytes,
+    return search_impl(ix, nullptr, m->attn, nullptr, kt, upad, n_queries, level_topn, tq, workspace, search_bytes,
                        out_item_ids, out_scores, out_index, status, counters, nullptr, st);
   }
   float* q = reinterpret_cast<float*>(qbuf);
   rc = nann_user_seq_mean(comm_seq_f16, n_queries, m->seq_len, m->d, q, stream);
   if (rc) return rc;
-  return search_impl(ix, m->scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, workspace, search_bytes,
+  return search_impl(ix, m->scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, tq, workspace, search_bytes,
                      out_item_ids, out_scores, out_index, status, counters, nullptr, st);
+}
+
+int nann_search_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                      const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
+                      int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
+                      int32_t* counters, nann_stream_t stream) {
+  return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn, nullptr, workspace, workspace_bytes, out_item_ids,
+                           out_scores, out_index, status, counters, stream);
+}
+
+int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                        const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
+                        int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                        int32_t* status, int32_t* counters, nann_stream_t stream) {
+  return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn_max, level_topn, workspace, workspace_bytes,
+                           out_item_ids, out_scores, out_index, status, counters, stream);
+}
+
+int nann_model_prepare(const nann_model* m, const nann_index* ix, nann_stream_t stream) {
+  if (!m || !ix) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_prepare: null argument");
+  return prepare_impl(m->scorer, m->kind == NANN_MODEL_ATTENTION ? m->attn : nullptr, ix, as_stream(stream));
+}
+int nann_model_release(const nann_model* m, const nann_index* ix) {
+  if (!m || !ix) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_release: null argument");
+  const nann_attn_scorer* at = m->kind == NANN_MODEL_ATTENTION ? m->attn : nullptr;
+  if (table_width(m->scorer, at) == 0) return NANN_OK;
+  return projection_release(at ? at->proj : m->scorer->proj, ix);
+}
+int nann_model_table_bytes(const nann_model* m, const nann_index* ix, int64_t* table_bytes, int64_t* resident_bytes) {
+  if (!m) return fail(NANN_ERR_BAD_ARGUMENT, "nann_model_table_bytes: null model");
+  return table_bytes_impl(m->scorer, m->kind == NANN_MODEL_ATTENTION ? m->attn : nullptr, ix, table_bytes, resident_bytes);
 }
 
 // ---- the evaluation graph's traversal (nann_eval.h) ----------------------------------------

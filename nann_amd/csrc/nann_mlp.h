@@ -10,10 +10,12 @@
 // walks k in the same order, so scores are bit-identical, not merely close.
 //
 // Mapping (one wavefront = 32 candidates):
-//   layer 1, tile t (32 hidden units):  D1_t[j][c] = u[j] + sum_k W1e[k][32t+j] * e[c][k]
+//   layer 1, tile t (32 hidden units):  D1_t[j][c] = u[j] + P[j][c],  P[j][c] = sum_k W1e[k][32t+j] * e[c][k]
 //       A operand = W1e^T tile (lane l: hidden unit l&31, k-slot l>>5), streamed through LDS
 //       B operand = the candidate's embedding (lane l: candidate l&31, its half row in registers)
-//       the per-query part u = b1 + W1q^T q is hoisted out and seeds the accumulators
+//       P is a chain from 0 (ORDER_E) -- the very bits nann_search's pre-projected table holds (nann_mlp3.h,
+//       nann_mlp5.h) -- and the per-query part u = b1 + W1q^T q, hoisted out, is added ONCE (round 4; rounds 1-3
+//       seeded the accumulators with u)
 //   layer 2, tile m: D2_m[o][c] = b2[o] + sum_j W2[j][32m+o] * h1[c][j]
 //       B operand = the layer-1 accumulators THEMSELVES: in the 32x32 C/D layout lane l
 //       holds, for candidate l&31, exactly the hidden units its k-slot needs, so h1 never
@@ -42,6 +44,8 @@ struct MlpParams {  // device pointers
   // packed on the host in MFMA A-fragment order (pack_split_weights in nann_hip.hip)
   const uint4* p1;  // [h1/32 tiles][d/16 chunks][hi, lo][64 lanes] x 8 halves
   const uint4* p2;  // [h1/32 tiles][2 chunks][h2/32 tiles][hi, lo][64 lanes] x 8 halves
+  // exact form with W2 resident in LDS (nann_mlp5.h): f32 A fragments of v_mfma_f32_32x32x2_f32, four chain steps per 16 bytes
+  const float4* p2x;  // [h1/32 tiles][h2/32 tiles][4][64 lanes] x 4 floats
 };
 
 constexpr int kMlpNT = 512;  // 8 wavefronts: 2 per SIMD -> 256 VGPRs each for the accumulators
@@ -210,9 +214,9 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
         pre0 = *slice_src(s + 1, tid);
         pre1 = *slice_src(s + 1, tid + NT);
       }
-      if (ks == 0) {  // the per-query part seeds the tile
+      if (ks == 0) {  // the item part P = W1e^T e is its own chain from 0 (round 4: the same bits as the pre-projected table)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = V->u[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot];
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
       }
       if (ks < KS1) {
 #pragma unroll
@@ -221,10 +225,12 @@ __device__ __forceinline__ void wg_score_mlp(const MlpParams& P, const void* __r
           const float b = packed_elem<DT>(ev, ks * 64 + kkl);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
         }
-        if (ks == KS1 - 1) {  // tile complete: PReLU in place
+        if (ks == KS1 - 1) {  // tile complete: a1 = u + P (the per-query part, one add), PReLU in place
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc1[r] = prelu(acc1[r], V->alpha1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot]);
+          for (int r = 0; r < 16; ++r) {
+            const int unit = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * slot;
+            acc1[r] = prelu(V->u[unit] + acc1[r], V->alpha1[unit]);
+          }
         }
       } else {
         // the accumulators of tile t ARE the B operand: lane (cand, slot) holds hidden units

@@ -38,7 +38,7 @@ static_assert(sizeof(Mlp3Scratch) <= sizeof(MlpSplitScratch), "fits the phase sc
 
 constexpr int kMlpProjWidth = 256;  // f32 per item in the pre-projected table (h1)
 
-// P'[i][j] = 2^7 sum_k e_i[k] W1[d + k][j] (k ascending, fmaf), rows i0 .. i0 + kRows of one workgroup.
+// P'[i][j] = 2^7 sum_k e_i[k] W1[d + k][j] (fmaf chain from 0 in ORDER_E), rows i0 .. i0 + kRows of one workgroup.
 // 256 threads = hidden units; the rows of the block are staged in LDS as f32, W1's item half streams through L2.
 template <int DT>
 __global__ __launch_bounds__(256) void k_mlp_preproject(const void* __restrict__ emb, long long n_rows, int d,
@@ -58,17 +58,20 @@ __global__ __launch_bounds__(256) void k_mlp_preproject(const void* __restrict__
 #pragma unroll
   for (int r = 0; r < kRows; ++r) acc[r] = 0.0f;
   const float* w = w1 + (size_t)d * 256 + j;  // item half: rows d .. 2d - 1
-  for (int k = 0; k < d; k += 4) {
-    float wv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wv[u] = w[(size_t)(k + u) * 256];
+  const int hd = d >> 1;
+  // ORDER_E (oracle/nann_oracle.c): k = 0, d/2, 1, d/2 + 1, ... -- the order in which the f32 MFMA of the stand-alone
+  // exact scorer (wg_score_mlp) consumes a row, so that table and scorer hold the same bits
+  for (int kk = 0; kk < hd; kk += 2) {
+    const float wa0 = w[(size_t)kk * 256], wb0 = w[(size_t)(hd + kk) * 256];
+    const float wa1 = w[(size_t)(kk + 1) * 256], wb1 = w[(size_t)(hd + kk + 1) * 256];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
-      const float4 ev = *reinterpret_cast<const float4*>(&e[r][k]);
-      acc[r] = __fmaf_rn(ev.x, wv[0], acc[r]);
-      acc[r] = __fmaf_rn(ev.y, wv[1], acc[r]);
-      acc[r] = __fmaf_rn(ev.z, wv[2], acc[r]);
-      acc[r] = __fmaf_rn(ev.w, wv[3], acc[r]);
+      const float2 ea = *reinterpret_cast<const float2*>(&e[r][kk]);
+      const float2 eb = *reinterpret_cast<const float2*>(&e[r][hd + kk]);
+      acc[r] = __fmaf_rn(ea.x, wa0, acc[r]);
+      acc[r] = __fmaf_rn(eb.x, wb0, acc[r]);
+      acc[r] = __fmaf_rn(ea.y, wa1, acc[r]);
+      acc[r] = __fmaf_rn(eb.y, wb1, acc[r]);
     }
   }
 #pragma unroll

@@ -8,6 +8,7 @@
 #include "nann_mlp.h"
 #include "nann_mlp2.h"
 #include "nann_mlp3.h"
+#include "nann_mlp5.h"
 #include "nann_attn_kernels.h"
 #include "nann_attn_split.h"
 #include "nann_attn_proj.h"
@@ -107,7 +108,9 @@ struct SearchArgs {
   int d;
   const float* q;
   int n_queries;
-  int t[6];
+  int t[6];                // level_topn of the launch; with tq: the per-launch maxima (workspace, plan, output row stride t[5])
+  const int32_t* tq;       // optional device i32[n_queries, 6]: level_topn PER QUERY (the reference feeds it per request,
+                           // build_opt_graph.py:75,151-159); each entry in [0, t[i]], else the query fails with BAD_ARGUMENT
   unsigned char* ws;
   unsigned long long slot_bytes;
   uint32_t bm_words;  // padded to a multiple of 4
@@ -120,6 +123,7 @@ struct SearchArgs {
   long long* phase_ticks;  // optional [n_queries, NANN_NUM_PHASES] shader-clock ticks
   MlpParams mlp;           // NANN_SCORER_MLP only
   const float* proj;       // kScorerMlpProj: the pre-projected item half of layer 1, f32 [n_items, 256] (nann_mlp3.h);
+                           // kScorerMlpRes / kScorerMlpXRes: the same table (nann_mlp5.h);
                            // kScorerAttnProj: the item-only layers of the attention model, f32 [n_items, 384] (nann_attn_proj.h)
   AttnParams attn;         // kScorerAttn only
   const float* kt;         //   per-query projected keys f32 [n_queries, 256, 64] (k_attn_prepare)
@@ -162,6 +166,9 @@ constexpr int kScorerAttn = 3;  // the reference's attention + DNN model (nann_a
 constexpr int kScorerAttnSplit = 4;  //   the same on the 16-bit MFMA with split operands (nann_attn_split.h)
 constexpr int kScorerMlpProj = 5;    // split-f16 MLP with the item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h)
 constexpr int kScorerAttnProj = 6;   // split-f16 attention model with its item-only layers pre-projected per (model, index) (nann_attn_proj.h)
+constexpr int kScorerMlpRes = 7;     // split-f16 MLP on the pre-projected table with ALL of layer 2 resident in LDS (nann_mlp5.h)
+constexpr int kScorerMlpXRes = 8;    // exact f32 MLP on the pre-projected table, layer 2 resident in LDS: bit-identical to the oracle
+constexpr bool is_mlp_res(int sc) { return sc == kScorerMlpRes || sc == kScorerMlpXRes; }
 constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj; }
 
 // where a query's visited set lives
@@ -187,6 +194,8 @@ template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int base = hash ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
+  // resident layer 2: 128 KB + vectors laid over [visited set | phase scratch] (hash plan) or the phase scratch alone
+  if (is_mlp_res(SC)) return hash ? kMlpResBytes - vis_slots(VIS) * 4 : kMlpResBytes;
   if (is_attn(SC) && base < kAttnScratch) return kAttnScratch;
   if ((SC == kScorerMlpSplit || SC == kScorerMlpProj) && base < kMlpSplitScratch) return kMlpSplitScratch;
   return base;
@@ -200,7 +209,16 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   constexpr bool LDSBM = VIS == VIS_LDS_BITMAP;
   constexpr int SLOTS = HASH ? vis_slots(VIS) : 16384;
   const int tid = local_tid();
-  const int k5 = a.t[5];
+  const int k5 = a.t[5];  // output row stride
+  int t[6];               // this query's level_topn (uniform)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) t[i] = a.tq ? a.tq[(size_t)qi * 6 + i] : a.t[i];
+  if (a.tq) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bad |= t[i] < 0 || t[i] > a.t[i];
+    if (bad) return NANN_ERR_BAD_ARGUMENT;
+  }
   // bitmap kernels, L2: candidate scores are mirrored in LDS for the selection; the MLP uses that
   // space for its weight slices (and its selection time is negligible next to the MFMAs)
   float* lds_scores = (SC == NANN_SCORER_L2 && !HASH) ? reinterpret_cast<float*>(scratch + kLdsScoresOff) : nullptr;
@@ -215,7 +233,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   __syncthreads();
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
   float mlp_u = 0.0f;              // MLP: thread j's per-query part of hidden unit j, once per query
-  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit || SC == kScorerMlpProj) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
+  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit || SC == kScorerMlpProj || is_mlp_res(SC)) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
 
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
@@ -250,7 +268,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           __syncthreads();
           mark(PH_ZERO);
           src = (r == 1) ? sv.beam_ids : sv.pool_ids;
-          n_in = (r == 1) ? a.t[0] : a.t[1];
+          n_in = (r == 1) ? t[0] : t[1];
           dst = (r == 1) ? sv.cand_ids : sv.beam_ids;
           rs = nullptr;
         } else {
@@ -306,7 +324,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         if (kept < 0) return NANN_ERR_INDEX_OUT_OF_RANGE;
         if (ss == 0) {
           if (r == 1) {
-            if (kept != a.t[0]) return NANN_ERR_BAD_ARGUMENT;  // duplicate enter points
+            if (kept != t[0]) return NANN_ERR_BAD_ARGUMENT;  // duplicate enter points
             base_off = kept;
           }
           frontier = sv.beam_ids;  // r == 1: the entry winners; r == 2: diff(P) written there
@@ -349,6 +367,29 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
                                a.proj, (long long)a.n_items, sc_ids, (long long)sc_n,
                                reinterpret_cast<float*>(scratch), sc_out);
+      } else if constexpr (is_mlp_res(SC)) {
+        // layer 2 resident in LDS over [visited set | phase scratch] (nann_mlp5.h).  The set is parked in the slot's HBM
+        // scratch when a later stage still needs it: stages 2 and 3 (it is empty before stage 0, cleared after stage 1
+        // -- :129-133 -- and dead after stage 4)
+        static_assert(NT == 512, "the resident scorers: eight wavefronts, two per SIMD");
+        static_assert(VIS == VIS_LDS_HASH || VIS == VIS_HBM_BITMAP, "resident layer 2: 16K-slot set or HBM bitmap");
+        uint4* lds0 = reinterpret_cast<uint4*>(HASH ? reinterpret_cast<unsigned char*>(bm) : scratch);
+        Mlp2Vectors* V = reinterpret_cast<Mlp2Vectors*>(reinterpret_cast<unsigned char*>(lds0) + kMlpResW2Bytes);
+        uint4* park = (HASH && (r == 2 || r == 3)) ? reinterpret_cast<uint4*>(sv.gbitmap) : nullptr;
+        __syncthreads();
+        if constexpr (SC == kScorerMlpXRes) {
+          wg_mlp_res_enter<NT>(lds0, reinterpret_cast<const uint4*>(a.mlp.p2x), park, SLOTS / 4);
+          wg_mlp_xres_vectors<NT>(a.mlp, mlp_u, V);
+          __syncthreads();
+          wg_score_mlp_xres<NT>(a.proj, a.n_items, sc_ids, sc_n, reinterpret_cast<const float4*>(lds0), V, sc_out);
+        } else {
+          wg_mlp_res_enter<NT>(lds0, a.mlp.p2, park, SLOTS / 4);
+          wg_mlp_res_vectors<NT>(a.mlp, mlp_u, V);
+          __syncthreads();
+          wg_score_mlp_res<NT>(a.proj, a.n_items, sc_ids, sc_n, lds0, V, sc_out);
+        }
+        __syncthreads();
+        wg_mlp_res_leave<NT>(lds0, park, SLOTS / 4);
       } else {
         // (the phase scratch was reused since the last stage)
         if constexpr (SC == kScorerMlpProj) {  // item half of layer 1 pre-projected: gather P rows, layer 2 on the matrix cores
@@ -379,16 +420,16 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     const int32_t* tk_ids; const float* tk_sc; int tk_n, tk_k;
     int32_t* tk_out_ids; float* tk_out_sc; const int64_t* tk_map = nullptr; int64_t* tk_out_map = nullptr;
     if (r == 0) {          // R, sR = topk(EP, s, t0)                      :112
-      tk_ids = a.enter; tk_sc = sv.cand_scores; tk_n = E; tk_k = a.t[0];
+      tk_ids = a.enter; tk_sc = sv.cand_scores; tk_n = E; tk_k = t[0];
       tk_out_ids = sv.beam_ids; tk_out_sc = sv.beam_scores;
     } else if (r == 1) {   // P, sP = topk(R || C, sR || sC, t1)           :125-127
-      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = base_off + sc_n; tk_k = a.t[1];
+      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = base_off + sc_n; tk_k = t[1];
       tk_out_ids = sv.pool_ids; tk_out_sc = sv.pool_scores;
     } else if (r < NANN_NUM_ROUNDS) {  // B, sB = topk(C, sC, t[r]); appended to the pool  :139-141
-      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = sc_n; tk_k = a.t[r];
+      tk_ids = sv.cand_ids; tk_sc = sv.cand_scores; tk_n = sc_n; tk_k = t[r];
       tk_out_ids = sv.pool_ids + nP; tk_out_sc = sv.pool_scores + nP;
     } else {               // final: topk(pool, t5) -> item_ids           :143-149
-      tk_ids = sv.pool_ids; tk_sc = sv.pool_scores; tk_n = nP; tk_k = k5;
+      tk_ids = sv.pool_ids; tk_sc = sv.pool_scores; tk_n = nP; tk_k = t[5];
       tk_out_ids = a.out_index ? a.out_index + (size_t)qi * k5 : nullptr;
       tk_out_sc = a.out_scores ? a.out_scores + (size_t)qi * k5 : nullptr;
       tk_map = a.item_ids; tk_out_map = a.out_ids + (size_t)qi * k5;
@@ -399,10 +440,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     mark(PH_TOPK);
     if (st) return st;
     if (r == 1) {
-      nP = a.t[1];
+      nP = t[1];
     } else if (r >= 2 && r < NANN_NUM_ROUNDS) {
       frontier = sv.pool_ids + nP;  // the beam = best NEW nodes only
-      nB = a.t[r];
+      nB = t[r];
       nP += nB;
     }
   }
@@ -436,7 +477,7 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
   long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
 
   unsigned long long off[8];
-  slot_layout(a.max_cand, a.max_raw, a.pool_cap, VIS == VIS_HBM_BITMAP ? a.bm_words : 0u, off);
+  slot_layout(a.max_cand, a.max_raw, a.pool_cap, VIS == VIS_HBM_BITMAP ? a.bm_words : 0u, off);  // (only the offsets are used)
   unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
   SlotView sv;
   sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
@@ -473,8 +514,10 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
     if (qi >= a.n_queries) break;
     const int st = search_one<LPR, DT, VIS, SC, NT>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
     __syncthreads();
-    if (st) {  // a request the reference would fail: zeroed outputs + its code
-      for (int i = threadIdx.x; i < k5; i += NT) {
+    // a request the reference would fail: zeroed outputs + its code; per-query level_topn: the row's tail is zero
+    const int k_done = st ? 0 : (a.tq ? a.tq[(size_t)qi * 6 + 5] : k5);
+    if (k_done < k5) {
+      for (int i = k_done + (int)threadIdx.x; i < k5; i += NT) {
         a.out_ids[(size_t)qi * k5 + i] = 0;
         if (a.out_scores) a.out_scores[(size_t)qi * k5 + i] = 0.0f;
         if (a.out_index) a.out_index[(size_t)qi * k5 + i] = 0;
@@ -535,8 +578,11 @@ int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_byt
 // the pre-projected form (nann_mlp3.h): ONE instantiation for every d / row dtype (it never reads the embedding table);
 // lives in the d = 128 object.  launch_mlp_preproject fills the table.
 int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+// layer 2 resident in LDS (nann_mlp5.h), split-f16 (exact = 0) or exact f32 (exact = 1); vis in {VIS_LDS_HASH, VIS_HBM_BITMAP}
+int launch_search_mlp_res(int exact, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
-// which form of the split-f16 MLP the traversal runs: 3 = pre-projected (default), 2 = second mapping, 1 = first
+// which form of the MLP the traversal runs: 5 = pre-projected + layer 2 resident in LDS (default, both precisions),
+// split-f16 only: 3 = pre-projected with streamed slices (round 3), 4 = its 256-thread form, 2 = second mapping, 1 = first
 // (NANN_MLP_MAPPING in the environment: A/B measurements on one build, not a product knob)
 int mlp_mapping_choice();
 // attention-scorer instantiations live in nann_attn_inst.hip: (vis, 512 threads) for vis in

@@ -17,9 +17,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "csrc", "host", "hnsw_build.cpp")
-# every source of libnann_host.so (the HNSW builder + the CPU hook onto the frozen-GraphDef reader) and what they include
-_SRCS = [_SRC, os.path.join(_HERE, "csrc", "host", "nann_graphdef_c.cpp")]
-_DEPS = _SRCS + [os.path.join(_HERE, "csrc", "host", "nann_graphdef.h")]
+# every source of libnann_host.so (the HNSW builder + the CPU hooks onto the frozen-GraphDef reader and the
+# pre-projected tables' cache) and what they include
+_SRCS = [_SRC, os.path.join(_HERE, "csrc", "host", "nann_graphdef_c.cpp"),
+         os.path.join(_HERE, "csrc", "host", "nann_projcache_c.cpp")]
+_DEPS = _SRCS + [os.path.join(_HERE, "csrc", "host", "nann_graphdef.h"),
+                 os.path.join(_HERE, "csrc", "host", "nann_projcache.h")]
 _LIB_PATH = os.path.join(_HERE, "_build", "libnann_host.so")
 _LIB = None
 
@@ -28,7 +31,7 @@ def build_host_lib(force=False):
     """g++ -O3 the host-side builder into nann_amd/_build/libnann_host.so."""
     if force or not os.path.exists(_LIB_PATH) or max(os.path.getmtime(p) for p in _DEPS) > os.path.getmtime(_LIB_PATH):
         os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
-        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-mavx2", "-mfma",
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-mavx2", "-mfma", "-Wno-invalid-offsetof",
                                "-o", _LIB_PATH] + _SRCS)
     return _LIB_PATH
 

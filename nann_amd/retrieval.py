@@ -129,16 +129,29 @@ class SearchResult:
         self.phase_ticks = phase_ticks
 
 
+def _level_topn_args(level_topn, b, dev):
+    """level_topn as the C ABI takes it: uniform i32[6] -> (maxima, NULL); per query [B, 6] (the reference feeds
+    `level_topn` per request, build_opt_graph.py:75,151-159) -> (column maxima [host], device i32[B, 6])."""
+    lt = np.asarray(level_topn.cpu() if isinstance(level_topn, torch.Tensor) else level_topn, dtype=np.int64)
+    if lt.ndim == 1:
+        assert lt.shape[0] == 6
+        return (C.c_int32 * 6)(*[int(x) for x in lt]), None, int(lt[5])
+    assert lt.shape == (b, 6), "per-query level_topn: [n_queries, 6]"
+    mx = np.maximum(lt.max(axis=0), 0)
+    tq = torch.as_tensor(lt.astype(np.int32)).to(dev).contiguous()
+    return (C.c_int32 * 6)(*[int(x) for x in mx]), tq, int(mx[5])
+
+
 def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=False):
     """Fused execution of build_model()'s schedule for a batch of queries.
-    q: f32[B, d] CUDA tensor (ops.user_seq_mean of `comm_seq`).  Asynchronous:
-    the returned tensors are valid once the current stream reaches them.
+    q: f32[B, d] CUDA tensor (ops.user_seq_mean of `comm_seq`).  level_topn: i32[6] for the whole batch, or
+    [B, 6] per query (nann_search_v; rows of the outputs are level_topn.max(0)[5] wide, zero behind a query's
+    own k).  Asynchronous: the returned tensors are valid once the current stream reaches them.
     status[b] != 0 marks a request the reference would have failed."""
     q = q.to(device=index.device, dtype=torch.float32).contiguous()
     b = q.shape[0]
-    t = (C.c_int32 * 6)(*[int(x) for x in level_topn])
-    k = int(level_topn[5])
     dev = index.device
+    t, tq, k = _level_topn_args(level_topn, b, dev)
     out_ids = torch.empty((b, k), dtype=torch.int64, device=dev)
     out_scores = torch.empty((b, k), dtype=torch.float32, device=dev)
     out_index = torch.empty((b, k), dtype=torch.int32, device=dev)
@@ -146,24 +159,30 @@ def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=Fa
     counters = torch.zeros((b, 3, _lib.NUM_ROUNDS), dtype=torch.int32, device=dev) if want_counters else None
     ticks = (torch.zeros((b, _lib.NUM_PHASES), dtype=torch.int64, device=dev)
              if want_phase_ticks else None)
-    ws = index.workspace(level_topn, b)
+    ws = index.workspace(list(t), b)
     with torch.cuda.device(dev):
-        _check(lib().nann_search_ex(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(ws),
-                                    C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores),
-                                    _ptr(out_index), _ptr(status), _ptr(counters), _ptr(ticks),
-                                    _stream()), "search")
+        if tq is None:
+            _check(lib().nann_search_ex(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(ws),
+                                        C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores),
+                                        _ptr(out_index), _ptr(status), _ptr(counters), _ptr(ticks),
+                                        _stream()), "search")
+        else:
+            assert not want_phase_ticks, "phase ticks: uniform level_topn only"
+            _check(lib().nann_search_v(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(tq), _ptr(ws),
+                                       C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores),
+                                       _ptr(out_index), _ptr(status), _ptr(counters), _stream()), "search")
     return SearchResult(out_ids, out_scores, out_index, status, counters, ticks)
 
 
 def search_model(index, model, comm_seq, level_topn, want_counters=True):
     """The serving signature (build_opt_graph.py:151-159) for a batch: comm_seq f16[B, seq_len, E] +
-    level_topn -> SearchResult, scored by `model` (ops.Model: l2 / mlp / the reference's attention + DNN
-    model -- the per-user projection runs once per request, then the fused traversal; nann_search_model)."""
+    level_topn (i32[6], or [B, 6] per request) -> SearchResult, scored by `model` (ops.Model: l2 / mlp / the
+    reference's attention + DNN model -- the per-user projection runs once per request, then the fused traversal;
+    nann_search_model / nann_search_model_v)."""
     seq = comm_seq.to(device=index.device, dtype=torch.float16).contiguous()
     b = seq.shape[0]
-    t = (C.c_int32 * 6)(*[int(x) for x in level_topn])
-    k = int(level_topn[5])
     dev = index.device
+    t, tq, k = _level_topn_args(level_topn, b, dev)
     out_ids = torch.empty((b, k), dtype=torch.int64, device=dev)
     out_scores = torch.empty((b, k), dtype=torch.float32, device=dev)
     out_index = torch.empty((b, k), dtype=torch.int32, device=dev)
@@ -173,10 +192,36 @@ def search_model(index, model, comm_seq, level_topn, want_counters=True):
     _check(lib().nann_search_model_workspace_bytes(index.handle, model.handle, t, C.c_int64(b), C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _check(lib().nann_search_model(index.handle, model.handle, _ptr(seq), C.c_int64(b), t, _ptr(ws),
-                                       C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
-                                       _ptr(status), _ptr(counters), _stream()), "search")
+        _check(lib().nann_search_model_v(index.handle, model.handle, _ptr(seq), C.c_int64(b), t, _ptr(tq), _ptr(ws),
+                                         C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
+                                         _ptr(status), _ptr(counters), _stream()), "search")
     return SearchResult(out_ids, out_scores, out_index, status, counters, None)
+
+
+def prepare(index, scorer):
+    """Build the pre-projected table of (scorer | model, index) now and pin it (nann_scorer_prepare /
+    nann_model_prepare): no request pays for it.  Returns (table_bytes, resident_bytes)."""
+    is_model = isinstance(scorer, ops.Model)
+    L = lib()
+    with torch.cuda.device(index.device):
+        _check((L.nann_model_prepare if is_model else L.nann_scorer_prepare)(scorer.handle, index.handle, _stream()),
+               "prepare")
+    return table_bytes(index, scorer)
+
+
+def release(index, scorer):
+    is_model = isinstance(scorer, ops.Model)
+    L = lib()
+    _check((L.nann_model_release if is_model else L.nann_scorer_release)(scorer.handle, index.handle), "release")
+
+
+def table_bytes(index, scorer):
+    is_model = isinstance(scorer, ops.Model)
+    L = lib()
+    tb, rb = C.c_int64(0), C.c_int64(0)
+    _check((L.nann_model_table_bytes if is_model else L.nann_scorer_table_bytes)(
+        scorer.handle, index.handle if index is not None else None, C.byref(tb), C.byref(rb)), "table_bytes")
+    return tb.value, rb.value
 
 
 class EvalResult:

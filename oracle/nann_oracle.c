@@ -13,7 +13,9 @@
  *      score = 0.0f - p[0]
  *  MLP scorer (x=[q;e], W1 [2d,H1], W2 [H1,H2], w3 [H2]):
  *      u[j]  = b1[j];  for k in 0..d-1:      u[j]  = fmaf(q[k], W1[k][j], u[j])
- *      a1[j] = u[j];   for k in ORDER_E(d):  a1[j] = fmaf(e[k], W1[d+k][j], a1[j])
+ *      P[j]  = 0;      for k in ORDER_E(d):  P[j]  = fmaf(e[k], W1[d+k][j], P[j])
+ *      a1[j] = u[j] + P[j]        (round 4: the item part is a chain of its own, so
+ *                                  that a table of P per item holds the same bits)
  *      h1[j] = prelu(a1[j], alpha1[j])
  *      a2[m] = b2[m];  for k in ORDER_H(H1): a2[m] = fmaf(h1[k], W2[k][m], a2[m])
  *      h2[m] = prelu(a2[m], alpha2[m])
@@ -518,12 +520,12 @@ static float score_mlp_row(const oracle_scorer_t* sc, const float* u, const void
   float e[512];
   for (int k = 0; k < d; ++k) e[k] = load_elem(row, sc->emb_dtype, k);
   for (int j = 0; j < H1; ++j) {
-    float acc = u[j];
+    float acc = 0.0f; /* the item part is its own chain: the same value whoever scores the item */
     for (int kk = 0; kk < d / 2; ++kk) { /* ORDER_E */
       acc = fmaf(e[kk], sc->w1[(int64_t)(d + kk) * H1 + j], acc);
       acc = fmaf(e[d / 2 + kk], sc->w1[(int64_t)(d + d / 2 + kk) * H1 + j], acc);
     }
-    h1[j] = prelu(acc, sc->alpha1[j]);
+    h1[j] = prelu(u[j] + acc, sc->alpha1[j]);
   }
   for (int m = 0; m < H2; ++m) {
     float acc = sc->b2[m];

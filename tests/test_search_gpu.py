@@ -622,3 +622,198 @@ def test_projection_tables_follow_the_index(oracle):
         assert (r.status.cpu().numpy() == st).all()
         ok = st == 0
         assert (r.index.cpu().numpy()[ok] == idx[ok]).all() and (bits(r.scores.cpu().numpy()[ok]) == bits(sc[ok])).all(), k
+
+
+@pytest.mark.parametrize("kind,mode", [("l2", "lds_hash"), ("l2", "lds_bitmap"), ("l2", "hbm_bitmap"), ("mlp", "auto")])
+def test_level_topn_per_query(oracle, kind, mode):
+    """The reference feeds `level_topn` PER REQUEST (build_opt_graph.py:75,151-159): one launch (nann_search_v) mixing
+    four different level_topn -- beams of different widths, a different k, one the reference fails in TopKV2 (k > n:
+    more entry winners asked for than there are enter points) and one outside the launch's maxima -- must give every
+    request the oracle's answer for ITS values, bit for bit, with zeros behind its own k."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 64, 32)
+    nq = 64
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, nq, seed=29)])
+    E = len(g["enter_points"])
+    variants = [[32] * 5 + [20], [16, 24, 32, 8, 12, 10], [8] * 5 + [5], [32, 32, 20, 20, 20, 33], [E + 1] + [32] * 4 + [20]]
+    rows = np.asarray([variants[b % len(variants)] for b in range(nq)], np.int32)
+    w = synth.make_mlp_weights(64) if kind == "mlp" else None
+    sc = ops.Scorer(kind, 64, torch.float16, w, precision="exact")
+    osc = oracle.Scorer(kind, 64, oracle.EMB_F16, w)
+    with traversal_mode(mode):
+        r = retrieval.search(dix, sc, cuda(q), rows)
+        torch.cuda.synchronize()
+    kmax = int(rows[:, 5].max())
+    assert r.item_ids.shape == (nq, kmax)
+    st, ids, scs, idx, ctr = (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+                              r.index.cpu().numpy(), r.counters.cpu().numpy())
+    seen_ok = 0
+    for v, topn in enumerate(variants):
+        sel = np.arange(v, nq, len(variants))
+        est, eids, esc, eidx, ectr = oracle.search_batch(oix, osc, q[sel], topn, n_threads=8)
+        k = topn[5]
+        assert (st[sel] == est).all(), (v, st[sel], est)
+        ok = est == 0
+        seen_ok += int(ok.sum())
+        assert (idx[sel][ok][:, :k] == eidx[ok]).all() and (ids[sel][ok][:, :k] == eids[ok]).all(), v
+        assert (bits(scs[sel][ok][:, :k]) == bits(esc[ok])).all() and (ctr[sel][ok] == ectr[ok]).all(), v
+        assert (ids[sel][:, k:] == 0).all() and (scs[sel][:, k:] == 0).all(), v   # zeros behind a query's own k
+        assert (ids[sel][~ok] == 0).all()
+        if topn[0] > E:
+            assert (est == 4).all()  # TopKV2: k > n (topk_op.cc:67-71), per request
+    assert seen_ok >= nq // 2
+    # a request whose level_topn exceeds the launch's maxima fails alone with BAD_ARGUMENT
+    from nann_amd import _lib
+    import ctypes as C
+    mx = (C.c_int32 * 6)(*[32] * 5 + [20])
+    tq = torch.as_tensor(np.asarray([[32] * 5 + [20], [33] + [32] * 4 + [20], [32] * 5 + [20]], np.int32)).cuda()
+    out_ids = torch.empty((3, 20), dtype=torch.int64, device="cuda")
+    status = torch.empty(3, dtype=torch.int32, device="cuda")
+    ws = dix.workspace([32] * 5 + [20], 3)
+    rc = _lib.lib().nann_search_v(dix.handle, sc.handle, C.c_void_p(cuda(q[:3]).data_ptr()), C.c_int64(3), mx,
+                                  C.c_void_p(tq.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()),
+                                  C.c_void_p(out_ids.data_ptr()), None, None, C.c_void_p(status.data_ptr()), None, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and status.cpu().tolist()[1] == 7 and (out_ids[1] == 0).all()
+    assert status.cpu().tolist()[0] == st[0] and (out_ids[0].cpu().numpy() == ids[0][:20]).all()
+
+
+def test_level_topn_per_query_serving_signature(oracle, tmp_path):
+    """nann_search_model_v: comm_seq + per-request level_topn -> top_k, as the serving graph's signature has it."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 64, 32)
+    seqs = queries_for(g, 24, seed=31)
+    ops.save_scorer_dir(str(tmp_path), "l2")
+    model = ops.Model(str(tmp_path), 64, seqs[0].shape[0])
+    variants = [[32] * 5 + [20], [16] * 5 + [10]]
+    rows = np.asarray([variants[b % 2] for b in range(24)], np.int32)
+    r = retrieval.search_model(dix, model, cuda(np.stack(seqs)), rows)
+    torch.cuda.synchronize()
+    q = np.stack([oracle.user_seq_mean(s) for s in seqs])
+    for v, topn in enumerate(variants):
+        sel = np.arange(v, 24, 2)
+        est, eids, esc, eidx, ectr = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q[sel], topn)
+        ok = est == 0
+        assert (r.status.cpu().numpy()[sel] == est).all()
+        assert (r.item_ids.cpu().numpy()[sel][ok][:, :topn[5]] == eids[ok]).all()
+
+
+def test_prepared_tables_first_request_latency_and_release(oracle):
+    """nann_scorer_prepare builds (and pins) the pre-projected table ahead of traffic: the first search of the pair then
+    costs what every later one costs (no hipMalloc, no build, no stream wait inside the request), the bytes are
+    reported, pinned tables survive searches of other indices, release returns the memory, and a search after the
+    release still answers identically (it rebuilds)."""
+    import time
+    from nann_amd import ops, retrieval, synth
+    w = synth.make_mlp_weights(64)
+    topn = [32] * 5 + [20]
+    idxs = [synth_index(20000, 64, 32, seed=s) for s in (1234, 77, 901)]
+    qs = [cuda(np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 24, seed=5)])) for g, _, _ in idxs]
+
+    def timed(sc, dix, q):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = retrieval.search(dix, sc, q, topn)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+
+    # cold scorer, no prepare: the first request pays the build
+    cold = ops.Scorer("mlp", 64, torch.float16, w, precision="split")
+    t_cold, r_ref = timed(cold, idxs[0][2], qs[0])
+    sc = ops.Scorer("mlp", 64, torch.float16, w, precision="split")
+    tb, resident = retrieval.table_bytes(idxs[0][2], sc)
+    assert tb == 20000 * 256 * 4 and resident == 0
+    tb, resident = retrieval.prepare(idxs[0][2], sc)
+    assert resident == tb
+    t_first, r = timed(sc, idxs[0][2], qs[0])
+    steady = sorted(timed(sc, idxs[0][2], qs[0])[0] for _ in range(7))[3]
+    print(f"first request: cold {t_cold * 1e3:.2f} ms, after prepare {t_first * 1e3:.2f} ms, steady {steady * 1e3:.2f} ms")
+    assert t_first < 3.0 * steady + 1e-3, (t_first, steady)   # no build in the request (cold: tens of ms more)
+    assert (r.index.cpu().numpy() == r_ref.index.cpu().numpy()).all()
+    assert (bits(r.scores.cpu().numpy()) == bits(r_ref.scores.cpu().numpy())).all()
+    # the pinned table survives the scorer searching two other indices (which fill the two unpinned places) and a third
+    for k in (1, 2):
+        retrieval.search(idxs[k][2], sc, qs[k], topn)
+    torch.cuda.synchronize()
+    _, resident = retrieval.table_bytes(idxs[0][2], sc)
+    assert resident >= 3 * tb
+    t_again, _ = timed(sc, idxs[0][2], qs[0])
+    assert t_again < 3.0 * steady + 1e-3
+    retrieval.release(idxs[0][2], sc)
+    torch.cuda.synchronize()
+    _, resident = retrieval.table_bytes(idxs[0][2], sc)
+    assert resident <= 2 * tb   # the released table is gone (retired, then freed once its launches were done)
+    _, r2 = timed(sc, idxs[0][2], qs[0])
+    assert (r2.index.cpu().numpy() == r_ref.index.cpu().numpy()).all()
+
+
+def test_tables_under_concurrent_threads(oracle):
+    """3 indices x 4 host threads on ONE scorer, each thread on its own stream, searching the indices in turn so that
+    the two unpinned places keep turning over: every reply equals the single-threaded one (round 3 could free a table
+    another thread was about to launch with -- ADVICE r3)."""
+    import threading
+    from nann_amd import ops, retrieval, synth
+    w = synth.make_mlp_weights(64)
+    topn = [32] * 5 + [20]
+    idxs = [synth_index(20000, 64, 32, seed=s) for s in (1234, 77, 901)]
+    qs = [cuda(np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 24, seed=5)])) for g, _, _ in idxs]
+    ref = []
+    for (g, _, dix), q in zip(idxs, qs):
+        r = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w, precision="split"), q, topn)
+        torch.cuda.synchronize()
+        ref.append((r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()))
+    shared = ops.Scorer("mlp", 64, torch.float16, w, precision="split")
+    errors = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(12):
+                    k = (tid + it) % 3
+                    r = retrieval.search(idxs[k][2], shared, qs[k], topn)
+                    stream.synchronize()
+                    st, ix, sc_ = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
+                    ok = ref[k][0] == 0
+                    if not ((st == ref[k][0]).all() and (ix[ok] == ref[k][1][ok]).all()
+                            and (bits(sc_[ok]) == bits(ref[k][2][ok])).all()):
+                        errors.append((tid, it, k))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    tb, resident = retrieval.table_bytes(idxs[0][2], shared)
+    torch.cuda.synchronize()
+    assert retrieval.table_bytes(idxs[0][2], shared)[1] <= 3 * tb   # two kept + at most one retired not yet reaped
+
+
+def test_search_without_preprojection_matches(oracle):
+    """nann_set_preprojection(0) (what a host without HBM to spare asks for, and what a failed table allocation falls
+    back to): the kernels that read the embedding rows -- exact form bit-identical to the oracle, i.e. to the
+    pre-projected form; split form within tolerance."""
+    from nann_amd import _lib, ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 64, 32)
+    w = synth.make_mlp_weights(64)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 24, seed=23)])
+    topn = [32] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("mlp", 64, oracle.EMB_F16, w), q, topn, n_threads=8)
+    try:
+        _lib.lib().nann_set_preprojection(0)
+        sc = ops.Scorer("mlp", 64, torch.float16, w, precision="exact")
+        r = retrieval.search(dix, sc, cuda(q), topn)
+        torch.cuda.synchronize()
+        assert retrieval.table_bytes(dix, sc)[1] == 0
+        _assert_same((r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+                      r.index.cpu().numpy(), r.counters.cpu().numpy()), exp)
+        r = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w, precision="split"), cuda(q), topn)
+        torch.cuda.synchronize()
+        ok = exp[0] == 0
+        kinds = [tolerant_parity(r.index.cpu().numpy()[b], r.scores.cpu().numpy()[b], exp[3][b], exp[2][b]) for b in np.nonzero(ok)[0]]
+        assert kinds.count("diverged") <= 1, kinds
+    finally:
+        _lib.lib().nann_set_preprojection(1)

@@ -310,4 +310,32 @@ def test_config4_full_shard_4m_256d_bf16_ef256(oracle):
     sel = slice(0, 32)
     exp = oracle.search_batch(oix, oracle.Scorer("l2", 256, oracle.EMB_BF16), q[sel].cpu().numpy(), topn, n_threads=16)
     _assert_equals_oracle(r, exp, sel)
+
+
+def test_config4_full_shard_4m_256d_bf16_ef256_mlp(oracle):
+    """configs[4]'s shard at its own size UNDER THE MLP SCORER BASELINE.md names for it (the 4M shard ran
+    under L2 only, the MLP stopped at 1.2M): 4M x 256-d bf16, ef = 256, top-200, 256-128-1 scorer; the pre-projected
+    table of this pair is 4 GB.  Split-f16 (the default precision): properties on 1024 queries + a sample against the
+    oracle's fp32 chain within 1e-5 (ids tie-aware).  Exact f32: a sample bitwise against the oracle, ids / scores /
+    counters.  Both on the planner's kernel for a beam this wide (HBM bitmap, layer 2 resident in LDS)."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = _index(4_000_000, 256, 256, dtype="bf16")
+    topn = [256] * 5 + [200]
+    q = _queries(256, 1024, seed=19, items=4_000_000, ef=256)
+    w = synth.make_mlp_weights(256)
+    osc = oracle.Scorer("mlp", 256, oracle.EMB_BF16, w)
+    split = ops.Scorer("mlp", 256, torch.bfloat16, w, precision="split")
+    tb, _ = retrieval.prepare(dix, split)
+    assert tb == 4_000_000 * 256 * 4
+    r = _search(dix, split, q, topn)
+    _properties(r, g, topn, len(g["enter_points"]))
+    sel = slice(0, 12)
+    exp = oracle.search_batch(oix, osc, q[sel].cpu().numpy(), topn, n_threads=16)
+    _assert_within_tolerance(oracle, r, exp, sel, max_diverged=1, min_exact_frac=0.6)
+    retrieval.release(dix, split)
+    del split
+    exact = ops.Scorer("mlp", 256, torch.bfloat16, w, precision="exact")
+    r = _search(dix, exact, q[:64], topn)
+    _properties(r, g, topn, len(g["enter_points"]))
+    _assert_equals_oracle(r, exp, sel)
     del _IDX[(4_000_000, 256, 256, "bf16", 0)]  # 4 GB of host + device arrays: not kept for the session
