@@ -240,13 +240,15 @@ int nann_score(const nann_scorer* scorer, const float* q, const void* table,
  * The reference's op takes the path of a frozen TensorFlow GraphDef in its `graph_def` attr and runs it in a
  * nested session (blaze_xla_kernel.cc:156-180, blaze_xla_predictor.cc:360-459).  nann_model_load takes the
  * same attr value:
- *   a FILE       the frozen GraphDef itself, binary, as convert_meta.py:361-398 writes it (`frozen_graph.pb`:
- *                Model.forward(training=False), model.py:189-233, frozen + fold_constants'ed or merely frozen).
+ *   a FILE       the frozen GraphDef itself as convert_meta.py:361-398 writes it (`frozen_graph.pb`:
+ *                Model.forward(training=False), model.py:189-233, frozen + fold_constants'ed or merely frozen),
+ *                text or binary: read as text first, then as binary, the reference's order (blaze_xla_kernel.cc:
+ *                169-175; csrc/host/nann_graphdef_text.h, nann_graphdef.h).
  *                No TensorFlow here and nothing of the graph is executed: the weights are pulled out of the
  *                Const nodes by the names the reference's Python gives their consumers (csrc/host/
  *                nann_graphdef.h), batch norm folded to scale / shift, and handed to the hand-written kernels
  *                (nann_attn_desc).  A graph that is not that model -> NANN_ERR_UNSUPPORTED naming what is
- *                missing; a text-format GraphDef -> NANN_ERR_IO.  An optional `<file>.precision` beside it
+ *                missing; a file that parses as neither -> NANN_ERR_IO.  An optional `<file>.precision` beside it
  *                holds "split" | "exact".
  *   a DIRECTORY  of .npy weight files, for scorers that have no frozen graph in the reference (BASELINE's L2
  *                and MLP) and for hosts that hold the model as arrays:

@@ -23,26 +23,52 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 namespace nann_gd {
 
-enum { DT_FLOAT = 1, DT_DOUBLE = 2, DT_INT32 = 3, DT_INT64 = 9, DT_BFLOAT16 = 14, DT_HALF = 19 };
+enum { DT_FLOAT = 1, DT_DOUBLE = 2, DT_INT32 = 3, DT_STRING = 7, DT_INT64 = 9, DT_BOOL = 10, DT_BFLOAT16 = 14, DT_HALF = 19 };
 
 struct Tensor {
   int dtype = 0;
   std::vector<int64_t> shape;
   std::vector<float> f;    // float-like payloads (f32 / f64 / f16 / bf16), converted to f32
-  std::vector<int64_t> i;  // integer payloads (int32 / int64): shapes, permutations
+  std::vector<int64_t> i;  // integer payloads (int32 / int64 / bool): shapes, permutations
+  std::vector<std::string> s;  // string_val (DT_STRING)
   int64_t count() const { int64_t c = 1; for (int64_t v : shape) c *= v; return c; }
 };
 
+// AttrValue (attr_value.proto), every member of its oneof: what the pinning tests compare between the binary and the
+// text decode of the same graph.  kind: 's' bytes, 'i' int, 'f' float, 'b' bool, 't' type, 'h' shape, 'T' tensor,
+// 'l' list, 'n' func (name only), 'p' placeholder, 0 = empty value.
+struct Attr {
+  char kind = 0;
+  std::string s;
+  int64_t i = 0;
+  float f = 0.0f;
+  bool b = false;
+  int type = 0;
+  std::vector<int64_t> shape;
+  bool unknown_rank = false;
+  Tensor tensor;
+  std::vector<std::string> ls;
+  std::vector<int64_t> li;
+  std::vector<float> lf;
+  std::vector<int> lb, lt;
+  std::vector<std::vector<int64_t>> lshape;
+  int n_list_tensors = 0, n_list_funcs = 0;
+};
+
 struct Node {
-  std::string name, op;
+  std::string name, op, device;
   std::vector<std::string> inputs;
+  std::map<std::string, Attr> attrs;
   bool has_value = false;
   Tensor value;  // attr["value"] of a Const
 };
@@ -147,6 +173,11 @@ inline bool parse_tensor(Cursor c, Tensor* t) {
       if (wire == 2) { Cursor s = c.sub(); while (!s.done()) hv.push_back((uint16_t)s.varint()); if (!s.ok) return false; }
       else if (wire == 0) hv.push_back((uint16_t)c.varint());
       else c.skip(wire);
+    } else if (field == 8 && wire == 2) t->s.push_back(c.str());  // string_val
+    else if (field == 11) {                                       // bool_val
+      if (wire == 2) { Cursor s = c.sub(); while (!s.done()) iv.push_back((int64_t)s.varint()); if (!s.ok) return false; }
+      else if (wire == 0) iv.push_back((int64_t)c.varint());
+      else c.skip(wire);
     } else c.skip(wire);
   }
   if (!c.ok || unknown_rank) return false;
@@ -198,13 +229,88 @@ inline bool parse_tensor(Cursor c, Tensor* t) {
         fill(t->i, iv);
       }
       return true;
+    case DT_BOOL:
+      if (!content.empty()) { t->i.resize((size_t)n); for (int64_t k = 0; k < n; ++k) t->i[(size_t)k] = content[(size_t)k] != 0; }
+      else fill(t->i, iv);
+      return true;
     default:
-      return true;  // other dtypes (strings, bools ...): kept as a node without payload
+      return true;  // other dtypes (strings ...): string_val kept as it is, no numeric payload
   }
 }
 
-// NodeDef (node_def.proto): name = 1, op = 2, input = 3, attr = 5 (map entry: key = 1, value = 2);
-// AttrValue (attr_value.proto): tensor = 8.
+// TensorShapeProto -> dims / unknown_rank
+inline bool parse_shape(Cursor s, std::vector<int64_t>* dims, bool* unknown_rank) {
+  while (!s.done()) {
+    const uint64_t k2 = s.varint();
+    if ((k2 >> 3) == 2 && (k2 & 7) == 2) {
+      Cursor d = s.sub();
+      int64_t size = 0;
+      while (!d.done()) {
+        const uint64_t k3 = d.varint();
+        if ((k3 >> 3) == 1 && (k3 & 7) == 0) size = (int64_t)d.varint(); else d.skip((int)(k3 & 7));
+      }
+      if (!d.ok) return false;
+      dims->push_back(size);
+    } else if ((k2 >> 3) == 3 && (k2 & 7) == 0) *unknown_rank = s.varint() != 0;
+    else s.skip((int)(k2 & 7));
+  }
+  return s.ok;
+}
+
+// AttrValue: list = 1, s = 2, i = 3, f = 4, b = 5, type = 6, shape = 7, tensor = 8, placeholder = 9, func = 10;
+// ListValue: s = 2, i = 3, f = 4, b = 5, type = 6 (packed or not), shape = 7, tensor = 8, func = 9
+inline bool parse_attr(Cursor v, Attr* a) {
+  auto ints = [](Cursor& c, int wire, auto&& push) {
+    if (wire == 2) { Cursor s = c.sub(); while (!s.done()) push((int64_t)s.varint()); return s.ok; }
+    if (wire == 0) { push((int64_t)c.varint()); return c.ok; }
+    c.skip(wire); return c.ok;
+  };
+  while (!v.done()) {
+    const uint64_t key = v.varint();
+    const int field = (int)(key >> 3), wire = (int)(key & 7);
+    if (field == 2 && wire == 2) { a->kind = 's'; a->s = v.str(); }
+    else if (field == 3 && wire == 0) { a->kind = 'i'; a->i = (int64_t)v.varint(); }
+    else if (field == 4 && wire == 5) { a->kind = 'f'; if (v.end - v.p < 4) return false; std::memcpy(&a->f, v.p, 4); v.p += 4; }
+    else if (field == 5 && wire == 0) { a->kind = 'b'; a->b = v.varint() != 0; }
+    else if (field == 6 && wire == 0) { a->kind = 't'; a->type = (int)v.varint(); }
+    else if (field == 7 && wire == 2) { a->kind = 'h'; if (!parse_shape(v.sub(), &a->shape, &a->unknown_rank)) return false; }
+    else if (field == 8 && wire == 2) {
+      a->kind = 'T';
+      Cursor t = v.sub();
+      if (!v.ok || !parse_tensor(t, &a->tensor)) return false;
+    } else if (field == 9 && wire == 2) { a->kind = 'p'; a->s = v.str(); }
+    else if (field == 10 && wire == 2) {  // NameAttrList: name = 1
+      a->kind = 'n';
+      Cursor f = v.sub();
+      while (!f.done()) { const uint64_t k = f.varint(); if ((k >> 3) == 1 && (k & 7) == 2) a->s = f.str(); else f.skip((int)(k & 7)); }
+      if (!f.ok) return false;
+    } else if (field == 1 && wire == 2) {
+      a->kind = 'l';
+      Cursor l = v.sub();
+      while (!l.done()) {
+        const uint64_t k = l.varint();
+        const int lf = (int)(k >> 3), lw = (int)(k & 7);
+        if (lf == 2 && lw == 2) a->ls.push_back(l.str());
+        else if (lf == 3) { if (!ints(l, lw, [&](int64_t x) { a->li.push_back(x); })) return false; }
+        else if (lf == 4) {
+          if (lw == 2) { Cursor s = l.sub(); while (s.end - s.p >= 4) { float x; std::memcpy(&x, s.p, 4); s.p += 4; a->lf.push_back(x); } }
+          else if (lw == 5) { if (l.end - l.p < 4) return false; float x; std::memcpy(&x, l.p, 4); l.p += 4; a->lf.push_back(x); }
+          else l.skip(lw);
+        }
+        else if (lf == 5) { if (!ints(l, lw, [&](int64_t x) { a->lb.push_back(x != 0); })) return false; }
+        else if (lf == 6) { if (!ints(l, lw, [&](int64_t x) { a->lt.push_back((int)x); })) return false; }
+        else if (lf == 7 && lw == 2) { std::vector<int64_t> d; bool ur = false; if (!parse_shape(l.sub(), &d, &ur)) return false; a->lshape.push_back(d); }
+        else if (lf == 8 && lw == 2) { (void)l.sub(); ++a->n_list_tensors; }
+        else if (lf == 9 && lw == 2) { (void)l.sub(); ++a->n_list_funcs; }
+        else l.skip(lw);
+      }
+      if (!l.ok) return false;
+    } else v.skip(wire);
+  }
+  return v.ok;
+}
+
+// NodeDef (node_def.proto): name = 1, op = 2, input = 3, device = 4, attr = 5 (map entry: key = 1, value = 2)
 inline bool parse_node(Cursor c, Node* n) {
   while (!c.done()) {
     const uint64_t key = c.varint();
@@ -212,6 +318,7 @@ inline bool parse_node(Cursor c, Node* n) {
     if (field == 1 && wire == 2) n->name = c.str();
     else if (field == 2 && wire == 2) n->op = c.str();
     else if (field == 3 && wire == 2) n->inputs.push_back(c.str());
+    else if (field == 4 && wire == 2) n->device = c.str();
     else if (field == 5 && wire == 2) {
       Cursor e = c.sub();
       std::string k;
@@ -224,17 +331,10 @@ inline bool parse_node(Cursor c, Node* n) {
         else e.skip((int)(k2 & 7));
       }
       if (!e.ok) return false;
-      if (k == "value" && have_val) {
-        while (!val.done()) {
-          const uint64_t k3 = val.varint();
-          if ((k3 >> 3) == 8 && (k3 & 7) == 2) {
-            Cursor t = val.sub();
-            if (!val.ok || !parse_tensor(t, &n->value)) return false;
-            n->has_value = true;
-          } else val.skip((int)(k3 & 7));
-        }
-        if (!val.ok) return false;
-      }
+      Attr a;
+      if (have_val && !parse_attr(val, &a)) return false;
+      if (k == "value" && a.kind == 'T') { n->value = a.tensor; n->has_value = true; }
+      n->attrs[k] = std::move(a);
     } else c.skip(wire);
   }
   return c.ok;
@@ -258,6 +358,32 @@ inline bool parse_graph(const uint8_t* data, size_t n, Graph* g, std::string* er
   if (!c.ok) { *err = "not a binary GraphDef (protobuf wire format error)"; return false; }
   if (g->nodes.empty()) { *err = "GraphDef holds no nodes"; return false; }
   return true;
+}
+
+// SavedModel (saved_model.proto): meta_graphs = 2; MetaGraphDef (meta_graph.proto): graph_def = 2.  The graph of the
+// first meta graph.  (BlazeXlaOp itself only reads GraphDef files; this is for the TensorFlow-written fixtures the
+// fork holds as SavedModels -- tests/test_tf_written_protos.py.)
+inline bool parse_saved_model(const uint8_t* data, size_t n, Graph* g, std::string* err) {
+  Cursor c{data, data + n};
+  while (!c.done()) {
+    const uint64_t key = c.varint();
+    if ((key >> 3) == 2 && (key & 7) == 2) {
+      Cursor mg = c.sub();
+      if (!c.ok) break;
+      while (!mg.done()) {
+        const uint64_t k2 = mg.varint();
+        if ((k2 >> 3) == 2 && (k2 & 7) == 2) {
+          Cursor gd = mg.sub();
+          if (!mg.ok) break;
+          return parse_graph(gd.p, (size_t)(gd.end - gd.p), g, err);
+        }
+        mg.skip((int)(k2 & 7));
+      }
+      if (!mg.ok) break;
+    } else c.skip((int)(key & 7));
+  }
+  *err = "not a binary SavedModel with a graph_def";
+  return false;
 }
 
 // ---- constant evaluation of an operand ---------------------------------------------------------------

@@ -5,7 +5,7 @@
 #include <fstream>
 #include <iterator>
 
-#include "nann_graphdef.h"
+#include "nann_graphdef_text.h"
 
 extern "C" {
 
@@ -20,7 +20,8 @@ int nann_graphdef_attention(const char* path, int64_t counts[26], float* flat, i
   const std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   nann_gd::Graph g;
   std::string msg;
-  if (!nann_gd::parse_graph(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &g, &msg)) return fail(msg);
+  // text first, then binary: the reference's order (blaze_xla_kernel.cc:169-175)
+  if (!nann_gd::parse_graph_any(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &g, &msg)) return fail(msg);
   nann_gd::AttnWeights w;
   if (!nann_gd::extract_attention(g, &w, &msg)) return fail(msg);
   const std::vector<float>* v[26] = {&w.wq1, &w.bq1, &w.aq, &w.wq2, &w.bq2, &w.wk1, &w.bk1, &w.ak, &w.wk2, &w.bk2,
@@ -33,6 +34,31 @@ int nann_graphdef_attention(const char* path, int64_t counts[26], float* flat, i
   }
   if (d) *d = w.d;
   if (e) *e = w.e;
+  return 0;
+}
+
+// The decoded graph of `path` as canonical JSON (nodes in file order: name, op, device, inputs, every attr by kind).
+// format: 0 = as BlazeXlaOp reads a graph_def (text first, then binary GraphDef), 1 = binary GraphDef, 2 = binary
+// SavedModel (first meta graph), 3 = text (GraphDef or SavedModel).  *need = bytes of the JSON incl. the NUL; written
+// to out when it fits cap.  Returns 0, or 1 with a message in err.
+int nann_graphdef_dump(const char* path, int32_t format, char* out, int64_t cap, int64_t* need, char* err, int32_t err_len) {
+  auto fail = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); return 1; };
+  std::ifstream f(path, std::ifstream::binary);
+  if (!f) return fail(std::string("Fail to open file: ") + path);
+  const std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const uint8_t* d = reinterpret_cast<const uint8_t*>(bytes.data());
+  nann_gd::Graph g;
+  std::string msg;
+  bool ok = false;
+  if (format == 0) ok = nann_gd::parse_graph_any(d, bytes.size(), &g, &msg);
+  else if (format == 1) ok = nann_gd::parse_graph(d, bytes.size(), &g, &msg);
+  else if (format == 2) ok = nann_gd::parse_saved_model(d, bytes.size(), &g, &msg);
+  else if (format == 3) ok = nann_gd::parse_graph_text(bytes.data(), bytes.size(), &g, &msg);
+  else return fail("unknown format");
+  if (!ok) return fail(msg);
+  const std::string js = nann_gd::graph_to_json(g);
+  if (need) *need = (int64_t)js.size() + 1;
+  if (out && cap >= (int64_t)js.size() + 1) std::memcpy(out, js.c_str(), js.size() + 1);
   return 0;
 }
 

@@ -1,0 +1,387 @@
+// nann_graphdef_text.h -- protobuf TEXT format for the messages nann_graphdef.h reads in binary.
+//
+// BlazeXlaOp tries ReadTextProto FIRST and ReadBinaryProto second (UO/blaze_op/blaze_xla_kernel.cc:169-175), so a
+// `graph_def` attr may name a text-format GraphDef (`frozen_graph.pbtxt`: tf.io.write_graph(as_text=True)).  Round 3
+// rejected those; this is the text reader: a generic tokenizer / message tree (`name: value`, `name { ... }`,
+// `name < ... >`, adjacent string literals, C escapes, `#` comments), then the same Graph the binary reader builds,
+// field by field from the .proto definitions cited in nann_graphdef.h.  parse_graph_any() reproduces the
+// reference's order: text, then binary.
+//
+// Also reads a text-format SavedModel (`meta_graphs { graph_def { node { ... } } }`): the fork holds the same
+// TensorFlow-written graph as saved_model.pb AND saved_model.pbtxt (cc/saved_model/testdata/half_plus_two*), which
+// is what pins both decoders to each other on bytes TensorFlow wrote (tests/test_tf_written_protos.py).
+#pragma once
+#include <cctype>
+#include <memory>
+
+#include "nann_graphdef.h"
+
+namespace nann_gd {
+
+struct TMsg;
+struct TField {
+  std::string name;
+  bool is_msg = false;
+  std::string scalar;  // identifier, number, or the (unescaped) bytes of a string literal
+  bool quoted = false;
+  std::shared_ptr<TMsg> msg;
+};
+struct TMsg {
+  std::vector<TField> fields;
+  const TField* first(const char* name) const {
+    for (const auto& f : fields)
+      if (f.name == name) return &f;
+    return nullptr;
+  }
+};
+
+struct TextParser {
+  const char* p;
+  const char* end;
+  std::string err;
+  int depth = 0;
+  void ws() {
+    for (;;) {
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == ',' || *p == ';')) ++p;
+      if (p < end && *p == '#') { while (p < end && *p != '\n') ++p; continue; }
+      return;
+    }
+  }
+  bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+  bool ident(std::string* out) {
+    ws();
+    const char* b = p;
+    // field names; extensions / Any ("[type.url]") do not occur in these messages
+    while (p < end && (std::isalnum((unsigned char)*p) || *p == '_' || *p == '.')) ++p;
+    if (p == b) return fail("field name expected");
+    out->assign(b, p);
+    return true;
+  }
+  bool string_lit(std::string* out) {  // one or more adjacent literals
+    out->clear();
+    for (;;) {
+      ws();
+      if (p >= end || (*p != '"' && *p != '\'')) return true;
+      const char q = *p++;
+      while (p < end && *p != q) {
+        char c = *p++;
+        if (c == '\n') return fail("newline in a string literal");
+        if (c != '\\') { out->push_back(c); continue; }
+        if (p >= end) return fail("dangling escape");
+        c = *p++;
+        switch (c) {
+          case 'n': out->push_back('\n'); break;
+          case 'r': out->push_back('\r'); break;
+          case 't': out->push_back('\t'); break;
+          case 'a': out->push_back('\a'); break;
+          case 'b': out->push_back('\b'); break;
+          case 'f': out->push_back('\f'); break;
+          case 'v': out->push_back('\v'); break;
+          case '\\': case '\'': case '"': case '?': out->push_back(c); break;
+          case 'x': case 'X': {
+            int v = 0, n = 0;
+            while (p < end && n < 2 && std::isxdigit((unsigned char)*p)) { v = v * 16 + (std::isdigit((unsigned char)*p) ? *p - '0' : (std::tolower(*p) - 'a' + 10)); ++p; ++n; }
+            if (!n) return fail("bad \\x escape");
+            out->push_back((char)v);
+            break;
+          }
+          default:
+            if (c >= '0' && c <= '7') {
+              int v = c - '0', n = 1;
+              while (p < end && n < 3 && *p >= '0' && *p <= '7') { v = v * 8 + (*p - '0'); ++p; ++n; }
+              out->push_back((char)v);
+            } else return fail("unknown escape in a string literal");
+        }
+      }
+      if (p >= end) return fail("unterminated string literal");
+      ++p;
+    }
+  }
+  bool message(TMsg* m, char closer) {
+    if (++depth > 64) return fail("message nesting too deep");
+    for (;;) {
+      ws();
+      if (p >= end) { --depth; return closer == 0 ? true : fail("unexpected end of a message"); }
+      if (closer && *p == closer) { ++p; --depth; return true; }
+      if (*p == '}' || *p == '>') return fail("unbalanced closing bracket");
+      TField f;
+      if (!ident(&f.name)) return false;
+      ws();
+      bool colon = false;
+      if (p < end && *p == ':') { colon = true; ++p; ws(); }
+      if (p < end && (*p == '{' || *p == '<')) {
+        const char close = *p == '{' ? '}' : '>';
+        ++p;
+        f.is_msg = true;
+        f.msg = std::make_shared<TMsg>();
+        if (!message(f.msg.get(), close)) return false;
+      } else {
+        if (!colon) return fail("':' expected after field '" + f.name + "'");
+        if (p < end && (*p == '"' || *p == '\'')) {
+          f.quoted = true;
+          if (!string_lit(&f.scalar)) return false;
+        } else if (p < end && *p == '[') {  // repeated scalar shorthand: name: [a, b, c]
+          ++p;
+          for (;;) {
+            ws();
+            if (p < end && *p == ']') { ++p; break; }
+            TField e;
+            e.name = f.name;
+            if (p < end && (*p == '"' || *p == '\'')) { e.quoted = true; if (!string_lit(&e.scalar)) return false; }
+            else {
+              const char* b = p;
+              while (p < end && !std::isspace((unsigned char)*p) && *p != ',' && *p != ']') ++p;
+              if (p == b) return fail("value expected in a list");
+              e.scalar.assign(b, p);
+            }
+            m->fields.push_back(std::move(e));
+          }
+          continue;
+        } else {
+          const char* b = p;
+          while (p < end && !std::isspace((unsigned char)*p) && *p != ',' && *p != ';' && *p != '}' && *p != '>' && *p != '#') ++p;
+          if (p == b) return fail("value expected for field '" + f.name + "'");
+          f.scalar.assign(b, p);
+        }
+      }
+      m->fields.push_back(std::move(f));
+    }
+  }
+};
+
+inline bool parse_text(const char* data, size_t n, TMsg* root, std::string* err) {
+  // a binary protobuf is not text: reject on the first NUL or other control byte outside string literals (cheap and
+  // what makes "text first" safe on binary files)
+  TextParser tp{data, data + n, {}};
+  if (!tp.message(root, 0)) { *err = "not a text-format protobuf: " + tp.err; return false; }
+  return true;
+}
+
+// DataType names (types.proto); *_REF = base + 100
+inline int dtype_from_name(const std::string& s) {
+  static const char* names[] = {"DT_INVALID", "DT_FLOAT", "DT_DOUBLE", "DT_INT32", "DT_UINT8", "DT_INT16", "DT_INT8", "DT_STRING",
+                                "DT_COMPLEX64", "DT_INT64", "DT_BOOL", "DT_QINT8", "DT_QUINT8", "DT_QINT32", "DT_BFLOAT16",
+                                "DT_QINT16", "DT_QUINT16", "DT_UINT16", "DT_COMPLEX128", "DT_HALF", "DT_RESOURCE", "DT_VARIANT",
+                                "DT_UINT32", "DT_UINT64"};
+  if (!s.empty() && (std::isdigit((unsigned char)s[0]) || s[0] == '-')) return (int)std::strtol(s.c_str(), nullptr, 10);
+  std::string base = s;
+  int add = 0;
+  if (base.size() > 4 && base.compare(base.size() - 4, 4, "_REF") == 0) { base.resize(base.size() - 4); add = 100; }
+  for (int i = 0; i < (int)(sizeof(names) / sizeof(names[0])); ++i)
+    if (base == names[i]) return i + add;
+  return -1;
+}
+
+inline bool text_bool(const std::string& s) { return s == "true" || s == "True" || s == "t" || s == "1"; }
+inline float text_float(const std::string& s) {
+  std::string v = s;
+  if (!v.empty() && (v.back() == 'f' || v.back() == 'F') && v.find("inf") == std::string::npos && v.find("nan") == std::string::npos) v.pop_back();
+  return std::strtof(v.c_str(), nullptr);  // strtof reads inf / -inf / nan as TextFormat prints them
+}
+
+inline void text_shape(const TMsg& m, std::vector<int64_t>* dims, bool* unknown_rank) {
+  for (const auto& f : m.fields) {
+    if (f.name == "dim" && f.is_msg) {
+      const TField* sz = f.msg->first("size");
+      dims->push_back(sz ? std::strtoll(sz->scalar.c_str(), nullptr, 10) : 0);
+    } else if (f.name == "unknown_rank") *unknown_rank = text_bool(f.scalar);
+  }
+}
+
+// TensorProto from text: re-encoded onto the wire and handed to parse_tensor, so that BOTH formats share one
+// interpretation of dtype / shape / tensor_content / *_val (repeat-last-value rule included)
+inline void put_varint(std::string* o, uint64_t v) { while (v >= 0x80) { o->push_back((char)(v | 0x80)); v >>= 7; } o->push_back((char)v); }
+inline void put_key(std::string* o, int field, int wire) { put_varint(o, (uint64_t)field << 3 | (uint64_t)wire); }
+inline void put_bytes(std::string* o, int field, const std::string& b) { put_key(o, field, 2); put_varint(o, b.size()); o->append(b); }
+inline bool text_tensor(const TMsg& m, Tensor* t) {
+  std::string w;
+  for (const auto& f : m.fields) {
+    if (f.name == "dtype") { put_key(&w, 1, 0); put_varint(&w, (uint64_t)dtype_from_name(f.scalar)); }
+    else if (f.name == "tensor_shape" && f.is_msg) {
+      std::vector<int64_t> dims; bool ur = false;
+      text_shape(*f.msg, &dims, &ur);
+      std::string sh;
+      for (int64_t d : dims) { std::string dm; put_key(&dm, 1, 0); put_varint(&dm, (uint64_t)d); put_bytes(&sh, 2, dm); }
+      if (ur) { put_key(&sh, 3, 0); put_varint(&sh, 1); }
+      put_bytes(&w, 2, sh);
+    }
+    else if (f.name == "tensor_content") put_bytes(&w, 4, f.scalar);
+    else if (f.name == "float_val") { const float v = text_float(f.scalar); put_key(&w, 5, 5); w.append(reinterpret_cast<const char*>(&v), 4); }
+    else if (f.name == "double_val") { const double v = std::strtod(f.scalar.c_str(), nullptr); put_key(&w, 6, 1); w.append(reinterpret_cast<const char*>(&v), 8); }
+    else if (f.name == "int_val") { put_key(&w, 7, 0); put_varint(&w, (uint64_t)(int64_t)std::strtoll(f.scalar.c_str(), nullptr, 10)); }
+    else if (f.name == "int64_val") { put_key(&w, 10, 0); put_varint(&w, (uint64_t)std::strtoll(f.scalar.c_str(), nullptr, 10)); }
+    else if (f.name == "half_val") { put_key(&w, 13, 0); put_varint(&w, (uint64_t)std::strtoll(f.scalar.c_str(), nullptr, 10)); }
+    else if (f.name == "bool_val") { put_key(&w, 11, 0); put_varint(&w, text_bool(f.scalar) ? 1 : 0); }
+    else if (f.name == "string_val") put_bytes(&w, 8, f.scalar);
+  }
+  return parse_tensor(Cursor{reinterpret_cast<const uint8_t*>(w.data()), reinterpret_cast<const uint8_t*>(w.data()) + w.size()}, t);
+}
+
+inline bool text_attr(const TMsg& m, Attr* a) {
+  for (const auto& f : m.fields) {
+    if (f.name == "s") { a->kind = 's'; a->s = f.scalar; }
+    else if (f.name == "i") { a->kind = 'i'; a->i = std::strtoll(f.scalar.c_str(), nullptr, 10); }
+    else if (f.name == "f") { a->kind = 'f'; a->f = text_float(f.scalar); }
+    else if (f.name == "b") { a->kind = 'b'; a->b = text_bool(f.scalar); }
+    else if (f.name == "type") { a->kind = 't'; a->type = dtype_from_name(f.scalar); }
+    else if (f.name == "shape" && f.is_msg) { a->kind = 'h'; text_shape(*f.msg, &a->shape, &a->unknown_rank); }
+    else if (f.name == "tensor" && f.is_msg) { a->kind = 'T'; if (!text_tensor(*f.msg, &a->tensor)) return false; }
+    else if (f.name == "placeholder") { a->kind = 'p'; a->s = f.scalar; }
+    else if (f.name == "func" && f.is_msg) { a->kind = 'n'; const TField* nm = f.msg->first("name"); if (nm) a->s = nm->scalar; }
+    else if (f.name == "list" && f.is_msg) {
+      a->kind = 'l';
+      for (const auto& e : f.msg->fields) {
+        if (e.name == "s") a->ls.push_back(e.scalar);
+        else if (e.name == "i") a->li.push_back(std::strtoll(e.scalar.c_str(), nullptr, 10));
+        else if (e.name == "f") a->lf.push_back(text_float(e.scalar));
+        else if (e.name == "b") a->lb.push_back(text_bool(e.scalar));
+        else if (e.name == "type") a->lt.push_back(dtype_from_name(e.scalar));
+        else if (e.name == "shape" && e.is_msg) { std::vector<int64_t> d; bool ur = false; text_shape(*e.msg, &d, &ur); a->lshape.push_back(d); }
+        else if (e.name == "tensor") ++a->n_list_tensors;
+        else if (e.name == "func") ++a->n_list_funcs;
+      }
+    }
+  }
+  return true;
+}
+
+// GraphDef message tree -> Graph
+inline bool graph_from_text(const TMsg& gd, Graph* g, std::string* err) {
+  for (const auto& f : gd.fields) {
+    if (f.name != "node" || !f.is_msg) continue;
+    Node n;
+    for (const auto& nf : f.msg->fields) {
+      if (nf.name == "name") n.name = nf.scalar;
+      else if (nf.name == "op") n.op = nf.scalar;
+      else if (nf.name == "input") n.inputs.push_back(nf.scalar);
+      else if (nf.name == "device") n.device = nf.scalar;
+      else if (nf.name == "attr" && nf.is_msg) {
+        const TField* k = nf.msg->first("key");
+        const TField* v = nf.msg->first("value");
+        if (!k) continue;
+        Attr a;
+        if (v && v->is_msg && !text_attr(*v->msg, &a)) { *err = "malformed attr '" + k->scalar + "' of node '" + n.name + "'"; return false; }
+        if (k->scalar == "value" && a.kind == 'T') { n.value = a.tensor; n.has_value = true; }
+        n.attrs[k->scalar] = std::move(a);
+      }
+    }
+    g->by_name.emplace(n.name, (int)g->nodes.size());
+    g->nodes.push_back(std::move(n));
+  }
+  if (g->nodes.empty()) { *err = "text-format GraphDef holds no nodes"; return false; }
+  return true;
+}
+
+// text-format GraphDef, or text-format SavedModel (first meta graph's graph_def)
+inline bool parse_graph_text(const char* data, size_t n, Graph* g, std::string* err) {
+  for (size_t k = 0; k < n && k < 4096; ++k) {  // binary files fail fast (NUL / control bytes never occur in text format)
+    const unsigned char c = (unsigned char)data[k];
+    if (c < 9 || (c > 13 && c < 32)) { *err = "not a text-format protobuf (control bytes)"; return false; }
+  }
+  TMsg root;
+  if (!parse_text(data, n, &root, err)) return false;
+  if (root.first("node")) return graph_from_text(root, g, err);
+  if (const TField* mg = root.first("meta_graphs"))
+    if (mg->is_msg)
+      if (const TField* gd = mg->msg->first("graph_def"))
+        if (gd->is_msg) return graph_from_text(*gd->msg, g, err);
+  *err = "text-format protobuf without GraphDef nodes";
+  return false;
+}
+
+// The reference's order (blaze_xla_kernel.cc:169-175): ReadTextProto, then ReadBinaryProto.
+inline bool parse_graph_any(const uint8_t* data, size_t n, Graph* g, std::string* err) {
+  std::string text_err;
+  {
+    Graph tmp;
+    if (parse_graph_text(reinterpret_cast<const char*>(data), n, &tmp, &text_err)) { *g = std::move(tmp); return true; }
+  }
+  if (parse_graph(data, n, g, err)) return true;
+  *err = "parse proto failed: as text: " + text_err + "; as binary: " + *err;
+  return false;
+}
+
+// ---- canonical JSON dump of a Graph (tests compare the binary and the text decode of one graph with it) -----------
+inline void json_str(std::string* o, const std::string& s) {
+  o->push_back('"');
+  for (unsigned char c : s) {
+    if (c == '"' || c == '\\') { o->push_back('\\'); o->push_back((char)c); }
+    else if (c < 32 || c >= 127) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); o->append(b); }
+    else o->push_back((char)c);
+  }
+  o->push_back('"');
+}
+inline void json_f32(std::string* o, float v) {
+  char b[40];
+  if (std::isnan(v)) std::snprintf(b, sizeof b, "\"nan\"");
+  else if (std::isinf(v)) std::snprintf(b, sizeof b, v > 0 ? "\"inf\"" : "\"-inf\"");
+  else std::snprintf(b, sizeof b, "%.9g", (double)v);
+  o->append(b);
+}
+template <class V, class F>
+inline void json_list(std::string* o, const V& v, F one) {
+  o->push_back('[');
+  bool first = true;
+  for (const auto& e : v) { if (!first) o->push_back(','); first = false; one(e); }
+  o->push_back(']');
+}
+inline void json_tensor(std::string* o, const Tensor& t) {
+  *o += "{\"dtype\":" + std::to_string(t.dtype) + ",\"shape\":";
+  json_list(o, t.shape, [&](int64_t d) { *o += std::to_string(d); });
+  *o += ",\"f\":";
+  json_list(o, t.f, [&](float v) { json_f32(o, v); });
+  *o += ",\"i\":";
+  json_list(o, t.i, [&](int64_t v) { *o += std::to_string(v); });
+  *o += ",\"s\":";
+  json_list(o, t.s, [&](const std::string& v) { json_str(o, v); });
+  o->push_back('}');
+}
+inline std::string graph_to_json(const Graph& g) {
+  std::string o = "{\"nodes\":[";
+  bool firstn = true;
+  for (const Node& n : g.nodes) {
+    if (!firstn) o.push_back(',');
+    firstn = false;
+    o += "{\"name\":"; json_str(&o, n.name);
+    o += ",\"op\":"; json_str(&o, n.op);
+    o += ",\"device\":"; json_str(&o, n.device);
+    o += ",\"inputs\":"; json_list(&o, n.inputs, [&](const std::string& s) { json_str(&o, s); });
+    o += ",\"attrs\":{";
+    bool firsta = true;
+    for (const auto& kv : n.attrs) {
+      if (!firsta) o.push_back(',');
+      firsta = false;
+      json_str(&o, kv.first);
+      const Attr& a = kv.second;
+      o += ":{\"kind\":\""; if (a.kind) o.push_back(a.kind); o += "\",\"v\":";
+      switch (a.kind) {
+        case 's': case 'p': case 'n': json_str(&o, a.s); break;
+        case 'i': o += std::to_string(a.i); break;
+        case 'f': json_f32(&o, a.f); break;
+        case 'b': o += a.b ? "true" : "false"; break;
+        case 't': o += std::to_string(a.type); break;
+        case 'h':
+          o += "{\"dims\":"; json_list(&o, a.shape, [&](int64_t d) { o += std::to_string(d); });
+          o += std::string(",\"unknown_rank\":") + (a.unknown_rank ? "true" : "false") + "}";
+          break;
+        case 'T': json_tensor(&o, a.tensor); break;
+        case 'l':
+          o += "{\"s\":"; json_list(&o, a.ls, [&](const std::string& s) { json_str(&o, s); });
+          o += ",\"i\":"; json_list(&o, a.li, [&](int64_t v) { o += std::to_string(v); });
+          o += ",\"f\":"; json_list(&o, a.lf, [&](float v) { json_f32(&o, v); });
+          o += ",\"b\":"; json_list(&o, a.lb, [&](int v) { o += v ? "true" : "false"; });
+          o += ",\"type\":"; json_list(&o, a.lt, [&](int v) { o += std::to_string(v); });
+          o += ",\"shape\":"; json_list(&o, a.lshape, [&](const std::vector<int64_t>& d) { json_list(&o, d, [&](int64_t x) { o += std::to_string(x); }); });
+          o += ",\"n_tensors\":" + std::to_string(a.n_list_tensors) + ",\"n_funcs\":" + std::to_string(a.n_list_funcs) + "}";
+          break;
+        default: o += "null";
+      }
+      o.push_back('}');
+    }
+    o += "}}";
+  }
+  o += "]}";
+  return o;
+}
+
+}  // namespace nann_gd

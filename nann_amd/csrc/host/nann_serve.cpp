@@ -55,12 +55,16 @@ using Clock = std::chrono::steady_clock;
 #define CHECK(expr) do { if ((expr) != NANN_OK) die(#expr); } while (0)
 
 struct ClientThread;
+// admission control, as BlazeXlaOp has it: "waiting pool is full" / "blaze wait too long" (blaze_xla_kernel.cc:229-236)
+constexpr int32_t kStatusQueueFull = -2, kStatusDeadline = -3;
 
 struct Request {
   const uint16_t* comm_seq = nullptr;  // f16 bits [L * d]: the request as the caller sent it (attention model: staged as it is)
   const float* q = nullptr;            // l2 / mlp: the query vector the submitting thread reduced it to (f32 [d])
-  int64_t* top_k = nullptr;            // [k]
-  int32_t status = -1;
+  int64_t* top_k = nullptr;            // [level_topn[5]]
+  int32_t level_topn[6] = {0, 0, 0, 0, 0, 0};  // the request's own `level_topn` feed (build_opt_graph.py:75,151-159)
+  Clock::time_point t_submit;          // for the deadline (BlazeXlaOp's wait_ms, blaze_xla_kernel.cc:221-258)
+  int32_t status = -1;                 // nann_status, or kStatusQueueFull / kStatusDeadline (refused before any search)
   std::atomic<int> done{0};
   ClientThread* owner = nullptr;       // whose completion counter the reply bumps
 };
@@ -195,14 +199,16 @@ void* load(const std::string& path, int dtype, int64_t* count, int64_t elem_byte
 int main(int argc, char** argv) {
   if (argc < 4) {
     std::fprintf(stderr, "usage: %s <index_dir> <item_embs_dir> <dim> [--clients N] [--client-threads T] [--seconds S] [--max-batch B] "
-                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE] [--no-pin 1]\n", argv[0]);
+                         "[--max-wait-us U] [--ef E] [--topk K] [--seq-len L] [--lanes N] [--model-dir DIR] [--probe-out FILE] [--no-pin 1] "
+                         "[--mixed-topn 1] [--probe-topn a,b,c,d,e,k] [--max-queue N] [--deadline-ms MS]\n", argv[0]);
     return 2;
   }
   const std::string index_dir = argv[1], embs_dir = argv[2];
   const int d = std::atoi(argv[3]);
   int clients = 64, client_threads = 0, max_batch = 256, max_wait_us = 200, ef = 128, topk = 200, L = 50, lanes = 2, no_pin = 0;
-  double seconds = 3.0;
-  std::string model_dir, probe_out;
+  int mixed_topn = 0, max_queue = 0;
+  double seconds = 3.0, deadline_ms = 0.0;
+  std::string model_dir, probe_out, probe_topn;
   for (int i = 4; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     if (k == "--clients") clients = std::atoi(argv[i + 1]);
@@ -217,6 +223,10 @@ int main(int argc, char** argv) {
     else if (k == "--model-dir") model_dir = argv[i + 1];
     else if (k == "--probe-out") probe_out = argv[i + 1];  // after the run: one fixed request, its reply written as text
     else if (k == "--no-pin") no_pin = std::atoi(argv[i + 1]);
+    else if (k == "--mixed-topn") mixed_topn = std::atoi(argv[i + 1]);  // every other logical client asks for half the beam and half the k
+    else if (k == "--probe-topn") probe_topn = argv[i + 1];             // the probe request's own level_topn (within --ef / --topk)
+    else if (k == "--max-queue") max_queue = std::atoi(argv[i + 1]);    // requests refused while this many wait ("waiting pool is full")
+    else if (k == "--deadline-ms") deadline_ms = std::atof(argv[i + 1]); // a request that waited longer is failed, not searched ("blaze wait too long")
     else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
   }
   if (nann_device_count() < 1) { std::fprintf(stderr, "nann_serve: no HIP device\n"); return 1; }
@@ -262,7 +272,16 @@ int main(int argc, char** argv) {
   const int seq_d = attention ? 64 : d;  // the attention model's sequence is [L, 64]
   const size_t seq_elems = (size_t)L * seq_d;
 
+  // the scorer's per-index table goes in BEFORE traffic (nann_scorer_prepare: built, waited for and pinned here, so no
+  // request pays the hipMalloc + build + stream wait of a first search); without room for it the searches read the
+  // embedding rows -- slower, same answers
+  {
+    const int rc = model ? nann_model_prepare(model, ix, nullptr) : nann_scorer_prepare(scorer, ix, nullptr);
+    if (rc == NANN_ERR_CAPACITY) std::fprintf(stderr, "nann_serve: %s\n", nann_last_error());
+    else if (rc != NANN_OK) die("nann_scorer_prepare");
+  }
   // ---- per lane: a stream, the device buffers of one launch, page-locked staging
+  // --ef / --topk are the server's MAXIMA (workspace, plan, row stride of a reply); a request carries its own level_topn
   const int32_t level_topn[6] = {ef, ef, ef, ef, ef, topk};
   int64_t ws_bytes = 0;
   if (attention) CHECK(nann_search_model_workspace_bytes(ix, model, level_topn, max_batch, &ws_bytes));
@@ -270,8 +289,9 @@ int main(int argc, char** argv) {
   const int64_t in_bytes = attention ? (int64_t)seq_elems * 2 : (int64_t)d * 4;  // staged per request
   struct Lane {
     nann_stream_t stream = nullptr;
-    void *ws = nullptr, *d_in = nullptr, *d_topk = nullptr, *d_status = nullptr;
+    void *ws = nullptr, *d_in = nullptr, *d_topk = nullptr, *d_status = nullptr, *d_topn = nullptr;
     unsigned char* h_in = nullptr;
+    int32_t* h_topn = nullptr;
     int64_t* h_topk = nullptr;
     int32_t* h_status = nullptr;
     std::vector<ClientThread*> touched;
@@ -283,6 +303,8 @@ int main(int argc, char** argv) {
     CHECK(nann_malloc(&ln.d_in, (int64_t)max_batch * in_bytes));
     CHECK(nann_malloc(&ln.d_topk, (int64_t)max_batch * topk * 8));
     CHECK(nann_malloc(&ln.d_status, (int64_t)max_batch * 4));
+    CHECK(nann_malloc(&ln.d_topn, (int64_t)max_batch * 6 * 4));
+    CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_topn), (int64_t)max_batch * 6 * 4));
     CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_in), (int64_t)max_batch * in_bytes));
     CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_topk), (int64_t)max_batch * topk * 8));
     CHECK(nann_host_malloc(reinterpret_cast<void**>(&ln.h_status), (int64_t)max_batch * 4));
@@ -295,7 +317,20 @@ int main(int argc, char** argv) {
   CHECK(nann_stream_synchronize(nullptr));
 
   Queue q;
-  std::atomic<long long> served{0}, failed{0}, launches{0}, batched{0};
+  std::atomic<long long> served{0}, failed{0}, launches{0}, batched{0}, refused{0}, expired{0};
+  // a request that is answered without a search (admission control): its caller is told like any other
+  auto finish_unsearched = [&](Request* r, int32_t status) {
+    r->status = status;
+    ClientThread* owner = r->owner;
+    r->done.store(1, std::memory_order_release);
+    if (owner) {
+      owner->completed.fetch_add(1, std::memory_order_seq_cst);
+      if (owner->sleeping.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lk(owner->mu);
+        owner->cv.notify_one();
+      }
+    }
+  };
   std::vector<ClientThread> cthreads((size_t)client_threads);
   std::vector<std::vector<float>> lat((size_t)client_threads);
   const auto t_end = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
@@ -307,13 +342,25 @@ int main(int argc, char** argv) {
       std::memcpy(ln.h_in + (size_t)i * in_bytes, attention ? static_cast<const void*>(batch[i]->comm_seq) : static_cast<const void*>(batch[i]->q),
                   (size_t)in_bytes);
     CHECK(nann_memcpy(ln.d_in, ln.h_in, (int64_t)b * in_bytes, 0, ln.stream));
+    // level_topn is a per-request feed of the serving signature: a batch whose requests all ask for the server's values
+    // takes the uniform launch, a mixed one carries its [b, 6] table to the device (nann_search_v)
+    bool uniform = true;
+    for (int i = 0; i < b; ++i) {
+      std::memcpy(ln.h_topn + (size_t)i * 6, batch[i]->level_topn, 6 * sizeof(int32_t));
+      uniform = uniform && std::memcmp(batch[i]->level_topn, level_topn, sizeof(level_topn)) == 0;
+    }
+    const int32_t* d_topn = nullptr;
+    if (!uniform) {
+      CHECK(nann_memcpy(ln.d_topn, ln.h_topn, (int64_t)b * 6 * 4, 0, ln.stream));
+      d_topn = static_cast<const int32_t*>(ln.d_topn);
+    }
     if (attention) {
-      CHECK(nann_search_model(ix, model, ln.d_in, b, level_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk), nullptr,
-                              nullptr, static_cast<int32_t*>(ln.d_status), nullptr, ln.stream));
+      CHECK(nann_search_model_v(ix, model, ln.d_in, b, level_topn, d_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk),
+                                nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr, ln.stream));
     } else {
-      CHECK(nann_search(ix, scorer, static_cast<const float*>(ln.d_in), b, level_topn, ln.ws, ws_bytes,
-                        static_cast<int64_t*>(ln.d_topk), nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr,
-                        ln.stream));
+      CHECK(nann_search_v(ix, scorer, static_cast<const float*>(ln.d_in), b, level_topn, d_topn, ln.ws, ws_bytes,
+                          static_cast<int64_t*>(ln.d_topk), nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr,
+                          ln.stream));
     }
     CHECK(nann_memcpy(ln.h_topk, ln.d_topk, (int64_t)b * topk * 8, 1, ln.stream));
     CHECK(nann_memcpy(ln.h_status, ln.d_status, (int64_t)b * 4, 1, ln.stream));
@@ -324,17 +371,21 @@ int main(int argc, char** argv) {
     touched.clear();
     for (int i = 0; i < b; ++i) {
       Request* r = batch[i];
-      std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)topk * 8);
+      std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)r->level_topn[5] * 8);  // the request's own k
       r->status = ln.h_status[(size_t)i];
       ClientThread* owner = r->owner;  // (read before the release: the request may be reused the moment `done` is seen)
       r->done.store(1, std::memory_order_release);
       if (owner) {
-        owner->completed.fetch_add(1, std::memory_order_release);
+        owner->completed.fetch_add(1, std::memory_order_seq_cst);
         if (std::find(touched.begin(), touched.end(), owner) == touched.end()) touched.push_back(owner);
       }
     }
-    for (ClientThread* t : touched)  // one wake-up per client THREAD per batch, and only if it sleeps
-      if (t->sleeping.load(std::memory_order_acquire)) {
+    // one wake-up per client THREAD per batch, and only if it sleeps.  The client stores `sleeping` and THEN loads
+    // `completed`; this side adds to `completed` and THEN loads `sleeping`: both pairs are seq_cst, so at least one side
+    // sees the other's store (with release / acquire alone the two loads may both read the old values -- store-to-load
+    // reordering -- and the client sleeps through its last reply: ADVICE r3)
+    for (ClientThread* t : touched)
+      if (t->sleeping.load(std::memory_order_seq_cst)) {
         std::lock_guard<std::mutex> lk(t->mu);
         t->cv.notify_one();
       }
@@ -362,18 +413,37 @@ int main(int argc, char** argv) {
           batch.assign(q.pending.begin(), q.pending.begin() + (long)take);
           q.pending.erase(q.pending.begin(), q.pending.begin() + (long)take);
         }
+        if (deadline_ms > 0.0) {  // "blaze wait too long": a request that waited past its deadline is failed, not searched
+          const auto now = Clock::now();
+          size_t keep = 0;
+          for (Request* r : batch) {
+            if (std::chrono::duration<double, std::milli>(now - r->t_submit).count() > deadline_ms) {
+              expired.fetch_add(1);
+              finish_unsearched(r, kStatusDeadline);
+            } else batch[keep++] = r;
+          }
+          batch.resize(keep);
+        }
         if (!batch.empty()) run_batch(lane[(size_t)li], batch);
       }
     });
 
   // what a server's request handler does before queueing: reduce the history to the query vector (l2 / mlp)
   auto submit = [&](Request* const* reqs, int n) {
+    const auto now = Clock::now();
+    std::vector<Request*> turned_away;
+    bool wake = false;
     {
       std::lock_guard<std::mutex> lk(q.mu);
-      for (int i = 0; i < n; ++i) q.pending.push_back(reqs[i]);
-      if (!q.waiting) return;
+      for (int i = 0; i < n; ++i) {
+        reqs[i]->t_submit = now;
+        if (max_queue > 0 && (int)q.pending.size() >= max_queue) turned_away.push_back(reqs[i]);  // "waiting pool is full"
+        else q.pending.push_back(reqs[i]);
+      }
+      wake = q.waiting > 0;
     }
-    q.cv.notify_all();
+    if (wake) q.cv.notify_all();
+    for (Request* r : turned_away) { refused.fetch_add(1); finish_unsearched(r, kStatusQueueFull); }
   };
 
   // ---- closed-loop clients (predict_request_consumer.cc:17-53), `clients` of them over `client_threads` OS threads
@@ -406,6 +476,11 @@ int main(int argc, char** argv) {
         r.comm_seq = &seqs[(size_t)(turn++ % kVariants) * seq_elems];
         r.top_k = &outs[(size_t)i * topk];
         r.owner = &me;
+        for (int j = 0; j < 6; ++j) r.level_topn[j] = level_topn[j];
+        if (mixed_topn && (i & 1)) {  // every other logical client: half the beam, half the k (its own `level_topn` feed)
+          for (int j = 0; j < 5; ++j) r.level_topn[j] = std::max(1, ef / 2);
+          r.level_topn[5] = std::max(1, std::min(topk / 2, 2 * (ef / 2)));
+        }
         r.status = -1;
         r.done.store(0, std::memory_order_relaxed);
         t0[(size_t)i] = Clock::now();
@@ -425,9 +500,9 @@ int main(int argc, char** argv) {
         // sleep until at least one reply is in (spin briefly first: a batch takes ~0.5 ms)
         if (me.completed.load(std::memory_order_acquire) == seen) {
           std::unique_lock<std::mutex> lk(me.mu);
-          me.sleeping.store(1, std::memory_order_release);
-          me.cv.wait(lk, [&] { return me.completed.load(std::memory_order_acquire) != seen; });
-          me.sleeping.store(0, std::memory_order_release);
+          me.sleeping.store(1, std::memory_order_seq_cst);
+          me.cv.wait(lk, [&] { return me.completed.load(std::memory_order_seq_cst) != seen; });
+          me.sleeping.store(0, std::memory_order_seq_cst);
         }
         const auto now = Clock::now();
         stop = stop || now >= t_end;
@@ -462,10 +537,11 @@ int main(int argc, char** argv) {
   std::printf("{\"host\": \"nann_serve (C++ over the C ABI)\", \"scorer\": \"%s\", \"items\": %lld, \"dim\": %d, \"ef\": %d, "
               "\"topk\": %d, \"clients\": %d, \"client_threads\": %d, \"max_batch\": %d, \"max_wait_us\": %d, \"lanes\": %d, \"pinned\": %s, "
               "\"staged_bytes_per_request\": %lld, \"seconds\": %.2f, \"requests\": %lld, "
-              "\"failed_requests\": %lld, \"qps\": %.1f, \"launches\": %lld, \"mean_batch\": %.1f, "
+              "\"failed_requests\": %lld, \"refused_queue_full\": %lld, \"expired_deadline\": %lld, \"mixed_level_topn\": %s, \"qps\": %.1f, \"launches\": %lld, \"mean_batch\": %.1f, "
               "\"latency_ms\": {\"p50\": %.3f, \"p90\": %.3f, \"p99\": %.3f, \"max\": %.3f}}\n",
               model_dir.empty() ? "l2" : model_dir.c_str(), (long long)n_ids, d, ef, topk, clients, client_threads, max_batch, max_wait_us,
-              lanes, no_pin ? "false" : "true", (long long)in_bytes, wall, total, failed.load(), (double)total / wall, launches.load(),
+              lanes, no_pin ? "false" : "true", (long long)in_bytes, wall, total, failed.load(), refused.load(), expired.load(),
+              mixed_topn ? "true" : "false", (double)total / wall, launches.load(),
               launches.load() ? (double)batched.load() / (double)launches.load() : 0.0, pct(0.5), pct(0.9), pct(0.99),
               all.empty() ? 0.0f : all.back());
 
@@ -475,21 +551,33 @@ int main(int argc, char** argv) {
       for (int k = 0; k < seq_d; ++k) seq[(size_t)l * seq_d + k] = pool[(size_t)(k % d)];
     std::vector<int64_t> out((size_t)topk);
     std::vector<float> qv((size_t)d);
-    Request r;
+    // two requests in ONE launch: the server's level_topn, and -- with --probe-topn -- one with its own; the file holds
+    // the second when there is one (status, then its k ids)
+    Request r, r2;
+    std::vector<int64_t> out2((size_t)topk);
     r.comm_seq = seq.data();
     r.top_k = out.data();
+    for (int j = 0; j < 6; ++j) r.level_topn[j] = r2.level_topn[j] = level_topn[j];
     if (!attention) { seq_mean_host(seq.data(), L, d, qv.data()); r.q = qv.data(); }
-    run_batch(lane[0], {&r});
+    r2.comm_seq = r.comm_seq; r2.q = r.q; r2.top_k = out2.data();
+    std::vector<Request*> probes{&r};
+    if (!probe_topn.empty()) {
+      if (std::sscanf(probe_topn.c_str(), "%d,%d,%d,%d,%d,%d", &r2.level_topn[0], &r2.level_topn[1], &r2.level_topn[2],
+                      &r2.level_topn[3], &r2.level_topn[4], &r2.level_topn[5]) != 6) die("--probe-topn a,b,c,d,e,k");
+      probes.push_back(&r2);
+    }
+    run_batch(lane[0], probes);
+    const Request& shown = probes.size() > 1 ? r2 : r;
     FILE* f = std::fopen(probe_out.c_str(), "w");
     if (!f) { std::fprintf(stderr, "nann_serve: cannot write %s\n", probe_out.c_str()); return 1; }
-    std::fprintf(f, "%d\n", r.status);
-    for (int i = 0; i < topk; ++i) std::fprintf(f, "%lld\n", (long long)out[(size_t)i]);
+    std::fprintf(f, "%d\n", shown.status);
+    for (int i = 0; i < shown.level_topn[5]; ++i) std::fprintf(f, "%lld\n", (long long)shown.top_k[(size_t)i]);
     std::fclose(f);
   }
 
   for (Lane& ln : lane) {
-    nann_free(ln.ws); nann_free(ln.d_in); nann_free(ln.d_topk); nann_free(ln.d_status);
-    nann_host_free(ln.h_in); nann_host_free(ln.h_topk); nann_host_free(ln.h_status);
+    nann_free(ln.ws); nann_free(ln.d_in); nann_free(ln.d_topk); nann_free(ln.d_status); nann_free(ln.d_topn);
+    nann_host_free(ln.h_in); nann_host_free(ln.h_topk); nann_host_free(ln.h_status); nann_host_free(ln.h_topn);
     nann_stream_destroy(ln.stream);
   }
   if (own_scorer) nann_scorer_destroy(own_scorer);

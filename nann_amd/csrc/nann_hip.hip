@@ -3,7 +3,7 @@
 // in nann_device.h.  Reference citations are relative to /root/reference/.
 #include "nann_eval.h"
 #include "nann_attn.h"
-#include "host/nann_graphdef.h"
+#include "host/nann_graphdef_text.h"
 #include "host/nann_projcache.h"
 
 #include <algorithm>
@@ -1470,7 +1470,8 @@ static int model_from_graphdef(const std::string& path, int32_t d, int32_t emb_d
   const std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
   nann_gd::Graph g;
   std::string msg;
-  if (!nann_gd::parse_graph(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &g, &msg))
+  // text first, then binary: the reference's order (blaze_xla_kernel.cc:169-175)
+  if (!nann_gd::parse_graph_any(reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size(), &g, &msg))
     return fail(NANN_ERR_IO, "parse proto from " + path + " failed: " + msg);  // blaze_xla_kernel.cc:169-175
   nann_gd::AttnWeights w;
   if (!nann_gd::extract_attention(g, &w, &msg))

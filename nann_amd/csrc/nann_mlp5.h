@@ -26,7 +26,20 @@
 //                       score_mlp_row), so the traversal runs layer 2 only: 512 x v_mfma_f32_32x32x2_f32 per 32 rows
 //                       instead of 1024, bit-identical to the oracle.
 #pragma once
+#include <cstddef>
+
 #include "nann_mlp3.h"
+
+#ifndef NANN_RES_SKEW
+#define NANN_RES_SKEW 0    // s_sleep units (64 cycles) the second wavefront of every SIMD starts late; measured (r4c): 0 / 6 / 12 / 24
+                           // make no difference to the split-f16 form
+#endif
+#ifndef NANN_RES_XSKEW
+#define NANN_RES_XSKEW 32  // the same for the exact form (a tile = 64 f32 MFMAs of 64 cycles)
+#endif
+#ifndef NANN_RES_VAR
+#define NANN_RES_VAR 0  // timing builds only (tools/build_res_variant.py): bit 0 no split arithmetic, bit 1 no gathers, bit 2 no epilogue
+#endif
 
 namespace nann {
 
@@ -91,6 +104,34 @@ __device__ __forceinline__ void wg_mlp_res_leave(uint4* lds, const uint4* park, 
 // ---------------------------------------------------------------------------------------------------------------
 // split-f16, W2 resident.  W2 = the scorer's p2 planes ([t][q][m][hi, lo][lane] uint4, nann_hip.hip pack_split_weights)
 // in LDS; V staged by wg_mlp_res_vectors.  No barrier inside; every wavefront returns on its own.
+//
+// What the loop costs, in shader cycles per scored row of the workgroup (timing builds r4b / r4c, normalised by the rows
+// each build scored -- a build with wrong scores walks other beams): 48 of MFMA issue (192 x 32 cycles per 32 rows on
+// four SIMDs); +22..31 for the PReLU + operand-split arithmetic -- a SIMD does not overlap its vector and matrix
+// instructions, not even across the two wavefronts it hosts (confirmed here: the build without
+// that arithmetic runs 76.8 instead of 96.9) --; +11..22 for the gathers of the table rows; the rest LDS reads, the
+// per-call weight load and the ragged last blocks of a call.
+//
+// The eight hidden tiles of a 32-row block are UNROLLED (NANN_RES_ROLLED = 1: two tiles per trip of a rolled loop, the
+// form of r4b): hipcc puts `s_waitcnt vmcnt(0)` at the head of a rolled loop that carries gathers in flight, i.e. every
+// trip waited for the gathers issued one tile earlier (a random 128-byte access takes 2-3 k cycles under this load, a
+// tile of a wavefront ~1.6 k).  Unrolled, the waits inside a block are exact (`vmcnt(4)`: this tile's four loads, not
+// the next tile's).  For the unrolled body to keep its registers the LDS addresses are formed from THREE opaque bases
+// (weights below / above the 64 KB an instruction's offset field reaches, and the vectors) + immediate offsets; left to
+// itself the compiler hoists ~60 address registers out of the block loop and spills them into it.
+#ifndef NANN_RES_ROLLED
+#define NANN_RES_ROLLED 0
+#endif
+#ifndef NANN_RES_WF16
+#define NANN_RES_WF16 0  // 1: all sixteen A fragments of a tile read at its top (32 more live registers) instead of 8 + 8
+#endif
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4v* lds_u4_ptr;
+typedef const __attribute__((address_space(3))) f32x4v* lds_f4_ptr;
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {  // a generic pointer into LDS -> its LDS byte address
+  return (uint32_t)(size_t)p;  // (the LDS aperture's low 32 bits are the LDS address)
+}
 template <int NT>
 __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj, uint32_t n_table_rows,
                                                  const int32_t* ids, int n, const uint4* W2, const Mlp2Vectors* V,
@@ -100,6 +141,7 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
   const int cand = lane & 31, g = lane >> 5;
   const int nblk = (n + 31) >> 5;
   if (wave >= nblk) return;
+  if (NANN_RES_SKEW > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(NANN_RES_SKEW);  // (see NANN_RES_SKEW)
   auto row_ptr = [&](int i) -> const float* {
     const int ic = min(i, n - 1);
     const uint32_t rid = ids ? (uint32_t)ids[ic] : (uint32_t)ic;
@@ -110,10 +152,28 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) p[rr] = *reinterpret_cast<const float4*>(row + 32 * t + 8 * rr);
   };
+  // LDS bases (byte addresses), made opaque so that every read is `base + immediate`
+  uint32_t w_lo = lds_offset_of(W2) + (uint32_t)lane * 16u;
+  uint32_t w_hi = w_lo + 65536u;
+  uint32_t v_at = lds_offset_of(V) + (uint32_t)g * 16u;
+  asm volatile("" : "+v"(w_lo), "+v"(w_hi), "+v"(v_at));
+  auto frag = [&](int t, int k) -> f16x8 {  // fragment k (0..15: [q][m][hi, lo]) of tile t
+    const uint32_t base = t < 4 ? w_lo : w_hi;
+    const int off = (t & 3) * 16384 + k * 1024;
+    const u32x4v v = *reinterpret_cast<lds_u4_ptr>(base + off);
+    return __builtin_bit_cast(f16x8, v);
+  };
+  auto vec4 = [&](int float_index) -> f32x4v {  // four floats of the vectors at float_index + 4 g
+    return *reinterpret_cast<lds_f4_ptr>(v_at + 4 * float_index);
+  };
+  constexpr int kU = 0, kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
+  static_assert(offsetof(Mlp2Vectors, beta1) == 4 * kBeta1 && offsetof(Mlp2Vectors, b2) == 4 * kB2 &&
+                offsetof(Mlp2Vectors, beta2) == 4 * kBeta2 && offsetof(Mlp2Vectors, w3) == 4 * kW3, "Mlp2Vectors layout");
   const float* row = row_ptr(wave * 32 + cand);
-  float4 pE[4], pO[4];  // even / odd tiles, refilled two tiles ahead
-  load_tile(row, 0, pE);
-  load_tile(row, 1, pO);
+  // gathers run two tiles ahead of their use
+  float4 x[2][4];
+  load_tile(row, 0, x[0]);
+  load_tile(row, 1, x[1]);
   for (int b = wave; b < nblk; b += NW) {
     const int i = b * 32 + cand;
     const float* next = (b + NW < nblk) ? row_ptr(i + NW * 32) : row;
@@ -122,15 +182,19 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float4 v = *reinterpret_cast<const float4*>(&V->b2[32 * mt + 8 * rr + 4 * g]);
+        const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
         a2[mt][4 * rr] = v.x; a2[mt][4 * rr + 1] = v.y; a2[mt][4 * rr + 2] = v.z; a2[mt][4 * rr + 3] = v.w;
       }
-    auto tile = [&](int t, float4 (&x)[4]) {
-      const uint4* L2 = W2 + t * 1024 + lane;
-      // the tile's sixteen A fragments leave LDS while the operand split runs
-      f16x8 Wf[4 * H2T];
+    auto tile = [&](int t, float4 (&xt)[4]) {
+      // everything the tile reads from LDS leaves in one burst: the A fragments of its first 16-deep step and the
+      // query's part / slopes of its 16 hidden units
+      f16x8 Wf[(NANN_RES_WF16 ? 4 : 2) * H2T];
 #pragma unroll
-      for (int k = 0; k < 4 * H2T; ++k) Wf[k] = as_f16x8(L2[k * 64]);
+      for (int k = 0; k < (NANN_RES_WF16 ? 4 : 2) * H2T; ++k) Wf[k] = frag(t, k);
+      f32x4v ub[8];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { ub[rr] = vec4(kU + 32 * t + 8 * rr); ub[4 + rr] = vec4(kBeta1 + 32 * t + 8 * rr); }
+      __builtin_amdgcn_sched_barrier(0);
       f16x8 bh[2], bl[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -138,44 +202,60 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int rr = 2 * q + half;
-          const float4 u = *reinterpret_cast<const float4*>(&V->u[32 * t + 8 * rr + 4 * g]);
-          const float4 be = *reinterpret_cast<const float4*>(&V->beta1[32 * t + 8 * rr + 4 * g]);
+          const f32x4v u = ub[rr], be = ub[4 + rr];
           uint32_t h0, l0, h1, l1;
-          prelu_split_pair_pk(f32x2{x[rr].x, x[rr].y}, f32x2{u.x, u.y}, f32x2{be.x, be.y}, h0, l0);
-          prelu_split_pair_pk(f32x2{x[rr].z, x[rr].w}, f32x2{u.z, u.w}, f32x2{be.z, be.w}, h1, l1);
+#if (NANN_RES_VAR & 1)  // timing build: no PReLU / operand split arithmetic
+          h0 = __float_as_uint(xt[rr].x + u.x); l0 = __float_as_uint(xt[rr].y + be.x); h1 = __float_as_uint(xt[rr].z); l1 = __float_as_uint(xt[rr].w);
+#else
+          prelu_split_pair_pk(f32x2{xt[rr].x, xt[rr].y}, f32x2{u.x, u.y}, f32x2{be.x, be.y}, h0, l0);
+          prelu_split_pair_pk(f32x2{xt[rr].z, xt[rr].w}, f32x2{u.z, u.w}, f32x2{be.z, be.w}, h1, l1);
+#endif
           if (half == 0) { h.x = h0; h.y = h1; l.x = l0; l.y = l1; } else { h.z = h0; h.w = h1; l.z = l0; l.w = l1; }
         }
         bh[q] = as_f16x8(h); bl[q] = as_f16x8(l);
       }
       __builtin_amdgcn_sched_barrier(0);
-      {
-        const bool wrap = t + 2 >= H1T;
-        load_tile(wrap ? next : row, wrap ? t + 2 - H1T : t + 2, x);
-      }
+#if !(NANN_RES_VAR & 2)  // (timing build bit 1: no gathers after the first tiles)
+      load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < 2; ++q) {
 #pragma unroll
         for (int mt = 0; mt < H2T; ++mt) {
-          const f16x8 wh = Wf[(q * H2T + mt) * 2], wl = Wf[(q * H2T + mt) * 2 + 1];
+          const int fo = NANN_RES_WF16 ? q * 2 * H2T : 0;
+          const f16x8 wh = Wf[fo + mt * 2], wl = Wf[fo + mt * 2 + 1];
           a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[q], a2[mt], 0, 0, 0);
           a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[q], a2[mt], 0, 0, 0);
           a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[q], a2[mt], 0, 0, 0);
+          if (q == 0 && !NANN_RES_WF16) {  // the second step's fragments travel underneath the first step's MFMAs
+            Wf[mt * 2] = frag(t, 2 * H2T + mt * 2);
+            Wf[mt * 2 + 1] = frag(t, 2 * H2T + mt * 2 + 1);
+          }
         }
+      }
     };
+#if NANN_RES_ROLLED
 #pragma unroll 1
-    for (int t = 0; t < H1T; t += 2) {
-      tile(t, pE);
-      tile(t + 1, pO);
+    for (int t = 0; t < H1T; t += 2) {  // (runtime t: frag / vec4 fall back to computed addresses)
+      tile(t, x[0]);
+      tile(t + 1, x[1]);
     }
+#else
+#pragma unroll
+    for (int t = 0; t < H1T; t += 2) {
+      tile(t, x[0]);
+      tile(t + 1, x[1]);
+    }
+#endif
     row = next;
     float part = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float4 be = *reinterpret_cast<const float4*>(&V->beta2[32 * mt + 8 * rr + 4 * g]);
-        const float4 w3 = *reinterpret_cast<const float4*>(&V->w3[32 * mt + 8 * rr + 4 * g]);
+        const f32x4v be = vec4(kBeta2 + 32 * mt + 8 * rr);
+        const f32x4v w3 = vec4(kW3 + 32 * mt + 8 * rr);
         const float bes[4] = {be.x, be.y, be.z, be.w}, w3s[4] = {w3.x, w3.y, w3.z, w3.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -213,10 +293,20 @@ __device__ __forceinline__ void wg_score_mlp_xres(const float* __restrict__ proj
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) p[rr] = *reinterpret_cast<const float4*>(row + 32 * t + 8 * rr);
   };
+  if (NANN_RES_XSKEW > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(NANN_RES_XSKEW);  // SIMD partners half a tile apart (see the split form)
+  auto load_ub = [&](int t, float4 (&ub)[8]) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      ub[rr] = *reinterpret_cast<const float4*>(&V->u[32 * t + 8 * rr + 4 * g]);
+      ub[4 + rr] = *reinterpret_cast<const float4*>(&V->beta1[32 * t + 8 * rr + 4 * g]);
+    }
+  };
   const float* row = row_ptr(wave * 32 + cand);
   float4 pE[4], pO[4];
   load_tile(row, 0, pE);
   load_tile(row, 1, pO);
+  float4 ubE[8], ubO[8];  // u / alpha1 of the even / odd tile, read underneath the previous tile's MFMAs
+  load_ub(0, ubE);
   for (int b = wave; b < nblk; b += NW) {
     const int i = b * 32 + cand;
     const float* next = (b + NW < nblk) ? row_ptr(i + NW * 32) : row;
@@ -228,23 +318,31 @@ __device__ __forceinline__ void wg_score_mlp_xres(const float* __restrict__ proj
         const float4 v = *reinterpret_cast<const float4*>(&V->b2[32 * mt + 8 * rr + 4 * g]);
         acc2[mt][4 * rr] = v.x; acc2[mt][4 * rr + 1] = v.y; acc2[mt][4 * rr + 2] = v.z; acc2[mt][4 * rr + 3] = v.w;
       }
-    auto tile = [&](int t, float4 (&x)[4]) {
+    auto tile = [&](int t, float4 (&x)[4], float4 (&cur)[8], float4 (&nxt)[8]) {
       // h1 of this lane's 16 hidden units of tile t (register r = 4 rr + e <-> unit 32 t + 8 rr + 4 g + e)
       float h[16];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float4 u = *reinterpret_cast<const float4*>(&V->u[32 * t + 8 * rr + 4 * g]);
-        const float4 al = *reinterpret_cast<const float4*>(&V->beta1[32 * t + 8 * rr + 4 * g]);
+        const float4 u = cur[rr], al = cur[4 + rr];
         constexpr float kInv = 1.0f / kSplit2Scale;  // the table holds 2^7 P: exact both ways
+#if (NANN_RES_VAR & 1)  // timing build: no layer-1 arithmetic
+        h[4 * rr + 0] = x[rr].x + u.x; h[4 * rr + 1] = x[rr].y + al.x; h[4 * rr + 2] = x[rr].z; h[4 * rr + 3] = x[rr].w;
+#else
         h[4 * rr + 0] = prelu(u.x + x[rr].x * kInv, al.x);
         h[4 * rr + 1] = prelu(u.y + x[rr].y * kInv, al.y);
         h[4 * rr + 2] = prelu(u.z + x[rr].z * kInv, al.z);
         h[4 * rr + 3] = prelu(u.w + x[rr].w * kInv, al.w);
+#endif
       }
+      __builtin_amdgcn_sched_barrier(0);
+#if !(NANN_RES_VAR & 2)
       {
         const bool wrap = t + 2 >= H1T;
         load_tile(wrap ? next : row, wrap ? t + 2 - H1T : t + 2, x);
       }
+#endif
+      load_ub((t + 1) & (H1T - 1), nxt);
+      __builtin_amdgcn_sched_barrier(0);
       const float4* A = W2 + (size_t)t * (H2T * 4 * 64) + lane;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -262,12 +360,15 @@ __device__ __forceinline__ void wg_score_mlp_xres(const float* __restrict__ proj
     };
 #pragma unroll 1
     for (int t = 0; t < H1T; t += 2) {
-      tile(t, pE);
-      tile(t + 1, pO);
+      tile(t, pE, ubE, ubO);
+      tile(t + 1, pO, ubO, ubE);
     }
     row = next;
     // PReLU of layer 2 and the bias-free output layer: per-lane chain over its 64 outputs (wg_score_mlp's epilogue)
     float part = 0.0f;
+#if (NANN_RES_VAR & 4)  // timing build: no output chain
+    part = acc2[0][0] + acc2[1][1] + acc2[2][2] + acc2[3][3];
+#else
 #pragma unroll
     for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
@@ -275,6 +376,7 @@ __device__ __forceinline__ void wg_score_mlp_xres(const float* __restrict__ proj
         const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
         part = __fmaf_rn(prelu(acc2[mt][r], V->beta2[m]), V->w3[m], part);
       }
+#endif
     const float other = __shfl_xor(part, 32);
     const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
     if (g == 0 && i < n) scores[i] = p0 + p1;

@@ -32,11 +32,22 @@ class RequestFailed(RuntimeError):
         self.status = status
 
 
+class Overloaded(RuntimeError):
+    """admission control, as BlazeXlaOp has it (blaze_xla_kernel.cc:229-258): 'waiting pool is full' / 'blaze wait too long'"""
+
+
 class BatchingServer:
-    def __init__(self, backend, seq_len, emb_dim, level_topn, max_batch=1024, max_wait_us=200):
+    """level_topn: the server's DEFAULT and per-entry MAXIMUM.  A request may carry its own `level_topn` -- the reference
+    feeds it per request (build_opt_graph.py:75,151-159) --, each entry within the server's; a batch whose requests all
+    use one value is launched uniformly, a mixed batch hands the backend an i32[B, 6] array (nann_search_v).
+    max_queue / deadline_ms: refuse a request while that many wait / fail one that waited longer, without searching."""
+
+    def __init__(self, backend, seq_len, emb_dim, level_topn, max_batch=1024, max_wait_us=200, max_queue=0, deadline_ms=0.0):
         self.backend, self.seq_len, self.emb_dim = backend, seq_len, emb_dim
         self.level_topn = [int(x) for x in level_topn]
         self.max_batch, self.max_wait = int(max_batch), max_wait_us * 1e-6
+        self.max_queue, self.deadline = int(max_queue), deadline_ms * 1e-3
+        self.refused = self.expired = 0
         self._q = queue.Queue()
         self._stop = threading.Event()
         self.batches = 0
@@ -44,18 +55,26 @@ class BatchingServer:
         self._thread = threading.Thread(target=self._run, name="nann-dispatch", daemon=True)
         self._thread.start()
 
-    def submit(self, comm_seq):
-        """comm_seq: f16 array of seq_len*emb_dim elements (any shape).  -> Future of i64[1, k]."""
+    def submit(self, comm_seq, level_topn=None):
+        """comm_seq: f16 array of seq_len*emb_dim elements (any shape); level_topn: this request's i32[6] (default: the
+        server's).  -> Future of i64[1, level_topn[5]]."""
         a = np.asarray(comm_seq, dtype=np.float16).reshape(-1)
         if a.size != self.seq_len * self.emb_dim:
             raise ValueError(f"comm_seq must hold {self.seq_len}x{self.emb_dim} values, got {a.size}")
+        t = self.level_topn if level_topn is None else [int(x) for x in level_topn]
+        if len(t) != 6 or any(v < 0 or v > m for v, m in zip(t, self.level_topn)):
+            raise ValueError(f"level_topn must be six values within the server's {self.level_topn}, got {t}")
         f = Future()
-        self._q.put((a, f))
+        if self.max_queue and self._q.qsize() >= self.max_queue:
+            self.refused += 1
+            f.set_exception(Overloaded("waiting pool is full"))
+            return f
+        self._q.put((a, f, t, time.perf_counter()))
         return f
 
-    def predict(self, comm_seq, timeout=None):
+    def predict(self, comm_seq, level_topn=None, timeout=None):
         """Blocking call with the reference's request/response shapes."""
-        return self.submit(comm_seq).result(timeout)
+        return self.submit(comm_seq, level_topn).result(timeout)
 
     def close(self):
         self._stop.set()
@@ -79,19 +98,32 @@ class BatchingServer:
                     self._stop.set()
                     break
                 batch.append(item)
+            if self.deadline > 0:
+                now, kept = time.perf_counter(), []
+                for item in batch:
+                    if now - item[3] > self.deadline:
+                        self.expired += 1
+                        item[1].set_exception(Overloaded("request waited too long"))
+                    else:
+                        kept.append(item)
+                batch = kept
+                if not batch:
+                    continue
             seqs = np.stack([b[0] for b in batch]).reshape(len(batch), self.seq_len, self.emb_dim)
+            topns = [b[2] for b in batch]
+            uniform = all(t == topns[0] for t in topns)
             try:
-                ids, status = self.backend(seqs, self.level_topn)
+                ids, status = self.backend(seqs, topns[0] if uniform else np.asarray(topns, np.int32))
                 ids, status = np.asarray(ids), np.asarray(status)
-                for i, (_, fut) in enumerate(batch):
+                for i, (_, fut, t, _) in enumerate(batch):
                     if status[i]:
                         fut.set_exception(RequestFailed(int(status[i])))
                     else:
-                        fut.set_result(ids[i:i + 1].copy())
+                        fut.set_result(ids[i:i + 1, :t[5]].copy())
             except Exception as e:  # a failed launch fails every request of the batch
-                for _, fut in batch:
-                    if not fut.done():
-                        fut.set_exception(e)
+                for item in batch:
+                    if not item[1].done():
+                        item[1].set_exception(e)
             self.batches += 1
             self.requests += len(batch)
 
@@ -167,7 +199,8 @@ def build_serve_host(force=False):
 
 
 def run_serve_host(index_dir, item_embs_dir, dim, clients=64, seconds=3.0, max_batch=256, max_wait_us=200, ef=128,
-                   topk=200, seq_len=50, model_dir=None, probe_out=None, lanes=2, client_threads=0):
+                   topk=200, seq_len=50, model_dir=None, probe_out=None, lanes=2, client_threads=0, mixed_topn=False,
+                   probe_topn=None, max_queue=0, deadline_ms=0.0):
     """Run the C++ host's closed-loop load test; returns its JSON line as a dict.  probe_out: file that receives
     the reply to one fixed request (item row 0 as the history): status, then top_k ids, one per line."""
     import json
@@ -179,5 +212,13 @@ def run_serve_host(index_dir, item_embs_dir, dim, clients=64, seconds=3.0, max_b
         cmd += ["--model-dir", model_dir]
     if probe_out:
         cmd += ["--probe-out", probe_out]
+    if mixed_topn:
+        cmd += ["--mixed-topn", "1"]
+    if probe_topn is not None:
+        cmd += ["--probe-topn", ",".join(str(int(x)) for x in probe_topn)]
+    if max_queue:
+        cmd += ["--max-queue", str(int(max_queue))]
+    if deadline_ms:
+        cmd += ["--deadline-ms", str(float(deadline_ms))]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=120 + 2 * seconds).stdout
     return json.loads(out.strip().splitlines()[-1])

@@ -504,8 +504,12 @@ REGISTER_KERNEL_BUILDER(Name("HugeConst").Device(DEVICE_CPU), HugeConstHip);
 // ---------------------------------------------------------------------------------
 // BlazeXlaOp: same interface as blaze_xla_kernel.cc:24-33.  The reference runs the frozen
 // scoring GraphDef named by `graph_def` in a nested session, padded to warmed-up static batch
-// sizes; here `graph_def` names the model's weights directory (include/nann_hip.h,
-// nann_model_load) and the batch is scored as it comes -- rows are independent, which is all
+// sizes; here `graph_def` names the same FILE -- the frozen GraphDef convert_meta.py:361-398 writes, text or binary,
+// read in the reference's order (ReadTextProto, then ReadBinaryProto: blaze_xla_kernel.cc:169-175) by a dependency-free
+// reader that pulls the weights out of its Const nodes (csrc/host/nann_graphdef.h, nann_graphdef_text.h) -- or, for the
+// scorers that have no frozen graph in the reference (L2, MLP), a weights directory (include/nann_hip.h,
+// nann_model_load); nothing of the graph is executed, the weights feed the hand-written kernels, and the batch is
+// scored as it comes -- rows are independent, which is all
 // PadToStatic / SliceToDynamic rely on (blaze_xla_predictor.cc:227-315).  Inputs are matched by
 // `input_names` (constant.py:9-11): .../user_seq_emb f16 [1, L, E] and .../item_emb f16 [n, d];
 // the one output is .../logits f32 [n, 1] (model.py:226-227).  `blaze_option_path` is accepted

@@ -256,6 +256,21 @@ def test_cpp_serving_host_over_the_c_abi(oracle, tmp_path):
     assert got[0] == rc
     if rc == 0:
         assert got[1:] == eids.tolist()
+    # level_topn is a per-request feed (build_opt_graph.py:75,151-159): clients with two different level_topn share the
+    # launches (--mixed-topn), and a probe with ITS OWN level_topn, launched next to one with the server's, gets the
+    # oracle's answer for its values
+    own = [16, 24, 32, 8, 12, 10]
+    stats = serving.run_serve_host(d, d, 64, clients=48, seconds=1.0, max_batch=64, max_wait_us=300, ef=32, topk=20,
+                                   seq_len=L, probe_out=probe, mixed_topn=True, probe_topn=own)
+    assert stats["requests"] > 100 and stats["mixed_level_topn"] is True and stats["failed_requests"] <= stats["requests"] // 2, stats
+    rc, eids, _, _, _ = oracle.search(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), oracle.user_seq_mean(seq), own)
+    got = [int(x) for x in open(probe).read().split()]
+    assert got[0] == rc and (rc != 0 or got[1:] == eids.tolist()), (got[:4], rc)
+    # admission control (BlazeXlaOp's waiting pool / wait_ms, blaze_xla_kernel.cc:221-258): with a queue bound far below
+    # the offered load, requests are refused instead of queueing without limit, and the rest are still served
+    stats = serving.run_serve_host(d, d, 64, clients=256, seconds=1.0, max_batch=16, max_wait_us=50, ef=32, topk=20,
+                                   seq_len=L, max_queue=8, lanes=1)
+    assert stats["refused_queue_full"] > 0 and stats["requests"] > stats["refused_queue_full"], stats
 
 
 @pytest.mark.parametrize("kind", ["mlp", "attention"])

@@ -13,7 +13,8 @@ def fake_backend(log):
     def run(seqs, level_topn):
         log.append(len(seqs))
         time.sleep(0.002)  # a launch
-        k = level_topn[5]
+        lt = np.asarray(level_topn)
+        k = int(lt[5]) if lt.ndim == 1 else int(lt[:, 5].max())  # mixed batch: rows as wide as the largest k
         first = seqs[:, 0, 0].astype(np.float32)          # request tag
         ids = (first[:, None] * 1000 + np.arange(k)[None, :]).astype(np.int64)
         status = (first < 0).astype(np.int32) * 4          # negative tag -> TopKV2 failure code
@@ -63,3 +64,36 @@ def test_launch_failure_and_closed_loop():
     srv.close()
     assert stats["requests"] > 16 and stats["failures"] == 0 and stats["mean_batch"] > 1.5
     assert stats["latency_us"]["p50"] >= 2000  # at least one launch
+
+
+def test_level_topn_per_request_and_admission_control():
+    """`level_topn` is a per-request feed of the reference's signature (build_opt_graph.py:75,151-159): requests with
+    different values share a launch and each reply has ITS k; values beyond the server's are refused at submit; a full
+    queue refuses (BlazeXlaOp: "waiting pool is full") and a request that waited past the deadline fails unsearched."""
+    seen = []
+
+    def backend(seqs, level_topn):
+        seen.append(np.asarray(level_topn).copy())
+        return fake_backend([])(seqs, level_topn)
+
+    srv = serving.BatchingServer(backend, 50, 64, [8] * 5 + [6], max_batch=16, max_wait_us=30000)
+    seq = np.zeros(3200, np.float16); seq[0] = 2
+    fa, fb, fc = srv.submit(seq), srv.submit(seq, [4] * 5 + [3]), srv.submit(seq, [8, 8, 4, 4, 4, 6])
+    assert fa.result(5).shape == (1, 6) and fb.result(5).shape == (1, 3) and fc.result(5).shape == (1, 6)
+    assert fb.result(5)[0, 0] == 2000
+    assert any(t.ndim == 2 and t.shape[1] == 6 and {tuple(r) for r in t} == {(8,) * 5 + (6,), (4,) * 5 + (3,), (8, 8, 4, 4, 4, 6)} for t in seen)
+    with pytest.raises(ValueError):
+        srv.submit(seq, [9] * 5 + [6])
+    srv.close()
+    slow = serving.BatchingServer(lambda s, t: (time.sleep(0.05), fake_backend([])(s, t))[1], 50, 64, [8] * 5 + [5],
+                                  max_batch=1, max_wait_us=100, max_queue=2, deadline_ms=20.0)
+    futs = [slow.submit(seq) for _ in range(12)]
+    outcomes = []
+    for f in futs:
+        try:
+            f.result(5); outcomes.append("ok")
+        except serving.Overloaded as e:
+            outcomes.append(str(e))
+    slow.close()
+    assert "ok" in outcomes and "waiting pool is full" in outcomes and slow.refused >= 1
+    assert slow.expired >= 1 and "request waited too long" in outcomes

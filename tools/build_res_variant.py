@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Timing / tuning builds of the resident-layer-2 MLP traversal (nann_amd/csrc/nann_mlp5.h): recompiles ONLY
+nann_mlp_res_inst.hip with extra -D flags and links it with the objects of the shipped build into
+nann_amd/_build/var_<name>/libnann_hip.so (load with NANN_HIP_LIB=...).  ~20 s per variant instead of a full rebuild.
+usage: tools/build_res_variant.py <name> [-DNANN_RES_PF=2] [-DNANN_RES_VAR=1] ..."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nann_amd import build as B  # noqa: E402
+
+
+def main():
+    name, flags = sys.argv[1], sys.argv[2:]
+    B.build()  # the shipped objects must exist
+    out = os.path.join(B.OUT_DIR, "var_" + name)
+    os.makedirs(out, exist_ok=True)
+    obj = os.path.join(out, "nann_mlp_res.o")
+    log = os.path.join(out, "compile.log")
+    cmd = [B._hipcc()] + B.FLAGS + flags + ["-Rpass-analysis=kernel-resource-usage", "-c",
+                                            os.path.join(B.SRC_DIR, "nann_mlp_res_inst.hip"), "-o", obj]
+    with open(log, "w") as f:
+        subprocess.check_call(cmd, stderr=f, stdout=f)
+    objs = [obj if o == "nann_mlp_res.o" else os.path.join(B.OUT_DIR, o[:-2] + ".d", o) for _, _, o in B.UNITS]
+    lib = os.path.join(out, "libnann_hip.so")
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
+    import re
+    txt = open(log, errors="replace").read()
+    for b in txt.split("Function Name: ")[1:]:
+        g = lambda k: re.search(k + r": (\d+)", b)  # noqa: E731
+        print(b.split()[0][:64], "vgpr", g("VGPRs").group(1), "scratch", g(r"ScratchSize \[bytes/lane\]").group(1))
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()

@@ -203,6 +203,64 @@ for STEP in "$@"; do
       pmc attn_b k_search GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS -- python $R/tools/attn_bench.py /tmp/idx 512
       pmc attn_fetch k_search FETCH_SIZE -- python $R/tools/attn_bench.py /tmp/idx 512
       pmc attn_write k_search WRITE_SIZE -- python $R/tools/attn_bench.py /tmp/idx 512 ;;
+    bench_vars)  # every tuning / timing build under nann_amd/_build/var_*/ (tools/build_res_variant.py) + the shipped one, same box
+      for L in $R/nann_amd/_build/libnann_hip.so $R/nann_amd/_build/var_*/libnann_hip.so; do
+        V=$(basename $(dirname $L)); [ "$V" = "_build" ] && V=shipped
+        for P in ${VAR_PRECISIONS:-split exact}; do
+          NANN_HIP_LIB=$L timeout 200 $BENCH --scorer mlp --mlp-precision $P --batch 1024 --steps 3 --warmup 1 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_var_${V}_${P}_$TAG.json 2> $OUT/bench_var_${V}_${P}_$TAG.err
+          python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench_var_${V}_${P}_$TAG.json').read().strip().splitlines()[-1])
+    t = d['phase_breakdown']['ticks_per_query']
+    rows = d['roofline']['rows_scored_per_query']
+    tot = sum(t[k] for k in ('zero', 'walk', 'expand', 'score', 'topk', 'other'))
+    print('VAR %-14s %-5s qps %9.0f kernel_ms %7.3f rows/q %6.0f score_ticks/row %6.1f (MFMA floor %s) other_ticks/q %7.0f clk %.2f GHz parity %s' % ('$V', '$P', d['value'], d['roofline']['kernel_ms'], rows, t['score'] / rows, '48' if '$P' == 'split' else '256', tot - t['score'], tot * 4 / d['roofline']['kernel_ms'] / 1e6, d.get('parity', {}).get('ids_identical', d.get('parity', {}).get('ids_equal'))))
+except Exception as e:
+    print('VAR $V $P failed', e)
+PY
+        done
+      done ;;
+    power)  # board power + shader clock sampled (rocm-smi) while a workload runs long enough to be sampled: is the MLP traversal at the power limit?
+      rocm-smi --showmaxpower --showpower --showclocks 2>/dev/null | grep -v "^=" | head -30 > $OUT/power_idle_$TAG.txt
+      for W in "l2 --batch 4096 --steps 2500" "mlp_split --scorer mlp --batch 1024 --steps 2500" "mlp_exact --scorer mlp --mlp-precision exact --batch 1024 --steps 1000"; do
+        set -- $W; N=$1; shift
+        ( timeout 200 $BENCH "$@" --warmup 3 --no-secondary --no-cpu-baseline > $OUT/bench_power_${N}_$TAG.json 2> $OUT/bench_power_${N}_$TAG.err ) &
+        BP=$!
+        : > $OUT/power_${N}_$TAG.txt
+        while kill -0 $BP 2>/dev/null; do
+          rocm-smi --showpower --showclocks --json 2>/dev/null >> $OUT/power_${N}_$TAG.txt; echo >> $OUT/power_${N}_$TAG.txt
+          sleep 0.15
+        done
+        wait $BP
+        python - <<PY
+import json, re
+pw, ck = [], []
+for line in open('$OUT/power_${N}_$TAG.txt'):
+    line = line.strip()
+    if not line.startswith('{'): continue
+    try: d = json.loads(line)
+    except ValueError: continue
+    for card, v in d.items():
+        for k, x in v.items():
+            if 'Power' in k and 'W' in k:
+                try: pw.append(float(x))
+                except ValueError: pass
+            if k.startswith('sclk'):
+                m = re.search(r'(\d+)Mhz', str(x))
+                if m: ck.append(int(m.group(1)))
+try:
+    d = json.loads(open('$OUT/bench_power_${N}_$TAG.json').read().strip().splitlines()[-1])
+    extra = 'qps %.0f kernel_ms %.3f' % (d['value'], d['roofline']['kernel_ms'])
+except Exception as e:
+    extra = 'bench failed %s' % e
+pw.sort(); ck.sort()
+top = pw[len(pw) // 2:] if pw else [0]
+print('POWER %-10s samples %3d power W: median-of-upper-half %.0f max %.0f | sclk MHz upper-half-median %s min %s | %s' % (
+    '$N', len(pw), top[len(top) // 2], max(pw or [0]), ck[len(ck) * 3 // 4] if ck else None, min(ck) if ck else None, extra))
+PY
+      done
+      head -12 $OUT/power_idle_$TAG.txt ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
