@@ -312,6 +312,11 @@ enum nann_traversal_mode { NANN_TRAVERSAL_AUTO = 0, NANN_TRAVERSAL_LDS_BITMAP = 
                            NANN_TRAVERSAL_HBM_BITMAP = 2, NANN_TRAVERSAL_LDS_HASH = 3,
                            NANN_TRAVERSAL_LDS_HASH32 = 4 };
 int nann_set_traversal_mode(int32_t mode);
+/* Workgroup slots the persistent traversal grid leaves free on the device (default 0: it takes every CU, two
+ * workgroups each for the L2 plan).  A host that runs other kernels NEXT TO a search -- the exchange of batch i on its
+ * own stream while batch i + 1 is searched (8(e), nann_sharded_topk) -- reserves a few: without them those kernels
+ * only start when the first traversal workgroups exit (measured, profiles/r4_overlap_*.json).  Process-wide. */
+int nann_set_search_reserve(int32_t workgroups);
 
 /* Workspace bytes nann_search needs for (index, level_topn, n_queries), any scorer. */
 int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6] /*[host]*/,

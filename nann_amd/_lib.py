@@ -34,7 +34,7 @@ SYMBOLS = [
     "nann_group_gather_fill", "nann_bitmap_ref_difference", "nann_bloom_filter_difference", "nann_gather_rows", "nann_topk",
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
-    "nann_search", "nann_search_v", "nann_search_ex", "nann_set_traversal_mode", "nann_search_model_workspace_bytes",
+    "nann_search", "nann_search_v", "nann_search_ex", "nann_set_traversal_mode", "nann_set_search_reserve", "nann_search_model_workspace_bytes",
     "nann_search_model", "nann_search_model_v",
     "nann_scorer_prepare", "nann_scorer_release", "nann_scorer_table_bytes", "nann_set_preprojection",
     "nann_model_prepare", "nann_model_release", "nann_model_table_bytes", "nann_search_eval_workspace_bytes", "nann_search_eval", "nann_search_eval_model",

@@ -1702,6 +1702,19 @@ int nann_index_info(const nann_index* ix, int64_t out[6]) {
 
 // ---- fused search -----------------------------------------------------------------------
 static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
+// workgroup slots the persistent traversal grid leaves FREE (nann_set_search_reserve): a host that overlaps another
+// stream's kernels with the search -- the exchange step of a sharded search, DESIGN.md 7 -- keeps a few for them; the
+// grid otherwise owns every CU's LDS until its first workgroups exit.  -1: NANN_SEARCH_SLOT_RESERVE from the environment.
+static std::atomic<int> g_slot_reserve{-1};
+static int slot_reserve() {
+  int v = g_slot_reserve.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("NANN_SEARCH_SLOT_RESERVE");
+    v = e ? std::max(0, std::atoi(e)) : 0;
+    g_slot_reserve.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
@@ -1813,6 +1826,18 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     p->slots = p->fb_slots;
   }
   if (kind < 0) p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * 2));  // sizing: the widest plan
+  else if (const int reserve = slot_reserve()) {  // leave workgroup slots to kernels of other streams (nann_set_search_reserve)
+    const int per_cu = p->vis == VIS_LDS_HASH && p->nt == 512 && !res && kind != kKindAttn && kind != kKindMlpSplit ? 2
+                       : p->vis == VIS_HBM_BITMAP && !res ? 2 : 1;
+    p->slots = std::max(1, std::min(p->slots, di.cus * per_cu - reserve));
+    p->fb_slots = std::max(1, std::min(p->fb_slots, di.cus * bm_per_cu - reserve));
+  }
+  return NANN_OK;
+}
+
+int nann_set_search_reserve(int32_t workgroups) {
+  if (workgroups < 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_set_search_reserve: negative");
+  g_slot_reserve.store(workgroups, std::memory_order_relaxed);
   return NANN_OK;
 }
 

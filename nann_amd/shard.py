@@ -101,6 +101,7 @@ class Comm:
         """Single-process test communicator: every one of `world` shards returns this rank's record."""
         self = cls.__new__(cls)
         self.world, self.rank, self.handle = world, 0, C.c_void_p(0)
+        self.is_loopback = True
         _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(0), None, C.byref(self.handle)), "comm create")
         return self
 
@@ -115,6 +116,7 @@ class Comm:
 
 class ShardedSearch:
     """Exchange + merge for one rank of a sharded search."""
+    RESERVED_SLOTS = 16  # workgroup slots kept free for the exchange's kernels when it overlaps the next search
 
     def __init__(self, level_topn, world, rank=0, merge="device", group=None, transport="torch", comm=None):
         self.world, self.k, self.merge_kind, self.group = world, int(level_topn[5]), merge, group
@@ -158,6 +160,12 @@ class ShardedSearch:
             cur = torch.cuda.current_stream(dev)
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=dev)
+                if self.world > 1 and not getattr(self.comm, "is_loopback", False):
+                    # the persistent traversal grid owns every CU's LDS until its first workgroups exit; RCCL's kernels
+                    # need a few workgroup slots of their own to run NEXT TO it (nann_set_search_reserve; measured on
+                    # one GPU, profiles/r4g_overlap.txt: 16 slots of 512 cost the search ~3 %, an exchange that only
+                    # starts when the grid drains costs the whole overlap)
+                    _check(lib().nann_set_search_reserve(C.c_int32(self.RESERVED_SLOTS)), "search reserve")
             cs = self._comm_stream
             cs.wait_stream(cur)  # the search that wrote `result`
             with torch.cuda.stream(cs):

@@ -207,7 +207,7 @@ for STEP in "$@"; do
       for L in $R/nann_amd/_build/libnann_hip.so $R/nann_amd/_build/var_*/libnann_hip.so; do
         V=$(basename $(dirname $L)); [ "$V" = "_build" ] && V=shipped
         for P in ${VAR_PRECISIONS:-split exact}; do
-          NANN_HIP_LIB=$L timeout 200 $BENCH --scorer mlp --mlp-precision $P --batch 1024 --steps 3 --warmup 1 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_var_${V}_${P}_$TAG.json 2> $OUT/bench_var_${V}_${P}_$TAG.err
+          NANN_HIP_LIB=$L timeout 200 $BENCH --scorer mlp --mlp-precision $P --batch 1024 --steps ${VAR_STEPS:-3} --warmup ${VAR_WARMUP:-1} --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_var_${V}_${P}_$TAG.json 2> $OUT/bench_var_${V}_${P}_$TAG.err
           python - <<PY
 import json
 try:
@@ -261,6 +261,36 @@ print('POWER %-10s samples %3d power W: median-of-upper-half %.0f max %.0f | scl
 PY
       done
       head -12 $OUT/power_idle_$TAG.txt ;;
+    overlap)  # item 7a: does the exchange overlap the next batch's search on one GPU (8-shard loopback), with and without reserved slots
+      for RSV in 0 8 32; do
+        NANN_SEARCH_SLOT_RESERVE=$RSV timeout 300 python tools/overlap_bench.py /tmp/idx 30 > $OUT/overlap_rsv${RSV}_$TAG.json 2> $OUT/overlap_rsv${RSV}_$TAG.err
+        python -c "import json;d=json.loads(open('$OUT/overlap_rsv${RSV}_$TAG.json').read().strip().splitlines()[-1]);print('OVERLAP reserve $RSV', d['summary'])" || tail -3 $OUT/overlap_rsv${RSV}_$TAG.err
+      done
+      rm -rf /tmp/prof/kt_overlap
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof/kt_overlap -o kt -- python $R/tools/overlap_bench.py /tmp/idx 8 > $OUT/overlap_trace_$TAG.log 2>&1 )
+      python - <<PY
+import csv, glob
+rows = []
+for f in glob.glob('/tmp/prof/kt_overlap/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:40]))
+rows.sort()
+srch = [(a, b) for a, b, n in rows if 'k_search' in n]
+mrg = [(a, b, n) for a, b, n in rows if 'k_merge_records' in n or 'k_pack_record' in n]
+inside = sum(1 for a, b, n in mrg if any(sa < a and b < sb for sa, sb in srch))
+partly = sum(1 for a, b, n in mrg if any(a < sb and sa < b for sa, sb in srch))
+print('OVERLAP trace: exchange kernels', len(mrg), 'fully inside a k_search interval', inside, 'overlapping one', partly)
+open('$OUT/overlap_trace_$TAG.txt', 'w').write('\n'.join('%d %d %s' % r for r in rows[-400:]))
+PY
+      ;;
+    dry8)  # item 7b: the whole 8-rank flow of bench.py on ONE GPU (gloo, exchange staged through the host), merged parity vs the oracle
+      NANN_BENCH_SHARED_GPU=1 timeout 900 python bench.py --gpus 8 --dist-backend gloo --items 200000 --batch 1024 --steps 3 --warmup 1 --index-cache /tmp/idx --no-secondary --no-cpu-baseline > $OUT/bench_dry8_$TAG.json 2> $OUT/bench_dry8_$TAG.err
+      tail -1 $OUT/bench_dry8_$TAG.json | cut -c1-900; tail -3 $OUT/bench_dry8_$TAG.err ;;
+    bench_mlp_batches)  # configs[2] at batch 1024 / 2048 / 4096, steady state: the tail of a 4-queries-per-workgroup launch
+      for B in 1024 2048 4096; do
+        timeout 300 $BENCH --scorer mlp --batch $B --steps 60 --warmup 100 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_mlp_b${B}_$TAG.json 2> $OUT/bench_mlp_b${B}_$TAG.err
+        show $OUT/bench_mlp_b${B}_$TAG.json "MLP_SPLIT_B$B"
+      done ;;
     *) echo "unknown step $STEP" ;;
   esac
 done

@@ -45,20 +45,31 @@ def main():
         "config 5's shard shape at half size: 2M x 256-d bf16, ef=256, batch 2048")
     hbm(["shard4m_fetch", "shard4m_write"], "k_search<32, 1, 3, 0, 1024>", ["4000000x256bf16_ef256_k200_b2048_l2_hnsw"],
         "config 5's shard: 4M x 256-d bf16, ef=256, batch 2048")
-    # the fused MLP traversal = the k_search instance that issued the most MFMA instructions in the pass
-    mlp_kernel, most = None, 0.0
-    for (c, k), (mean, n) in rows.get("mlp_a", {}).items():
-        if c == "SQ_INSTS_MFMA" and "k_search" in k and mean > most:
-            mlp_kernel, most = k, mean
-    if mlp_kernel:
-        e = {"kernel": mlp_kernel, "kernel_version": note,
-             "workload": "BASELINE configs[2]: 1M x 128-d f16, ef=128, top-200, MLP 256-128-1 split-f16, batch 1024"}
-        for g in ("mlp_a", "mlp_b"):
+    # the fused MLP traversals = the k_search instance that issued the most MFMA instructions in the pass
+    def mlp(groups_a, fetch_g, write_g, tags, workload):
+        kern, most = None, 0.0
+        for (c, k), (mean, n) in rows.get(groups_a[0], {}).items():
+            if c == "SQ_INSTS_MFMA" and "k_search" in k and mean > most:
+                kern, most = k, mean
+        if not kern:
+            return
+        e = {"kernel": kern, "kernel_version": note, "workload": workload}
+        for g in groups_a:
             for (c, k), (mean, n) in rows.get(g, {}).items():
-                if k == mlp_kernel:
+                if k == kern:
                     e[c] = mean
-        for t in ("1000000x128f16_ef128_k200_b1024_mlp_hnsw", "1000000x128f16_ef128_k200_b4096_l2_hnsw_mlp_split"):
+        f, w = pick([fetch_g], "FETCH_SIZE", kern[:60]), pick([write_g], "WRITE_SIZE", kern[:60])
+        if f and w:  # HBM traffic of the same kernel (separate --pmc passes; KiB, gfx950 FETCH_SIZE x 2: MI355X_MICROARCH.md)
+            e.update({"FETCH_SIZE_KiB": f[0], "WRITE_SIZE_KiB": w[0], "fetch_correction": 2.0})
+        for t in tags:
             out["workloads"].setdefault(t, {}).update(e)
+
+    mlp(["mlp_a", "mlp_b"], "mlp_fetch", "mlp_write",
+        ["1000000x128f16_ef128_k200_b1024_mlp_hnsw", "1000000x128f16_ef128_k200_b4096_l2_hnsw_mlp_split"],
+        "BASELINE configs[2]: 1M x 128-d f16, ef=128, top-200, MLP 256-128-1 split-f16, batch 1024")
+    mlp(["mlpx_a", "mlpx_b"], "mlpx_fetch", "mlpx_write",
+        ["1000000x128f16_ef128_k200_b1024_mlp_hnsw_exact", "1000000x128f16_ef128_k200_b4096_l2_hnsw_mlp_exact"],
+        "BASELINE configs[2]: 1M x 128-d f16, ef=128, top-200, MLP 256-128-1 exact f32, batch 1024")
     # the attention model's fused traversal (tools/attn_bench.py): split-f16 form = the instance with the most MFMAs
     attn_kernel, most = None, 0.0
     for (c, k), (mean, n) in rows.get("attn_a", {}).items():
@@ -71,6 +82,9 @@ def main():
             for (c, k), (mean, n) in rows.get(g, {}).items():
                 if k == attn_kernel:
                     e[c] = mean
+        f, w = pick(["attn_fetch"], "FETCH_SIZE", attn_kernel[:60]), pick(["attn_write"], "WRITE_SIZE", attn_kernel[:60])
+        if f and w:
+            e.update({"FETCH_SIZE_KiB": f[0], "WRITE_SIZE_KiB": w[0], "fetch_correction": 2.0})
         out["workloads"].setdefault("attention_model_f2_split", {}).update(e)
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
