@@ -1806,7 +1806,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     // attention model / split-f16 MLP: 16K-slot set + two weight-slice buffers, one 512-thread workgroup per CU
     p->vis = VIS_LDS_HASH;
     p->nt = 512;
-    p->lds_bytes = res ? bm_scratch + tail  // the weights lie over [set | scratch]: the same bytes as the bitmap plan
+    p->lds_bytes = res ? (size_t)kMlpResBytes + hash_phase_scratch<512, 16384>() + tail  // [W2 (set over its head) | vectors | phase scratch]
                        : (size_t)vis_slots(VIS_LDS_HASH) * 4 + bm_scratch + tail;
     p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus));
   } else if (hash_ok && hash_vis == VIS_LDS_HASH) {

@@ -77,22 +77,23 @@ __device__ __forceinline__ void wg_mlp_res_vectors(const MlpParams& P, float u, 
   }
 }
 
-// Park `park_vec` uint4 of LDS at `lds` (the visited set) in global memory and load the resident weights over
-// lds[0 .. kMlpResW2Vec).  A thread parks exactly the addresses it then overwrites, in program order, so no barrier
+// Park `park_vec` uint4 of LDS at `lds` (the visited set) in global memory and reload the head of the resident weights,
+// lds[0 .. RELOAD_VEC) -- what the set / the phase scratch overwrote since the last scoring call; the rest of W2 was
+// loaded once per launch (k_search).  A thread parks exactly the addresses it then overwrites, in program order, so no barrier
 // sits between the two; the caller's barrier before this call covers the earlier phases, the one after it the loads.
-template <int NT>
+template <int NT, int RELOAD_VEC>
 __device__ __forceinline__ void wg_mlp_res_enter(uint4* lds, const uint4* __restrict__ w2, uint4* park, int park_vec) {
   const int tid = local_tid();
-  static_assert(kMlpResW2Vec % (NT * 8) == 0, "two batches of eight 16-byte loads per thread");
+  static_assert(RELOAD_VEC % (NT * 4) == 0, "batches of four 16-byte loads per thread");
   if (park != nullptr)
     for (int i = tid; i < park_vec; i += NT) park[i] = lds[i];
 #pragma unroll
-  for (int b = 0; b < kMlpResW2Vec / (NT * 8); ++b) {
-    uint4 v[8];
+  for (int b = 0; b < RELOAD_VEC / (NT * 4); ++b) {
+    uint4 v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = w2[(b * 8 + j) * NT + tid];
+    for (int j = 0; j < 4; ++j) v[j] = w2[(b * 4 + j) * NT + tid];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) lds[(b * 8 + j) * NT + tid] = v[j];
+    for (int j = 0; j < 4; ++j) lds[(b * 4 + j) * NT + tid] = v[j];
   }
 }
 template <int NT>

@@ -169,6 +169,10 @@ constexpr int kScorerAttnProj = 6;   // split-f16 attention model with its item-
 constexpr int kScorerMlpRes = 7;     // split-f16 MLP on the pre-projected table with ALL of layer 2 resident in LDS (nann_mlp5.h)
 constexpr int kScorerMlpXRes = 8;    // exact f32 MLP on the pre-projected table, layer 2 resident in LDS: bit-identical to the oracle
 constexpr bool is_mlp_res(int sc) { return sc == kScorerMlpRes || sc == kScorerMlpXRes; }
+// bytes at the head of the resident weights that another phase overwrites between two scoring calls (reloaded per call):
+// the 16K-slot set (hash plan) or the bitmap filter's phase scratch (HBM-bitmap plan)
+constexpr int mlp_res_reload_bytes(bool hash) { return hash ? 65536 : 32768; }
+static_assert(kPhaseScratch <= 32768, "the bitmap kernels' phase scratch lies over the first two weight tiles");
 constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj; }
 
 // where a query's visited set lives
@@ -194,8 +198,11 @@ template <int VIS, int SC, int NT>
 constexpr int phase_scratch() {
   constexpr bool hash = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int base = hash ? hash_phase_scratch<NT, vis_slots(VIS) ? vis_slots(VIS) : 16384>() : kPhaseScratch;
-  // resident layer 2: 128 KB + vectors laid over [visited set | phase scratch] (hash plan) or the phase scratch alone
-  if (is_mlp_res(SC)) return hash ? kMlpResBytes - vis_slots(VIS) * 4 : kMlpResBytes;
+  // resident layer 2 (nann_mlp5.h), LDS = [W2 128 KB | vectors | ...]:
+  //   hash plan        the 16K-slot set lies over W2's first 64 KB, the phase scratch BEHIND the vectors: a scoring call
+  //                    reloads 64 KB of weights, the other 64 KB stay for the whole launch
+  //   HBM-bitmap plan  the (larger) phase scratch of the bitmap filter lies over W2's first 32 KB: 32 KB reloaded per call
+  if (is_mlp_res(SC)) return hash ? base : kMlpResBytes;
   if (is_attn(SC) && base < kAttnScratch) return kAttnScratch;
   if ((SC == kScorerMlpSplit || SC == kScorerMlpProj) && base < kMlpSplitScratch) return kMlpSplitScratch;
   return base;
@@ -373,17 +380,18 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         // -- :129-133 -- and dead after stage 4)
         static_assert(NT == 512, "the resident scorers: eight wavefronts, two per SIMD");
         static_assert(VIS == VIS_LDS_HASH || VIS == VIS_HBM_BITMAP, "resident layer 2: 16K-slot set or HBM bitmap");
-        uint4* lds0 = reinterpret_cast<uint4*>(HASH ? reinterpret_cast<unsigned char*>(bm) : scratch);
+        uint4* lds0 = reinterpret_cast<uint4*>(HASH ? reinterpret_cast<unsigned char*>(bm) : scratch);  // = the kernel's LDS base
         Mlp2Vectors* V = reinterpret_cast<Mlp2Vectors*>(reinterpret_cast<unsigned char*>(lds0) + kMlpResW2Bytes);
+        constexpr int kReload = mlp_res_reload_bytes(HASH) / 16;  // uint4 of W2 that the set / the phase scratch overwrote
         uint4* park = (HASH && (r == 2 || r == 3)) ? reinterpret_cast<uint4*>(sv.gbitmap) : nullptr;
         __syncthreads();
         if constexpr (SC == kScorerMlpXRes) {
-          wg_mlp_res_enter<NT>(lds0, reinterpret_cast<const uint4*>(a.mlp.p2x), park, SLOTS / 4);
+          wg_mlp_res_enter<NT, kReload>(lds0, reinterpret_cast<const uint4*>(a.mlp.p2x), park, SLOTS / 4);
           wg_mlp_xres_vectors<NT>(a.mlp, mlp_u, V);
           __syncthreads();
           wg_score_mlp_xres<NT>(a.proj, a.n_items, sc_ids, sc_n, reinterpret_cast<const float4*>(lds0), V, sc_out);
         } else {
-          wg_mlp_res_enter<NT>(lds0, a.mlp.p2, park, SLOTS / 4);
+          wg_mlp_res_enter<NT, kReload>(lds0, a.mlp.p2, park, SLOTS / 4);
           wg_mlp_res_vectors<NT>(a.mlp, mlp_u, V);
           __syncthreads();
           wg_score_mlp_res<NT>(a.proj, a.n_items, sc_ids, sc_n, lds0, V, sc_out);
@@ -470,7 +478,8 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
   constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int kScratchBytes = phase_scratch<VIS, SC, NT>();
   uint32_t* bm_lds = reinterpret_cast<uint32_t*>(smem);
-  unsigned char* scratch = smem + (VIS == VIS_LDS_BITMAP ? (size_t)a.bm_words * 4 : (size_t)vis_slots(VIS) * 4);
+  unsigned char* scratch = smem + (VIS == VIS_LDS_BITMAP ? (size_t)a.bm_words * 4
+                                   : (is_mlp_res(SC) && HASH) ? (size_t)kMlpResBytes : (size_t)vis_slots(VIS) * 4);
   float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);
   int* misc = reinterpret_cast<int*>(qv + kMaxD);  // [0] next query
   int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
@@ -496,6 +505,11 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
     if (__hip_atomic_load(&hdr->n_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   }
   unsigned int* queue = a.redo ? &hdr->redo_queue : &hdr->queue;
+  if constexpr (is_mlp_res(SC)) {  // the part of the resident weights no other phase overwrites: once per launch
+    const uint4* w2 = SC == kScorerMlpXRes ? reinterpret_cast<const uint4*>(a.mlp.p2x) : a.mlp.p2;
+    constexpr int keep_from = mlp_res_reload_bytes(HASH) / 16;
+    for (int i = keep_from + (int)threadIdx.x; i < kMlpResW2Vec; i += NT) reinterpret_cast<uint4*>(smem)[i] = w2[i];
+  }
 
   // queries are pulled from one device-wide counter: a slot that finishes early takes
   // the next request instead of idling until the slowest slot is done
