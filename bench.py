@@ -142,6 +142,9 @@ def load_pmc_counters(tag):
               "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
         if k in p:
             out[k] = p[k]
+    sc = p.get("by_kernel", {}).get("k_mlp_phase_score")
+    if sc:  # the pipeline of phases: the scoring launches on their own (their share of the call: profiles/r4*_phase_trace_*.txt)
+        out["scoring_launches"] = {k: sc[k] for k in ("mfma_busy_frac", "shader_clock_GHz_in_pass", "SQ_INSTS_MFMA", "FETCH_SIZE_KiB") if k in sc}
     return out
 
 
@@ -350,8 +353,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         # row -- which counts the hoisted query half and the looked-up item half of layer 1 as if they were computed per
         # candidate -- is the second figure.  The issued count is cross-checked against SQ_INSTS_MFMA of the committed
         # rocprofv3 pass (profiles/pmc_latest.json).
-        mapping = os.environ.get("NANN_MLP_MAPPING", "5")
-        table_form = os.environ.get("NANN_PREPROJECT", "1") != "0" and (mapping == "5" or (precision == "split" and mapping in "34"))
+        mapping = os.environ.get("NANN_MLP_MAPPING", "6")
+        table_form = os.environ.get("NANN_PREPROJECT", "1") != "0" and (mapping in "56" or (precision == "split" and mapping in "34"))
+        phased = table_form and mapping == "6" and cfg.get("traversal", "auto") == "auto"  # (beams that fit the 16K-slot set: nann_hip.hip plan_search)
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
         if precision == "split":
             per_row = 3 * 2.0 * 256 * 128 + (0 if table_form else 2 * 2.0 * dim * 256)
@@ -369,7 +373,10 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         # bytes the scorer gathers per row: the 1 KB row of the table (f32 x 256) instead of the d x 2 B embedding row
         row_bytes = 1024 if table_form else dim * 2
         tot_b2, _ = algorithmic_bytes(counters[ok], row_bytes // 2, 2, len(g["enter_points"]), topk)
-        roofline = {"bound": "mfma", "kernel": "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form and mapping == "5" else ""),
+        kernel_label = ("pipeline of phases (nann_mlp6.h): k_mlp_phase_score<%s> x 5 rounds [dominant] + k_search<phase> x 6 + k_mlp_phase_prefix x 5; "
+                        "kernel_ms = the whole call" % precision) if phased else (
+                        "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form and mapping == "5" else ""))
+        roofline = {"bound": "mfma", "kernel": kernel_label,
                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                     "traffic": None, "kernel_ms": round(kern_ms, 4),
                     "flops": "EXECUTED matrix-core flops per scored row x rows scored: " + flops_note,

@@ -1702,6 +1702,7 @@ int nann_index_info(const nann_index* ix, int64_t out[6]) {
 
 // ---- fused search -----------------------------------------------------------------------
 static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
+constexpr int64_t kPhaseTail = 8192;  // behind the slots: the block prefix of the phased MLP pipeline (nann_mlp6.h)
 // workgroup slots the persistent traversal grid leaves FREE (nann_set_search_reserve): a host that overlaps another
 // stream's kernels with the search -- the exchange step of a sharded search, DESIGN.md 7 -- keeps a few for them; the
 // grid otherwise owns every CU's LDS until its first workgroups exit.  -1: NANN_SEARCH_SLOT_RESERVE from the environment.
@@ -1792,7 +1793,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
       !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
     return fail(NANN_ERR_UNSUPPORTED, "hash-set traversal: shards below 2^27 items; the 32K-slot set: L2 scorer only");
-  unsigned long long off[8];
+  unsigned long long off[9];
   // the slot's last region: the HBM bitmap of a bitmap plan, and where a resident-layer-2 traversal parks its 16K-slot
   // set while it scores (nann_mlp5.h); "any" sizes for both
   uint32_t gbm_words = bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u;
@@ -1825,7 +1826,13 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     p->lds_bytes = bm_lds;
     p->slots = p->fb_slots;
   }
-  if (kind < 0) p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * 2));  // sizing: the widest plan
+  // the MLP's pipeline of phases (nann_mlp6.h): traversal stages at the 16K-slot plan's geometry, one slot per query of a chunk
+  p->phased = res && own_hash_plan && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP &&
+              2 * hash16_lds <= di.lds_max && mlp_mapping_choice() >= 6;
+  p->phase_lds_bytes = hash16_lds;
+  p->phase_slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), (int64_t)di.cus * 2));
+  if (kind < 0)  // sizing: the widest plan (two workgroups per CU, or one slot per query of a phased chunk)
+    p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, std::max<int64_t>((int64_t)di.cus * 2, kPhaseChunk)));
   else if (const int reserve = slot_reserve()) {  // leave workgroup slots to kernels of other streams (nann_set_search_reserve)
     const int per_cu = p->vis == VIS_LDS_HASH && p->nt == 512 && !res && kind != kKindAttn && kind != kKindMlpSplit ? 2
                        : p->vis == VIS_HBM_BITMAP && !res ? 2 : 1;
@@ -1854,7 +1861,7 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
   SearchPlan p;
   const int rc = plan_search(ix, level_topn, n_queries, -1, &p);
   if (rc) return rc;
-  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots));
+  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots) + kPhaseTail);
   return NANN_OK;
 }
 
@@ -1864,7 +1871,7 @@ namespace nann {
 int mlp_mapping_choice() {
   static const int choice = [] {
     const char* e = std::getenv("NANN_MLP_MAPPING");
-    return (e && e[0] >= '1' && e[0] <= '5' && e[1] == 0) ? e[0] - '0' : 5;
+    return (e && e[0] >= '1' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : 6;
   }();
   return choice;
 }
@@ -1964,7 +1971,8 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   SearchPlan p;
   rc = plan_search(ix, level_topn, n_queries, mlp_res ? kKindMlpRes : mlp_split ? kKindMlpSplit : kind, &p);
   if (rc) return rc;
-  if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots)))
+  const int64_t need_slots = p.phased ? std::max<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), p.fb_slots) : std::max(p.slots, p.fb_slots);
+  if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)need_slots + (p.phased ? kPhaseTail : 0)))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");
   SearchArgs a;
   a.emb = ix->desc.item_embs;
@@ -1987,6 +1995,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   a.phase_ticks = reinterpret_cast<long long*>(phase_ticks);
   a.id_bits = p.id_bits;
   a.redo = 0;
+  a.phase = 0;
   a.proj = tab ? tab->table : nullptr;
   a.mlp = MlpParams{};
   a.attn = AttnParams{};
@@ -2013,9 +2022,50 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
     return both([&](int vis, int, int slots, size_t lds) { return launch(ix->desc.d, dt, vis, slots, lds, a, st); });
   }
   a.mlp = scorer->mlp;
-  if (mlp_res)  // the default form of both precisions: item half of layer 1 from the table, layer 2 resident in LDS
+  a.phase = 0;
+  const int exact = scorer->desc.kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_EXACT_F32;
+  if (mlp_res && p.phased) {
+    // The default form of both precisions at beams that fit the 16K-slot set: the pipeline of phases (nann_mlp6.h).  Per
+    // chunk of <= 1024 queries: traversal stage 0, then for every round its block prefix, its scoring launch and the
+    // traversal stage behind it; last the rerun of the queries whose set could have overflowed (fused kernel, HBM bitmap).
+    DeviceInfo di;
+    rc = device_info(&di);
+    if (rc) return rc;
+    int* blk_prefix = reinterpret_cast<int*>(static_cast<unsigned char*>(workspace) + 256 + p.slot_bytes * (unsigned long long)need_slots);
+    const int k5 = level_topn[5];
+    for (int64_t c0 = 0; c0 < n_queries && !rc; c0 += kPhaseChunk) {
+      SearchArgs c = a;
+      c.n_queries = (int)std::min<int64_t>(kPhaseChunk, n_queries - c0);
+      c.q = q + (size_t)c0 * a.d;
+      if (tq) c.tq = tq + (size_t)c0 * 6;
+      c.out_ids = out_item_ids + (size_t)c0 * k5;
+      if (out_scores) c.out_scores = out_scores + (size_t)c0 * k5;
+      if (out_index) c.out_index = out_index + (size_t)c0 * k5;
+      c.status = status + c0;
+      if (counters) c.counters = counters + (size_t)c0 * 3 * NANN_NUM_ROUNDS;
+      if (phase_ticks) c.phase_ticks = reinterpret_cast<long long*>(phase_ticks) + (size_t)c0 * NANN_NUM_PHASES;
+      if (c0) HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+      const int slots = (int)std::min<int64_t>(c.n_queries, (int64_t)di.cus * 2);
+      for (int ph = 0; ph <= NANN_NUM_ROUNDS && !rc; ++ph) {
+        c.phase = ph;
+        rc = launch_search_mlp_phase(slots, p.phase_lds_bytes, c, st);
+        if (!rc && ph < NANN_NUM_ROUNDS) {
+          rc = launch_mlp_phase_prefix(c, ph, blk_prefix, st);
+          if (!rc) rc = launch_mlp_phase_score(exact, c, ph, blk_prefix, di.cus, st);
+        }
+      }
+      if (!rc) {
+        c.redo = 1;
+        c.phase = 0;
+        rc = launch_search_mlp_res(exact, p.fb_vis, p.fb_slots, p.fb_lds_bytes, c, st);
+      }
+    }
+    if (cache) projection_used(*cache, tab, st);
+    return rc;
+  }
+  if (mlp_res)  // wide beams / large shards / forced plans: the fused kernel with layer 2 resident in LDS (nann_mlp5.h)
     return both([&](int vis, int, int slots, size_t lds) {
-      return launch_search_mlp_res(scorer->desc.precision == NANN_MLP_EXACT_F32, vis, slots, lds, a, st);
+      return launch_search_mlp_res(exact, vis, slots, lds, a, st);
     });
   if (mlp_split && tab)  // round 3's form (NANN_MLP_MAPPING=3|4): the table, layer-2 slices streamed per pass (nann_mlp3.h)
     return both([&](int vis, int, int slots, size_t lds) { return launch_search_mlp_proj(vis, slots, lds, a, st); });
@@ -2110,7 +2160,7 @@ int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m,
   SearchPlan p;
   const int rc = plan_search(ix, level_topn, n_queries, m->kind == NANN_MODEL_ATTENTION ? kKindAttn : -1, &p);
   if (rc) return rc;
-  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots) + 256 +
+  *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots) + kPhaseTail + 256 +
                       model_query_bytes(m, n_queries));
   return NANN_OK;
 }

@@ -1,0 +1,472 @@
+// nann_mlp6.h -- the MLP traversal as a PIPELINE OF PHASES (round 4): scoring in a kernel of its own.
+//
+// The fused traversal with the MLP scorer (nann_mlp5.h inside k_search) keeps the matrix pipe 0.41 busy: 0.54 inside the
+// scoring calls, and 18 % of a query -- expand, top-k -- with the pipe idle, because the scorer's 256 registers and
+// 137 KB of LDS allow ONE workgroup per CU, so nothing runs beside a query's latency-bound phases.  Both halves do better
+// apart:
+//   * the traversal stages (top-k of the last round, marks, expand of the next: search_one between two scoring calls) are
+//     the L2 kernel's code at its occupancy -- two 512-thread workgroups per CU, 64 KB set + 11 KB scratch each -- so
+//     one query's dependent HBM / LDS trips hide behind another's;
+//   * the scoring of ALL queries' candidate lists of a round is one launch of k_mlp_phase_score: W2 loaded into LDS once
+//     per workgroup for the whole launch (no per-call reload, no set to park), the 32-row blocks of every query laid end
+//     to end and cut into 2048 equal runs, one per wavefront -- no ragged last blocks per call, no barrier anywhere.
+// Per 1024-query chunk: 6 traversal launches, 5 prefix launches (one workgroup: blocks of every query -> their prefix
+// sums), 5 scoring launches; state between launches lives in the query's slot (PhaseState, the candidate arrays the
+// fused kernel uses anyway, the set parked in the slot's bitmap region around rounds 2 and 3).  Results are what the
+// fused kernel computes: the same building blocks run on the same lists (exact precision: bit-identical to the oracle).
+#pragma once
+#include "nann_mlp5.h"
+
+namespace nann {
+
+constexpr int kPhaseChunk = 1024;     // queries per pipeline pass (one prefix workgroup, bounded workspace)
+constexpr int kPhasePending = -100;   // PhaseState.status while a query waits for its scores
+constexpr int kPhaseScoreWaves = 2048;  // 256 workgroups x 8 wavefronts: runs of the scoring launch
+
+// what a query carries from one launch to the next (in its slot)
+struct PhaseState {
+  int status;     // kPhasePending | final nann_status
+  int r;          // the round whose scoring call is pending
+  int sc_n;       // rows of that call
+  int base_off;   // they are cand_ids[base_off ..] (r == 0: the index's enter points), scores to cand_scores[base_off ..]
+  int nP;         // pool size so far
+  int vis_count;  // ids in the parked set
+  int ctr[3 * NANN_NUM_ROUNDS];
+  int pad[11];
+  float u[256];   // b1 + W1q^T q: the query's part of layer 1, computed once (stage 0)
+};
+static_assert(sizeof(PhaseState) == 128 + 1024, "PhaseState layout");
+
+struct PhaseScoreArgs {
+  unsigned char* ws;            // the search workspace: [header | slots]
+  unsigned long long slot_bytes;
+  unsigned long long off_cand_ids, off_cand_scores, off_state;  // within a slot
+  const int* blk_prefix;        // [n_queries + 1]: blocks of the queries before q (k_mlp_phase_prefix)
+  const int32_t* enter;
+  const float* proj;            // the pre-projected table
+  uint32_t n_items;
+  int n_queries;
+  int round;
+  int dry;                      // timing launches (NANN_PHASE_SHADOW, tools/): everything but the store of the scores
+  MlpParams mlp;
+};
+
+// timing builds (tools/build_res_variant.py -DNANN_PHASE_VAR=bits): the split-f16 scoring launch WITHOUT 1 = its gathers,
+// 2 = its W2 fragment reads, 4 = the PReLU / split arithmetic, 8 = the MFMAs -- run as a second, dry launch behind the real
+// one (NANN_PHASE_SHADOW=1), so that both see the same lists
+#ifndef NANN_PHASE_VAR
+#define NANN_PHASE_VAR 0
+#endif
+
+// blocks (32 rows) each pending query contributes to round `round`, as exclusive prefix sums.  One workgroup of
+// kPhaseChunk threads.
+template <int NTHREADS>  // (a template only so that the header may be included by several translation units)
+__global__ __launch_bounds__(NTHREADS) void k_mlp_phase_prefix(unsigned char* ws, unsigned long long slot_bytes,
+                                                                 unsigned long long off_state, int n_queries, int round,
+                                                                 int* blk_prefix) {
+  __shared__ uint32_t wave_tot[NTHREADS / 64];
+  const int q = threadIdx.x;
+  uint32_t nblk = 0;
+  if (q < n_queries) {
+    const PhaseState* st = reinterpret_cast<const PhaseState*>(ws + 256 + (unsigned long long)q * slot_bytes + off_state);
+    if (st->status == kPhasePending && st->r == round) nblk = (uint32_t)(st->sc_n + 31) >> 5;
+  }
+  const uint32_t inc = wave_scan_add(nblk);
+  if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_tot[w];
+  if (q < n_queries) blk_prefix[q] = (int)(base + inc - nblk);
+  if (q == n_queries - 1) blk_prefix[n_queries] = (int)(base + inc);
+}
+
+// One launch scores the pending candidate lists of every query of the chunk.  256 workgroups x 8 wavefronts; wavefront
+// gw takes blocks [gw T / 2048, (gw + 1) T / 2048) of the T blocks laid end to end.  EXACT: f32 MFMA on the table
+// (wg_score_mlp_xres's arithmetic), else split-f16 (wg_score_mlp_res's).
+template <bool EXACT, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int H1T = 8, H2T = 4, NT = 512;
+  // LDS: [W2 128 KB | beta1 b2 beta2 w3 (Mlp2Vectors without u) | per-wavefront u: 8 x 1 KB | block prefix]
+  uint4* W2 = reinterpret_cast<uint4*>(smem);
+  Mlp2Vectors* V = reinterpret_cast<Mlp2Vectors*>(smem + kMlpResW2Bytes);
+  float* u_all = reinterpret_cast<float*>(smem + kMlpResBytes);
+  int* prefix = reinterpret_cast<int*>(smem + kMlpResBytes + 8 * 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cand = lane & 31, g = lane >> 5;
+  const int total = a.blk_prefix[a.n_queries];
+  if (total == 0) return;
+  {  // once per launch: the weights, the vectors that do not depend on the query, the block prefix
+    const uint4* src = EXACT ? reinterpret_cast<const uint4*>(a.mlp.p2x) : a.mlp.p2;
+    for (int i = tid; i < kMlpResW2Vec; i += NT) W2[i] = src[i];
+    if (EXACT) wg_mlp_xres_vectors<NT>(a.mlp, 0.0f, V); else wg_mlp_res_vectors<NT>(a.mlp, 0.0f, V);
+    if (!EXACT && tid < 128) V->u[tid] = a.mlp.w3[tid] * (a.mlp.alpha2[tid] - 1.0f);  // (the same thread wrote the 0 above)
+    for (int i = tid; i <= a.n_queries; i += NT) prefix[i] = a.blk_prefix[i];
+  }
+  __syncthreads();
+  const int gw = (int)blockIdx.x * (NT / 64) + wave;
+  const int nw = (int)gridDim.x * (NT / 64);
+  const int b_lo = (int)((long long)total * gw / nw), b_hi = (int)((long long)total * (gw + 1) / nw);
+  if (b_lo >= b_hi) return;
+  float* u_w = u_all + wave * 256;  // this wavefront's copy of the current query's u
+
+  // the query of block b (prefix[q] <= b < prefix[q + 1]); uniform over the wavefront
+  auto query_of = [&](int b) {
+    int lo = 0, hi = a.n_queries - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  // a query's u into the wavefront's LDS copy (the split form keeps it x 2^7 like the table; exact powers of two)
+  auto load_u_of = [&](const PhaseState* st) {
+    float4 v = reinterpret_cast<const float4*>(st->u)[lane];
+    if constexpr (!EXACT) { v.x *= kSplit2Scale; v.y *= kSplit2Scale; v.z *= kSplit2Scale; v.w *= kSplit2Scale; }
+    reinterpret_cast<float4*>(u_w)[lane] = v;
+  };
+  struct Cur {  // the query the wavefront is in
+    int q, first, n;
+    const int32_t* ids;
+    float* out;
+  };
+  auto enter_query = [&](int q, Cur& c, bool load_u) {
+    unsigned char* slot = a.ws + 256 + (unsigned long long)q * a.slot_bytes;
+    const PhaseState* st = reinterpret_cast<const PhaseState*>(slot + a.off_state);
+    c.q = q;
+    c.first = prefix[q];
+    c.n = st->sc_n;
+    const int off = st->base_off;
+    c.ids = a.round == 0 ? a.enter : reinterpret_cast<const int32_t*>(slot + a.off_cand_ids) + off;
+    c.out = reinterpret_cast<float*>(slot + a.off_cand_scores) + off;
+    if (load_u) load_u_of(st);
+  };
+  auto row_ptr = [&](const Cur& c, int b) -> const float* {
+    const int i = min((b - c.first) * 32 + cand, c.n - 1);
+    const uint32_t rid = (uint32_t)c.ids[i];
+    return a.proj + (size_t)(rid < a.n_items ? rid : 0u) * kMlpProjWidth + 4 * g;
+  };
+  auto load_tile = [&](const float* row, int t, float4 (&p)[4]) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) p[rr] = *reinterpret_cast<const float4*>(row + 32 * t + 8 * rr);
+  };
+  // LDS bases (byte addresses), opaque: every read is `base + immediate` (nann_mlp5.h)
+  uint32_t w_lo = lds_offset_of(W2) + (uint32_t)lane * 16u;
+  uint32_t w_hi = w_lo + 65536u;
+  uint32_t v_at = lds_offset_of(V) + (uint32_t)g * 16u;
+  uint32_t u_at = lds_offset_of(u_w) + (uint32_t)g * 16u;
+  asm volatile("" : "+v"(w_lo), "+v"(w_hi), "+v"(v_at), "+v"(u_at));
+  auto vec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(v_at + 4 * float_index); };
+  auto uvec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(u_at + 4 * float_index); };
+  constexpr int kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
+  constexpr int kW3b = 0;  // split-f16: w3 (alpha2 - 1), in the place of the fused kernel's per-workgroup u (here: one u per wavefront)
+
+  if constexpr (!EXACT) {
+    // ---- split-f16: one software pipeline over the wavefront's blocks ------------------------------------------------
+    // A block is 8 tiles x 2 steps (16 k each) x 12 MFMAs (hi.hi, hi.lo, lo.hi for four 32-unit output tiles).  Two
+    // symmetric wavefronts per SIMD that alternate "convert a tile" / "multiply a tile" drift into step and add their
+    // VALU time to their MFMA time (profiles/r4d: 88.7 cycles per row against an MFMA floor of 48).  Here every MFMA
+    // carries a slice of the NEXT step's other work in its shadow, in source order, fenced by sched_barrier:
+    //   hi.hi of output tile mt   -> PReLU of pair mt of the next tile's step
+    //   hi.lo                     -> its f16 halves; the hi fragment of W2 for the next step into the register just freed
+    //                                (ds_read); one ds_read of the next conversion's u / beta
+    //   lo.hi                     -> the lo fragment likewise; step 0: one 16-byte gather of the tile after next
+    // so that one wavefront alone keeps the matrix pipe fed.  Per accumulator the order of products is the fused
+    // kernel's (nann_mlp5.h): same bits.
+    auto fragt = [&](int t, int k) -> f16x8 {
+      const u32x4v v = *reinterpret_cast<lds_u4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + k * 1024);
+      return __builtin_bit_cast(f16x8, v);
+    };
+    auto lds_write_u = [&](float4 v) {
+      typedef __attribute__((address_space(3))) f32x4v* lds_f4_wptr;
+      *reinterpret_cast<lds_f4_wptr>(lds_offset_of(u_w) + (uint32_t)lane * 16u) = f32x4v{v.x, v.y, v.z, v.w};
+    };
+    auto read_u_of = [&](int q) -> float4 {
+      const PhaseState* st = reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)q * a.slot_bytes + a.off_state);
+      float4 v = reinterpret_cast<const float4*>(st->u)[lane];
+      v.x *= kSplit2Scale; v.y *= kSplit2Scale; v.z *= kSplit2Scale; v.w *= kSplit2Scale;
+      return v;
+    };
+    Cur cur, nxt;
+    enter_query(query_of(b_lo), cur, true);
+    const float* row = row_ptr(cur, b_lo);
+    f32x4v x[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) x[t][rr] = *reinterpret_cast<const f32x4v*>(row + 32 * t + 8 * rr);
+    f16x8 Wf[2 * H2T];
+    uint32_t Bh[2][2][4], Bl[2][2][4];  // [tile parity][step][pair]: the B fragments of a tile, high and low halves
+    f32x4v cu[2], cb[2];                // u / beta of the step being converted
+#pragma unroll
+    for (int k = 0; k < 2 * H2T; ++k) Wf[k] = fragt(0, k);
+    // PReLU + split of one pair in two halves, so that each rides in another MFMA's shadow: a = PReLU(x + u) ...
+    auto convert_a = [&](const f32x4v (&xt)[4], int q, int p) -> f32x2 {
+      const int half = p >> 1;
+      const f32x4v xv = xt[2 * q + half], u = cu[half], be = cb[half];
+      const f32x2 xp = (p & 1) ? f32x2{xv.z, xv.w} : f32x2{xv.x, xv.y};
+      const f32x2 up = (p & 1) ? f32x2{u.z, u.w} : f32x2{u.x, u.y};
+      const f32x2 bp = (p & 1) ? f32x2{be.z, be.w} : f32x2{be.x, be.y};
+      // packed f32 forms by hand (left to itself hipcc scalarises about half of them; the vector pipe's issue slots
+      // are what bounds this loop): x + u, min(., 0) per half (there is no packed f32 min), (alpha - 1) min + (x + u)
+      f32x2 xs, h;
+      asm("v_pk_add_f32 %0, %1, %2" : "=v"(xs) : "v"(xp), "v"(up));
+      f32x2 m;
+      asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xs.x));
+      asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xs.y));
+      asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(bp), "v"(xs));
+      return h;
+    };
+    // ... and its f16 halves: hi = rtz(a), lo = a - hi (prelu_split_pair_pk's arithmetic, nann_mlp2.h)
+    auto convert_b = [&](f32x2 h, uint32_t& hi, uint32_t& lo) {
+      typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+      hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h.x, h.y));
+      uint32_t l;
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(h.x));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(h.y));
+      lo = l;
+    };
+    auto convert_pair = [&](const f32x4v (&xt)[4], int q, int p, uint32_t& h, uint32_t& l) { convert_b(convert_a(xt, q, p), h, l); };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // the first block's tile 0, outside the pipeline
+      cu[0] = uvec4(8 * (2 * q)); cu[1] = uvec4(8 * (2 * q + 1));
+      cb[0] = vec4(kBeta1 + 8 * (2 * q)); cb[1] = vec4(kBeta1 + 8 * (2 * q + 1));
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) convert_pair(x[0], q, pp, Bh[0][q][pp], Bl[0][q][pp]);
+    }
+    cu[0] = uvec4(32); cu[1] = uvec4(32 + 8); cb[0] = vec4(kBeta1 + 32); cb[1] = vec4(kBeta1 + 32 + 8);  // tile 1, step 0
+    for (int b = b_lo; b < b_hi; ++b) {
+      nxt = cur;
+      bool change = false;
+      if (b + 1 < b_hi && b + 1 >= prefix[cur.q + 1]) {
+        int q2 = cur.q + 1;
+        while (prefix[q2 + 1] <= b + 1) ++q2;  // (queries without blocks)
+        enter_query(q2, nxt, false);
+        change = true;
+      }
+      const float* next = (b + 1 < b_hi) ? row_ptr(nxt, b + 1) : row;
+      float4 u_next = float4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (change) u_next = read_u_of(nxt.q);
+      const int i = (b - cur.first) * 32 + cand;
+      f32x16 acc[H2T];
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
+          acc[mt][4 * rr] = v.x; acc[mt][4 * rr + 1] = v.y; acc[mt][4 * rr + 2] = v.z; acc[mt][4 * rr + 3] = v.w;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < H1T; ++t) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int cbuf = t & 1, nbuf = (t + 1) & 1;
+          const int nt = (q ? t + 1 : t) & (H1T - 1), nq = q ^ 1;  // the next step: its W2 fragments ...
+          const int ct = ((q ? t + 1 : t) + 1) & (H1T - 1);        // ... and the tile whose conversion rides on it
+          // the next block's query takes over the wavefront's u: behind the last read of this block's (step (6, 0)),
+          // in front of the first read for the next block's tile 0 (below)
+          if (t == H1T - 2 && q == 1 && change) lds_write_u(u_next);
+          const f16x8 bh = as_f16x8(uint4{Bh[cbuf][q][0], Bh[cbuf][q][1], Bh[cbuf][q][2], Bh[cbuf][q][3]});
+          const f16x8 bl = as_f16x8(uint4{Bl[cbuf][q][0], Bl[cbuf][q][1], Bl[cbuf][q][2], Bl[cbuf][q][3]});
+          f32x2 hv[H2T] = {};
+#pragma unroll
+          for (int mt = 0; mt < H2T; ++mt) {
+            if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bh, acc[mt], 0, 0, 0);
+            if (!(VAR & 4)) hv[mt] = convert_a(x[nbuf], q, mt);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int mt = 0; mt < H2T; ++mt) {
+            if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bl, acc[mt], 0, 0, 0);
+            if (!(VAR & 2)) Wf[2 * mt] = fragt(nt, nq * 2 * H2T + 2 * mt);
+            const int rr = 2 * nq + (mt & 1);  // u / beta of the next step's conversion (this step's were read above)
+            if (!(VAR & 4)) {
+              if (mt < 2) cu[mt & 1] = uvec4(32 * ct + 8 * rr); else cb[mt & 1] = vec4(kBeta1 + 32 * ct + 8 * rr);
+              convert_b(hv[mt], Bh[nbuf][q][mt], Bl[nbuf][q][mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int mt = 0; mt < H2T; ++mt) {
+            if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt + 1], bh, acc[mt], 0, 0, 0);
+            if (!(VAR & 2)) Wf[2 * mt + 1] = fragt(nt, nq * 2 * H2T + 2 * mt + 1);
+            if (q == 0 && !(VAR & 1))  // tile t + 2 (of the next block behind tile 5) into the buffer tile t was converted from
+              x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // PReLU of layer 2 and the bias-free output layer: sum_j w3_j (x_j + beta2_j min(x_j, 0)) as two packed-f32 dot
+      // products, w3 . x and (w3 beta2) . min(x, 0) -- 2 vector instructions per unit instead of 3
+      f32x2 dot[4] = {};
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v w3 = vec4(kW3 + 32 * mt + 8 * rr), wb = vec4(kW3b + 32 * mt + 8 * rr);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 xa = f32x2{acc[mt][4 * rr + e], acc[mt][4 * rr + e + 1]};
+            const f32x2 w3p = e ? f32x2{w3.z, w3.w} : f32x2{w3.x, w3.y}, wbp = e ? f32x2{wb.z, wb.w} : f32x2{wb.x, wb.y};
+            f32x2 m;
+            asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xa.x));
+            asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xa.y));
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dot[e >> 1]) : "v"(xa), "v"(w3p));
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dot[2 + (e >> 1)]) : "v"(m), "v"(wbp));
+          }
+        }
+      const float part = ((dot[0].x + dot[0].y) + (dot[1].x + dot[1].y)) + ((dot[2].x + dot[2].y) + (dot[3].x + dot[3].y));
+      const float other = __shfl_xor(part, 32);
+      constexpr float kUnscale = 1.0f / (kSplit2Scale * kSplit2Scale);
+      if (g == 0 && i < cur.n && !a.dry) cur.out[i] = (part + other) * kUnscale;
+      row = next;
+      cur = nxt;
+    }
+    return;
+  }
+  Cur cur, nxt;
+  enter_query(query_of(b_lo), cur, true);
+  const float* row = row_ptr(cur, b_lo);
+  float4 x[2][4];
+  load_tile(row, 0, x[0]);
+  load_tile(row, 1, x[1]);
+  for (int b = b_lo; b < b_hi; ++b) {
+    // the next block: of this query or of the next one that has blocks (its rows are gathered from tile 6 on; its u
+    // replaces this one's behind the last tile)
+    nxt = cur;
+    bool change = false;
+    if (b + 1 < b_hi && b + 1 >= prefix[cur.q + 1]) {
+      int q2 = cur.q + 1;
+      while (prefix[q2 + 1] <= b + 1) ++q2;  // (queries without blocks)
+      enter_query(q2, nxt, false);
+      change = true;
+    }
+    const float* next = (b + 1 < b_hi) ? row_ptr(nxt, b + 1) : row;
+    const int i = (b - cur.first) * 32 + cand;
+    f32x16 acc[H2T];
+#pragma unroll
+    for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
+        acc[mt][4 * rr] = v.x; acc[mt][4 * rr + 1] = v.y; acc[mt][4 * rr + 2] = v.z; acc[mt][4 * rr + 3] = v.w;
+      }
+    auto tile = [&](int t, float4 (&xt)[4]) {
+      f32x4v ub[8];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { ub[rr] = uvec4(32 * t + 8 * rr); ub[4 + rr] = vec4(kBeta1 + 32 * t + 8 * rr); }
+      if constexpr (!EXACT) {
+        auto frag = [&](int k) -> f16x8 {  // fragment k (0..15: [q][m][hi, lo]) of tile t
+          const u32x4v v = *reinterpret_cast<lds_u4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + k * 1024);
+          return __builtin_bit_cast(f16x8, v);
+        };
+        f16x8 Wf[2 * H2T];
+#pragma unroll
+        for (int k = 0; k < 2 * H2T; ++k) Wf[k] = frag(k);
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 bh[2], bl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint4 h, l;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int rr = 2 * q + half;
+            const f32x4v u = ub[rr], be = ub[4 + rr];
+            uint32_t h0, l0, h1, l1;
+            prelu_split_pair_pk(f32x2{xt[rr].x, xt[rr].y}, f32x2{u.x, u.y}, f32x2{be.x, be.y}, h0, l0);
+            prelu_split_pair_pk(f32x2{xt[rr].z, xt[rr].w}, f32x2{u.z, u.w}, f32x2{be.z, be.w}, h1, l1);
+            if (half == 0) { h.x = h0; h.y = h1; l.x = l0; l.y = l1; } else { h.z = h0; h.w = h1; l.z = l0; l.w = l1; }
+          }
+          bh[q] = as_f16x8(h); bl[q] = as_f16x8(l);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int mt = 0; mt < H2T; ++mt) {
+            const f16x8 wh = Wf[mt * 2], wl = Wf[mt * 2 + 1];
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[q], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[q], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[q], acc[mt], 0, 0, 0);
+            if (q == 0) {  // the second step's fragments travel underneath the first step's MFMAs
+              Wf[mt * 2] = frag(2 * H2T + mt * 2);
+              Wf[mt * 2 + 1] = frag(2 * H2T + mt * 2 + 1);
+            }
+          }
+      } else {
+        float h[16];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v u = ub[rr], al = ub[4 + rr];
+          constexpr float kInv = 1.0f / kSplit2Scale;  // the table holds 2^7 P: exact both ways
+          h[4 * rr + 0] = prelu(u.x + xt[rr].x * kInv, al.x);
+          h[4 * rr + 1] = prelu(u.y + xt[rr].y * kInv, al.y);
+          h[4 * rr + 2] = prelu(u.z + xt[rr].z * kInv, al.z);
+          h[4 * rr + 3] = prelu(u.w + xt[rr].w * kInv, al.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4v f[H2T];
+#pragma unroll
+          for (int mt = 0; mt < H2T; ++mt)  // p2x[t][mt][j][lane]: four chain steps per 16 bytes
+            f[mt] = *reinterpret_cast<lds_f4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + (mt * 4 + j) * 1024);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < H2T; ++mt)
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[mt][e], h[4 * j + e], acc[mt], 0, 0, 0);
+        }
+      }
+    };
+    if constexpr (!EXACT) {
+#pragma unroll
+      for (int t = 0; t < H1T; t += 2) { tile(t, x[0]); tile(t + 1, x[1]); }
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < H1T; t += 2) { tile(t, x[0]); tile(t + 1, x[1]); }
+    }
+    // the next block's query takes over the wavefront's u (every lane has read this block's)
+    if (change) load_u_of(reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)nxt.q * a.slot_bytes + a.off_state));
+    // PReLU of layer 2 and the bias-free output layer (the fused kernels' epilogues)
+    float part = 0.0f;
+    if constexpr (!EXACT) {
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v be = vec4(kBeta2 + 32 * mt + 8 * rr), w3 = vec4(kW3 + 32 * mt + 8 * rr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xa = acc[mt][4 * rr + e];
+            part = __builtin_fmaf(__builtin_fmaf(neg_part(xa), be[e], xa), w3[e], part);
+          }
+        }
+      const float other = __shfl_xor(part, 32);
+      constexpr float kUnscale = 1.0f / (kSplit2Scale * kSplit2Scale);
+      if (g == 0 && i < cur.n) cur.out[i] = (part + other) * kUnscale;
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+          part = __fmaf_rn(prelu(acc[mt][r], V->beta2[m]), V->w3[m], part);
+        }
+      const float other = __shfl_xor(part, 32);
+      const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
+      if (g == 0 && i < cur.n && !a.dry) cur.out[i] = p0 + p1;
+    }
+    row = next;
+    cur = nxt;
+  }
+}
+
+constexpr size_t kPhaseScoreLds = (size_t)kMlpResBytes + 8 * 1024 + (size_t)(kPhaseChunk + 1 + 3) / 4 * 16;
+
+}  // namespace nann

@@ -9,6 +9,7 @@
 #include "nann_mlp2.h"
 #include "nann_mlp3.h"
 #include "nann_mlp5.h"
+#include "nann_mlp6.h"
 #include "nann_attn_kernels.h"
 #include "nann_attn_split.h"
 #include "nann_attn_proj.h"
@@ -130,6 +131,8 @@ struct SearchArgs {
   const float* upad;       //   per-query padded sequence f32 [n_queries, 64, 64]
   int id_bits;             // VIS_LDS_HASH*: bits of the shard's id space (set entries are (remainder, step) tags: vis_key)
   int redo;                // 1: fallback launch, only queries with status NANN_ERR_CAPACITY
+  int phase;               // kScorerMlpPhase: which traversal stage this launch runs (0: up to the entry layer's scoring call,
+                           // p = 1..5: from behind round p - 1's scoring call up to round p's, 5: to the end); nann_mlp6.h
 };
 
 static_assert(PH_COUNT == NANN_NUM_PHASES, "phase list out of sync with include/nann_hip.h");
@@ -143,10 +146,11 @@ struct SlotView {
   int32_t* pool_ids;
   float* pool_scores;
   uint32_t* gbitmap;
+  PhaseState* phase;  // kScorerMlpPhase: what the query carries between launches
 };
 
 __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_raw, int pool_cap,
-                                                          uint32_t gbm_words, unsigned long long off[8]) {
+                                                          uint32_t gbm_words, unsigned long long off[9]) {
   unsigned long long o = 0;
   auto put = [&](int i, unsigned long long bytes) { off[i] = o; o += (bytes + 255ull) & ~255ull; };
   put(0, 4ull * max_cand);  // cand_ids
@@ -156,7 +160,8 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
   put(4, 4ull * kMaxK);     // beam_scores
   put(5, 4ull * pool_cap);  // pool_ids
   put(6, 4ull * pool_cap);  // pool_scores
-  put(7, 4ull * gbm_words); // bitmap in HBM (large shards only)
+  put(8, sizeof(PhaseState));  // (fixed size, hence in front of the last region: a kernel that passes gbm_words = 0 still finds it)
+  put(7, 4ull * gbm_words); // LAST: bitmap in HBM (large shards only); where a set is parked (nann_mlp5.h, nann_mlp6.h)
   return o;
 }
 
@@ -168,6 +173,8 @@ constexpr int kScorerMlpProj = 5;    // split-f16 MLP with the item half of laye
 constexpr int kScorerAttnProj = 6;   // split-f16 attention model with its item-only layers pre-projected per (model, index) (nann_attn_proj.h)
 constexpr int kScorerMlpRes = 7;     // split-f16 MLP on the pre-projected table with ALL of layer 2 resident in LDS (nann_mlp5.h)
 constexpr int kScorerMlpXRes = 8;    // exact f32 MLP on the pre-projected table, layer 2 resident in LDS: bit-identical to the oracle
+constexpr int kScorerMlpPhase = 9;   // the MLP traversal as a pipeline of phases (nann_mlp6.h): this instance runs the traversal stages BETWEEN
+                                     // scoring calls (k_mlp_phase_score runs those), one slot per QUERY, two workgroups per CU
 constexpr bool is_mlp_res(int sc) { return sc == kScorerMlpRes || sc == kScorerMlpXRes; }
 // bytes at the head of the resident weights that another phase overwrites between two scoring calls (reloaded per call):
 // the 16K-slot set (hash plan) or the bitmap filter's phase scratch (HBM-bitmap plan)
@@ -241,6 +248,17 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
   float mlp_u = 0.0f;              // MLP: thread j's per-query part of hidden unit j, once per query
   if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit || SC == kScorerMlpProj || is_mlp_res(SC)) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
+  constexpr bool PHASED = SC == kScorerMlpPhase;
+  bool resumed = false;  // PHASED, stage > 0: this launch starts BEHIND the scoring call of round a.phase - 1
+  if constexpr (PHASED) {
+    if (a.phase == 0) {  // the query's part of layer 1, once: the scoring launches read it from the slot
+      const float u = wg_mlp_query_u<NT>(a.mlp, qv);
+      if (tid < 256) sv.phase->u[tid] = u;
+    } else {
+      resumed = true;
+      if (tid < 3 * NANN_NUM_ROUNDS) ctr[tid] = sv.phase->ctr[tid];
+    }
+  }
 
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
@@ -250,10 +268,30 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   int nP = 0;                         // pool size so far
   const int32_t* frontier = nullptr;  // beam walked by the next stage
   int nB = 0;
-  for (int r = 0; r <= NANN_NUM_ROUNDS; ++r) {
+  int r_first = 0;
+  if constexpr (PHASED) {
+    if (resumed) {
+      r_first = a.phase - 1;
+      nP = sv.phase->nP;
+      vis_count = sv.phase->vis_count;
+      if constexpr (HASH) {
+        if (r_first == 2 || r_first == 3) {  // the level-0 set goes on: back from where it was parked
+          const uint4* park = reinterpret_cast<const uint4*>(sv.gbitmap);
+          for (int i = tid; i < SLOTS / 4; i += NT) reinterpret_cast<uint4*>(bm)[i] = park[i];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = r_first; r <= NANN_NUM_ROUNDS; ++r) {
     const int32_t* sc_ids = nullptr;  // what this stage scores
     float* sc_out = nullptr;
     int sc_n = 0, base_off = 0;
+    const bool behind_score = PHASED && resumed && r == r_first;  // this round's lists were built and scored by earlier launches
+    if (behind_score) {
+      sc_n = sv.phase->sc_n;
+      base_off = sv.phase->base_off;
+    } else
     if (r == 0) {
       sc_ids = a.enter; sc_out = sv.cand_scores; sc_n = E;
       if (tid == 0) ctr[2 * NANN_NUM_ROUNDS + 0] = E;
@@ -350,9 +388,27 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       if (tid == 0) { ctr[0 * 5 + r] = nB; ctr[1 * 5 + r] = G; ctr[2 * 5 + r] = nC; }
       sc_ids = sv.cand_ids + base_off; sc_out = sv.cand_scores + base_off; sc_n = nC;
     }
-    if (r < NANN_NUM_ROUNDS) {  // forward(): GatherV2 + scorer (:91-107)
+    if (r < NANN_NUM_ROUNDS && !behind_score) {  // forward(): GatherV2 + scorer (:91-107)
       if (sc_n == 0) return NANN_ERR_EMPTY_SCORE_BATCH;
       mark(PH_OTHER);
+      if constexpr (PHASED) {
+        // the scoring call is another launch's (k_mlp_phase_score over every query's list): leave what the stage behind
+        // it needs in the slot -- and the set, when a later round still reads it (rounds 2 and 3; see nann_mlp5.h)
+        __syncthreads();
+        if (tid == 0) {
+          sv.phase->r = r; sv.phase->sc_n = sc_n; sv.phase->base_off = base_off; sv.phase->nP = nP;
+          sv.phase->vis_count = vis_count;
+        }
+        if (tid < 3 * NANN_NUM_ROUNDS) sv.phase->ctr[tid] = ctr[tid];
+        if constexpr (HASH) {
+          if (r == 2 || r == 3) {
+            uint4* park = reinterpret_cast<uint4*>(sv.gbitmap);
+            for (int i = tid; i < SLOTS / 4; i += NT) park[i] = reinterpret_cast<const uint4*>(bm)[i];
+          }
+        }
+        return kPhasePending;
+      }
+      if constexpr (!PHASED) {
       if constexpr (SC == NANN_SCORER_L2) {
         wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, 0, sc_n, qv, sc_out, tid >> 6);
         if (lds_scores != nullptr) {
@@ -420,10 +476,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           wg_score_mlp<LPR * 8, H1T, H2T, DT, NT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
         }
       }
+      }  // !PHASED
       __syncthreads();
       mark(PH_SCORE);
-      if (sc_n == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
     }
+    if (r < NANN_NUM_ROUNDS && sc_n == 1) return NANN_ERR_TOPK_SCALAR_INPUT;
     // top_k(): TopKV2 + Gather of the ids (:52-66)
     const int32_t* tk_ids; const float* tk_sc; int tk_n, tk_k;
     int32_t* tk_out_ids; float* tk_out_sc; const int64_t* tk_map = nullptr; int64_t* tk_out_map = nullptr;
@@ -466,6 +523,8 @@ struct WsHeader {
   unsigned int redo_queue;   // next query of the fallback launch
   unsigned int pad1[15];
   unsigned int n_redo;       // queries the hash-set kernel handed back (NANN_ERR_CAPACITY)
+  unsigned int pad2[15];
+  unsigned int pqueue[8];    // next query of traversal stage p of the phased MLP pipeline (nann_mlp6.h)
 };
 static_assert(sizeof(WsHeader) <= 256, "workspace header");
 
@@ -473,7 +532,7 @@ static_assert(sizeof(WsHeader) <= 256, "workspace header");
 // hash-set kernel lives off TWO 512-thread workgroups per CU (16 waves = 4 per SIMD -> at most 128
 // VGPRs; at 130 the second workgroup silently stops fitting and the kernel runs at half occupancy).
 template <int LPR, int DT, int VIS, int SC, int NT>
-__global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) ? 2 : 1) * NT / 256) void k_search(SearchArgs a) {
+__global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && (SC == NANN_SCORER_L2 || SC == kScorerMlpPhase)) ? 2 : 1) * NT / 256) void k_search(SearchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool HASH = VIS == VIS_LDS_HASH || VIS == VIS_LDS_HASH32;
   constexpr int kScratchBytes = phase_scratch<VIS, SC, NT>();
@@ -485,10 +544,12 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
   int32_t* s_ctr = misc + 2;                        // [3 * NANN_NUM_ROUNDS]
   long long* s_ticks = reinterpret_cast<long long*>(misc + 20);  // [NANN_NUM_PHASES]
 
-  unsigned long long off[8];
+  unsigned long long off[9];
   slot_layout(a.max_cand, a.max_raw, a.pool_cap, VIS == VIS_HBM_BITMAP ? a.bm_words : 0u, off);  // (only the offsets are used)
-  unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
+  constexpr bool PHASED = SC == kScorerMlpPhase;  // one slot per QUERY: its state outlives the launch (nann_mlp6.h)
   SlotView sv;
+  auto bind_slot = [&](unsigned long long index) {
+  unsigned char* slot = a.ws + 256 + index * a.slot_bytes;
   sv.cand_ids = reinterpret_cast<int32_t*>(slot + off[0]);
   sv.cand_scores = reinterpret_cast<float*>(slot + off[1]);
   sv.raw = reinterpret_cast<int32_t*>(slot + off[2]);
@@ -497,6 +558,9 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
   sv.pool_ids = reinterpret_cast<int32_t*>(slot + off[5]);
   sv.pool_scores = reinterpret_cast<float*>(slot + off[6]);
   sv.gbitmap = reinterpret_cast<uint32_t*>(slot + off[7]);
+  sv.phase = reinterpret_cast<PhaseState*>(slot + off[8]);
+  };
+  bind_slot(blockIdx.x);
   uint32_t* bm = VIS == VIS_HBM_BITMAP ? sv.gbitmap : bm_lds;
   const int k5 = a.t[5];
   WsHeader* hdr = reinterpret_cast<WsHeader*>(a.ws);
@@ -504,7 +568,7 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
   if (a.redo) {
     if (__hip_atomic_load(&hdr->n_redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   }
-  unsigned int* queue = a.redo ? &hdr->redo_queue : &hdr->queue;
+  unsigned int* queue = a.redo ? &hdr->redo_queue : PHASED ? &hdr->pqueue[a.phase] : &hdr->queue;
   if constexpr (is_mlp_res(SC)) {  // the part of the resident weights no other phase overwrites: once per launch
     const uint4* w2 = SC == kScorerMlpXRes ? reinterpret_cast<const uint4*>(a.mlp.p2x) : a.mlp.p2;
     constexpr int keep_from = mlp_res_reload_bytes(HASH) / 16;
@@ -519,6 +583,10 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
       int qn = (int)atomicAdd(queue, 1u);
       if (a.redo)  // skip the queries that are done
         while (qn < a.n_queries && a.status[qn] != NANN_ERR_CAPACITY) qn = (int)atomicAdd(queue, 1u);
+      if (PHASED && a.phase > 0)  // ... and the ones an earlier stage has finished (failed requests)
+        while (qn < a.n_queries &&
+               reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)qn * a.slot_bytes + off[8])->status != kPhasePending)
+          qn = (int)atomicAdd(queue, 1u);
       misc[0] = qn;
     }
     if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
@@ -526,8 +594,18 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && SC == NANN_SCORER_L2) 
     __syncthreads();
     const int qi = misc[0];
     if (qi >= a.n_queries) break;
+    if constexpr (PHASED) bind_slot((unsigned long long)qi);
     const int st = search_one<LPR, DT, VIS, SC, NT>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
     __syncthreads();
+    if constexpr (PHASED) {
+      if (threadIdx.x == 0) sv.phase->status = st;
+      if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES) {  // ticks add up over the stages (scoring launches: not in here)
+        long long* dst = &a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x];
+        s_ticks[threadIdx.x] += a.phase ? *dst : 0;
+        if (st == kPhasePending) *dst = s_ticks[threadIdx.x];
+      }
+      if (st == kPhasePending) continue;  // its scoring call is the next launch's
+    }
     // a request the reference would fail: zeroed outputs + its code; per-query level_topn: the row's tail is zero
     const int k_done = st ? 0 : (a.tq ? a.tq[(size_t)qi * 6 + 5] : k5);
     if (k_done < k5) {
@@ -560,6 +638,11 @@ struct SearchPlan {
   int fb_vis;
   size_t fb_lds_bytes;
   int fb_slots;
+  // MLP with a pre-projected table, beams that fit the 16K-slot set: the pipeline of phases (nann_mlp6.h) -- traversal
+  // stages at this geometry (one slot per query of a chunk), scoring launches between them
+  bool phased;
+  size_t phase_lds_bytes;
+  int phase_slots;
 };
 
 template <int LPR, int DT, int VIS, int SC, int NT>
@@ -594,6 +677,10 @@ int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_byt
 int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 // layer 2 resident in LDS (nann_mlp5.h), split-f16 (exact = 0) or exact f32 (exact = 1); vis in {VIS_LDS_HASH, VIS_HBM_BITMAP}
 int launch_search_mlp_res(int exact, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+// the pipeline of phases (nann_mlp6.h): a traversal stage (a.phase), the block prefix of a round, its scoring launch
+int launch_search_mlp_phase(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_mlp_phase_prefix(const SearchArgs& a, int round, int* blk_prefix, hipStream_t st);
+int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, const int* blk_prefix, int workgroups, hipStream_t st);
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
 // which form of the MLP the traversal runs: 5 = pre-projected + layer 2 resident in LDS (default, both precisions),
 // split-f16 only: 3 = pre-projected with streamed slices (round 3), 4 = its 256-thread form, 2 = second mapping, 1 = first

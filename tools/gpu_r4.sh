@@ -291,6 +291,52 @@ PY
         timeout 300 $BENCH --scorer mlp --batch $B --steps 60 --warmup 100 --no-secondary --phase-ticks --no-cpu-baseline > $OUT/bench_mlp_b${B}_$TAG.json 2> $OUT/bench_mlp_b${B}_$TAG.err
         show $OUT/bench_mlp_b${B}_$TAG.json "MLP_SPLIT_B$B"
       done ;;
+    bench_mlp_phased)  # same box, steady state: the pipeline of phases (mapping 6, default) against the fused resident kernel (5), both precisions
+      for P in split exact; do for M in 6 5; do
+        NANN_MLP_MAPPING=$M timeout 300 $BENCH --scorer mlp --mlp-precision $P --batch ${MLP_BATCH:-1024} --steps 60 --warmup 100 --no-secondary --no-cpu-baseline > $OUT/bench_mlp_${P}_map${M}_$TAG.json 2> $OUT/bench_mlp_${P}_map${M}_$TAG.err
+        show $OUT/bench_mlp_${P}_map${M}_$TAG.json "MLP_${P}_MAPPING_$M"; tail -2 $OUT/bench_mlp_${P}_map${M}_$TAG.err | grep -v amdgpu.ids
+      done; done ;;
+    prof_phased)  # per-launch durations of the pipeline of phases at steady-state clock, both precisions
+      for P in split exact; do
+        rm -rf /tmp/prof/kt_ph_$P
+        ( cd /tmp && timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt_ph_$P -o kt -- $BENCH --scorer mlp --mlp-precision $P --batch ${MLP_BATCH:-1024} --steps 30 --warmup 60 --no-secondary --no-cpu-baseline > $OUT/prof_kt_ph_${P}_$TAG.log 2>&1 )
+        find /tmp/prof/kt_ph_$P -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_phased_${P}_$TAG.csv \;
+        F=$(find /tmp/prof/kt_ph_$P -name '*kernel_trace.csv' | head -1)
+        echo "PHASED $P"; python tools/phase_trace.py $F 20 | tee $OUT/phase_trace_${P}_$TAG.txt
+      done ;;
+    phase_vars)  # timing builds of the split-f16 scoring launch (nann_mlp6.h NANN_PHASE_VAR) as dry launches behind the real ones
+      for L in $R/nann_amd/_build/libnann_hip.so $R/nann_amd/_build/var_ph*/libnann_hip.so; do
+        V=$(basename $(dirname $L)); [ "$V" = "_build" ] && V=shipped
+        rm -rf /tmp/prof/kt_pv
+        ( cd /tmp && NANN_PHASE_SHADOW=1 NANN_HIP_LIB=$L timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof/kt_pv -o kt -- $BENCH --scorer mlp --mlp-precision split --batch 1024 --steps 20 --warmup 40 --no-secondary --no-cpu-baseline > $OUT/prof_kt_pv_${V}_$TAG.log 2>&1 )
+        F=$(find /tmp/prof/kt_pv -name '*kernel_trace.csv' | head -1)
+        echo "PHASEVAR $V"; python tools/phase_trace.py $F 12 | tee $OUT/phase_vars_${V}_$TAG.txt | grep -E "phase_score|sum of"
+      done ;;
+    pmc_phased)  # counters of the pipeline of phases, per kernel (sums over all dispatches of the run; clock = GRBM cycles / duration)
+      for P in ${PH_PRECISIONS:-split}; do
+        S="--scorer mlp --mlp-precision $P --batch 1024 --steps 8 --warmup 24 --no-secondary --no-cpu-baseline"
+        for PASS in "a SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" \
+                    "b GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+                    "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+          set -- $PASS; N=$1; shift
+          rm -rf /tmp/prof/pmcph
+          ( cd /tmp && timeout 240 rocprofv3 --pmc "$@" --output-format csv -d /tmp/prof/pmcph -o pmc -- $BENCH $S > $OUT/prof_pmcph_${P}_${N}_$TAG.log 2>&1 )
+          python - <<PY | tee -a $OUT/pmc_phased_${P}_$TAG.txt
+import csv, glob, collections
+acc = collections.defaultdict(float); cnt = collections.Counter(); dur = collections.defaultdict(float)
+for f in glob.glob('/tmp/prof/pmcph/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get('Kernel_Name', '')
+        k = 'k_mlp_phase_score' if 'k_mlp_phase_score' in k else 'k_mlp_phase_prefix' if 'phase_prefix' in k else ('k_search' + ('<phase>' if ', 9,' in k else '')) if 'k_search' in k else None
+        if k is None: continue
+        acc[(k, r['Counter_Name'])] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
+        if 'Start_Timestamp' in r and r['Counter_Name'] in ('GRBM_GUI_ACTIVE', 'SQ_BUSY_CYCLES', 'FETCH_SIZE', 'WRITE_SIZE'):
+            dur[k] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+for (k, c), v in sorted(acc.items()):
+    print('PMCPH $P $N', k, c, 'dispatches', cnt[(k, c)], 'sum', v, ('dur_ns %.0f' % dur[k]) if dur.get(k) else '')
+PY
+        done
+      done ;;
     *) echo "unknown step $STEP" ;;
   esac
 done

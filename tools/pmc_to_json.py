@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc_<tag>.txt (tools/gpu_r3.sh: per-kernel means of the rocprofv3 --pmc passes) -> profiles/pmc_latest.json,
 the per-workload counter record bench.py attaches to its roofline objects (`traffic`, `mfma_busy_frac`).
-usage: tools/pmc_to_json.py <gpurun tag> <kernel version note>"""
+usage: tools/pmc_to_json.py <gpurun tag> <kernel version note>
+       tools/pmc_to_json.py --phased <gpurun tag> <note>   gpurun_out/pmc_phased_{split,exact}_<tag>.txt (tools/gpu_r4.sh
+           pmc_phased: per-kernel SUMS over a run of the MLP pipeline of phases) -> the two MLP entries, per search call"""
 import json
 import os
 import re
@@ -10,7 +12,54 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def phased(tag, note):
+    """One search call of the pipeline = 6 traversal launches + 5 prefix + 5 scoring launches + the fallback launch:
+    counters summed over all of them per call (so that mfma_busy_frac is the call's), the scoring launches' own beside."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    out = json.load(open(path))
+    for prec, tags, wl in (("split", ["1000000x128f16_ef128_k200_b1024_mlp_hnsw", "1000000x128f16_ef128_k200_b4096_l2_hnsw_mlp_split"],
+                            "BASELINE configs[2]: 1M x 128-d f16, ef=128, top-200, MLP 256-128-1 split-f16, batch 1024"),
+                           ("exact", ["1000000x128f16_ef128_k200_b1024_mlp_hnsw_exact", "1000000x128f16_ef128_k200_b4096_l2_hnsw_mlp_exact"],
+                            "BASELINE configs[2]: 1M x 128-d f16, ef=128, top-200, MLP 256-128-1 exact f32, batch 1024")):
+        f = os.path.join(ROOT, "gpurun_out", f"pmc_phased_{prec}_{tag}.txt")
+        if not os.path.exists(f):
+            continue
+        by = {}
+        for line in open(f):
+            m = re.match(r"PMCPH \S+ (\S+) (\S+) (\S+) dispatches (\d+) sum (\S+)(?: dur_ns (\S+))?", line)
+            if not m:
+                continue
+            _, kern, ctr, n, v, dur = m.groups()
+            by.setdefault(kern, {})[ctr] = float(v)
+            by[kern]["dispatches"] = int(n)
+            if dur and ctr == "GRBM_GUI_ACTIVE":
+                by[kern]["dur_ns"] = float(dur)
+        calls = by["k_mlp_phase_score"]["dispatches"] / 5.0
+        e = {"kernel": "pipeline of phases (nann_mlp6.h): k_search<phase> x 6, k_mlp_phase_prefix x 5, k_mlp_phase_score x 5, fallback launch",
+             "kernel_version": note, "workload": wl, "search_calls_in_pass": calls, "fetch_correction": 2.0, "by_kernel": {}}
+        for kern, c in by.items():
+            per = {k: v / calls for k, v in c.items() if k not in ("dispatches", "dur_ns")}
+            if "FETCH_SIZE" in per:
+                per["FETCH_SIZE_KiB"] = per.pop("FETCH_SIZE")
+            if "WRITE_SIZE" in per:
+                per["WRITE_SIZE_KiB"] = per.pop("WRITE_SIZE")
+            if c.get("dur_ns") and "GRBM_GUI_ACTIVE" in c:
+                per["shader_clock_GHz_in_pass"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / c["dur_ns"], 3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in per and "GRBM_GUI_ACTIVE" in per:
+                per["mfma_busy_frac"] = round(per["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * per["GRBM_GUI_ACTIVE"] / 8.0 * 256), 4)
+            e["by_kernel"][kern] = per
+            for k, v in per.items():
+                if k not in ("shader_clock_GHz_in_pass", "mfma_busy_frac"):
+                    e[k] = e.get(k, 0.0) + v
+        for t in tags:
+            out["workloads"][t] = e
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps({t: sorted(e) for t, e in out["workloads"].items()}, indent=1)[:1500])
+
+
 def main():
+    if sys.argv[1] == "--phased":
+        return phased(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
     tag, note = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
     rows = {}
     for line in open(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}.txt")):
