@@ -398,7 +398,7 @@ int nann_model_table_bytes(const nann_model* m, const nann_index* ix, int64_t* t
  * num_scoring_per_level[level] rounds each; neighbours taken as an ascending SET minus visited
  * (tf.unique + tf.sets.difference), top_k = min(k, n), next frontier = new nodes scoring at least
  * the worst kept result, an exhausted frontier is not an error.  Arrays are indexed by level
- * (config.py:50-58); num_scoring_per_level[2] must be 1, top_k_per_level and topk_eval in [1, 1024].
+ * (config.py:50-58); num_scoring_per_level[2] must be 1, top_k_per_level and topk_eval in [1, 2048].
  * Outputs [n_queries, topk_eval] (out_scores / out_index may be NULL); n_out[q] = valid rows of
  * query q (the rest is zero); status[q] as nann_search (NANN_ERR_CAPACITY: more than 1024 new nodes
  * tie at the threshold of one round).  Bit-identical to oracle_search_eval for the l2 and exact mlp

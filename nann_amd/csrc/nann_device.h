@@ -1095,13 +1095,15 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
 //   4. rank sort of the k pairs in LDS, outputs written in rank order.
 // out_pos / out_ids / out_scores / out_mapped may each be null.  ids == null
 // means "ids are positions".  Returns NANN status (uniform).
-struct TopkScratch {
-  unsigned long long sel[kMaxK < 512 ? 512 : kMaxK];  // first: 16-byte aligned (the four 256-bin radix histograms alias it)
+template <int KCAP>  // largest k (kMaxK for the serving kernels; the evaluation traversal keeps more per level)
+struct TopkScratchT {
+  unsigned long long sel[KCAP < 512 ? 512 : KCAP];  // first: 16-byte aligned (the four 256-bin radix histograms alias it)
   unsigned short prank[kNT];      // partial ranks of the rank sort: [segment][element]
   uint32_t misc[4];               // [0] nsel, [2] unordered append cursor
   uint32_t orv, andv;
   uint32_t wcnt[kNW];
 };
+typedef TopkScratchT<kMaxK> TopkScratch;
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
 // the selection does not wait on L2 (positions < kLdsScores only)
 static_assert(sizeof(TopkScratch) <= kLdsScoresOff, "top-k scratch overlaps the LDS scores");
@@ -1110,12 +1112,12 @@ static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too sma
 
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
 // SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
-template <int NS, bool SCL, int NT>
+template <int NS, bool SCL, int NT, int KCAP = kMaxK>
 __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
                                             const float* lds_scores, int n, int k, int32_t* out_pos,
                                             int32_t* out_ids, float* out_scores, const int64_t* id_map,
                                             int64_t* out_mapped, unsigned char* scratch, SubTimer pt) {
-  TopkScratch* S = reinterpret_cast<TopkScratch*>(scratch);
+  TopkScratchT<KCAP>* S = reinterpret_cast<TopkScratchT<KCAP>*>(scratch);
   long long tsub = pt.now();
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const uint64_t lt = lanemask_lt(lane);
@@ -1280,7 +1282,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   // spread over all threads: element e = tid % K2, comparison segment = tid / K2.
   int K2 = 64;
   while (K2 < k) K2 <<= 1;
-  const bool split = K2 <= NT;  // else (k > NT, only for NT < kMaxK): one thread per element
+  const bool split = K2 <= NT;  // else (k > NT: NT < kMaxK, or the evaluation traversal's k up to 2048): every thread ranks its elements in full
   // the id of "my" element (e = tid) is fetched now so that its latency hides under the ranking
   int32_t my_id = 0;
   if (tid < k && ids) my_id = ids[(int)(~(uint32_t)(S->sel[tid] & 0xffffffffull))];
@@ -1311,7 +1313,15 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     if (split) {
       for (int sg = 0; sg < NT / K2; ++sg) rank += S->prank[sg * K2 + e];
     } else {
-      for (int o = 0; o < k; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
+      int o = 0;
+      for (; o + 8 <= k; o += 8) {  // (eight broadcast reads in flight, as above)
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = S->sel[o + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (v[u] > mine) ? 1 : 0;
+      }
+      for (; o < k; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
     }
     const int pos = (int)(~(uint32_t)(mine & 0xffffffffull));
     const int32_t idv = ids ? (e == tid ? my_id : ids[pos]) : pos;
@@ -1332,17 +1342,17 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
 }
 
 // lds_scores != nullptr: the first n scores are mirrored in LDS (n <= kLdsScores)
-template <int NT = kNT>
+template <int NT = kNT, int KCAP = kMaxK>
 __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, const float* lds_scores,
                                        int n, int k, int32_t* out_pos, int32_t* out_ids,
                                        float* out_scores, const int64_t* id_map, int64_t* out_mapped,
                                        unsigned char* scratch, SubTimer pt = no_timer()) {
-  if (k < 0 || k > kMaxK) return 7;  // NANN_ERR_BAD_ARGUMENT
+  if (k < 0 || k > KCAP) return 7;  // NANN_ERR_BAD_ARGUMENT
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;
 #define NANN_TOPK_CASE(NS_, SCL_)                                                                   \
-  return wg_topk_impl<NS_, SCL_, NT>(ids, scores, lds_scores, n, k, out_pos, out_ids, out_scores, \
-                                     id_map, out_mapped, scratch, pt)
+  return wg_topk_impl<NS_, SCL_, NT, KCAP>(ids, scores, lds_scores, n, k, out_pos, out_ids, out_scores, \
+                                           id_map, out_mapped, scratch, pt)
   if (lds_scores != nullptr && n <= kLdsScores) {
     if (n <= 1 * NT) NANN_TOPK_CASE(1, true);
     if (n <= 2 * NT) NANN_TOPK_CASE(2, true);

@@ -6,15 +6,22 @@
 //     (tf.unique + tf.sets.difference, :316-319);
 //   * top_k keeps min(k, n) (:268) and an exhausted frontier is not an error (plain TF scoring);
 //   * the next frontier = the new nodes scoring at least the worst kept result (:330-331).
-// Ascending sets want a bitmap, not a list: `seen` collects the neighbours that are not in
-// `visited` (one atomicOr each), and a word-order scan of `seen` IS the ascending, duplicate-free
-// list -- no sort.  Both bitmaps live in the slot's HBM scratch (they stay in L2): this job runs a
-// few thousand users per evaluation, it shares the scorers and the top-k with the serving kernel
-// but not its LDS budget.
+// Ascending sets want a bitmap, not a list.  Round 4's form (round 2-3: both bitmaps in HBM behind device-scope atomics
+// and fences, 5 ms per user):
+//   * `seen` takes one bit per neighbour of the frontier, visited or not -- atomics only, in LDS when the index's bitmap
+//     fits beside the phase scratch (1 M items: 125 KB), else in the slot (performed in L2);
+//   * a word-order scan of `seen` against `visited` IS the ascending, duplicate-free list of new nodes -- no sort; every
+//     bitmap word has ONE owner thread (wavefront w, trip j, lane l -> word w C + 64 j + l), which alone reads and writes
+//     that word of `visited` (plain loads / stores to the slot: no atomic, no fence) and clears its word of `seen`;
+//   * the rows of a frontier are walked eight per wavefront and trip, their bounds and first 64 neighbours in flight
+//     together.
+// top_k_per_level / topk_eval up to kEvalMaxK = 2048 (the reference's are defaults, config.py:50-58).
 #pragma once
 #include "nann_search.h"
 
 namespace nann {
+
+constexpr int kEvalMaxK = 2048;  // largest top_k_per_level / topk_eval / frontier
 
 struct EvalArgs {
   const void* emb;
@@ -62,9 +69,9 @@ __host__ __device__ inline unsigned long long eval_slot_layout(uint32_t bm_words
   put(1, 4ull * bm_words);
   put(2, 4ull * cat_cap);
   put(3, 4ull * cat_cap);
-  put(4, 4ull * kMaxK);
-  put(5, 4ull * kMaxK);
-  put(6, 4ull * kMaxK);
+  put(4, 4ull * kEvalMaxK);
+  put(5, 4ull * kEvalMaxK);
+  put(6, 4ull * kEvalMaxK);
   return o;
 }
 
@@ -92,15 +99,16 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, EvalScanScratch* S,
   return base + inc - v;
 }
 
-__device__ __forceinline__ uint32_t ld_word(const uint32_t* p) {  // past the L1: the word may have been changed by an atomic
+__device__ __forceinline__ uint32_t ld_word(const uint32_t* p) {  // past the L1: the word is changed by atomics performed in L2
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// barrier between phases that hand the HBM bitmaps from atomics to plain loads / stores and back: the
-// stores are in L2 before it, the L1 is dropped after it
-__device__ __forceinline__ void wg_sync_mem() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+// LDS scratch of the evaluation kernel: the scorer's phase scratch or the (larger-k) top-k scratch, whichever is larger
+template <int SC, int NT>
+constexpr int eval_scratch_bytes() {
+  constexpr int a = phase_scratch<VIS_HBM_BITMAP, SC, NT>();
+  constexpr int b = (int)((sizeof(TopkScratchT<kEvalMaxK>) + 255) & ~(size_t)255);
+  return a > b ? a : b;
 }
 
 template <int LPR, int DT, int SC, int NT>
@@ -121,16 +129,31 @@ __device__ __forceinline__ void eval_score(const EvalArgs& a, int qi, const int3
   __syncthreads();
 }
 
-template <int LPR, int DT, int SC, int NT>
-__device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const EvalSlot& sv, unsigned char* scratch,
-                                               float* qv, int* n_result) {
+template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
+__device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
+                                               unsigned char* scratch, float* qv, int* n_result) {
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NT / 64;
   EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
   if constexpr (SC != kScorerAttn) {
     for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
   }
-  wg_zero_words(sv.seen, a.bm_words);
-  wg_sync_mem();
+  // the words of the bitmaps a thread owns: wavefront w, trip j, lane l -> word w C + 64 j + l (C a multiple of 64)
+  const uint32_t C = (((a.bm_words + NW - 1) / NW) + 63u) & ~63u;
+  const int J = (int)(C >> 6);
+  const uint32_t w0 = (uint32_t)wave * C + (uint32_t)lane;
+  auto seen_load = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? seen[w] : ld_word(&seen[w]); };
+  auto seen_or = [&](uint32_t id) {
+    const uint32_t bit = 1u << (id & 31);
+    if constexpr (SEEN_LDS) atomicOr(&seen[id >> 5], bit);
+    else __hip_atomic_fetch_or(&seen[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (int j = 0; j < J; ++j) {  // (a user that failed may have left bits)
+    const uint32_t w = w0 + 64u * j;
+    if (w < a.bm_words) seen[w] = 0u;
+  }
+  if (tid < 2) SS->flags[tid] = 0;
+  __syncthreads();
   float mlp_u = 0.0f;
   if constexpr (SC == NANN_SCORER_MLP) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
 
@@ -139,73 +162,114 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   if (E <= 0) return NANN_ERR_EMPTY_SCORE_BATCH;
   eval_score<LPR, DT, SC, NT>(a, qi, a.enter, E, sv.cat_sc, scratch, qv, mlp_u);
   int n_res = min(a.top_k[2], E);
-  int st = wg_topk<NT>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr, scratch);
+  int st = wg_topk<NT, kEvalMaxK>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr, scratch);
   if (st) return st;
 
-  // words of the bitmaps each thread scans: a contiguous run, so that thread order = id order
-  const uint32_t per_thread = ((a.bm_words + NT - 1) / NT + 3u) & ~3u;
-  const uint32_t w_lo = min((uint32_t)tid * per_thread, a.bm_words), w_hi = min(w_lo + per_thread, a.bm_words);
-
   for (int level = 1; level >= 0; --level) {  // search_level (:299-337)
-    wg_zero_words(sv.visited, a.bm_words);
-    if (tid < 2) SS->flags[tid] = 0;
-    wg_sync_mem();
-    // visited = idx_ep (:311); result -> front of the concat arrays; candidates = result
+    if (tid < 2) SS->flags[tid] = 0;  // (the scratch was reused since)
+    __syncthreads();
+    // visited = idx_ep (:311): the marks go through `seen`; result -> front of the concat arrays; candidates = result
     for (int i = tid; i < n_res; i += NT) {
       const int32_t id = sv.res_ids[i];
       if ((uint32_t)id >= a.n_items) { SS->flags[1] = 1; continue; }
-      atomicOr(&sv.visited[(uint32_t)id >> 5], 1u << (id & 31));
+      seen_or((uint32_t)id);
       sv.cand[i] = id;
       sv.cat_ids[i] = id;
       sv.cat_sc[i] = sv.res_sc[i];
     }
-    wg_sync_mem();
+    __syncthreads();
     if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+    for (int j = 0; j < J; ++j) {  // the owners: visited = marks, seen = 0
+      const uint32_t w = w0 + 64u * j;
+      if (w < a.bm_words) {
+        const uint32_t s = seen_load(w);
+        sv.visited[w] = s;
+        if (s) seen[w] = 0u;
+      }
+    }
+    __syncthreads();
     int n_cand = n_res;
     const int32_t* __restrict__ values = a.nbv[level];
     const int64_t* __restrict__ rs = a.nbrs[level];
     for (int it = 0; it < a.num_scoring[level]; ++it) {
-      // neighbours of the candidates that are not visited -> bits of `seen` (one wavefront per row)
-      __syncthreads();
-      if (tid < 2) SS->flags[tid] = 0;  // (the scratch was reused since)
-      __syncthreads();
-      for (int i = wave; i < n_cand; i += NT / 64) {
-        const int32_t c = sv.cand[i];
-        const int64_t s = rs[c], e = rs[c + 1];
-        for (int64_t j = s + lane; j < e; j += 64) {
-          const int32_t v = values[j];
-          if ((uint32_t)v >= a.n_items) { SS->flags[1] = 1; continue; }
-          const uint32_t bit = 1u << (v & 31);
-          if (!(ld_word(&sv.visited[(uint32_t)v >> 5]) & bit)) atomicOr(&sv.seen[(uint32_t)v >> 5], bit);
-        }
-      }
-      wg_sync_mem();
-      if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-      // ascending list of the set (:316-319), visited |= it (:321), seen = 0
-      uint32_t cnt = 0;
-      for (uint32_t w = w_lo; w < w_hi; w += 4) {
-        const uint4 s4 = *reinterpret_cast<const uint4*>(&sv.seen[w]);
-        cnt += __popc(s4.x) + __popc(s4.y) + __popc(s4.z) + __popc(s4.w);
-      }
-      uint32_t total;
-      uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);
-      const int n_next = (int)total;
-      if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
-      if (cnt) {
-        int32_t* dst = sv.cat_ids + n_res;
-        for (uint32_t w = w_lo; w < w_hi; ++w) {
-          uint32_t s = sv.seen[w];
-          if (!s) continue;
-          sv.visited[w] |= s;
-          sv.seen[w] = 0u;
-          while (s) {
-            const int b = __ffs(s) - 1;
-            s &= s - 1;
-            dst[at++] = (int32_t)(w * 32u + (uint32_t)b);
+      // ---- neighbours of the candidates -> bits of `seen`: eight rows per wavefront and trip
+      {
+        int bad = 0;
+        for (int base = wave * 8; base < n_cand; base += NW * 8) {
+          long long s = 0, e = 0;
+          if (lane < 8 && base + lane < n_cand) {
+            const int32_t c = sv.cand[base + lane];
+            s = rs[c]; e = rs[c + 1];
+          }
+          int32_t v[8];
+          long long sr[8], er[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            sr[r] = __shfl(s, r); er[r] = __shfl(e, r);
+            v[r] = (sr[r] + lane < er[r]) ? values[sr[r] + lane] : -1;
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            if (sr[r] + lane < er[r]) {
+              if ((uint32_t)v[r] < a.n_items) seen_or((uint32_t)v[r]); else bad = 1;
+            }
+            for (long long j = sr[r] + 64 + lane; j < er[r]; j += 64) {  // (rows of more than 64 neighbours)
+              const int32_t x = values[j];
+              if ((uint32_t)x < a.n_items) seen_or((uint32_t)x); else bad = 1;
+            }
           }
         }
+        if (bad) SS->flags[1] = 1;
       }
-      wg_sync_mem();
+      __syncthreads();
+      if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+      // ---- new = seen & ~visited, counted per owner ...
+      uint32_t cnt = 0;
+      for (int j = 0; j < J; ++j) {
+        const uint32_t w = w0 + 64u * j;
+        if (w < a.bm_words) {
+          const uint32_t s = seen_load(w);
+          if (s) cnt += (uint32_t)__popc(s & ~sv.visited[w]);
+        }
+      }
+      const uint32_t wtot = wave_total(wave_scan_add(cnt));
+      if (lane == 0) SS->wave_tot[wave] = wtot;
+      __syncthreads();
+      uint32_t run = 0, total = 0;
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t t = SS->wave_tot[w];
+        if (w < wave) run += t;
+        total += t;
+      }
+      const int n_next = (int)total;
+      if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
+      // ---- ... and written out in word order = ascending ids (:316-319); visited |= new (:321), seen = 0
+      {
+        int32_t* dst = sv.cat_ids + n_res;
+        for (int j = 0; j < J; ++j) {
+          const uint32_t w = w0 + 64u * j;
+          uint32_t nw = 0;
+          if (w < a.bm_words) {
+            const uint32_t s = seen_load(w);
+            if (s) {
+              const uint32_t vis = sv.visited[w];
+              nw = s & ~vis;
+              sv.visited[w] = vis | s;
+              seen[w] = 0u;
+            }
+          }
+          const uint32_t c = (uint32_t)__popc(nw);
+          const uint32_t inc = wave_scan_add(c);
+          uint32_t at = run + inc - c;
+          while (nw) {
+            const int b = __ffs(nw) - 1;
+            nw &= nw - 1;
+            dst[at++] = (int32_t)(w * 32u + (uint32_t)b);
+          }
+          run += wave_total(inc);
+        }
+      }
+      __syncthreads();
       if (n_next == 0) {  // plain TF ops score an empty batch as an empty tensor: the result is cut to min(k, n), no candidate is left
         n_res = min(a.top_k[level], n_res);
         n_cand = 0;
@@ -214,8 +278,8 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       eval_score<LPR, DT, SC, NT>(a, qi, sv.cat_ids + n_res, n_next, sv.cat_sc + n_res, scratch, qv, mlp_u);  // :323
       const int n_cat = n_res + n_next;
       const int k = min(a.top_k[level], n_cat);
-      st = wg_topk<NT>(sv.cat_ids, sv.cat_sc, nullptr, n_cat, k, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr,
-                       scratch);  // :326-328
+      st = wg_topk<NT, kEvalMaxK>(sv.cat_ids, sv.cat_sc, nullptr, n_cat, k, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr,
+                                  scratch);  // :326-328
       if (st) return st;
       // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331)
       const float worst = sv.res_sc[k - 1];
@@ -225,10 +289,10 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
         const bool keep = i < n_next && sv.cat_sc[n_res + i] >= worst;
         uint32_t tot;
         const uint32_t pos = n_new + wg_excl_scan<NT>(keep ? 1u : 0u, SS, &tot);
-        if (keep && pos < (uint32_t)kMaxK) sv.cand[pos] = sv.cat_ids[n_res + i];
+        if (keep && pos < (uint32_t)kEvalMaxK) sv.cand[pos] = sv.cat_ids[n_res + i];
         n_new += tot;
       }
-      if (n_new > (uint32_t)kMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
+      if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
       __syncthreads();
       n_cand = (int)n_new;
       n_res = k;
@@ -236,6 +300,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
         sv.cat_ids[i] = sv.res_ids[i];
         sv.cat_sc[i] = sv.res_sc[i];
       }
+      if (tid < 2) SS->flags[tid] = 0;  // (the scratch was reused since)
       __syncthreads();
     }
   }
@@ -243,11 +308,13 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   return NANN_OK;
 }
 
-template <int LPR, int DT, int SC, int NT>
+// LDS: [seen bitmap (SEEN_LDS) | scratch | q | misc]
+template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
 __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int kScratchBytes = phase_scratch<VIS_HBM_BITMAP, SC, NT>();
-  unsigned char* scratch = smem;
+  constexpr int kScratchBytes = eval_scratch_bytes<SC, NT>();
+  const size_t bm_bytes = SEEN_LDS ? (((size_t)a.bm_words * 4 + 255) & ~(size_t)255) : 0;
+  unsigned char* scratch = smem + bm_bytes;
   float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);
   int* misc = reinterpret_cast<int*>(qv + kMaxD);
 
@@ -271,7 +338,9 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
     const int qi = misc[0];
     if (qi >= a.n_queries) break;
     int n_res = 0;
-    const int st = search_eval_one<LPR, DT, SC, NT>(a, qi, sv, scratch, qv, &n_res);
+    int st;
+    if constexpr (SEEN_LDS) st = search_eval_one<LPR, DT, SC, NT, true>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res);
+    else st = search_eval_one<LPR, DT, SC, NT, false>(a, qi, sv, sv.seen, scratch, qv, &n_res);
     __syncthreads();
     const int n = st ? 0 : min(K, n_res);  // results[:topk_eval] (:358), item ids (:360)
     for (int i = threadIdx.x; i < K; i += NT) {
@@ -287,10 +356,14 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
   }
 }
 
-template <int LPR, int DT, int SC, int NT>
+// LDS bytes of an instance: the scratch + q + misc, + the bitmap when `seen` lives there
+template <int SC, int NT>
+constexpr size_t eval_lds_base() { return (size_t)eval_scratch_bytes<SC, NT>() + kMaxD * 4 + 256; }
+
+template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
 inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
-  auto kern = k_search_eval<LPR, DT, SC, NT>;
-  const size_t lds_bytes = (size_t)phase_scratch<VIS_HBM_BITMAP, SC, NT>() + kMaxD * 4 + 256;
+  auto kern = k_search_eval<LPR, DT, SC, NT, SEEN_LDS>;
+  const size_t lds_bytes = eval_lds_base<SC, NT>() + (SEEN_LDS ? (((size_t)a.bm_words * 4 + 255) & ~(size_t)255) : 0);
   if (lds_bytes > 48 * 1024)
     NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -299,8 +372,10 @@ inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
   return NANN_OK;
 }
 
-// instantiations: nann_eval_inst.hip (L2, attention model), nann_mlp_inst.hip (MLP, f32 MFMA)
-int launch_eval_l2(int lpr, int dt, int slots, const EvalArgs& a, hipStream_t st);
+// instantiations: nann_eval_inst.hip (L2, attention model), nann_mlp_inst.hip (MLP, f32 MFMA).  seen_lds: the L2
+// instances only (eval_l2_lds_bytes() = what the plan checks against the CU's LDS)
+size_t eval_l2_lds_base();
+int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_attn(int d, int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d64(int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d128(int dt, int slots, const EvalArgs& a, hipStream_t st);

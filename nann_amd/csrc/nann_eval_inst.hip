@@ -4,27 +4,31 @@
 
 namespace nann {
 
-template <int LPR>
+template <int LPR, bool SEEN_LDS>
 static int eval_l2(int dt, int slots, const EvalArgs& a, hipStream_t st) {
-  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_L2, kNT>(slots, a, st);
-  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_L2, kNT>(slots, a, st);
-  return launch_eval_as<LPR, DT_F32, NANN_SCORER_L2, kNT>(slots, a, st);
+  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_L2, kNT, SEEN_LDS>(slots, a, st);
+  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_L2, kNT, SEEN_LDS>(slots, a, st);
+  return launch_eval_as<LPR, DT_F32, NANN_SCORER_L2, kNT, SEEN_LDS>(slots, a, st);
 }
 
-int launch_eval_l2(int lpr, int dt, int slots, const EvalArgs& a, hipStream_t st) {
+size_t eval_l2_lds_base() { return eval_lds_base<NANN_SCORER_L2, kNT>(); }
+
+int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st) {
+#define NANN_EVAL_L2(LPR_) return seen_lds ? eval_l2<LPR_, true>(dt, slots, a, st) : eval_l2<LPR_, false>(dt, slots, a, st)
   switch (lpr) {
-    case 8: return eval_l2<8>(dt, slots, a, st);
-    case 16: return eval_l2<16>(dt, slots, a, st);
-    case 32: return eval_l2<32>(dt, slots, a, st);
-    default: return eval_l2<64>(dt, slots, a, st);
+    case 8: NANN_EVAL_L2(8);
+    case 16: NANN_EVAL_L2(16);
+    case 32: NANN_EVAL_L2(32);
+    default: NANN_EVAL_L2(64);
   }
+#undef NANN_EVAL_L2
 }
 
 int launch_eval_attn(int d, int dt, int slots, const EvalArgs& a, hipStream_t st) {
-  if (d == 64 && dt == NANN_F16) return launch_eval_as<8, DT_F16, kScorerAttn, kAttnNT>(slots, a, st);
-  if (d == 64 && dt == NANN_BF16) return launch_eval_as<8, DT_BF16, kScorerAttn, kAttnNT>(slots, a, st);
-  if (d == 128 && dt == NANN_F16) return launch_eval_as<16, DT_F16, kScorerAttn, kAttnNT>(slots, a, st);
-  if (d == 128 && dt == NANN_BF16) return launch_eval_as<16, DT_BF16, kScorerAttn, kAttnNT>(slots, a, st);
+  if (d == 64 && dt == NANN_F16) return launch_eval_as<8, DT_F16, kScorerAttn, kAttnNT, false>(slots, a, st);
+  if (d == 64 && dt == NANN_BF16) return launch_eval_as<8, DT_BF16, kScorerAttn, kAttnNT, false>(slots, a, st);
+  if (d == 128 && dt == NANN_F16) return launch_eval_as<16, DT_F16, kScorerAttn, kAttnNT, false>(slots, a, st);
+  if (d == 128 && dt == NANN_BF16) return launch_eval_as<16, DT_BF16, kScorerAttn, kAttnNT, false>(slots, a, st);
   return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d in {64, 128}, rows f16 or bf16");
 }
 

@@ -2231,18 +2231,25 @@ int nann_model_table_bytes(const nann_model* m, const nann_index* ix, int64_t* t
 // ---- the evaluation graph's traversal (nann_eval.h) ----------------------------------------
 }  // extern "C"
 
-static int eval_plan(const nann_index* ix, int64_t n_queries, int* cat_cap, unsigned long long* slot_bytes, int* slots) {
+// l2: the L2 scorer's instances may keep `seen` in LDS (nann_eval.h) -- when the index's bitmap fits beside their scratch
+static int eval_plan(const nann_index* ix, int64_t n_queries, bool l2, int* cat_cap, unsigned long long* slot_bytes, int* slots,
+                     int* seen_lds) {
   DeviceInfo di;
   const int rc = device_info(&di);
   if (rc) return rc;
-  // result || next: a frontier holds at most kMaxK rows, a set at most every item
+  // result || next: a frontier holds at most kEvalMaxK rows, a set at most every item
   const int64_t deg = std::max<int64_t>(std::max(ix->max_deg[0], ix->max_deg[1]), 1);
-  const int64_t nxt = std::max<int64_t>(std::min<int64_t>(ix->desc.n_items, (int64_t)kMaxK * deg), ix->desc.n_enter);
-  if (kMaxK + nxt > 0x3fffffffll) return fail(NANN_ERR_UNSUPPORTED, "candidate bound too large");
-  *cat_cap = (int)(kMaxK + nxt);
+  const int64_t nxt = std::max<int64_t>(std::min<int64_t>(ix->desc.n_items, (int64_t)kEvalMaxK * deg), ix->desc.n_enter);
+  if (kEvalMaxK + nxt > 0x3fffffffll) return fail(NANN_ERR_UNSUPPORTED, "candidate bound too large");
+  *cat_cap = (int)(kEvalMaxK + nxt);
   unsigned long long off[7];
   *slot_bytes = eval_slot_layout(ix->bm_words, *cat_cap, off);
-  *slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * 2));
+  const size_t lds = eval_l2_lds_base() + (((size_t)ix->bm_words * 4 + 255) & ~(size_t)255);
+  static const bool force_hbm = [] { const char* e = std::getenv("NANN_EVAL_SEEN"); return e && std::string(e) == "hbm"; }();
+  *seen_lds = l2 && lds <= di.lds_max && !force_hbm;
+  // workgroups per CU: two (2048 threads) unless the LDS bitmap leaves room for one
+  const int per_cu = (*seen_lds && 2 * lds > di.lds_max) ? 1 : 2;
+  *slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
   return NANN_OK;
 }
 
@@ -2254,12 +2261,13 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
   if (num_scoring[2] != 1) return fail(NANN_ERR_BAD_ARGUMENT, "num_scoring_per_level[2] must be 1 (model.py:347)");
   for (int l = 0; l < 3; ++l)
-    if (top_k[l] < 1 || top_k[l] > kMaxK || num_scoring[l] < 0)
-      return fail(NANN_ERR_UNSUPPORTED, "top_k_per_level entries must be in [1, 1024]");
-  if (topk_eval < 1 || topk_eval > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "topk_eval must be in [1, 1024]");
+    if (top_k[l] < 1 || top_k[l] > kEvalMaxK || num_scoring[l] < 0)
+      return fail(NANN_ERR_UNSUPPORTED, "top_k_per_level entries must be in [1, 2048]");
+  if (topk_eval < 1 || topk_eval > kEvalMaxK) return fail(NANN_ERR_UNSUPPORTED, "topk_eval must be in [1, 2048]");
   EvalArgs a;
-  int slots = 0;
-  int rc = eval_plan(ix, n_queries, &a.cat_cap, &a.slot_bytes, &slots);
+  int slots = 0, seen_lds = 0;
+  const bool l2 = !attn && scorer->desc.kind != NANN_SCORER_MLP;
+  int rc = eval_plan(ix, n_queries, l2, &a.cat_cap, &a.slot_bytes, &slots, &seen_lds);
   if (rc) return rc;
   if (!workspace || workspace_bytes < (int64_t)(256 + a.slot_bytes * (unsigned long long)slots))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_eval_workspace_bytes()");
@@ -2293,16 +2301,16 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
     if (d == 256) return launch_eval_mlp_d256(dt, slots, a, st);
     return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d in {64, 128, 256}");
   }
-  return launch_eval_l2(d / 8, dt, slots, a, st);
+  return launch_eval_l2(d / 8, dt, seen_lds, slots, a, st);
 }
 
 extern "C" {
 
 int nann_search_eval_workspace_bytes(const nann_index* ix, const nann_model* m, int64_t n_queries, int64_t* nbytes) {
   if (!ix || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_eval_workspace_bytes: null argument");
-  int cat_cap = 0, slots = 0;
+  int cat_cap = 0, slots = 0, seen_lds = 0;
   unsigned long long slot_bytes = 0;
-  const int rc = eval_plan(ix, n_queries, &cat_cap, &slot_bytes, &slots);
+  const int rc = eval_plan(ix, n_queries, false, &cat_cap, &slot_bytes, &slots, &seen_lds);  // (the most slots any scorer's plan takes)
   if (rc) return rc;
   *nbytes = (int64_t)(256 + slot_bytes * (unsigned long long)slots + 256 + (m ? model_query_bytes(m, n_queries) : 0));
   return NANN_OK;

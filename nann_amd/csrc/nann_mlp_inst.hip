@@ -69,8 +69,8 @@ int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int sl
 // evaluation-graph traversal (nann_eval.h), f32 MFMA scorer
 int NANN_CAT(launch_eval_mlp_d, NANN_MLP_D)(int dt, int slots, const EvalArgs& a, hipStream_t st) {
   constexpr int LPR = NANN_MLP_D / 8;
-  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT>(slots, a, st);
-  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_MLP, kMlpNT>(slots, a, st);
+  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_MLP, kMlpNT, false>(slots, a, st);
+  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_MLP, kMlpNT, false>(slots, a, st);
   return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
 }
 

@@ -410,8 +410,9 @@ def test_fused_eval_graph_matches_oracle(oracle, kind):
     osc = oracle.Scorer(kind, 64, oracle.EMB_F16, w)
     sc = ops.Scorer(kind, 64, torch.float16, w, precision="exact")
     qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 40 if kind == "l2" else 12, seed=9)])
+    # (the last shape: top_k_per_level above the serving kernels' 1024 -- the reference's values are defaults, config.py:50-58)
     for cfg in [((3, 1, 1), (400, 200, 100), 200), ((2, 2, 1), (60, 40, 16), 30), ((1, 0, 1), (50, 50, 8), 64),
-                ((3, 2, 1), (1024, 700, 300), 1024)]:
+                ((3, 2, 1), (1024, 700, 300), 1024), ((3, 1, 1), (2000, 1000, 500), 1500)]:
         r = retrieval.search_eval(dix, sc, cuda(qs), *cfg)
         torch.cuda.synchronize()
         st, n_out = r.status.cpu().numpy(), r.n_out.cpu().numpy()

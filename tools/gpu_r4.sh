@@ -337,6 +337,11 @@ for (k, c), v in sorted(acc.items()):
 PY
         done
       done ;;
+    eval_bench)  # the evaluation traversal (f3) on the 1M index: users/s, both bitmap placements, oracle parity on a sample
+      timeout 400 python tools/eval_bench.py /tmp/idx 1024 6 > $OUT/eval_bench_$TAG.json 2> $OUT/eval_bench_$TAG.err; tail -1 $OUT/eval_bench_$TAG.json | cut -c1-900; tail -2 $OUT/eval_bench_$TAG.err | grep -v amdgpu.ids
+      NANN_EVAL_SEEN=hbm timeout 400 python tools/eval_bench.py /tmp/idx 1024 3 > $OUT/eval_bench_hbm_$TAG.json 2> $OUT/eval_bench_hbm_$TAG.err; tail -1 $OUT/eval_bench_hbm_$TAG.json | cut -c1-900 ;;
+    tests_eval)
+      timeout 600 python -m pytest tests/test_search_gpu.py -m gpu -q --timeout 300 -x -k "eval" > $OUT/pytest_eval_$TAG.log 2>&1; tail -5 $OUT/pytest_eval_$TAG.log ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
