@@ -45,4 +45,12 @@ int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, cons
   return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d in {64, 128}, rows f16 or bf16");
 }
 
+int launch_search_attn_xproj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  // the f32 form on the pre-projected table never reads the embedding rows: one instance serves every d and row dtype
+  if (vis == VIS_LDS_HASH) return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerAttnXProj, kAttnNT>(slots, lds_bytes, a, st);
+  if (vis == VIS_LDS_BITMAP || vis == VIS_HBM_BITMAP)
+    return launch_search_bitmap<16, DT_F16, kScorerAttnXProj, kAttnNT>(vis, slots, lds_bytes, a, st);
+  return fail(NANN_ERR_UNSUPPORTED, "attention traversal: no kernel for this plan");
+}
+
 }  // namespace nann

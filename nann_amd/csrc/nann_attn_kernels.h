@@ -26,21 +26,36 @@ __device__ __forceinline__ void attn_stage(float* slice, const float* __restrict
 
 // out[m0 + m] += sum over the KT k-tiles of `in` (tiles in0..) of W[k][32 m + unit] * in[k], for the
 // MT output tiles held in the staged slice ([KT*32 rows][NC floats], row-major)
+//
+// The A operands travel in groups of 4 k-rows x MT tiles, the next group's LDS reads issued in front of this group's MFMAs
+// and the schedule pinned group by group: left to itself hipcc hoists the reads of a whole layer (up to 256) above its
+// first MFMA and spills what they occupy (the f32 attention traversal ran with 1.3 KB of scratch per lane).
 template <int KT, int MT, int NC, int NIN, int NOUT>
 __device__ __forceinline__ void attn_mma(const float* slice, const f32x16 (&in)[NIN], int in0,
                                          f32x16 (&out)[NOUT], int out0, int lane) {
   const int unit = lane & 31, slot = lane >> 5;
+  const float* base = slice + 4 * slot * NC + unit;  // + (32 t + (r & 3) + 8 (r >> 2)) NC + 32 m
+  constexpr int G = KT * 4;  // groups: (t, r >> 2)
+  float a[2][4][MT];
+  auto load_group = [&](int g, float (&dst)[4][MT]) {
+    const int t = g >> 2, rq = g & 3;
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+    for (int rl = 0; rl < 4; ++rl)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int krow = 32 * t + cd_row(r, slot);
+      for (int m = 0; m < MT; ++m) dst[rl][m] = base[(32 * t + rl + 8 * rq) * NC + 32 * m];
+  };
+  load_group(0, a[0]);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float a = slice[krow * NC + 32 * m + unit];
-        out[out0 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[in0 + t][r], out[out0 + m], 0, 0, 0);
-      }
-    }
+  for (int g = 0; g < G; ++g) {
+    if (g + 1 < G) load_group(g + 1, a[(g + 1) & 1]);
+    const int t = g >> 2, rq = g & 3;
+#pragma unroll
+    for (int rl = 0; rl < 4; ++rl)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        out[out0 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][rl][m], in[in0 + t][4 * rq + rl], out[out0 + m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <int N>
@@ -106,7 +121,13 @@ __global__ __launch_bounds__(256) void k_attn_prepare(AttnParams P, const uint16
 // (kt / upad of that user), by all NT threads (NT/64 wavefronts x 32 candidates per pass); `slice` =
 // kAttnSlice floats of LDS.  Rows outside [0, n_table_rows) are read as row 0 (the caller reports
 // them).  Shared by the stand-alone scorer (k_score_attn) and the fused traversal (k_search).
-template <int D, int DT, int NT>
+//
+// PROJ (round 4): `table` is the (model, index) pair's table of pre-projected item-only layers (nann_attn_proj.h:
+// f32 [n, 384] = q_ x 2^4 ; (e W1e) x 2^11, f32 chains) instead of the embedding rows: q1, q_ and the rows of DNN layer 1
+// that multiply e are LOOKED UP -- 608 instead of 1632 v_mfma_f32_32x32x2_f32 per 32 candidates, 6 staged slices instead
+// of 24 (the keys four q_ tiles per slice).  Layer 1 then sums b1 + (e W1e) first and the attention half behind it (the
+// f32 form on rows: b1, attention half, e half): the same 1e-5 agreement with the oracle every attention test holds.
+template <int D, int DT, int NT, bool PROJ = false>
 __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* __restrict__ kt,
                                               const float* __restrict__ upad, const void* table,
                                               long long n_table_rows, const int32_t* indices, long long n,
@@ -115,17 +136,29 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
   static_assert(DT == DT_F16 || DT == DT_BF16, "item rows are f16 or bf16");
   static_assert(NT == kAttnNT, "attn_stage strides by kAttnNT");
   constexpr int ET = D / 32;  // tiles of the candidate row
+  constexpr int kProjW = 384;  // (= kAttnProjWidth, nann_attn_proj.h)
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, slot = lane >> 5;
   constexpr int CPP = (NT / 64) * 32;
   const float inv_sqrt_dk = 1.0f / sqrtf(256.0f);  // model_util.py:89-91
+  // PROJ: W2 and W3 (40 KB) stay in LDS for the whole call, behind the slice and the split form's vectors -- the part of
+  // the attention kernels' scratch (kAttnScratch, nann_search.h) no other phase of the traversal writes
+  float* res_w2 = slice + kAttnSlice + kAttnVecFloats;
+  float* res_w3 = res_w2 + 128 * 64;
+  if constexpr (PROJ) {
+    for (int f = tid; f < 128 * 64 / 4; f += NT) reinterpret_cast<float4*>(res_w2)[f] = reinterpret_cast<const float4*>(P.w2)[f];
+    for (int f = tid; f < 64 * 32 / 4; f += NT) reinterpret_cast<float4*>(res_w3)[f] = reinterpret_cast<const float4*>(P.w3)[f];
+  }
   for (long long c0 = 0; c0 < n; c0 += CPP) {
     const long long i = c0 + wave * 32 + cand;
     const long long ic = i < n ? i : n - 1;
     const long long rid = indices ? (long long)indices[ic] : ic;
     const size_t row = (rid >= 0 && rid < n_table_rows) ? (size_t)rid : 0u;
-    // the candidate row straight into the C/D layout: 4 consecutive elements per (tile, r >> 2)
     f32x16 e[ET];
+    f32x16 q1[4];
+    const float* prow = PROJ ? static_cast<const float*>(table) + row * kProjW + 4 * slot : nullptr;
+    if constexpr (!PROJ) {
+    // the candidate row straight into the C/D layout: 4 consecutive elements per (tile, r >> 2)
     {
       const uint16_t* src = static_cast<const uint16_t*>(table) + row * D;
 #pragma unroll
@@ -142,7 +175,6 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
         }
     }
     // ---- q1 = prelu(e Wq1 + bq1) : [128] = 4 tiles; Wq1 staged in two column halves
-    f32x16 q1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) attn_fill(q1, m, P.bq1, slot);
 #pragma unroll
@@ -152,10 +184,35 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) attn_act(q1, m, m, nullptr, nullptr, P.aq, slot);
+    }
     // ---- attention logits, q_ tile by q_ tile: att[l] += sum_{j in tile} q_[j] k_l[j]
     f32x16 att[2];
     attn_fill(att, 0, nullptr, slot);
     attn_fill(att, 1, nullptr, slot);
+    if constexpr (PROJ) {
+      float4 nx[4];  // the next q_ tile of the row, in flight under this tile's MFMAs
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nx[g] = *reinterpret_cast<const float4*>(prow + 8 * g);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // the keys of four q_ tiles per slice: kt[128 half .., :] = 32 KB
+        attn_stage<kAttnNT>(slice, kt + (size_t)128 * half * kAttnLP, 128, kAttnLP, kAttnLP);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          f32x16 qt[1];
+          constexpr float kInv = 1.0f / 16.0f;  // the table holds q_ x 2^4; the tile arrives in the C/D layout: four floats per (lane, g)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            qt[0][4 * g + 0] = nx[g].x * kInv; qt[0][4 * g + 1] = nx[g].y * kInv; qt[0][4 * g + 2] = nx[g].z * kInv; qt[0][4 * g + 3] = nx[g].w * kInv;
+          }
+          const int tn = 4 * half + tt + 1;
+          if (tn < 8) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nx[g] = *reinterpret_cast<const float4*>(prow + 32 * tn + 8 * g);
+          }
+          attn_mma<1, 2, kAttnLP>(slice + tt * 32 * kAttnLP, qt, 0, att, 0, lane);
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       f32x16 qt[1];
@@ -165,6 +222,7 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
       attn_mma<4, 1, 32>(slice, q1, 0, qt, 0, lane);
       attn_stage<kAttnNT>(slice, kt + (size_t)32 * t * kAttnLP, 32, kAttnLP, kAttnLP);  // kt[32t.., :]: 8 KB
       attn_mma<1, 2, kAttnLP>(slice, qt, 0, att, 0, lane);
+    }
     }
     // ---- softmax over the L positions (:93); positions >= L are padding of the layout, not of the sequence
     float mx = -INFINITY;
@@ -200,12 +258,24 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
     f32x16 h1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) attn_fill(h1, m, P.b1, slot);
+    if constexpr (PROJ) {  // + the row's (e W1e), looked up
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = *reinterpret_cast<const float4*>(prow + 256 + 32 * m + 8 * g);
+          constexpr float kInv = 1.0f / 2048.0f;  // x 2^11 in the table
+          h1[m][4 * g + 0] += v.x * kInv; h1[m][4 * g + 1] += v.y * kInv; h1[m][4 * g + 2] += v.z * kInv; h1[m][4 * g + 3] += v.w * kInv;
+        }
+    }
     attn_stage<kAttnNT>(slice, P.w1, kAttnE, 128, 128);  // rows of a: 32 KB
     attn_mma<2, 4, 128>(slice, x, 0, h1, 0, lane);
+    if constexpr (!PROJ) {
 #pragma unroll
     for (int part = 0; part < ET / 2; ++part) {  // rows of e, 64 at a time
       attn_stage<kAttnNT>(slice, P.w1 + (size_t)(kAttnE + 64 * part) * 128, 64, 128, 128);
       attn_mma<2, 4, 128>(slice, e, 2 * part, h1, 0, lane);
+    }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) attn_act(h1, m, m, P.s1, P.t1, P.a1, slot);
@@ -213,15 +283,23 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
     f32x16 h2[2];
     attn_fill(h2, 0, P.b2, slot);
     attn_fill(h2, 1, P.b2, slot);
-    attn_stage<kAttnNT>(slice, P.w2, 128, 64, 64);  // 32 KB
-    attn_mma<4, 2, 64>(slice, h1, 0, h2, 0, lane);
+    if constexpr (PROJ) {
+      attn_mma<4, 2, 64>(res_w2, h1, 0, h2, 0, lane);
+    } else {
+      attn_stage<kAttnNT>(slice, P.w2, 128, 64, 64);  // 32 KB
+      attn_mma<4, 2, 64>(slice, h1, 0, h2, 0, lane);
+    }
     attn_act(h2, 0, 0, P.s2, P.t2, P.a2, slot);
     attn_act(h2, 1, 1, P.s2, P.t2, P.a2, slot);
     // ---- layer 3: [32] = 1 tile
     f32x16 h3[1];
     attn_fill(h3, 0, P.b3, slot);
-    attn_stage<kAttnNT>(slice, P.w3, 64, 32, 32);  // 8 KB
-    attn_mma<2, 1, 32>(slice, h2, 0, h3, 0, lane);
+    if constexpr (PROJ) {
+      attn_mma<2, 1, 32>(res_w3, h2, 0, h3, 0, lane);
+    } else {
+      attn_stage<kAttnNT>(slice, P.w3, 64, 32, 32);  // 8 KB
+      attn_mma<2, 1, 32>(slice, h2, 0, h3, 0, lane);
+    }
     attn_act(h3, 0, 0, P.s3, P.t3, P.a3, slot);
     // ---- logit = h3 . w4 (no bias, :218-219): each lane its 16 units, then the other k-slot
     float part = 0.0f;

@@ -1959,7 +1959,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   std::shared_ptr<ProjTable> tab;
   ProjCache* cache = nullptr;
   int rc = NANN_OK;
-  if (attn && attn->precision == NANN_MLP_SPLIT_F16 && mapping >= 3) {
+  if (attn && mapping >= 3) {  // both precisions run on the table of item-only layers (nann_attn_proj.h; nann_attn_kernels.h PROJ)
     cache = &attn->proj;
     rc = attn_projection(attn, ix, st, false, &tab);
   } else if (mlp && (mapping >= 5 || (mlp_split && mapping >= 3))) {
@@ -2016,8 +2016,10 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   };
   if (attn) {
     a.attn = attn->P;
-    if (tab)  // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
-      return both([&](int vis, int, int slots, size_t lds) { return launch_search_attn_proj(vis, slots, lds, a, st); });
+    if (tab) {  // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
+      auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_proj : launch_search_attn_xproj;
+      return both([&](int vis, int, int slots, size_t lds) { return launch(vis, slots, lds, a, st); });
+    }
     auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_split : launch_search_attn;
     return both([&](int vis, int, int slots, size_t lds) { return launch(ix->desc.d, dt, vis, slots, lds, a, st); });
   }
@@ -2109,11 +2111,11 @@ int nann_set_preprojection(int32_t enabled) {
 }
 
 static int table_width(const nann_scorer* s, const nann_attn_scorer* at) {
-  if (at) return at->precision == NANN_MLP_SPLIT_F16 ? kAttnProjWidth : 0;
+  if (at) return kAttnProjWidth;
   return (s && s->desc.kind == NANN_SCORER_MLP) ? kMlpProjWidth : 0;
 }
 static int prepare_impl(const nann_scorer* s, const nann_attn_scorer* at, const nann_index* ix, hipStream_t st) {
-  if (table_width(s, at) == 0) return NANN_OK;  // L2 / f32-form attention: nothing to pre-project
+  if (table_width(s, at) == 0) return NANN_OK;  // L2: nothing to pre-project
   const int d = at ? at->P.d : s->desc.d, dt = at ? at->emb_dtype : s->desc.emb_dtype;
   if (d != ix->desc.d || dt != ix->desc.emb_dtype) return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
   std::shared_ptr<ProjTable> tab;

@@ -180,7 +180,8 @@ constexpr bool is_mlp_res(int sc) { return sc == kScorerMlpRes || sc == kScorerM
 // the 16K-slot set (hash plan) or the bitmap filter's phase scratch (HBM-bitmap plan)
 constexpr int mlp_res_reload_bytes(bool hash) { return hash ? 65536 : 32768; }
 static_assert(kPhaseScratch <= 32768, "the bitmap kernels' phase scratch lies over the first two weight tiles");
-constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj; }
+constexpr int kScorerAttnXProj = 10;  // the f32-MFMA attention model on the same pre-projected table (nann_attn_kernels.h, PROJ)
+constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj || sc == kScorerAttnXProj; }
 
 // where a query's visited set lives
 enum : int {
@@ -420,6 +421,10 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         wg_score_attn<LPR * 8, DT, NT>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
                                        a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
                                        reinterpret_cast<float*>(scratch), sc_out);
+      } else if constexpr (SC == kScorerAttnXProj) {
+        wg_score_attn<128, DT_F16, NT, true>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
+                                             a.proj, (long long)a.n_items, sc_ids, (long long)sc_n,
+                                             reinterpret_cast<float*>(scratch), sc_out);
       } else if constexpr (SC == kScorerAttnSplit) {
         wg_score_attn_split<LPR * 8, DT, NT>(a.attn, reinterpret_cast<const uint4*>(a.kt + (size_t)qi * 256 * kAttnLP),
                                              reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
@@ -693,6 +698,7 @@ int launch_search_attn_split(int d, int dt, int vis, int slots, size_t lds_bytes
 // the pre-projected form (nann_attn_proj.h): one instantiation per plan for every d / row dtype (it never reads the
 // embedding table); launch_attn_preproject fills the f32 [n_rows, kAttnProjWidth] table.  nann_attn_split_inst.hip
 int launch_search_attn_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_attn_xproj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);  // nann_attn_inst.hip
 int launch_attn_preproject(int dt, const AttnParams& P, const void* emb, long long n_rows, float* proj, hipStream_t st);
 int launch_score_mlp_d64(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,

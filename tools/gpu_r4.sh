@@ -342,6 +342,12 @@ PY
       NANN_EVAL_SEEN=hbm timeout 400 python tools/eval_bench.py /tmp/idx 1024 3 > $OUT/eval_bench_hbm_$TAG.json 2> $OUT/eval_bench_hbm_$TAG.err; tail -1 $OUT/eval_bench_hbm_$TAG.json | cut -c1-900 ;;
     tests_eval)
       timeout 600 python -m pytest tests/test_search_gpu.py -m gpu -q --timeout 300 -x -k "eval" > $OUT/pytest_eval_$TAG.log 2>&1; tail -5 $OUT/pytest_eval_$TAG.log ;;
+    tests_attn)
+      timeout 900 python -m pytest tests -m gpu -q --timeout 300 -x -k "attn or attention or model" > $OUT/pytest_attn_$TAG.log 2>&1; tail -5 $OUT/pytest_attn_$TAG.log ;;
+    bench_attn_ab)  # the attention model's serving rate: default forms (both on the pre-projected table) against the forms on the embedding rows
+      timeout 300 python tools/attn_bench.py /tmp/idx 512 > $OUT/bench_attn_$TAG.txt 2> $OUT/bench_attn_$TAG.err
+      NANN_PREPROJECT=0 timeout 300 python tools/attn_bench.py /tmp/idx 512 >> $OUT/bench_attn_$TAG.txt 2>> $OUT/bench_attn_$TAG.err
+      cut -c1-600 $OUT/bench_attn_$TAG.txt; tail -2 $OUT/bench_attn_$TAG.err | grep -v amdgpu.ids ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
