@@ -1724,7 +1724,7 @@ constexpr int kKindMlpSplit = 3;  //   the MLP scorer in split-f16 form (two sli
 constexpr int kKindMlpRes = 4;    //   the MLP scorer, either precision, on the pre-projected table with layer 2 resident in LDS
                                   //   (nann_mlp5.h): 16K-slot set under the weights, or the HBM bitmap
 // kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
-static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p) {
+static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p, bool mlp_exact_hint = false) {
   for (int i = 0; i < 6; ++i)
     if (t[i] < 0 || t[i] > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "level_topn entries must be in [0, 1024]");
   DeviceInfo di;
@@ -1827,8 +1827,15 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     p->slots = p->fb_slots;
   }
   // the MLP's pipeline of phases (nann_mlp6.h): traversal stages at the 16K-slot plan's geometry, one slot per query of a chunk
+  // Where it pays (profiles/r4tu_mlp_batch_sweep_phased_vs_fused.txt, configs[2]): exact f32 at every batch size (batch 32:
+  // 3.4x -- the scoring launch spreads 32 queries' rows over the chip, the fused kernel holds 32 CUs --, 128: 1.7x, >= 256:
+  // +3..8 %); split-f16 below ~160 queries (batch 32: 1.64x) and between ~640 and ~2048 (1024: +5 %); at 256-512 the fused
+  // kernel's single launch is ahead (its query-per-CU latency is shorter than 17 launches), at 4096 by 2.7 % (its queue
+  // balances four chunks' worth of queries in one grid).  NANN_MLP_MAPPING=7: always, =5: never.
+  const bool exact_form = mlp_exact_hint;
+  const bool pays = exact_form || n_queries <= 160 || (n_queries > 640 && n_queries <= 2048);
   p->phased = res && own_hash_plan && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP &&
-              2 * hash16_lds <= di.lds_max && mlp_mapping_choice() >= 6;
+              2 * hash16_lds <= di.lds_max && (mlp_mapping_choice() >= 7 || (mlp_mapping_choice() == 6 && pays));
   p->phase_lds_bytes = hash16_lds;
   p->phase_slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), (int64_t)di.cus * 2));
   if (kind < 0)  // sizing: the widest plan (two workgroups per CU, or one slot per query of a phased chunk)
@@ -1871,7 +1878,7 @@ namespace nann {
 int mlp_mapping_choice() {
   static const int choice = [] {
     const char* e = std::getenv("NANN_MLP_MAPPING");
-    return (e && e[0] >= '1' && e[0] <= '6' && e[1] == 0) ? e[0] - '0' : 6;
+    return (e && e[0] >= '1' && e[0] <= '7' && e[1] == 0) ? e[0] - '0' : 6;
   }();
   return choice;
 }
@@ -1969,7 +1976,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   if (rc) return rc;
   const bool mlp_res = mlp && tab && mapping >= 5;  // layer 2 resident in LDS, either precision (nann_mlp5.h)
   SearchPlan p;
-  rc = plan_search(ix, level_topn, n_queries, mlp_res ? kKindMlpRes : mlp_split ? kKindMlpSplit : kind, &p);
+  rc = plan_search(ix, level_topn, n_queries, mlp_res ? kKindMlpRes : mlp_split ? kKindMlpSplit : kind, &p, mlp && !mlp_split);
   if (rc) return rc;
   const int64_t need_slots = p.phased ? std::max<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), p.fb_slots) : std::max(p.slots, p.fb_slots);
   if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)need_slots + (p.phased ? kPhaseTail : 0)))

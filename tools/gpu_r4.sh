@@ -348,6 +348,18 @@ PY
       timeout 300 python tools/attn_bench.py /tmp/idx 512 > $OUT/bench_attn_$TAG.txt 2> $OUT/bench_attn_$TAG.err
       NANN_PREPROJECT=0 timeout 300 python tools/attn_bench.py /tmp/idx 512 >> $OUT/bench_attn_$TAG.txt 2>> $OUT/bench_attn_$TAG.err
       cut -c1-600 $OUT/bench_attn_$TAG.txt; tail -2 $OUT/bench_attn_$TAG.err | grep -v amdgpu.ids ;;
+    bench_mlp_small)  # where does the pipeline of phases (17 launches per chunk) stop paying?  batch sweep, mapping 6 against the fused kernel (5)
+      for B in ${SMALL_BATCHES:-32 128 256 512 2048 4096}; do for M in 6 5; do
+        NANN_MLP_MAPPING=$M timeout 200 $BENCH --scorer mlp --mlp-precision ${SMALL_PREC:-split} --batch $B --steps ${SMALL_STEPS:-60} --warmup ${SMALL_STEPS:-60} --no-secondary --no-cpu-baseline > $OUT/bench_mlp_small_b${B}_map${M}_$TAG.json 2> $OUT/bench_mlp_small_b${B}_map${M}_$TAG.err
+        python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench_mlp_small_b${B}_map${M}_$TAG.json').read().strip().splitlines()[-1])
+    print('SMALL batch %5d mapping $M  qps %9.0f  ms/step %7.4f  kernel_ms %7.4f' % ($B, d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))
+except Exception as e:
+    print('SMALL $B $M failed', e)
+PY
+      done; done ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
