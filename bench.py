@@ -562,24 +562,32 @@ def batch_sweep(handles, topn, sizes):
 
 
 def eval_graph_rate(handles, n_users=1024):
-    """f3: users/s of the evaluation graph's traversal in one kernel (nann_search_eval), the reference's
-    defaults (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned)"""
+    """f3: users/s of the evaluation graph's traversal in one kernel (nann_search_eval): the reference's defaults
+    (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned) and a wide setting above the serving kernels' 1024"""
     import torch
     from nann_amd import ops, retrieval
     index, scorer, seqs = handles
     q = ops.user_seq_mean(seqs[0][:n_users])
-    ts = []
-    for it in range(1 + 3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = retrieval.search_eval(index, scorer, q, (3, 1, 1), (400, 200, 100), 200)
-        e1.record()
-        torch.cuda.synchronize()
-        if it >= 1:
-            ts.append(e0.elapsed_time(e1))
-    ms = float(np.median(ts))
-    return {"users": int(q.shape[0]), "ms": round(ms, 3), "users_per_s": round(q.shape[0] / (ms * 1e-3), 1),
-            "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1)}
+    out = {}
+    for name, cfg in (("defaults", ((3, 1, 1), (400, 200, 100), 200)), ("top_k_2000_1000_500", ((3, 1, 1), (2000, 1000, 500), 1000))):
+        ts = []
+        for it in range(1 + 3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = retrieval.search_eval(index, scorer, q, *cfg)
+            e1.record()
+            torch.cuda.synchronize()
+            if it >= 1:
+                ts.append(e0.elapsed_time(e1))
+        ms = float(np.median(ts))
+        res = {"users": int(q.shape[0]), "ms": round(ms, 3), "users_per_s": round(q.shape[0] / (ms * 1e-3), 1),
+               "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1)}
+        if name == "defaults":
+            out.update(res)
+        else:
+            out[name] = res
+    out["kernel"] = "k_search_eval: seen bitmap in LDS, owner-thread scan against visited (nann_eval.h); parity: tests/test_search_gpu.py, tools/eval_bench.py"
+    return out
 
 
 def attention_model_rate(handles, dim, topn, precision, n_users=512):
@@ -607,8 +615,9 @@ def attention_model_rate(handles, dim, topn, precision, n_users=512):
     ms = float(np.median(ts))
     out = {"users": n_users, "precision": precision, "ms": round(ms, 3),
            "queries_per_s": round(n_users / (ms * 1e-3), 1), "failed": int((r.status != 0).sum())}
+    out["form"] = ("item-only layers pre-projected per (model, index): nann_attn_proj.h" if precision == "split" else
+                   "f32 MFMA on the same pre-projected table: nann_attn_kernels.h wg_score_attn<PROJ>")
     if precision == "split":
-        out["form"] = "item-only layers pre-projected per (model, index): nann_attn_proj.h"
         pmc = load_pmc_counters("attention_model_f2_split")
         if pmc is not None:
             out["counters"] = pmc
