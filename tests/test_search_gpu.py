@@ -149,6 +149,46 @@ def test_mlp_search_matches_oracle(oracle):
     _assert_same(got, exp)
 
 
+@pytest.mark.parametrize("precision", ["exact", "split"])
+def test_mlp_pipeline_of_phases_chunks_and_fused_agree(oracle, precision):
+    """The MLP traversal as a pipeline of phases (nann_mlp6.h) against the fused kernel (nann_mlp5.h) on the same
+    queries: 1100 queries in one call = two chunks of the pipeline (1024 + 76; split-f16 runs it at 641..2048 queries,
+    exact always), the same queries in calls of 300 = the fused kernel for split-f16 (161..640): exact results do
+    not depend on the batch size bit for bit; the two split-f16 kernels agree within the scorer's tolerance; and a
+    sample against the oracle (exact: bit for bit, counters included)."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 128, 32)
+    w = synth.make_mlp_weights(128)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 1100, seed=21)])
+    topn = [32] * 5 + [20]
+    sc = ops.Scorer("mlp", 128, torch.float16, w, precision=precision)
+
+    def run(qq):
+        r = retrieval.search(dix, sc, cuda(qq), topn)
+        torch.cuda.synchronize()
+        return (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy(),
+                r.counters.cpu().numpy())
+
+    whole = run(q)
+    parts = [run(q[i:i + 300]) for i in range(0, 1100, 300)]
+    cat = [np.concatenate([p_[j] for p_ in parts]) for j in range(5)]
+    assert (whole[0] == cat[0]).all() and (whole[0] == 0).mean() > 0.5
+    if precision == "exact":  # one arithmetic whatever the batch size
+        assert (whole[1] == cat[1]).all() and (bits(whole[2]) == bits(cat[2])).all() and (whole[4] == cat[4]).all()
+    else:  # the two split-f16 kernels sum the output layer in different orders: the scorer's tolerance
+        kinds = [tolerant_parity(whole[3][b], whole[2][b], cat[3][b], cat[2][b]) for b in range(1100) if whole[0][b] == 0]
+        assert kinds.count("diverged") <= len(kinds) // 50 and kinds.count("exact") >= len(kinds) * 0.9, (
+            kinds.count("exact"), kinds.count("diverged"), len(kinds))
+    sample = np.r_[0:24, 1020:1044, 1090:1100]  # both chunks and the seam
+    exp = oracle.search_batch(oix, oracle.Scorer("mlp", 128, oracle.EMB_F16, w), q[sample], topn, n_threads=8)
+    if precision == "exact":
+        _assert_same(tuple(a[sample] for a in whole), exp)
+    else:
+        assert (whole[0][sample] == exp[0]).all()
+        kinds = [tolerant_parity(whole[3][b], whole[2][b], exp[3][i], exp[2][i]) for i, b in enumerate(sample) if exp[0][i] == 0]
+        assert kinds.count("diverged") <= max(1, len(kinds) // 16), kinds
+
+
 @pytest.mark.parametrize("mode", ["auto", "lds_hash", "lds_bitmap", "hbm_bitmap"])
 def test_mlp_split_f16_search_within_tolerance(oracle, mode):
     """(auto = the 16K-slot hash set with one 512-thread workgroup per CU; the bitmap kernels are its overflow
