@@ -356,9 +356,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         mapping = os.environ.get("NANN_MLP_MAPPING", "6")
         table_form = os.environ.get("NANN_PREPROJECT", "1") != "0" and (mapping in "567" or (precision == "split" and mapping in "34"))
         # the pipeline of phases runs where it pays (nann_hip.hip plan_search: beams that fit the 16K-slot set; exact at every
-        # batch size, split-f16 at <= 160 and 641..2048 queries) -- the label follows the same rule
+        # batch size, split-f16 at <= 160 queries) -- the label follows the same rule
         phased = (table_form and cfg.get("traversal", "auto") == "auto" and
-                  (mapping == "7" or (mapping == "6" and (precision == "exact" or batch <= 160 or 640 < batch <= 2048))))
+                  (mapping == "7" or (mapping == "6" and (precision == "exact" or batch <= 160))))
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
         if precision == "split":
             per_row = 3 * 2.0 * 256 * 128 + (0 if table_form else 2 * 2.0 * dim * 256)

@@ -1827,13 +1827,13 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     p->slots = p->fb_slots;
   }
   // the MLP's pipeline of phases (nann_mlp6.h): traversal stages at the 16K-slot plan's geometry, one slot per query of a chunk
-  // Where it pays (profiles/r4tu_mlp_batch_sweep_phased_vs_fused.txt, configs[2]): exact f32 at every batch size (batch 32:
-  // 3.4x -- the scoring launch spreads 32 queries' rows over the chip, the fused kernel holds 32 CUs --, 128: 1.7x, >= 256:
-  // +3..8 %); split-f16 below ~160 queries (batch 32: 1.64x) and between ~640 and ~2048 (1024: +5 %); at 256-512 the fused
-  // kernel's single launch is ahead (its query-per-CU latency is shorter than 17 launches), at 4096 by 2.7 % (its queue
-  // balances four chunks' worth of queries in one grid).  NANN_MLP_MAPPING=7: always, =5: never.
+  // Where it pays (profiles/r4tu_mlp_batch_sweep_phased_vs_fused.txt, r4x_mlp_loop_ab.txt; configs[2]): exact f32 at every
+  // batch size (batch 32: 3.4x -- the scoring launch spreads 32 queries' rows over the chip, the fused kernel holds 32 CUs --,
+  // 128: 1.7x, >= 256: +3..8 %); split-f16 below ~160 queries (batch 32: 1.64x).  Above that the fused split-f16 kernel, which
+  // runs the same software-pipelined block loop, is level with it or ahead: 256-512 queries +8..19 % (one query per CU finishes
+  // sooner than 17 launches), 1024: within 2 % either way box to box, 4096: +2.7 %.  NANN_MLP_MAPPING=7: always, =5: never.
   const bool exact_form = mlp_exact_hint;
-  const bool pays = exact_form || n_queries <= 160 || (n_queries > 640 && n_queries <= 2048);
+  const bool pays = exact_form || n_queries <= 160;
   p->phased = res && own_hash_plan && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP &&
               2 * hash16_lds <= di.lds_max && (mlp_mapping_choice() >= 7 || (mlp_mapping_choice() == 6 && pays));
   p->phase_lds_bytes = hash16_lds;

@@ -123,6 +123,13 @@ __device__ __forceinline__ void wg_mlp_res_leave(uint4* lds, const uint4* park, 
 #ifndef NANN_RES_ROLLED
 #define NANN_RES_ROLLED 0
 #endif
+#ifndef NANN_PIPE_ASM
+#define NANN_PIPE_ASM 0  // 1: the pipeline's PReLU as hand-written packed-f32 asm -- fewer instructions (7 instead of ~9 per pair) and SLOWER
+                        // (379 k against 388 k queries/s, profiles/r4x_*: asm statements pin the order hipcc would otherwise choose)
+#endif
+#ifndef NANN_RES_PIPE
+#define NANN_RES_PIPE 1  // the software-pipelined block loop (wave_mlp_split_pipeline); 0: the tile-phased loop of r4a-r4j
+#endif
 #ifndef NANN_RES_WF16
 #define NANN_RES_WF16 0  // 1: all sixteen A fragments of a tile read at its top (32 more live registers) instead of 8 + 8
 #endif
@@ -133,6 +140,196 @@ typedef const __attribute__((address_space(3))) f32x4v* lds_f4_ptr;
 __device__ __forceinline__ uint32_t lds_offset_of(const void* p) {  // a generic pointer into LDS -> its LDS byte address
   return (uint32_t)(size_t)p;  // (the LDS aperture's low 32 bits are the LDS address)
 }
+// ---------------------------------------------------------------------------------------------------------------
+// split-f16 scoring of a sequence of 32-row blocks by ONE wavefront as a software pipeline (round 4, second half; used by
+// the fused kernel below and by the scoring launch of the pipeline of phases, nann_mlp6.h).
+//
+// A block is 8 tiles x 2 steps (16 k each) x 12 MFMAs (hi.hi, hi.lo, lo.hi for four 32-unit output tiles).  Two
+// symmetric wavefronts per SIMD that alternate "convert a tile" / "multiply a tile" drift into step and add their
+// vector time to their MFMA time (profiles/r4d: 88.7 cycles per row against an MFMA floor of 48).  Here every MFMA
+// carries a slice of the NEXT step's other work in its shadow, in source order, fenced by sched_barrier:
+//   hi.hi of output tile mt   -> PReLU of pair mt of the next tile's step (packed f32 by hand)
+//   hi.lo                     -> its f16 halves; the hi fragment of W2 for the next step into the register just freed
+//                                (ds_read); one ds_read of the next conversion's u / beta
+//   lo.hi                     -> the lo fragment likewise; step 0: one 16-byte gather of the tile after next
+// Per accumulator the order of products is the older loop's (hi.hi, hi.lo, lo.hi per step): same bits in layer 2.
+//
+// advance(k, row, next, change, u_next): called at the top of block k with this block's row pointer; sets the row
+// pointer of the block behind it (this lane's row + 4 g floats; `row` again when there is none), and, when that block
+// belongs to another query, change = true and u_next = this lane's 16 bytes of that query's u x 2^7 (written to L.u_wr
+// behind the last read of the current u).  store(k, score): every lane, the block's score of its row (lanes g and g ^ 1
+// hold the same value).  VAR: timing builds (nann_mlp6.h NANN_PHASE_VAR).  KW3B >= 0: the packed output layer (below).
+struct SplitPipeLds {  // opaque LDS byte addresses (an `asm volatile("" : "+v"(x))` behind each, see wg_score_mlp_res)
+  uint32_t w_lo, w_hi;  // W2 fragments below / above 64 KB, + lane * 16
+  uint32_t v_at;        // Mlp2Vectors, + g * 16
+  uint32_t u_at;        // the current query's u x 2^7 [256], + g * 16 (the fused kernel: = v_at)
+  uint32_t u_wr;        // where this lane writes its 16 bytes of the next query's u (fused kernel: unused)
+};
+template <int VAR, int KW3B, class Advance, class Store>
+__device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, const float* row, int n_blocks,
+                                                        Advance advance, Store store) {
+  constexpr int H1T = 8, H2T = 4;
+  constexpr int kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
+  const uint32_t w_lo = L.w_lo, w_hi = L.w_hi, v_at = L.v_at, u_at = L.u_at;
+  auto vec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(v_at + 4 * float_index); };
+  auto uvec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(u_at + 4 * float_index); };
+  auto fragt = [&](int t, int k) -> f16x8 {
+    const u32x4v v = *reinterpret_cast<lds_u4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + k * 1024);
+    return __builtin_bit_cast(f16x8, v);
+  };
+  auto lds_write_u = [&](float4 v) {
+    typedef __attribute__((address_space(3))) f32x4v* lds_f4_wptr;
+    *reinterpret_cast<lds_f4_wptr>(L.u_wr) = f32x4v{v.x, v.y, v.z, v.w};
+  };
+  f32x4v x[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) x[t][rr] = *reinterpret_cast<const f32x4v*>(row + 32 * t + 8 * rr);
+  f16x8 Wf[2 * H2T];
+  uint32_t Bh[2][2][4], Bl[2][2][4];  // [tile parity][step][pair]: the B fragments of a tile, high and low halves
+  f32x4v cu[2], cb[2];                // u / beta of the step being converted
+#pragma unroll
+  for (int k = 0; k < 2 * H2T; ++k) Wf[k] = fragt(0, k);
+  // PReLU + split of one pair in two halves, so that each rides in another MFMA's shadow: a = PReLU(x + u) ...
+  auto convert_a = [&](const f32x4v (&xt)[4], int q, int p) -> f32x2 {
+    const int half = p >> 1;
+    const f32x4v xv = xt[2 * q + half], u = cu[half], be = cb[half];
+    const f32x2 xp = (p & 1) ? f32x2{xv.z, xv.w} : f32x2{xv.x, xv.y};
+    const f32x2 up = (p & 1) ? f32x2{u.z, u.w} : f32x2{u.x, u.y};
+    const f32x2 bp = (p & 1) ? f32x2{be.z, be.w} : f32x2{be.x, be.y};
+    // packed f32 forms by hand (left to itself hipcc scalarises about half of them; the vector pipe's issue slots
+    // are what bounds this loop): x + u, min(., 0) per half (there is no packed f32 min), (alpha - 1) min + (x + u)
+#if NANN_PIPE_ASM
+    f32x2 xs, h;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(xs) : "v"(xp), "v"(up));
+    f32x2 m;
+    asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xs.x));
+    asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xs.y));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(bp), "v"(xs));
+    return h;
+#else
+    const f32x2 xs = xp + up;
+    const f32x2 m = __builtin_elementwise_min(xs, f32x2{0.0f, 0.0f});
+    return __builtin_elementwise_fma(m, bp, xs);
+#endif
+  };
+  // ... and its f16 halves: hi = rtz(a), lo = a - hi (prelu_split_pair_pk's arithmetic, nann_mlp2.h)
+  auto convert_b = [&](f32x2 h, uint32_t& hi, uint32_t& lo) {
+    typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h.x, h.y));
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(h.x));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(h.y));
+    lo = l;
+  };
+  auto convert_pair = [&](const f32x4v (&xt)[4], int q, int p, uint32_t& h, uint32_t& l) { convert_b(convert_a(xt, q, p), h, l); };
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {  // the first block's tile 0, outside the pipeline
+    cu[0] = uvec4(8 * (2 * q)); cu[1] = uvec4(8 * (2 * q + 1));
+    cb[0] = vec4(kBeta1 + 8 * (2 * q)); cb[1] = vec4(kBeta1 + 8 * (2 * q + 1));
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) convert_pair(x[0], q, pp, Bh[0][q][pp], Bl[0][q][pp]);
+  }
+  cu[0] = uvec4(32); cu[1] = uvec4(32 + 8); cb[0] = vec4(kBeta1 + 32); cb[1] = vec4(kBeta1 + 32 + 8);  // tile 1, step 0
+  for (int k = 0; k < n_blocks; ++k) {
+    const float* next = row;
+    bool change = false;
+    float4 u_next = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    advance(k, row, next, change, u_next);
+    f32x16 acc[H2T];
+#pragma unroll
+    for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
+        acc[mt][4 * rr] = v.x; acc[mt][4 * rr + 1] = v.y; acc[mt][4 * rr + 2] = v.z; acc[mt][4 * rr + 3] = v.w;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < H1T; ++t) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int cbuf = t & 1, nbuf = (t + 1) & 1;
+        const int nt = (q ? t + 1 : t) & (H1T - 1), nq = q ^ 1;  // the next step: its W2 fragments ...
+        const int ct = ((q ? t + 1 : t) + 1) & (H1T - 1);        // ... and the tile whose conversion rides on it
+        // the next block's query takes over the wavefront's u: behind the last read of this block's (step (6, 0)),
+        // in front of the first read for the next block's tile 0 (below)
+        if (t == H1T - 2 && q == 1 && change) lds_write_u(u_next);
+        const f16x8 bh = as_f16x8(uint4{Bh[cbuf][q][0], Bh[cbuf][q][1], Bh[cbuf][q][2], Bh[cbuf][q][3]});
+        const f16x8 bl = as_f16x8(uint4{Bl[cbuf][q][0], Bl[cbuf][q][1], Bl[cbuf][q][2], Bl[cbuf][q][3]});
+        f32x2 hv[H2T] = {};
+#pragma unroll
+        for (int mt = 0; mt < H2T; ++mt) {
+          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bh, acc[mt], 0, 0, 0);
+          if (!(VAR & 4)) hv[mt] = convert_a(x[nbuf], q, mt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < H2T; ++mt) {
+          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bl, acc[mt], 0, 0, 0);
+          if (!(VAR & 2)) Wf[2 * mt] = fragt(nt, nq * 2 * H2T + 2 * mt);
+          const int rr = 2 * nq + (mt & 1);  // u / beta of the next step's conversion (this step's were read above)
+          if (!(VAR & 4)) {
+            if (mt < 2) cu[mt & 1] = uvec4(32 * ct + 8 * rr); else cb[mt & 1] = vec4(kBeta1 + 32 * ct + 8 * rr);
+            convert_b(hv[mt], Bh[nbuf][q][mt], Bl[nbuf][q][mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < H2T; ++mt) {
+          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt + 1], bh, acc[mt], 0, 0, 0);
+          if (!(VAR & 2)) Wf[2 * mt + 1] = fragt(nt, nq * 2 * H2T + 2 * mt + 1);
+          if (q == 0 && !(VAR & 1))  // tile t + 2 (of the next block behind tile 5) into the buffer tile t was converted from
+            x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // PReLU of layer 2 and the bias-free output layer
+    float part;
+    if constexpr (KW3B >= 0) {
+      // sum_j w3_j (x_j + beta2_j min(x_j, 0)) as two packed-f32 dot products, w3 . x and (w3 beta2) . min(x, 0) -- 2 vector
+      // instructions per unit instead of 3 (the caller staged w3 beta2 at float KW3B of the vectors)
+      f32x2 dot[4] = {};
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v w3 = vec4(kW3 + 32 * mt + 8 * rr), wb = vec4(KW3B + 32 * mt + 8 * rr);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const f32x2 xa = f32x2{acc[mt][4 * rr + e], acc[mt][4 * rr + e + 1]};
+            const f32x2 w3p = e ? f32x2{w3.z, w3.w} : f32x2{w3.x, w3.y}, wbp = e ? f32x2{wb.z, wb.w} : f32x2{wb.x, wb.y};
+            f32x2 m;
+            asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xa.x));
+            asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xa.y));
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dot[e >> 1]) : "v"(xa), "v"(w3p));
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dot[2 + (e >> 1)]) : "v"(m), "v"(wbp));
+          }
+        }
+      part = ((dot[0].x + dot[0].y) + (dot[1].x + dot[1].y)) + ((dot[2].x + dot[2].y) + (dot[3].x + dot[3].y));
+    } else {  // one chain, unit by unit (the fused kernel since round 4's first half)
+      part = 0.0f;
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v be = vec4(kBeta2 + 32 * mt + 8 * rr), w3 = vec4(kW3 + 32 * mt + 8 * rr);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xa = acc[mt][4 * rr + e];
+            part = __builtin_fmaf(__builtin_fmaf(neg_part(xa), be[e], xa), w3[e], part);
+          }
+        }
+    }
+    const float other = __shfl_xor(part, 32);
+    constexpr float kUnscale = 1.0f / (kSplit2Scale * kSplit2Scale);
+    store(k, (part + other) * kUnscale);
+    row = next;
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj, uint32_t n_table_rows,
                                                  const int32_t* ids, int n, const uint4* W2, const Mlp2Vectors* V,
@@ -170,6 +367,24 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
   constexpr int kU = 0, kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
   static_assert(offsetof(Mlp2Vectors, beta1) == 4 * kBeta1 && offsetof(Mlp2Vectors, b2) == 4 * kB2 &&
                 offsetof(Mlp2Vectors, beta2) == 4 * kBeta2 && offsetof(Mlp2Vectors, w3) == 4 * kW3, "Mlp2Vectors layout");
+#if NANN_RES_PIPE
+  {  // round 4, second half: the software pipeline (NANN_RES_PIPE=0: the loop below, the form of r4a-r4j)
+    SplitPipeLds L;
+    L.w_lo = w_lo; L.w_hi = w_hi; L.v_at = v_at; L.u_at = v_at; L.u_wr = 0u;  // (kU = 0: the query's u heads the vectors)
+    int i_cur = 0;
+    wave_mlp_split_pipeline<0, -1>(
+        L, row_ptr(wave * 32 + cand), (nblk - wave + NW - 1) / NW,
+        [&](int k, const float* row_k, const float*& next, bool&, float4&) {
+          const int b = wave + k * NW;
+          i_cur = b * 32 + cand;
+          next = (b + NW < nblk) ? row_ptr(i_cur + NW * 32) : row_k;
+        },
+        [&](int, float score) {
+          if (g == 0 && i_cur < n) scores[i_cur] = score;
+        });
+    return;
+  }
+#endif
   const float* row = row_ptr(wave * 32 + cand);
   // gathers run two tiles ahead of their use
   float4 x[2][4];

@@ -57,6 +57,10 @@ struct PhaseScoreArgs {
 #ifndef NANN_PHASE_VAR
 #define NANN_PHASE_VAR 0
 #endif
+#ifndef NANN_PHASE_PACKED_EPI
+#define NANN_PHASE_PACKED_EPI 0  // 1: the scoring launch's output layer as two packed dot products (2 instead of 3 instructions per unit;
+                                 // measured 0.7 % slower, and other bits than the fused kernel's chain: profiles/r4x_*)
+#endif
 
 // blocks (32 rows) each pending query contributes to round `round`, as exclusive prefix sums.  One workgroup of
 // kPhaseChunk threads.
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
     const uint4* src = EXACT ? reinterpret_cast<const uint4*>(a.mlp.p2x) : a.mlp.p2;
     for (int i = tid; i < kMlpResW2Vec; i += NT) W2[i] = src[i];
     if (EXACT) wg_mlp_xres_vectors<NT>(a.mlp, 0.0f, V); else wg_mlp_res_vectors<NT>(a.mlp, 0.0f, V);
-    if (!EXACT && tid < 128) V->u[tid] = a.mlp.w3[tid] * (a.mlp.alpha2[tid] - 1.0f);  // (the same thread wrote the 0 above)
+    if (!EXACT && NANN_PHASE_PACKED_EPI && tid < 128) V->u[tid] = a.mlp.w3[tid] * (a.mlp.alpha2[tid] - 1.0f);  // (the same thread wrote the 0 above)
     for (int i = tid; i <= a.n_queries; i += NT) prefix[i] = a.blk_prefix[i];
   }
   __syncthreads();
@@ -162,25 +166,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
   constexpr int kW3b = 0;  // split-f16: w3 (alpha2 - 1), in the place of the fused kernel's per-workgroup u (here: one u per wavefront)
 
   if constexpr (!EXACT) {
-    // ---- split-f16: one software pipeline over the wavefront's blocks ------------------------------------------------
-    // A block is 8 tiles x 2 steps (16 k each) x 12 MFMAs (hi.hi, hi.lo, lo.hi for four 32-unit output tiles).  Two
-    // symmetric wavefronts per SIMD that alternate "convert a tile" / "multiply a tile" drift into step and add their
-    // VALU time to their MFMA time (profiles/r4d: 88.7 cycles per row against an MFMA floor of 48).  Here every MFMA
-    // carries a slice of the NEXT step's other work in its shadow, in source order, fenced by sched_barrier:
-    //   hi.hi of output tile mt   -> PReLU of pair mt of the next tile's step
-    //   hi.lo                     -> its f16 halves; the hi fragment of W2 for the next step into the register just freed
-    //                                (ds_read); one ds_read of the next conversion's u / beta
-    //   lo.hi                     -> the lo fragment likewise; step 0: one 16-byte gather of the tile after next
-    // so that one wavefront alone keeps the matrix pipe fed.  Per accumulator the order of products is the fused
-    // kernel's (nann_mlp5.h): same bits.
-    auto fragt = [&](int t, int k) -> f16x8 {
-      const u32x4v v = *reinterpret_cast<lds_u4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + k * 1024);
-      return __builtin_bit_cast(f16x8, v);
-    };
-    auto lds_write_u = [&](float4 v) {
-      typedef __attribute__((address_space(3))) f32x4v* lds_f4_wptr;
-      *reinterpret_cast<lds_f4_wptr>(lds_offset_of(u_w) + (uint32_t)lane * 16u) = f32x4v{v.x, v.y, v.z, v.w};
-    };
+    // ---- split-f16: one software pipeline over the wavefront's blocks (wave_mlp_split_pipeline, nann_mlp5.h)
     auto read_u_of = [&](int q) -> float4 {
       const PhaseState* st = reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)q * a.slot_bytes + a.off_state);
       float4 v = reinterpret_cast<const float4*>(st->u)[lane];
@@ -189,140 +175,29 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
     };
     Cur cur, nxt;
     enter_query(query_of(b_lo), cur, true);
-    const float* row = row_ptr(cur, b_lo);
-    f32x4v x[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) x[t][rr] = *reinterpret_cast<const f32x4v*>(row + 32 * t + 8 * rr);
-    f16x8 Wf[2 * H2T];
-    uint32_t Bh[2][2][4], Bl[2][2][4];  // [tile parity][step][pair]: the B fragments of a tile, high and low halves
-    f32x4v cu[2], cb[2];                // u / beta of the step being converted
-#pragma unroll
-    for (int k = 0; k < 2 * H2T; ++k) Wf[k] = fragt(0, k);
-    // PReLU + split of one pair in two halves, so that each rides in another MFMA's shadow: a = PReLU(x + u) ...
-    auto convert_a = [&](const f32x4v (&xt)[4], int q, int p) -> f32x2 {
-      const int half = p >> 1;
-      const f32x4v xv = xt[2 * q + half], u = cu[half], be = cb[half];
-      const f32x2 xp = (p & 1) ? f32x2{xv.z, xv.w} : f32x2{xv.x, xv.y};
-      const f32x2 up = (p & 1) ? f32x2{u.z, u.w} : f32x2{u.x, u.y};
-      const f32x2 bp = (p & 1) ? f32x2{be.z, be.w} : f32x2{be.x, be.y};
-      // packed f32 forms by hand (left to itself hipcc scalarises about half of them; the vector pipe's issue slots
-      // are what bounds this loop): x + u, min(., 0) per half (there is no packed f32 min), (alpha - 1) min + (x + u)
-      f32x2 xs, h;
-      asm("v_pk_add_f32 %0, %1, %2" : "=v"(xs) : "v"(xp), "v"(up));
-      f32x2 m;
-      asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xs.x));
-      asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xs.y));
-      asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(bp), "v"(xs));
-      return h;
-    };
-    // ... and its f16 halves: hi = rtz(a), lo = a - hi (prelu_split_pair_pk's arithmetic, nann_mlp2.h)
-    auto convert_b = [&](f32x2 h, uint32_t& hi, uint32_t& lo) {
-      typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
-      hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h.x, h.y));
-      uint32_t l;
-      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(h.x));
-      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(h.y));
-      lo = l;
-    };
-    auto convert_pair = [&](const f32x4v (&xt)[4], int q, int p, uint32_t& h, uint32_t& l) { convert_b(convert_a(xt, q, p), h, l); };
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {  // the first block's tile 0, outside the pipeline
-      cu[0] = uvec4(8 * (2 * q)); cu[1] = uvec4(8 * (2 * q + 1));
-      cb[0] = vec4(kBeta1 + 8 * (2 * q)); cb[1] = vec4(kBeta1 + 8 * (2 * q + 1));
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) convert_pair(x[0], q, pp, Bh[0][q][pp], Bl[0][q][pp]);
-    }
-    cu[0] = uvec4(32); cu[1] = uvec4(32 + 8); cb[0] = vec4(kBeta1 + 32); cb[1] = vec4(kBeta1 + 32 + 8);  // tile 1, step 0
-    for (int b = b_lo; b < b_hi; ++b) {
-      nxt = cur;
-      bool change = false;
-      if (b + 1 < b_hi && b + 1 >= prefix[cur.q + 1]) {
-        int q2 = cur.q + 1;
-        while (prefix[q2 + 1] <= b + 1) ++q2;  // (queries without blocks)
-        enter_query(q2, nxt, false);
-        change = true;
-      }
-      const float* next = (b + 1 < b_hi) ? row_ptr(nxt, b + 1) : row;
-      float4 u_next = float4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (change) u_next = read_u_of(nxt.q);
-      const int i = (b - cur.first) * 32 + cand;
-      f32x16 acc[H2T];
-#pragma unroll
-      for (int mt = 0; mt < H2T; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
-          acc[mt][4 * rr] = v.x; acc[mt][4 * rr + 1] = v.y; acc[mt][4 * rr + 2] = v.z; acc[mt][4 * rr + 3] = v.w;
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < H1T; ++t) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int cbuf = t & 1, nbuf = (t + 1) & 1;
-          const int nt = (q ? t + 1 : t) & (H1T - 1), nq = q ^ 1;  // the next step: its W2 fragments ...
-          const int ct = ((q ? t + 1 : t) + 1) & (H1T - 1);        // ... and the tile whose conversion rides on it
-          // the next block's query takes over the wavefront's u: behind the last read of this block's (step (6, 0)),
-          // in front of the first read for the next block's tile 0 (below)
-          if (t == H1T - 2 && q == 1 && change) lds_write_u(u_next);
-          const f16x8 bh = as_f16x8(uint4{Bh[cbuf][q][0], Bh[cbuf][q][1], Bh[cbuf][q][2], Bh[cbuf][q][3]});
-          const f16x8 bl = as_f16x8(uint4{Bl[cbuf][q][0], Bl[cbuf][q][1], Bl[cbuf][q][2], Bl[cbuf][q][3]});
-          f32x2 hv[H2T] = {};
-#pragma unroll
-          for (int mt = 0; mt < H2T; ++mt) {
-            if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bh, acc[mt], 0, 0, 0);
-            if (!(VAR & 4)) hv[mt] = convert_a(x[nbuf], q, mt);
-            __builtin_amdgcn_sched_barrier(0);
+    int i_cur = 0;
+    SplitPipeLds L;
+    L.w_lo = w_lo; L.w_hi = w_hi; L.v_at = v_at; L.u_at = u_at;
+    L.u_wr = lds_offset_of(u_w) + (uint32_t)lane * 16u;
+    wave_mlp_split_pipeline<VAR, NANN_PHASE_PACKED_EPI ? kW3b : -1>(
+        L, row_ptr(cur, b_lo), b_hi - b_lo,
+        [&](int k, const float* row, const float*& next, bool& change, float4& u_next) {  // the block behind block b_lo + k
+          const int b = b_lo + k;
+          nxt = cur;
+          if (b + 1 < b_hi && b + 1 >= prefix[cur.q + 1]) {
+            int q2 = cur.q + 1;
+            while (prefix[q2 + 1] <= b + 1) ++q2;  // (queries without blocks)
+            enter_query(q2, nxt, false);
+            change = true;
+            u_next = read_u_of(nxt.q);
           }
-#pragma unroll
-          for (int mt = 0; mt < H2T; ++mt) {
-            if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bl, acc[mt], 0, 0, 0);
-            if (!(VAR & 2)) Wf[2 * mt] = fragt(nt, nq * 2 * H2T + 2 * mt);
-            const int rr = 2 * nq + (mt & 1);  // u / beta of the next step's conversion (this step's were read above)
-            if (!(VAR & 4)) {
-              if (mt < 2) cu[mt & 1] = uvec4(32 * ct + 8 * rr); else cb[mt & 1] = vec4(kBeta1 + 32 * ct + 8 * rr);
-              convert_b(hv[mt], Bh[nbuf][q][mt], Bl[nbuf][q][mt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#pragma unroll
-          for (int mt = 0; mt < H2T; ++mt) {
-            if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt + 1], bh, acc[mt], 0, 0, 0);
-            if (!(VAR & 2)) Wf[2 * mt + 1] = fragt(nt, nq * 2 * H2T + 2 * mt + 1);
-            if (q == 0 && !(VAR & 1))  // tile t + 2 (of the next block behind tile 5) into the buffer tile t was converted from
-              x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      // PReLU of layer 2 and the bias-free output layer: sum_j w3_j (x_j + beta2_j min(x_j, 0)) as two packed-f32 dot
-      // products, w3 . x and (w3 beta2) . min(x, 0) -- 2 vector instructions per unit instead of 3
-      f32x2 dot[4] = {};
-#pragma unroll
-      for (int mt = 0; mt < H2T; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const f32x4v w3 = vec4(kW3 + 32 * mt + 8 * rr), wb = vec4(kW3b + 32 * mt + 8 * rr);
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const f32x2 xa = f32x2{acc[mt][4 * rr + e], acc[mt][4 * rr + e + 1]};
-            const f32x2 w3p = e ? f32x2{w3.z, w3.w} : f32x2{w3.x, w3.y}, wbp = e ? f32x2{wb.z, wb.w} : f32x2{wb.x, wb.y};
-            f32x2 m;
-            asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xa.x));
-            asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xa.y));
-            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dot[e >> 1]) : "v"(xa), "v"(w3p));
-            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dot[2 + (e >> 1)]) : "v"(m), "v"(wbp));
-          }
-        }
-      const float part = ((dot[0].x + dot[0].y) + (dot[1].x + dot[1].y)) + ((dot[2].x + dot[2].y) + (dot[3].x + dot[3].y));
-      const float other = __shfl_xor(part, 32);
-      constexpr float kUnscale = 1.0f / (kSplit2Scale * kSplit2Scale);
-      if (g == 0 && i < cur.n && !a.dry) cur.out[i] = (part + other) * kUnscale;
-      row = next;
-      cur = nxt;
-    }
+          next = (b + 1 < b_hi) ? row_ptr(nxt, b + 1) : row;
+          i_cur = (b - cur.first) * 32 + cand;
+        },
+        [&](int, float score) {
+          if (g == 0 && i_cur < cur.n && !a.dry) cur.out[i_cur] = score;
+          cur = nxt;
+        });
     return;
   }
   Cur cur, nxt;
