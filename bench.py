@@ -376,7 +376,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         # bytes the scorer gathers per row: the 1 KB row of the table (f32 x 256) instead of the d x 2 B embedding row
         row_bytes = 1024 if table_form else dim * 2
         tot_b2, _ = algorithmic_bytes(counters[ok], row_bytes // 2, 2, len(g["enter_points"]), topk)
-        kernel_label = ("pipeline of phases (nann_mlp6.h): k_mlp_phase_score<%s> x 5 rounds [dominant] + k_search<phase> x 6 + k_mlp_phase_prefix x 5; "
+        kernel_label = ("pipeline of phases (nann_mlp6.h): k_mlp_phase_score<%s> x 5 rounds [dominant] + k_search<phase> x 6; "
                         "kernel_ms = the whole call" % precision) if phased else (
                         "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form and mapping == "5" else ""))
         roofline = {"bound": "mfma", "kernel": kernel_label,

@@ -1702,7 +1702,7 @@ int nann_index_info(const nann_index* ix, int64_t out[6]) {
 
 // ---- fused search -----------------------------------------------------------------------
 static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
-constexpr int64_t kPhaseTail = 8192;  // behind the slots: the block prefix of the phased MLP pipeline (nann_mlp6.h)
+constexpr int64_t kPhaseTail = 8192;  // behind the slots: reserved (round 4's first pipeline of phases kept its block prefix here)
 // workgroup slots the persistent traversal grid leaves FREE (nann_set_search_reserve): a host that overlaps another
 // stream's kernels with the search -- the exchange step of a sharded search, DESIGN.md 7 -- keeps a few for them; the
 // grid otherwise owns every CU's LDS until its first workgroups exit.  -1: NANN_SEARCH_SLOT_RESERVE from the environment.
@@ -1831,7 +1831,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // batch size (batch 32: 3.4x -- the scoring launch spreads 32 queries' rows over the chip, the fused kernel holds 32 CUs --,
   // 128: 1.7x, >= 256: +3..8 %); split-f16 below ~160 queries (batch 32: 1.64x).  Above that the fused split-f16 kernel, which
   // runs the same software-pipelined block loop, is level with it or ahead: 256-512 queries +8..19 % (one query per CU finishes
-  // sooner than 17 launches), 1024: within 2 % either way box to box, 4096: +2.7 %.  NANN_MLP_MAPPING=7: always, =5: never.
+  // sooner than 12 launches), 1024: within 2 % either way box to box, 4096: +2.7 %.  NANN_MLP_MAPPING=7: always, =5: never.
   const bool exact_form = mlp_exact_hint;
   const bool pays = exact_form || n_queries <= 160;
   p->phased = res && own_hash_plan && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP &&
@@ -2035,12 +2035,11 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   const int exact = scorer->desc.kind == NANN_SCORER_MLP && scorer->desc.precision == NANN_MLP_EXACT_F32;
   if (mlp_res && p.phased) {
     // The default form of both precisions at beams that fit the 16K-slot set: the pipeline of phases (nann_mlp6.h).  Per
-    // chunk of <= 1024 queries: traversal stage 0, then for every round its block prefix, its scoring launch and the
+    // chunk of <= 1024 queries: traversal stage 0, then for every round its scoring launch and the
     // traversal stage behind it; last the rerun of the queries whose set could have overflowed (fused kernel, HBM bitmap).
     DeviceInfo di;
     rc = device_info(&di);
     if (rc) return rc;
-    int* blk_prefix = reinterpret_cast<int*>(static_cast<unsigned char*>(workspace) + 256 + p.slot_bytes * (unsigned long long)need_slots);
     const int k5 = level_topn[5];
     for (int64_t c0 = 0; c0 < n_queries && !rc; c0 += kPhaseChunk) {
       SearchArgs c = a;
@@ -2059,8 +2058,7 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
         c.phase = ph;
         rc = launch_search_mlp_phase(slots, p.phase_lds_bytes, c, st);
         if (!rc && ph < NANN_NUM_ROUNDS) {
-          rc = launch_mlp_phase_prefix(c, ph, blk_prefix, st);
-          if (!rc) rc = launch_mlp_phase_score(exact, c, ph, blk_prefix, di.cus, st);
+          rc = launch_mlp_phase_score(exact, c, ph, di.cus, st);
         }
       }
       if (!rc) {

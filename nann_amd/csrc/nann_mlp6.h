@@ -10,8 +10,8 @@
 //   * the scoring of ALL queries' candidate lists of a round is one launch of k_mlp_phase_score: W2 loaded into LDS once
 //     per workgroup for the whole launch (no per-call reload, no set to park), the 32-row blocks of every query laid end
 //     to end and cut into 2048 equal runs, one per wavefront -- no ragged last blocks per call, no barrier anywhere.
-// Per 1024-query chunk: 6 traversal launches, 5 prefix launches (one workgroup: blocks of every query -> their prefix
-// sums), 5 scoring launches; state between launches lives in the query's slot (PhaseState, the candidate arrays the
+// Per 1024-query chunk: 6 traversal launches and 5 scoring launches (each works out the blocks of every query -> their
+// prefix sums for itself); state between launches lives in the query's slot (PhaseState, the candidate arrays the
 // fused kernel uses anyway, the set parked in the slot's bitmap region around rounds 2 and 3).  Results are what the
 // fused kernel computes: the same building blocks run on the same lists (exact precision: bit-identical to the oracle).
 #pragma once
@@ -41,7 +41,6 @@ struct PhaseScoreArgs {
   unsigned char* ws;            // the search workspace: [header | slots]
   unsigned long long slot_bytes;
   unsigned long long off_cand_ids, off_cand_scores, off_state;  // within a slot
-  const int* blk_prefix;        // [n_queries + 1]: blocks of the queries before q (k_mlp_phase_prefix)
   const int32_t* enter;
   const float* proj;            // the pre-projected table
   uint32_t n_items;
@@ -62,28 +61,6 @@ struct PhaseScoreArgs {
                                  // measured 0.7 % slower, and other bits than the fused kernel's chain: profiles/r4x_*)
 #endif
 
-// blocks (32 rows) each pending query contributes to round `round`, as exclusive prefix sums.  One workgroup of
-// kPhaseChunk threads.
-template <int NTHREADS>  // (a template only so that the header may be included by several translation units)
-__global__ __launch_bounds__(NTHREADS) void k_mlp_phase_prefix(unsigned char* ws, unsigned long long slot_bytes,
-                                                                 unsigned long long off_state, int n_queries, int round,
-                                                                 int* blk_prefix) {
-  __shared__ uint32_t wave_tot[NTHREADS / 64];
-  const int q = threadIdx.x;
-  uint32_t nblk = 0;
-  if (q < n_queries) {
-    const PhaseState* st = reinterpret_cast<const PhaseState*>(ws + 256 + (unsigned long long)q * slot_bytes + off_state);
-    if (st->status == kPhasePending && st->r == round) nblk = (uint32_t)(st->sc_n + 31) >> 5;
-  }
-  const uint32_t inc = wave_scan_add(nblk);
-  if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_tot[w];
-  if (q < n_queries) blk_prefix[q] = (int)(base + inc - nblk);
-  if (q == n_queries - 1) blk_prefix[n_queries] = (int)(base + inc);
-}
-
 // One launch scores the pending candidate lists of every query of the chunk.  256 workgroups x 8 wavefronts; wavefront
 // gw takes blocks [gw T / 2048, (gw + 1) T / 2048) of the T blocks laid end to end.  EXACT: f32 MFMA on the table
 // (wg_score_mlp_xres's arithmetic), else split-f16 (wg_score_mlp_res's).
@@ -98,16 +75,46 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
   int* prefix = reinterpret_cast<int*>(smem + kMlpResBytes + 8 * 1024);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cand = lane & 31, g = lane >> 5;
-  const int total = a.blk_prefix[a.n_queries];
-  if (total == 0) return;
-  {  // once per launch: the weights, the vectors that do not depend on the query, the block prefix
+  // the 32-row blocks every pending query contributes to this round, as exclusive prefix sums in query order: every
+  // workgroup works them out for itself from the queries' PhaseState (two queries per thread; round 4's first form had
+  // a launch of its own for this -- 5 of a chunk's 17 launches, 24 us of a 32-query call's 308)
+  static_assert(kPhaseChunk == 2 * NT, "two queries per thread");
+  uint32_t* wave_tot = reinterpret_cast<uint32_t*>(prefix + kPhaseChunk + 4);
+  uint32_t nb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int q = 2 * tid + h;
+    nb[h] = 0;
+    if (q < a.n_queries) {
+      const PhaseState* st = reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)q * a.slot_bytes + a.off_state);
+      if (st->status == kPhasePending && st->r == a.round) nb[h] = (uint32_t)(st->sc_n + 31) >> 5;
+    }
+  }
+  const uint32_t inc = wave_scan_add(nb[0] + nb[1]);
+  if (lane == 63) wave_tot[wave] = inc;
+  {  // once per launch: the weights and the vectors that do not depend on the query
     const uint4* src = EXACT ? reinterpret_cast<const uint4*>(a.mlp.p2x) : a.mlp.p2;
     for (int i = tid; i < kMlpResW2Vec; i += NT) W2[i] = src[i];
     if (EXACT) wg_mlp_xres_vectors<NT>(a.mlp, 0.0f, V); else wg_mlp_res_vectors<NT>(a.mlp, 0.0f, V);
     if (!EXACT && NANN_PHASE_PACKED_EPI && tid < 128) V->u[tid] = a.mlp.w3[tid] * (a.mlp.alpha2[tid] - 1.0f);  // (the same thread wrote the 0 above)
-    for (int i = tid; i <= a.n_queries; i += NT) prefix[i] = a.blk_prefix[i];
   }
   __syncthreads();
+  int total = 0;
+  {
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < NT / 64; ++w) {
+      const uint32_t t = wave_tot[w];
+      if (w < wave) base += t;
+      tot += t;
+    }
+    total = (int)tot;
+    const uint32_t excl = base + inc - (nb[0] + nb[1]);
+    prefix[2 * tid] = (int)excl;
+    prefix[2 * tid + 1] = (int)(excl + nb[0]);
+    if (tid == 0) prefix[kPhaseChunk] = total;  // (queries behind n_queries contribute nothing: prefix[n_queries ..] = total)
+  }
+  __syncthreads();
+  if (total == 0) return;
   const int gw = (int)blockIdx.x * (NT / 64) + wave;
   const int nw = (int)gridDim.x * (NT / 64);
   const int b_lo = (int)((long long)total * gw / nw), b_hi = (int)((long long)total * (gw + 1) / nw);
@@ -342,6 +349,6 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
   }
 }
 
-constexpr size_t kPhaseScoreLds = (size_t)kMlpResBytes + 8 * 1024 + (size_t)(kPhaseChunk + 1 + 3) / 4 * 16;
+constexpr size_t kPhaseScoreLds = (size_t)kMlpResBytes + 8 * 1024 + (size_t)(kPhaseChunk + 4) * 4 + 64;  // + the scan's wavefront totals
 
 }  // namespace nann

@@ -27,22 +27,14 @@ static void phase_offsets(const SearchArgs& a, unsigned long long off[9]) {
   slot_layout(a.max_cand, a.max_raw, a.pool_cap, 0u, off);  // (offsets do not depend on the last region's size)
 }
 
-int launch_mlp_phase_prefix(const SearchArgs& a, int round, int* blk_prefix, hipStream_t st) {
+int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, int workgroups, hipStream_t st) {
   if (a.n_queries > kPhaseChunk) return fail(NANN_ERR_BAD_ARGUMENT, "phased MLP traversal: chunks of at most 1024 queries");
-  unsigned long long off[9];
-  phase_offsets(a, off);
-  hipLaunchKernelGGL(k_mlp_phase_prefix<kPhaseChunk>, dim3(1), dim3(kPhaseChunk), 0, st, a.ws, a.slot_bytes, off[8], a.n_queries, round, blk_prefix);
-  NANN_HIP_TRY(hipGetLastError());
-  return NANN_OK;
-}
-
-int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, const int* blk_prefix, int workgroups, hipStream_t st) {
   unsigned long long off[9];
   phase_offsets(a, off);
   PhaseScoreArgs p;
   p.ws = a.ws; p.slot_bytes = a.slot_bytes;
   p.off_cand_ids = off[0]; p.off_cand_scores = off[1]; p.off_state = off[8];
-  p.blk_prefix = blk_prefix; p.enter = a.enter; p.proj = a.proj; p.n_items = a.n_items; p.n_queries = a.n_queries;
+  p.enter = a.enter; p.proj = a.proj; p.n_items = a.n_items; p.n_queries = a.n_queries;
   p.round = round; p.mlp = a.mlp; p.dry = 0;
   auto launch = [&](auto kern) -> int {
     NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPhaseScoreLds));

@@ -682,10 +682,9 @@ int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_byt
 int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 // layer 2 resident in LDS (nann_mlp5.h), split-f16 (exact = 0) or exact f32 (exact = 1); vis in {VIS_LDS_HASH, VIS_HBM_BITMAP}
 int launch_search_mlp_res(int exact, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
-// the pipeline of phases (nann_mlp6.h): a traversal stage (a.phase), the block prefix of a round, its scoring launch
+// the pipeline of phases (nann_mlp6.h): a traversal stage (a.phase), a round's scoring launch
 int launch_search_mlp_phase(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
-int launch_mlp_phase_prefix(const SearchArgs& a, int round, int* blk_prefix, hipStream_t st);
-int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, const int* blk_prefix, int workgroups, hipStream_t st);
+int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, int workgroups, hipStream_t st);
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
 // which form of the MLP the traversal runs: 5 = pre-projected + layer 2 resident in LDS (default, both precisions),
 // split-f16 only: 3 = pre-projected with streamed slices (round 3), 4 = its 256-thread form, 2 = second mapping, 1 = first

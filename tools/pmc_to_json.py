@@ -35,7 +35,7 @@ def phased(tag, note):
             if dur and ctr == "GRBM_GUI_ACTIVE":
                 by[kern]["dur_ns"] = float(dur)
         calls = by["k_mlp_phase_score"]["dispatches"] / 5.0
-        e = {"kernel": "pipeline of phases (nann_mlp6.h): k_search<phase> x 6, k_mlp_phase_prefix x 5, k_mlp_phase_score x 5, fallback launch",
+        e = {"kernel": "pipeline of phases (nann_mlp6.h): k_search<phase> x 6, k_mlp_phase_score x 5, fallback launch",
              "kernel_version": note, "workload": wl, "search_calls_in_pass": calls, "fetch_correction": 2.0, "by_kernel": {}}
         for kern, c in by.items():
             per = {k: v / calls for k, v in c.items() if k not in ("dispatches", "dur_ns")}
