@@ -123,6 +123,9 @@ __device__ __forceinline__ void wg_mlp_res_leave(uint4* lds, const uint4* park, 
 #ifndef NANN_RES_ROLLED
 #define NANN_RES_ROLLED 0
 #endif
+#ifndef NANN_PIPE_MT_MAJOR
+#define NANN_PIPE_MT_MAJOR 0  // A/B build of the pipeline: products ordered output tile by output tile (see there)
+#endif
 #ifndef NANN_PIPE_ASM
 #define NANN_PIPE_ASM 0  // 1: the pipeline's PReLU as hand-written packed-f32 asm -- fewer instructions (7 instead of ~9 per pair) and SLOWER
                         // (379 k against 388 k queries/s, profiles/r4x_*: asm statements pin the order hipcc would otherwise choose)
@@ -258,6 +261,29 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
         if (t == H1T - 2 && q == 1 && change) lds_write_u(u_next);
         const f16x8 bh = as_f16x8(uint4{Bh[cbuf][q][0], Bh[cbuf][q][1], Bh[cbuf][q][2], Bh[cbuf][q][3]});
         const f16x8 bl = as_f16x8(uint4{Bl[cbuf][q][0], Bl[cbuf][q][1], Bl[cbuf][q][2], Bl[cbuf][q][3]});
+#if NANN_PIPE_MT_MAJOR
+        // (A/B build: the three products of an output tile back to back on one accumulator, each with its shadow)
+#pragma unroll
+        for (int mt = 0; mt < H2T; ++mt) {
+          f32x2 hvm = {};
+          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bh, acc[mt], 0, 0, 0);
+          if (!(VAR & 4)) hvm = convert_a(x[nbuf], q, mt);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bl, acc[mt], 0, 0, 0);
+          if (!(VAR & 2)) Wf[2 * mt] = fragt(nt, nq * 2 * H2T + 2 * mt);
+          if (!(VAR & 4)) convert_b(hvm, Bh[nbuf][q][mt], Bl[nbuf][q][mt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt + 1], bh, acc[mt], 0, 0, 0);
+          if (!(VAR & 2)) Wf[2 * mt + 1] = fragt(nt, nq * 2 * H2T + 2 * mt + 1);
+          if (q == 0 && !(VAR & 1))
+            x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(VAR & 4)) {  // u / beta of the next step's conversion (this step's conversions are done)
+          cu[0] = uvec4(32 * ct + 8 * (2 * nq)); cu[1] = uvec4(32 * ct + 8 * (2 * nq + 1));
+          cb[0] = vec4(kBeta1 + 32 * ct + 8 * (2 * nq)); cb[1] = vec4(kBeta1 + 32 * ct + 8 * (2 * nq + 1));
+        }
+#else
         f32x2 hv[H2T] = {};
 #pragma unroll
         for (int mt = 0; mt < H2T; ++mt) {
@@ -284,6 +310,7 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
             x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
           __builtin_amdgcn_sched_barrier(0);
         }
+#endif
       }
     }
     // PReLU of layer 2 and the bias-free output layer
