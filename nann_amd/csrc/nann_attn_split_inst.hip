@@ -85,6 +85,10 @@ int launch_search_attn_proj(int vis, int slots, size_t lds_bytes, const SearchAr
   return fail(NANN_ERR_UNSUPPORTED, "attention traversal: no kernel for this plan");
 }
 
+int launch_search_attn_res(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerAttnRes, kAttnNT>(slots, lds_bytes, a, st);
+}
+
 int launch_attn_preproject(int dt, const AttnParams& P, const void* emb, long long n_rows, float* proj, hipStream_t st) {
   if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "attention scorer: rows f16 or bf16");
   if (P.d <= 0 || P.d > 128) return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d <= 128");

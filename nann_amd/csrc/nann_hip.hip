@@ -1797,7 +1797,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // the slot's last region: the HBM bitmap of a bitmap plan, and where a resident-layer-2 traversal parks its 16K-slot
   // set while it scores (nann_mlp5.h); "any" sizes for both
   uint32_t gbm_words = bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u;
-  if (res || kind < 0) gbm_words = std::max<uint32_t>(std::max<uint32_t>(gbm_words, ix->bm_words), (uint32_t)vis_slots(VIS_LDS_HASH));
+  if (res || kind < 0 || kind == kKindAttn) gbm_words = std::max<uint32_t>(std::max<uint32_t>(gbm_words, ix->bm_words), (uint32_t)vis_slots(VIS_LDS_HASH));
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
   p->id_bits = id_bits;
   p->fb_vis = bm_vis;
@@ -2025,7 +2025,13 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
     a.attn = attn->P;
     if (tab) {  // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
       auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_proj : launch_search_attn_xproj;
-      return both([&](int vis, int, int slots, size_t lds) { return launch(vis, slots, lds, a, st); });
+      // split-f16 on the 16K-slot plan: the form with keys and weights resident for a scoring call (NANN_MLP_MAPPING <= 4:
+      // the slice-ring form, which the bitmap plans and the overflow rerun keep)
+      const bool resident = attn->precision == NANN_MLP_SPLIT_F16 && mapping >= 5;
+      return both([&](int vis, int, int slots, size_t lds) {
+        if (resident && vis == VIS_LDS_HASH && !a.redo) return launch_search_attn_res(slots, lds, a, st);
+        return launch(vis, slots, lds, a, st);
+      });
     }
     auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_split : launch_search_attn;
     return both([&](int vis, int, int slots, size_t lds) { return launch(ix->desc.d, dt, vis, slots, lds, a, st); });

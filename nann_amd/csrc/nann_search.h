@@ -180,8 +180,9 @@ constexpr bool is_mlp_res(int sc) { return sc == kScorerMlpRes || sc == kScorerM
 // the 16K-slot set (hash plan) or the bitmap filter's phase scratch (HBM-bitmap plan)
 constexpr int mlp_res_reload_bytes(bool hash) { return hash ? 65536 : 32768; }
 static_assert(kPhaseScratch <= 32768, "the bitmap kernels' phase scratch lies over the first two weight tiles");
+constexpr int kScorerAttnRes = 11;   // split-f16 attention model on its table with everything a scoring call reads resident in LDS (nann_attn_proj.h)
 constexpr int kScorerAttnXProj = 10;  // the f32-MFMA attention model on the same pre-projected table (nann_attn_kernels.h, PROJ)
-constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj || sc == kScorerAttnXProj; }
+constexpr bool is_attn(int sc) { return sc == kScorerAttn || sc == kScorerAttnSplit || sc == kScorerAttnProj || sc == kScorerAttnXProj || sc == kScorerAttnRes; }
 
 // where a query's visited set lives
 enum : int {
@@ -430,6 +431,21 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                              reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
                                              a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
                                              reinterpret_cast<float*>(scratch), sc_out);
+      } else if constexpr (SC == kScorerAttnRes) {
+        // the user's keys take the place of the visited set for the call (the set parked in the slot when a later stage
+        // still needs it: stages 2 and 3, as for the MLP with resident layer 2)
+        static_assert(VIS == VIS_LDS_HASH, "the resident attention scorer: the 16K-slot set's 64 KB hold the keys");
+        uint4* set4 = reinterpret_cast<uint4*>(bm);
+        uint4* park = (r == 2 || r == 3) ? reinterpret_cast<uint4*>(sv.gbitmap) : nullptr;
+        __syncthreads();
+        if (park != nullptr)
+          for (int i = tid; i < SLOTS / 4; i += NT) park[i] = set4[i];
+        wg_score_attn_res<NT>(a.attn, reinterpret_cast<const uint4*>(a.kt + (size_t)qi * 256 * kAttnLP),
+                              reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
+                              a.proj, (long long)a.n_items, sc_ids, (long long)sc_n, set4,
+                              reinterpret_cast<float*>(scratch), sc_out);
+        if (park != nullptr)
+          for (int i = tid; i < SLOTS / 4; i += NT) set4[i] = park[i];
       } else if constexpr (SC == kScorerAttnProj) {
         wg_score_attn_proj<NT>(a.attn, reinterpret_cast<const uint4*>(a.kt + (size_t)qi * 256 * kAttnLP),
                                reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
@@ -698,6 +714,7 @@ int launch_search_attn_split(int d, int dt, int vis, int slots, size_t lds_bytes
 // embedding table); launch_attn_preproject fills the f32 [n_rows, kAttnProjWidth] table.  nann_attn_split_inst.hip
 int launch_search_attn_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_attn_xproj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);  // nann_attn_inst.hip
+int launch_search_attn_res(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);  // (16K-slot hash plan only)
 int launch_attn_preproject(int dt, const AttnParams& P, const void* emb, long long n_rows, float* proj, hipStream_t st);
 int launch_score_mlp_d64(int dt, int split, unsigned blocks, hipStream_t st, const MlpParams& P, const void* table,
                          long long n_table_rows, const int32_t* indices, long long n, const float* q,

@@ -122,7 +122,7 @@ def main():
     # the attention model's fused traversal (tools/attn_bench.py): split-f16 form = the instance with the most MFMAs
     attn_kernel, most = None, 0.0
     for (c, k), (mean, n) in rows.get("attn_a", {}).items():
-        if c == "SQ_INSTS_MFMA" and "k_search" in k and ", 6, 512>" in k and mean > most:
+        if c == "SQ_INSTS_MFMA" and "k_search" in k and (", 6, 512>" in k or ", 11, 512>" in k) and mean > most:
             attn_kernel, most = k, mean
     if attn_kernel:
         e = {"kernel": attn_kernel, "kernel_version": note,
