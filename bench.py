@@ -615,7 +615,8 @@ def attention_model_rate(handles, dim, topn, precision, n_users=512):
     ms = float(np.median(ts))
     out = {"users": n_users, "precision": precision, "ms": round(ms, 3),
            "queries_per_s": round(n_users / (ms * 1e-3), 1), "failed": int((r.status != 0).sum())}
-    out["form"] = ("item-only layers pre-projected per (model, index): nann_attn_proj.h" if precision == "split" else
+    out["form"] = ("item-only layers pre-projected per (model, index), keys and weights resident in LDS per scoring call: "
+                   "nann_attn_proj.h wg_score_attn_res" if precision == "split" else
                    "f32 MFMA on the same pre-projected table: nann_attn_kernels.h wg_score_attn<PROJ>")
     if precision == "split":
         pmc = load_pmc_counters("attention_model_f2_split")
