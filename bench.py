@@ -357,8 +357,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         table_form = os.environ.get("NANN_PREPROJECT", "1") != "0" and (mapping in "567" or (precision == "split" and mapping in "34"))
         # the pipeline of phases runs where it pays (nann_hip.hip plan_search: beams that fit the 16K-slot set; exact at every
         # batch size, split-f16 at <= 160 queries) -- the label follows the same rule
+        # (wide beams -- a level's visited ids beyond the 16K-slot set, ef = 256 here -- always: the stages run the 32K-slot plan)
         phased = (table_form and cfg.get("traversal", "auto") == "auto" and
-                  (mapping == "7" or (mapping == "6" and (precision == "exact" or batch <= 160))))
+                  (mapping == "7" or (mapping == "6" and (precision == "exact" or batch <= 160 or ef > 160))))
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
         if precision == "split":
             per_row = 3 * 2.0 * 256 * 128 + (0 if table_form else 2 * 2.0 * dim * 256)

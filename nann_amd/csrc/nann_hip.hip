@@ -1797,7 +1797,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // the slot's last region: the HBM bitmap of a bitmap plan, and where a resident-layer-2 traversal parks its 16K-slot
   // set while it scores (nann_mlp5.h); "any" sizes for both
   uint32_t gbm_words = bm_vis == VIS_HBM_BITMAP ? ix->bm_words : 0u;
-  if (res || kind < 0 || kind == kKindAttn) gbm_words = std::max<uint32_t>(std::max<uint32_t>(gbm_words, ix->bm_words), (uint32_t)vis_slots(VIS_LDS_HASH));
+  if (res || kind < 0 || kind == kKindAttn) gbm_words = std::max<uint32_t>(std::max<uint32_t>(gbm_words, ix->bm_words), (uint32_t)vis_slots(kind < 0 ? VIS_LDS_HASH32 : VIS_LDS_HASH));
   p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
   p->id_bits = id_bits;
   p->fb_vis = bm_vis;
@@ -1834,10 +1834,27 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // sooner than 12 launches), 1024: within 2 % either way box to box, 4096: +2.7 %.  NANN_MLP_MAPPING=7: always, =5: never.
   const bool exact_form = mlp_exact_hint;
   const bool pays = exact_form || n_queries <= 160;
-  p->phased = res && own_hash_plan && mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP &&
-              2 * hash16_lds <= di.lds_max && (mlp_mapping_choice() >= 7 || (mlp_mapping_choice() == 6 && pays));
+  const bool no_forced_bitmap = mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP;
+  const int mapping_now = mlp_mapping_choice();
+  p->phased = res && own_hash_plan && no_forced_bitmap && 2 * hash16_lds <= di.lds_max &&
+              (mapping_now >= 7 || (mapping_now == 6 && pays));
+  p->phase_vis = VIS_LDS_HASH;
+  p->phase_per_cu = 2;
   p->phase_lds_bytes = hash16_lds;
-  p->phase_slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), (int64_t)di.cus * 2));
+  // Wide beams (ef = 256: a level's visited ids need the 32K-slot set): the fused kernel keeps its bitmap in HBM because the
+  // resident weights leave no room for a set; the pipeline's traversal stages own the LDS and run the L2 kernel's 32K-slot
+  // plan (one 1024-thread workgroup per CU).  Both precisions, every batch size (profiles/r5g_*).
+  const bool fits32 = worst_visited <= 32704.0 || est_visited <= 24000.0;
+  if (res && !own_hash_plan && tag_fits && fits32 && no_forced_bitmap && mode != NANN_TRAVERSAL_LDS_HASH && hash32_lds <= di.lds_max &&
+      mapping_now >= 6) {
+    p->phased = true;
+    p->phase_vis = VIS_LDS_HASH32;
+    p->phase_per_cu = 1;
+    p->phase_lds_bytes = hash32_lds;
+    gbm_words = std::max<uint32_t>(gbm_words, (uint32_t)vis_slots(VIS_LDS_HASH32));  // where the 32K-slot set is parked
+    p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
+  }
+  p->phase_slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), (int64_t)di.cus * p->phase_per_cu));
   if (kind < 0)  // sizing: the widest plan (two workgroups per CU, or one slot per query of a phased chunk)
     p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, std::max<int64_t>((int64_t)di.cus * 2, kPhaseChunk)));
   else if (const int reserve = slot_reserve()) {  // leave workgroup slots to kernels of other streams (nann_set_search_reserve)
@@ -2059,10 +2076,10 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
       if (counters) c.counters = counters + (size_t)c0 * 3 * NANN_NUM_ROUNDS;
       if (phase_ticks) c.phase_ticks = reinterpret_cast<long long*>(phase_ticks) + (size_t)c0 * NANN_NUM_PHASES;
       if (c0) HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
-      const int slots = (int)std::min<int64_t>(c.n_queries, (int64_t)di.cus * 2);
+      const int slots = (int)std::min<int64_t>(c.n_queries, (int64_t)di.cus * p.phase_per_cu);
       for (int ph = 0; ph <= NANN_NUM_ROUNDS && !rc; ++ph) {
         c.phase = ph;
-        rc = launch_search_mlp_phase(slots, p.phase_lds_bytes, c, st);
+        rc = launch_search_mlp_phase(p.phase_vis, slots, p.phase_lds_bytes, c, st);
         if (!rc && ph < NANN_NUM_ROUNDS) {
           rc = launch_mlp_phase_score(exact, c, ph, di.cus, st);
         }

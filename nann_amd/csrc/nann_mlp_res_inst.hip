@@ -18,8 +18,10 @@ int launch_search_mlp_res(int exact, int vis, int slots, size_t lds_bytes, const
   return launch_search_as<16, DT_F16, VIS_HBM_BITMAP, kScorerMlpRes, 512>(slots, lds_bytes, a, st);
 }
 
-int launch_search_mlp_phase(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
-  // the traversal stages read no embedding row and score nothing: one instance
+int launch_search_mlp_phase(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+  // the traversal stages read no embedding row and score nothing: one instance per set size (16K slots: two 512-thread
+  // workgroups per CU; 32K slots, wide beams: one of 1024)
+  if (vis == VIS_LDS_HASH32) return launch_search_as<16, DT_F16, VIS_LDS_HASH32, kScorerMlpPhase, kNT>(slots, lds_bytes, a, st);
   return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpPhase, 512>(slots, lds_bytes, a, st);
 }
 

@@ -664,6 +664,7 @@ struct SearchPlan {
   bool phased;
   size_t phase_lds_bytes;
   int phase_slots;
+  int phase_vis, phase_per_cu;  // VIS_LDS_HASH (two 512-thread workgroups per CU) | VIS_LDS_HASH32 (one of 1024: wide beams)
 };
 
 template <int LPR, int DT, int VIS, int SC, int NT>
@@ -699,7 +700,7 @@ int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArg
 // layer 2 resident in LDS (nann_mlp5.h), split-f16 (exact = 0) or exact f32 (exact = 1); vis in {VIS_LDS_HASH, VIS_HBM_BITMAP}
 int launch_search_mlp_res(int exact, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 // the pipeline of phases (nann_mlp6.h): a traversal stage (a.phase), a round's scoring launch
-int launch_search_mlp_phase(int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+int launch_search_mlp_phase(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, int workgroups, hipStream_t st);
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
 // which form of the MLP the traversal runs: 5 = pre-projected + layer 2 resident in LDS (default, both precisions),

@@ -360,6 +360,12 @@ except Exception as e:
     print('SMALL $B $M failed', e)
 PY
       done; done ;;
+    bench_mlp_wide_ab)  # config 5's row shape and beam under the MLP (1.2M x 256-d bf16, ef=256), steady state: the pipeline of phases on the 32K-slot plan (default) against the fused HBM-bitmap kernel (NANN_MLP_MAPPING=5), both precisions
+      for P in split exact; do for M in 6 5; do
+        S="--items 1200000 --dim 256 --dtype bf16 --ef 256 --scorer mlp --mlp-precision $P --batch 1024 --steps 20 --warmup 30 --no-secondary --no-cpu-baseline"
+        NANN_MLP_MAPPING=$M timeout 400 $BENCH $S > $OUT/bench_mlp_wide_${P}_map${M}_$TAG.json 2> $OUT/bench_mlp_wide_${P}_map${M}_$TAG.err
+        show $OUT/bench_mlp_wide_${P}_map${M}_$TAG.json "MLP_WIDE_${P}_MAPPING_$M"; tail -2 $OUT/bench_mlp_wide_${P}_map${M}_$TAG.err | grep -v amdgpu.ids
+      done; done ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
