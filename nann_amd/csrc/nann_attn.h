@@ -31,6 +31,7 @@ constexpr int kAttnE = 64;    // user-sequence embedding dim
 constexpr int kAttnLP = 64;   // sequence positions, padded
 constexpr int kAttnNT = 512;  // 8 wavefronts x 32 candidates per pass
 constexpr int kAttnSlice = 8192;  // floats staged per step (32 KB)
+constexpr int kAttnXResFloats = 64 * 64 + 64 * 128 + 128 * 64 + 64 * 32;  // f32 form, resident: padded sequence, W1a, W2, W3 (88 KB)
 constexpr int kAttnVecFloats = 1536;  // split form: the pre-scaled small vectors, kept in LDS behind the slices (6 KB)
 
 struct AttnParams {  // device pointers, f32

@@ -127,11 +127,17 @@ __global__ __launch_bounds__(256) void k_attn_prepare(AttnParams P, const uint16
 // that multiply e are LOOKED UP -- 608 instead of 1632 v_mfma_f32_32x32x2_f32 per 32 candidates, 6 staged slices instead
 // of 24 (the keys four q_ tiles per slice).  Layer 1 then sums b1 + (e W1e) first and the attention half behind it (the
 // f32 form on rows: b1, attention half, e half): the same 1e-5 agreement with the oracle every attention test holds.
-template <int D, int DT, int NT, bool PROJ = false>
+//
+// RES (with PROJ, the 16K-slot hash plan of the fused traversal): everything a scoring call reads is resident in LDS --
+// the user's keys (f32 [256][64] = 64 KB) in the place of the visited set, which the caller parks around the call
+// (nann_mlp5.h's scheme), the padded sequence, W1's attention rows, W2 and W3 (88 KB) in the scratch -- loaded once per
+// call; no staged slice, no barrier inside the call, every wavefront at its own pace.
+template <int D, int DT, int NT, bool PROJ = false, bool RES = false>
 __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* __restrict__ kt,
                                               const float* __restrict__ upad, const void* table,
                                               long long n_table_rows, const int32_t* indices, long long n,
-                                              float* slice, float* scores) {
+                                              float* slice, float* scores, float* keys = nullptr) {
+  static_assert(!RES || PROJ, "the resident form runs on the pre-projected table");
   static_assert(D == 64 || D == 128, "item embedding dim");
   static_assert(DT == DT_F16 || DT == DT_BF16, "item rows are f16 or bf16");
   static_assert(NT == kAttnNT, "attn_stage strides by kAttnNT");
@@ -143,13 +149,23 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
   const float inv_sqrt_dk = 1.0f / sqrtf(256.0f);  // model_util.py:89-91
   // PROJ: W2 and W3 (40 KB) stay in LDS for the whole call, behind the slice and the split form's vectors -- the part of
   // the attention kernels' scratch (kAttnScratch, nann_search.h) no other phase of the traversal writes
-  float* res_w2 = slice + kAttnSlice + kAttnVecFloats;
+  float* res_up = slice;                  // RES: [upad 16 KB | W1a 32 KB | W2 32 KB | W3 8 KB] = kAttnXResFloats
+  float* res_w1a = slice + kAttnLP * kAttnE;
+  float* res_w2 = RES ? res_w1a + kAttnE * 128 : slice + kAttnSlice + kAttnVecFloats;
   float* res_w3 = res_w2 + 128 * 64;
+  if constexpr (RES) {
+    __syncthreads();  // the caller is done with the set and the scratch
+    for (int f = tid; f < 256 * kAttnLP / 4; f += NT) reinterpret_cast<float4*>(keys)[f] = reinterpret_cast<const float4*>(kt)[f];
+    for (int f = tid; f < kAttnLP * kAttnE / 4; f += NT) reinterpret_cast<float4*>(res_up)[f] = reinterpret_cast<const float4*>(upad)[f];
+    for (int f = tid; f < kAttnE * 128 / 4; f += NT) reinterpret_cast<float4*>(res_w1a)[f] = reinterpret_cast<const float4*>(P.w1)[f];
+  }
   if constexpr (PROJ) {
     for (int f = tid; f < 128 * 64 / 4; f += NT) reinterpret_cast<float4*>(res_w2)[f] = reinterpret_cast<const float4*>(P.w2)[f];
     for (int f = tid; f < 64 * 32 / 4; f += NT) reinterpret_cast<float4*>(res_w3)[f] = reinterpret_cast<const float4*>(P.w3)[f];
   }
+  if constexpr (RES) __syncthreads();
   for (long long c0 = 0; c0 < n; c0 += CPP) {
+    if (RES && c0 + wave * 32 >= n) break;  // (no barrier below: a wavefront without rows is done)
     const long long i = c0 + wave * 32 + cand;
     const long long ic = i < n ? i : n - 1;
     const long long rid = indices ? (long long)indices[ic] : ic;
@@ -195,7 +211,8 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
       for (int g = 0; g < 4; ++g) nx[g] = *reinterpret_cast<const float4*>(prow + 8 * g);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {  // the keys of four q_ tiles per slice: kt[128 half .., :] = 32 KB
-        attn_stage<kAttnNT>(slice, kt + (size_t)128 * half * kAttnLP, 128, kAttnLP, kAttnLP);
+        if constexpr (!RES) attn_stage<kAttnNT>(slice, kt + (size_t)128 * half * kAttnLP, 128, kAttnLP, kAttnLP);
+        const float* kslice = RES ? keys + (size_t)128 * half * kAttnLP : slice;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           f32x16 qt[1];
@@ -209,7 +226,7 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
 #pragma unroll
             for (int g = 0; g < 4; ++g) nx[g] = *reinterpret_cast<const float4*>(prow + 32 * tn + 8 * g);
           }
-          attn_mma<1, 2, kAttnLP>(slice + tt * 32 * kAttnLP, qt, 0, att, 0, lane);
+          attn_mma<1, 2, kAttnLP>(kslice + tt * 32 * kAttnLP, qt, 0, att, 0, lane);
         }
       }
     } else {
@@ -252,8 +269,12 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
     f32x16 x[2];
     attn_fill(x, 0, nullptr, slot);
     attn_fill(x, 1, nullptr, slot);
-    attn_stage<kAttnNT>(slice, upad, kAttnLP, kAttnE, kAttnE);  // 16 KB
-    attn_mma<2, 2, kAttnE>(slice, att, 0, x, 0, lane);
+    if constexpr (RES) {
+      attn_mma<2, 2, kAttnE>(res_up, att, 0, x, 0, lane);
+    } else {
+      attn_stage<kAttnNT>(slice, upad, kAttnLP, kAttnE, kAttnE);  // 16 KB
+      attn_mma<2, 2, kAttnE>(slice, att, 0, x, 0, lane);
+    }
     // ---- DNN layer 1 on [a ; e] (model.py:211-214): [128] = 4 tiles
     f32x16 h1[4];
 #pragma unroll
@@ -268,8 +289,12 @@ __device__ __forceinline__ void wg_score_attn(const AttnParams& P, const float* 
           h1[m][4 * g + 0] += v.x * kInv; h1[m][4 * g + 1] += v.y * kInv; h1[m][4 * g + 2] += v.z * kInv; h1[m][4 * g + 3] += v.w * kInv;
         }
     }
-    attn_stage<kAttnNT>(slice, P.w1, kAttnE, 128, 128);  // rows of a: 32 KB
-    attn_mma<2, 4, 128>(slice, x, 0, h1, 0, lane);
+    if constexpr (RES) {
+      attn_mma<2, 4, 128>(res_w1a, x, 0, h1, 0, lane);
+    } else {
+      attn_stage<kAttnNT>(slice, P.w1, kAttnE, 128, 128);  // rows of a: 32 KB
+      attn_mma<2, 4, 128>(slice, x, 0, h1, 0, lane);
+    }
     if constexpr (!PROJ) {
 #pragma unroll
     for (int part = 0; part < ET / 2; ++part) {  // rows of e, 64 at a time

@@ -200,7 +200,8 @@ constexpr int hash_phase_scratch() {
   return ((a > b ? a : b) + 255) & ~255;
 }
 // phase scratch of a traversal kernel: the attention scorer stages 32 KB weight slices
-constexpr int kAttnScratch = (kAttnSlice + kAttnVecFloats) * 4 + kAttnResidentBytes;  // slice buffers, vectors, resident fragments (nann_attn_proj.h)
+constexpr int kAttnSplitScratch = (kAttnSlice + kAttnVecFloats) * 4 + kAttnResidentBytes;  // split forms: slice buffers, vectors, resident fragments (nann_attn_proj.h)
+constexpr int kAttnScratch = kAttnSplitScratch > kAttnXResFloats * 4 ? kAttnSplitScratch : kAttnXResFloats * 4;  // (f32 form, resident: nann_attn_kernels.h)
 constexpr int kMlpSplitScratch = (int)((sizeof(MlpSplitScratch) + 255) & ~(size_t)255);  // two slice buffers + the vectors
 static_assert(sizeof(Mlp2Scratch<128>) <= sizeof(MlpSplitScratch), "the second mapping's tile buffers fit the same phase scratch");
 template <int VIS, int SC, int NT>
@@ -423,9 +424,22 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
                                        a.emb, (long long)a.n_items, sc_ids, (long long)sc_n,
                                        reinterpret_cast<float*>(scratch), sc_out);
       } else if constexpr (SC == kScorerAttnXProj) {
-        wg_score_attn<128, DT_F16, NT, true>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
-                                             a.proj, (long long)a.n_items, sc_ids, (long long)sc_n,
-                                             reinterpret_cast<float*>(scratch), sc_out);
+        if constexpr (VIS == VIS_LDS_HASH) {  // everything resident for the call: the keys over the (parked) visited set
+          uint4* set4 = reinterpret_cast<uint4*>(bm);
+          uint4* park = (r == 2 || r == 3) ? reinterpret_cast<uint4*>(sv.gbitmap) : nullptr;
+          __syncthreads();
+          if (park != nullptr)
+            for (int i = tid; i < SLOTS / 4; i += NT) park[i] = set4[i];
+          wg_score_attn<128, DT_F16, NT, true, true>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
+                                                     a.proj, (long long)a.n_items, sc_ids, (long long)sc_n,
+                                                     reinterpret_cast<float*>(scratch), sc_out, reinterpret_cast<float*>(bm));
+          if (park != nullptr)
+            for (int i = tid; i < SLOTS / 4; i += NT) set4[i] = park[i];
+        } else {
+          wg_score_attn<128, DT_F16, NT, true>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
+                                               a.proj, (long long)a.n_items, sc_ids, (long long)sc_n,
+                                               reinterpret_cast<float*>(scratch), sc_out);
+        }
       } else if constexpr (SC == kScorerAttnSplit) {
         wg_score_attn_split<LPR * 8, DT, NT>(a.attn, reinterpret_cast<const uint4*>(a.kt + (size_t)qi * 256 * kAttnLP),
                                              reinterpret_cast<const uint4*>(a.upad + (size_t)qi * kAttnLP * kAttnE),
