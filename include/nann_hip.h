@@ -198,7 +198,7 @@ enum nann_mlp_precision { NANN_MLP_PRECISION_DEFAULT = 0, NANN_MLP_SPLIT_F16 = 1
 int nann_scorer_create(const nann_scorer_desc* desc /*[host]*/, nann_scorer** out);
 void nann_scorer_destroy(nann_scorer* s);
 
-/* Lifecycle of the pre-projected tables (MLP scorers; attention models in split precision: nann_model_* below).
+/* Lifecycle of the pre-projected tables (MLP scorers; attention models, both precisions since round 4: nann_model_* below).
  *   nann_scorer_prepare      builds the table of (scorer, index) on `stream` NOW (or finds it), waits for it, and PINS
  *                            it: a pinned table is never evicted.  A serving host calls this at start-up, so that no
  *                            request pays the build (a hipMalloc + ~10-20 ms per million items + one stream wait).
