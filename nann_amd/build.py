@@ -65,7 +65,19 @@ def build(force=False, verbose=False, variant=None, extra_flags=()):
     if variant is None:
         if not force and not is_stale():
             return LIB
-        return _build_into(OUT_DIR, LIB, (), verbose)
+        # one builder at a time: the ranks of a multi-process launch that all find the library stale (a snapshot whose
+        # sources are newer than its .so) must not compile into the same directory together -- the first one builds, the
+        # others wait on the lock and find a fresh library
+        import fcntl
+        os.makedirs(OUT_DIR, exist_ok=True)
+        with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not force and not is_stale():
+                    return LIB
+                return _build_into(OUT_DIR, LIB, (), verbose)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     out = os.path.join(OUT_DIR, "var_" + variant)
     return _build_into(out, os.path.join(out, "libnann_hip.so"), tuple(extra_flags), verbose)
 
