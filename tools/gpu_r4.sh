@@ -366,6 +366,11 @@ PY
         NANN_MLP_MAPPING=$M timeout 400 $BENCH $S > $OUT/bench_mlp_wide_${P}_map${M}_$TAG.json 2> $OUT/bench_mlp_wide_${P}_map${M}_$TAG.err
         show $OUT/bench_mlp_wide_${P}_map${M}_$TAG.json "MLP_WIDE_${P}_MAPPING_$M"; tail -2 $OUT/bench_mlp_wide_${P}_map${M}_$TAG.err | grep -v amdgpu.ids
       done; done ;;
+    prof_default)  # rocprofv3 --kernel-trace --stats of the DEFAULT bench command (every workload of its JSON line), CPU legs shortened
+      rm -rf /tmp/prof/kt_default
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt_default -o kt -- $BENCH --cpu-seconds 3 > $OUT/bench_profiled_$TAG.json 2> $OUT/prof_kt_default_$TAG.log )
+      find /tmp/prof/kt_default -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_default_bench_$TAG.csv \;
+      head -14 $OUT/kernel_stats_default_bench_$TAG.csv | cut -c1-200 ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
