@@ -207,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
         });
     return;
   }
+  // ---- exact f32 (wg_score_mlp_xres's arithmetic, nann_mlp5.h): tile by tile, two tiles per trip of a rolled loop
   Cur cur, nxt;
   enter_query(query_of(b_lo), cur, true);
   const float* row = row_ptr(cur, b_lo);
@@ -238,112 +239,48 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
       f32x4v ub[8];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) { ub[rr] = uvec4(32 * t + 8 * rr); ub[4 + rr] = vec4(kBeta1 + 32 * t + 8 * rr); }
-      if constexpr (!EXACT) {
-        auto frag = [&](int k) -> f16x8 {  // fragment k (0..15: [q][m][hi, lo]) of tile t
-          const u32x4v v = *reinterpret_cast<lds_u4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + k * 1024);
-          return __builtin_bit_cast(f16x8, v);
-        };
-        f16x8 Wf[2 * H2T];
+      float h[16];
 #pragma unroll
-        for (int k = 0; k < 2 * H2T; ++k) Wf[k] = frag(k);
-        __builtin_amdgcn_sched_barrier(0);
-        f16x8 bh[2], bl[2];
+      for (int rr = 0; rr < 4; ++rr) {
+        const f32x4v u = ub[rr], al = ub[4 + rr];
+        constexpr float kInv = 1.0f / kSplit2Scale;  // the table holds 2^7 P: exact both ways
+        h[4 * rr + 0] = prelu(u.x + xt[rr].x * kInv, al.x);
+        h[4 * rr + 1] = prelu(u.y + xt[rr].y * kInv, al.y);
+        h[4 * rr + 2] = prelu(u.z + xt[rr].z * kInv, al.z);
+        h[4 * rr + 3] = prelu(u.w + xt[rr].w * kInv, al.w);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          uint4 h, l;
+      for (int j = 0; j < 4; ++j) {
+        f32x4v f[H2T];
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const int rr = 2 * q + half;
-            const f32x4v u = ub[rr], be = ub[4 + rr];
-            uint32_t h0, l0, h1, l1;
-            prelu_split_pair_pk(f32x2{xt[rr].x, xt[rr].y}, f32x2{u.x, u.y}, f32x2{be.x, be.y}, h0, l0);
-            prelu_split_pair_pk(f32x2{xt[rr].z, xt[rr].w}, f32x2{u.z, u.w}, f32x2{be.z, be.w}, h1, l1);
-            if (half == 0) { h.x = h0; h.y = h1; l.x = l0; l.y = l1; } else { h.z = h0; h.w = h1; l.z = l0; l.w = l1; }
-          }
-          bh[q] = as_f16x8(h); bl[q] = as_f16x8(l);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int mt = 0; mt < H2T; ++mt)  // p2x[t][mt][j][lane]: four chain steps per 16 bytes
+          f[mt] = *reinterpret_cast<lds_f4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + (mt * 4 + j) * 1024);
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int mt = 0; mt < H2T; ++mt) {
-            const f16x8 wh = Wf[mt * 2], wl = Wf[mt * 2 + 1];
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[q], acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[q], acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[q], acc[mt], 0, 0, 0);
-            if (q == 0) {  // the second step's fragments travel underneath the first step's MFMAs
-              Wf[mt * 2] = frag(2 * H2T + mt * 2);
-              Wf[mt * 2 + 1] = frag(2 * H2T + mt * 2 + 1);
-            }
-          }
-      } else {
-        float h[16];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const f32x4v u = ub[rr], al = ub[4 + rr];
-          constexpr float kInv = 1.0f / kSplit2Scale;  // the table holds 2^7 P: exact both ways
-          h[4 * rr + 0] = prelu(u.x + xt[rr].x * kInv, al.x);
-          h[4 * rr + 1] = prelu(u.y + xt[rr].y * kInv, al.y);
-          h[4 * rr + 2] = prelu(u.z + xt[rr].z * kInv, al.z);
-          h[4 * rr + 3] = prelu(u.w + xt[rr].w * kInv, al.w);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4v f[H2T];
-#pragma unroll
-          for (int mt = 0; mt < H2T; ++mt)  // p2x[t][mt][j][lane]: four chain steps per 16 bytes
-            f[mt] = *reinterpret_cast<lds_f4_ptr>((t < 4 ? w_lo : w_hi) + (t & 3) * 16384 + (mt * 4 + j) * 1024);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int mt = 0; mt < H2T; ++mt)
-              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[mt][e], h[4 * j + e], acc[mt], 0, 0, 0);
-        }
+          for (int mt = 0; mt < H2T; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[mt][e], h[4 * j + e], acc[mt], 0, 0, 0);
       }
     };
-    if constexpr (!EXACT) {
-#pragma unroll
-      for (int t = 0; t < H1T; t += 2) { tile(t, x[0]); tile(t + 1, x[1]); }
-    } else {
 #pragma unroll 1
-      for (int t = 0; t < H1T; t += 2) { tile(t, x[0]); tile(t + 1, x[1]); }
-    }
+    for (int t = 0; t < H1T; t += 2) { tile(t, x[0]); tile(t + 1, x[1]); }
     // the next block's query takes over the wavefront's u (every lane has read this block's)
     if (change) load_u_of(reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)nxt.q * a.slot_bytes + a.off_state));
-    // PReLU of layer 2 and the bias-free output layer (the fused kernels' epilogues)
+    // PReLU of layer 2 and the bias-free output layer (wg_score_mlp_xres's epilogue: ORDER_O)
     float part = 0.0f;
-    if constexpr (!EXACT) {
 #pragma unroll
-      for (int mt = 0; mt < H2T; ++mt)
+    for (int mt = 0; mt < H2T; ++mt)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const f32x4v be = vec4(kBeta2 + 32 * mt + 8 * rr), w3 = vec4(kW3 + 32 * mt + 8 * rr);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xa = acc[mt][4 * rr + e];
-            part = __builtin_fmaf(__builtin_fmaf(neg_part(xa), be[e], xa), w3[e], part);
-          }
-        }
-      const float other = __shfl_xor(part, 32);
-      constexpr float kUnscale = 1.0f / (kSplit2Scale * kSplit2Scale);
-      if (g == 0 && i < cur.n) cur.out[i] = (part + other) * kUnscale;
-    } else {
-#pragma unroll
-      for (int mt = 0; mt < H2T; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
-          part = __fmaf_rn(prelu(acc[mt][r], V->beta2[m]), V->w3[m], part);
-        }
-      const float other = __shfl_xor(part, 32);
-      const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
-      if (g == 0 && i < cur.n && !a.dry) cur.out[i] = p0 + p1;
-    }
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+        part = __fmaf_rn(prelu(acc[mt][r], V->beta2[m]), V->w3[m], part);
+      }
+    const float other = __shfl_xor(part, 32);
+    const float p0 = g == 0 ? part : other, p1 = g == 0 ? other : part;
+    if (g == 0 && i < cur.n && !a.dry) cur.out[i] = p0 + p1;
     row = next;
     cur = nxt;
   }
