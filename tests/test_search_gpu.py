@@ -395,6 +395,33 @@ def test_hash_set_overflow_falls_back_to_the_bitmap_kernel(oracle, mode, cap):
     _assert_same(_run(dix, q, topn, mode), exp)
 
 
+def test_mlp_pipeline_hands_overflowing_queries_to_the_fused_bitmap_kernel(oracle):
+    """The MLP's pipeline of phases on a forced 16K-slot plan, one launch mixing (per-request level_topn) beams that
+    fit the set with beams that outgrow it: a traversal stage hands an overflowing query back (NANN_ERR_CAPACITY),
+    the later stages and scoring launches skip it, the fused HBM-bitmap kernel reruns it at the end of the call --
+    every reply bitwise equal to the oracle's."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(120000, 64, 256, n_clusters=4, mode="knn")
+    w = synth.make_mlp_weights(64)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 16, seed=33)])
+    variants = [[256, 512, 512, 512, 512, 200], [128, 128, 128, 128, 128, 200]]
+    rows = np.asarray([variants[b % 2] for b in range(len(q))], np.int32)
+    osc = oracle.Scorer("mlp", 64, oracle.EMB_F16, w)
+    with traversal_mode("lds_hash"):
+        r = retrieval.search(dix, ops.Scorer("mlp", 64, torch.float16, w, precision="exact"), cuda(q), rows)
+        torch.cuda.synchronize()
+    got = (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+           r.index.cpu().numpy(), r.counters.cpu().numpy())
+    for v, topn in enumerate(variants):
+        sel = np.arange(v, len(q), 2)
+        exp = oracle.search_batch(oix, osc, q[sel], topn, n_threads=16)
+        ok = exp[0] == 0
+        assert ok.mean() > 0.5
+        visited_l0 = topn[1] + exp[4][:, 2, 2:5].sum(1)  # marks + ids kept in the three level-0 rounds
+        assert ((visited_l0[ok] > 16320).all() if v == 0 else (visited_l0[ok] < 14000).all()), visited_l0
+        _assert_same(tuple(a[sel] for a in got), exp)
+
+
 def test_mlp_traversal_in_hbm_bitmap_mode(oracle):
     """The MLP traversal with the visited bitmap in HBM (what MLP shards beyond ~1.07M items run)."""
     from nann_amd import ops, retrieval, synth
