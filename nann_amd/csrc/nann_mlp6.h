@@ -21,6 +21,7 @@ namespace nann {
 
 constexpr int kPhaseChunk = 1024;     // queries per pipeline pass (one prefix workgroup, bounded workspace)
 constexpr int kPhasePending = -100;   // PhaseState.status while a query waits for its scores
+constexpr int kPhaseSkip = -101;      // search_one's return for a query an earlier stage finished (never stored)
 constexpr int kPhaseScoreWaves = 2048;  // 256 workgroups x 8 wavefronts: runs of the scoring launch
 
 // what a query carries from one launch to the next (in its slot)

@@ -227,6 +227,11 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   constexpr int SLOTS = HASH ? vis_slots(VIS) : 16384;
   const int tid = local_tid();
   const int k5 = a.t[5];  // output row stride
+  if constexpr (SC == kScorerMlpPhase) {
+    // a query an earlier stage finished (a failed request, or one handed back for the bitmap rerun) is skipped here, on the
+    // round trip that fetches the rest of its state -- not by a load of its own in the queue loop
+    if (a.phase > 0 && sv.phase->status != kPhasePending) return kPhaseSkip;
+  }
   int t[6];               // this query's level_topn (uniform)
 #pragma unroll
   for (int i = 0; i < 6; ++i) t[i] = a.tq ? a.tq[(size_t)qi * 6 + i] : a.t[i];
@@ -245,7 +250,8 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   auto mark = [&](int phase) { timer.mark(phase); };
 
   if constexpr (!is_attn(SC)) {
-    for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
+    if (SC != kScorerMlpPhase || a.phase == 0)  // (the later stages of the pipeline of phases score nothing: no query vector)
+      for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
   }
   __syncthreads();
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
@@ -618,10 +624,6 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && (SC == NANN_SCORER_L2 
       int qn = (int)atomicAdd(queue, 1u);
       if (a.redo)  // skip the queries that are done
         while (qn < a.n_queries && a.status[qn] != NANN_ERR_CAPACITY) qn = (int)atomicAdd(queue, 1u);
-      if (PHASED && a.phase > 0)  // ... and the ones an earlier stage has finished (failed requests)
-        while (qn < a.n_queries &&
-               reinterpret_cast<const PhaseState*>(a.ws + 256 + (unsigned long long)qn * a.slot_bytes + off[8])->status != kPhasePending)
-          qn = (int)atomicAdd(queue, 1u);
       misc[0] = qn;
     }
     if (threadIdx.x < 3 * NANN_NUM_ROUNDS) s_ctr[threadIdx.x] = 0;
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(NT, ((VIS == VIS_LDS_HASH && (SC == NANN_SCORER_L2 
     const int st = search_one<LPR, DT, VIS, SC, NT>(a, qi, sv, bm, scratch, qv, s_ctr, s_ticks);
     __syncthreads();
     if constexpr (PHASED) {
+      if (st == kPhaseSkip) continue;  // (finished by an earlier stage)
       if (threadIdx.x == 0) sv.phase->status = st;
       if (a.phase_ticks && threadIdx.x < NANN_NUM_PHASES) {  // ticks add up over the stages (scoring launches: not in here)
         long long* dst = &a.phase_ticks[(size_t)qi * NANN_NUM_PHASES + threadIdx.x];
