@@ -1854,6 +1854,16 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     gbm_words = std::max<uint32_t>(gbm_words, (uint32_t)vis_slots(VIS_LDS_HASH32));  // where the 32K-slot set is parked
     p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
   }
+  // few queries (at most one per CU): a query's stages run faster on ONE 1024-thread workgroup per CU than on one of two
+  // 512-thread workgroups that has no partner to overlap with (the L2 kernel's small-batch rule, above)
+  static const bool small32 = [] { const char* e = std::getenv("NANN_PHASE_SMALL32"); return !(e && e[0] == '0'); }();
+  if (p->phased && p->phase_vis == VIS_LDS_HASH && small32 && n_queries <= (int64_t)di.cus && tag_fits && hash32_lds <= di.lds_max) {
+    p->phase_vis = VIS_LDS_HASH32;
+    p->phase_per_cu = 1;
+    p->phase_lds_bytes = hash32_lds;
+    gbm_words = std::max<uint32_t>(gbm_words, (uint32_t)vis_slots(VIS_LDS_HASH32));
+    p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
+  }
   p->phase_slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), (int64_t)di.cus * p->phase_per_cu));
   if (kind < 0)  // sizing: the widest plan (two workgroups per CU, or one slot per query of a phased chunk)
     p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, std::max<int64_t>((int64_t)di.cus * 2, kPhaseChunk)));
