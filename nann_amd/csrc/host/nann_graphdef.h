@@ -230,8 +230,11 @@ inline bool parse_tensor(Cursor c, Tensor* t) {
       }
       return true;
     case DT_BOOL:
-      if (!content.empty()) { t->i.resize((size_t)n); for (int64_t k = 0; k < n; ++k) t->i[(size_t)k] = content[(size_t)k] != 0; }
-      else fill(t->i, iv);
+      if (!content.empty()) {
+        if ((int64_t)content.size() != n) return false;  // one byte per element, like every other dtype's size check
+        t->i.resize((size_t)n);
+        for (int64_t k = 0; k < n; ++k) t->i[(size_t)k] = content[(size_t)k] != 0;
+      } else fill(t->i, iv);
       return true;
     default:
       return true;  // other dtypes (strings ...): string_val kept as it is, no numeric payload

@@ -130,6 +130,15 @@ __device__ __forceinline__ void wg_mlp_res_leave(uint4* lds, const uint4* park, 
 #define NANN_PIPE_ASM 0  // 1: the pipeline's PReLU as hand-written packed-f32 asm -- fewer instructions (7 instead of ~9 per pair) and SLOWER
                         // (379 k against 388 k queries/s, profiles/r4x_*: asm statements pin the order hipcc would otherwise choose)
 #endif
+#ifndef NANN_PIPE_NOPK
+#define NANN_PIPE_NOPK 0  // 1: the pipeline's PReLU as scalar f32 instructions pinned by asm (no v_pk_fma_f32 in the MFMAs' shadow)
+#endif
+#ifndef NANN_PIPE_PRIO
+#define NANN_PIPE_PRIO 0  // n > 0: s_setprio n for wavefronts 4-7 of the workgroup over the whole pipeline (MI355X_MICROARCH.md, static priority)
+#endif
+#ifndef NANN_PIPE_AGPR
+#define NANN_PIPE_AGPR 0  // 1: one inline-asm "a" operand in the pipeline: hipcc then selects the AGPR form of every MFMA of the kernel
+#endif
 #ifndef NANN_RES_PIPE
 #define NANN_RES_PIPE 1  // the software-pipelined block loop (wave_mlp_split_pipeline); 0: the tile-phased loop of r4a-r4j
 #endif
@@ -174,6 +183,12 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
   constexpr int H1T = 8, H2T = 4;
   constexpr int kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
   const uint32_t w_lo = L.w_lo, w_hi = L.w_hi, v_at = L.v_at, u_at = L.u_at;
+#if NANN_PIPE_AGPR
+  { int z = 0; asm volatile("; accumulators in AGPRs" : "+a"(z)); }
+#endif
+#if NANN_PIPE_PRIO
+  if (__builtin_amdgcn_workitem_id_x() & 256) __builtin_amdgcn_s_setprio(NANN_PIPE_PRIO);  // the younger half of a 512-thread workgroup
+#endif
   auto vec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(v_at + 4 * float_index); };
   auto uvec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(u_at + 4 * float_index); };
   auto fragt = [&](int t, int k) -> f16x8 {
@@ -210,6 +225,13 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
     asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xs.x));
     asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xs.y));
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(bp), "v"(xs));
+    return h;
+#elif NANN_PIPE_NOPK
+    // scalar f32 forms (MI355X_MICROARCH.md: a packed-f32 instruction beside MFMAs costs +11..22 cycles over its two scalar halves)
+    f32x2 h;
+    const float x0 = xp.x + up.x, x1 = xp.y + up.y;
+    h.x = __builtin_fmaf(__builtin_fminf(x0, 0.0f), bp.x, x0);
+    h.y = __builtin_fmaf(__builtin_fminf(x1, 0.0f), bp.y, x1);
     return h;
 #else
     const f32x2 xs = xp + up;

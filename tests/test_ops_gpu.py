@@ -182,6 +182,19 @@ def test_user_seq_mean_bitwise(oracle):
         q = ops.user_seq_mean(cuda(seq)).cpu().numpy()
         exp = np.stack([oracle.user_seq_mean(s) for s in seq])
         assert (bits(q) == bits(exp)).all()
+    # round 5 (k_user_seq_mean_lds): rows of -0 halves are pad rows, a pad row between history rows does not count, one
+    # non-zero element in the LAST column makes a row count; shapes the LDS form refuses (d % 8 != 0, a history > 48 KB)
+    # take the generic kernel -- all bitwise the oracle's
+    for (n, L, d) in ((5, 50, 128), (3, 7, 72), (4, 50, 100), (2, 120, 256), (3, 1, 8), (2, 96, 256)):
+        seq = (rng.standard_normal((n, L, d)) * 0.3).astype(np.float16)
+        seq[0, L // 2] = 0
+        seq[-1, :] = np.float16(-0.0)
+        if L > 2:
+            seq[1 % n, 1:] = 0
+            seq[1 % n, -1, -1] = np.float16(6e-8)  # the smallest subnormal
+        q = ops.user_seq_mean(cuda(seq)).cpu().numpy()
+        exp = np.stack([oracle.user_seq_mean(s) for s in seq])
+        assert (bits(q) == bits(exp)).all(), (n, L, d)
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])

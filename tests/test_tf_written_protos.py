@@ -171,3 +171,43 @@ def test_text_reader_rejects_malformed_input(tmp_path):
         p.write_text(bad)
         with pytest.raises(ValueError):
             dump(p, TEXT)
+
+
+def test_tensor_content_shorter_than_its_shape_is_rejected(tmp_path):
+    """a DT_BOOL Const whose tensor_content is shorter than its shape read past the buffer (every other
+    dtype checked content.size() == n * element size).  Both readers must refuse it -- text and wire -- and the same
+    for a float tensor, and a bool tensor of the right length must still decode."""
+    def pbtxt(dtype, dim, content):
+        return ('node { name: "c" op: "Const" attr { key: "dtype" value { type: %s } } attr { key: "value" value { tensor { '
+                'dtype: %s tensor_shape { dim { size: %d } } tensor_content: "%s" } } } }' % (dtype, dtype, dim, content))
+
+    def wire(dtype_code, dim, content):
+        def vi(v):
+            out = b""
+            while True:
+                b7 = v & 0x7f
+                v >>= 7
+                out += bytes([b7 | (0x80 if v else 0)])
+                if not v:
+                    return out
+        def ld(field, payload):
+            return vi(field << 3 | 2) + vi(len(payload)) + payload
+        shape = ld(2, vi(1 << 3) + vi(dim))                              # TensorShapeProto.dim { size }
+        tensor = vi(1 << 3) + vi(dtype_code) + ld(2, shape) + ld(4, content)  # dtype, tensor_shape, tensor_content
+        attr_v = ld(8, tensor)                                           # AttrValue.tensor
+        entry = ld(1, b"value") + ld(2, attr_v)
+        node = ld(1, b"c") + ld(2, b"Const") + ld(5, entry)
+        return ld(1, node)
+
+    for dtype, code, dim, content, ok in (("DT_BOOL", 10, 200000000, b"\x01", False), ("DT_BOOL", 10, 3, b"\x01\x00\x01", True),
+                                          ("DT_BOOL", 10, 2, b"\x01\x00\x01", False), ("DT_FLOAT", 1, 4, b"\x00" * 8, False)):
+        pt, pb = tmp_path / "t.pbtxt", tmp_path / "t.pb"
+        pt.write_text(pbtxt(dtype, dim, "".join("\\%03o" % b for b in content)))
+        pb.write_bytes(wire(code, dim, content))
+        for path, fmt in ((pt, TEXT), (pb, BINARY_GRAPH)):
+            if ok:
+                g = dump(path, fmt)
+                assert by_name(g)["c"]["op"] == "Const"
+            else:
+                with pytest.raises(ValueError):
+                    dump(path, fmt)
