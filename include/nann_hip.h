@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NANN_ABI_VERSION 4
+#define NANN_ABI_VERSION 5
 
 /* status codes; 1..8 share the oracle's numbering (oracle/nann_oracle.h) and
  * map to the TF errors the reference raises at the cited lines */
@@ -109,6 +109,17 @@ int nann_group_gather_fill(const int32_t* params_values, const int64_t* params_r
                            const int64_t* indices_values, int64_t n_indices_values,
                            const int64_t* scratch_offsets, int32_t* ret_values,
                            nann_stream_t stream);
+
+/* GroupGather unique=true (UO/beam_search_op/GroupGather_kernel.cc:91-131): per group the SET of the gathered
+ * values -- the reference inserts the rows into a std::unordered_set per group and writes it in the set's iteration
+ * order, i.e. any order of a group's distinct values is its answer; this library emits first-occurrence order.
+ * Input = the unique=false result (values int32[n_values], row_splits int64[n_splits], both device: count + fill
+ * above, whose validation and void-input path are the shared head of Compute).  out_values (device) must hold
+ * n_values entries, out_row_splits n_splits; scratch: nann_group_gather_unique_scratch_bytes().  *n_out [host]. */
+int nann_group_gather_unique_scratch_bytes(int64_t n_values, int64_t n_splits, int64_t* nbytes);
+int nann_group_gather_unique(const int32_t* values, int64_t n_values, const int64_t* row_splits, int64_t n_splits,
+                             void* scratch, int32_t* out_values, int64_t* out_row_splits, int64_t* n_out,
+                             nann_stream_t stream);
 
 /* ---- a2: BitmapRefDifference<int32> (UO/bitmap_op/bitmap_ops.cc:175-257) ---
  * Serial-scan semantics: first occurrence of every id whose bit is clear is

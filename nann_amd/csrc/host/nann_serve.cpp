@@ -371,7 +371,10 @@ int main(int argc, char** argv) {
     touched.clear();
     for (int i = 0; i < b; ++i) {
       Request* r = batch[i];
-      std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)r->level_topn[5] * 8);  // the request's own k
+      // the request's own k, never more than the row holds (a k outside [0, topk] fails that query in the kernel --
+      // NANN_ERR_BAD_ARGUMENT, zeroed row -- and must not size a host copy: ADVICE r4)
+      const int own_k = std::min(std::max(r->level_topn[5], 0), topk);
+      std::memcpy(r->top_k, ln.h_topk + (size_t)i * topk, (size_t)own_k * 8);
       r->status = ln.h_status[(size_t)i];
       ClientThread* owner = r->owner;  // (read before the release: the request may be reused the moment `done` is seen)
       r->done.store(1, std::memory_order_release);
@@ -564,6 +567,8 @@ int main(int argc, char** argv) {
     if (!probe_topn.empty()) {
       if (std::sscanf(probe_topn.c_str(), "%d,%d,%d,%d,%d,%d", &r2.level_topn[0], &r2.level_topn[1], &r2.level_topn[2],
                       &r2.level_topn[3], &r2.level_topn[4], &r2.level_topn[5]) != 6) die("--probe-topn a,b,c,d,e,k");
+      for (int j = 0; j < 6; ++j)  // what BatchingServer.submit checks: 0 <= t[i] <= the launch's maxima
+        if (r2.level_topn[j] < 0 || r2.level_topn[j] > level_topn[j]) die("--probe-topn: every entry must lie in [0, the launch's --ef / --topk]");
       probes.push_back(&r2);
     }
     run_batch(lane[0], probes);

@@ -193,6 +193,122 @@ __global__ __launch_bounds__(256) void k_group_gather_fill(const int32_t* __rest
   }
 }
 
+// GroupGather unique=true (GroupGather_kernel.cc:91-131): per group the SET of the gathered values.  The reference
+// writes a group in its unordered_set's iteration order -- any order of the distinct values is its answer --; here:
+// first-occurrence order of the unique=false list, which is the input (values / row_splits = that op's outputs).
+// One open-addressing table for all groups, keyed by (group, value): a 64-bit entry is (value << 32 | position) with the
+// position global, so the group of an entry is grp[position] and "the smallest position of a key" is one atomicMin
+// on the entry (equal high halves).  Position p is kept iff its key's entry still says p.
+constexpr unsigned long long kGguEmpty = ~0ull;
+__device__ __forceinline__ uint32_t ggu_hash(uint32_t v, uint32_t g) {
+  uint32_t h = v * 0x9E3779B1u ^ (g * 0x85EBCA77u);
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+  return h;
+}
+__global__ __launch_bounds__(256) void k_ggu_groups(const int64_t* row_splits, long long n_groups, uint32_t* grp) {
+  for (long long g = blockIdx.x; g < n_groups; g += gridDim.x)
+    for (long long p = row_splits[g] + threadIdx.x; p < row_splits[g + 1]; p += blockDim.x) grp[p] = (uint32_t)g;
+}
+__global__ __launch_bounds__(256) void k_ggu_insert(const int32_t* values, long long n, const uint32_t* grp,
+                                                    unsigned long long* table, uint32_t mask) {
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+    const uint32_t v = (uint32_t)values[p], g = grp[p];
+    const unsigned long long mine = ((unsigned long long)v << 32) | (unsigned long long)(uint32_t)p;
+    uint32_t h = ggu_hash(v, g) & mask;
+    for (;;) {
+      unsigned long long e = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e == kGguEmpty) {
+        e = atomicCAS(&table[h], kGguEmpty, mine);
+        if (e == kGguEmpty) break;  // claimed
+      }
+      if ((uint32_t)(e >> 32) == v && grp[(uint32_t)e] == g) { atomicMin(&table[h], mine); break; }
+      h = (h + 1) & mask;
+    }
+  }
+}
+__device__ __forceinline__ bool ggu_is_first(const int32_t* values, const uint32_t* grp, const unsigned long long* table,
+                                             uint32_t mask, long long p) {
+  const uint32_t v = (uint32_t)values[p], g = grp[p];
+  uint32_t h = ggu_hash(v, g) & mask;
+  for (;;) {
+    const unsigned long long e = table[h];
+    if ((uint32_t)(e >> 32) == v && e != kGguEmpty && grp[(uint32_t)e] == g) return (uint32_t)e == (uint32_t)p;
+    h = (h + 1) & mask;
+  }
+}
+// per group: distinct values -> counts[g]
+__global__ __launch_bounds__(256) void k_ggu_count(const int32_t* values, const int64_t* row_splits, long long n_groups,
+                                                   const uint32_t* grp, const unsigned long long* table, uint32_t mask,
+                                                   long long* counts) {
+  __shared__ unsigned int s_n;
+  for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (long long p = row_splits[g] + threadIdx.x; p < row_splits[g + 1]; p += blockDim.x)
+      mine += ggu_is_first(values, grp, table, mask, p) ? 1u : 0u;
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[g] = s_n;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kNT) void k_ggu_scan(const long long* counts, long long n_groups, int64_t* out_row_splits,
+                                                  OpResult* res) {
+  __shared__ long long s_wave[kNW];
+  __shared__ long long s_running;
+  const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  if (tid == 0) { s_running = 0; out_row_splits[0] = 0; }
+  __syncthreads();
+  for (long long g0 = 0; g0 < n_groups; g0 += kNT) {
+    const long long g = g0 + tid;
+    const long long c = g < n_groups ? counts[g] : 0;
+    long long inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    long long wb = 0, tot = 0;
+    for (int w = 0; w < kNW; ++w) { const long long t = s_wave[w]; if (w < wave) wb += t; tot += t; }
+    const long long run = s_running;
+    if (g < n_groups) out_row_splits[g + 1] = run + wb + inc;
+    __syncthreads();
+    if (tid == 0) s_running = run + tot;
+    __syncthreads();
+  }
+  if (tid == 0) { res->n_out = s_running; res->n_out_splits = n_groups + 1; res->bad_i = -1; res->code = 0; res->err = 0; }
+}
+// per group: the kept positions in position order
+__global__ __launch_bounds__(256) void k_ggu_emit(const int32_t* values, const int64_t* row_splits, long long n_groups,
+                                                  const uint32_t* grp, const unsigned long long* table, uint32_t mask,
+                                                  const int64_t* out_row_splits, int32_t* out_values) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ long long s_base;
+  const int lane = lane_id(), wave = wave_id();
+  for (long long g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    if (threadIdx.x == 0) s_base = out_row_splits[g];
+    __syncthreads();
+    const long long b = row_splits[g], e = row_splits[g + 1];
+    for (long long p0 = b; p0 < e; p0 += 256) {
+      const long long p = p0 + threadIdx.x;
+      const bool keep = p < e && ggu_is_first(values, grp, table, mask, p);
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t wb = 0, tot = 0;
+      for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; if (w < wave) wb += t; tot += t; }
+      const long long base = s_base;
+      if (keep) out_values[base + wb + __popcll(m & ((1ull << lane) - 1ull))] = values[p];
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = base + tot;
+      __syncthreads();
+    }
+  }
+}
+
 // BitmapRefDifference (bitmap_ops.cc:175-257): one workgroup; the bitmap is
 // staged into LDS when it fits, walked by one wavefront, and written back.
 template <bool kLds>
@@ -897,6 +1013,56 @@ int nann_group_gather_fill(const int32_t* params_values, const int64_t* params_r
                      params_values, params_row_splits, indices_values, (long long)n_indices_values,
                      scratch_offsets, ret_values);
   HIP_TRY(hipGetLastError());
+  return NANN_OK;
+}
+
+// ---- GroupGather unique=true: the set of every group of a unique=false result, first-occurrence order ---------
+static uint64_t ggu_table_slots(int64_t n_values) {
+  uint64_t t = 64;
+  while (t < 2 * (uint64_t)n_values) t <<= 1;
+  return t;
+}
+int nann_group_gather_unique_scratch_bytes(int64_t n_values, int64_t n_splits, int64_t* nbytes) {
+  if (!nbytes || n_values < 0 || n_splits < 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_group_gather_unique_scratch_bytes: bad argument");
+  if (n_values > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "GroupGather unique: more than 2^31 values");
+  *nbytes = (int64_t)(ggu_table_slots(n_values) * 8 + (((uint64_t)n_values * 4 + 255) & ~255ull) + (uint64_t)(n_splits + 1) * 8);
+  return NANN_OK;
+}
+int nann_group_gather_unique(const int32_t* values, int64_t n_values, const int64_t* row_splits, int64_t n_splits,
+                             void* scratch, int32_t* out_values, int64_t* out_row_splits, int64_t* n_out,
+                             nann_stream_t stream) {
+  if (!n_out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_group_gather_unique: null out");
+  if (n_splits < 1) return fail(NANN_ERR_BAD_ARGUMENT, "nann_group_gather_unique: row_splits of the unique=false result expected");
+  if (n_values > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "GroupGather unique: more than 2^31 values");
+  hipStream_t st = as_stream(stream);
+  const long long n_groups = n_splits - 1;
+  if (n_values == 0 || n_groups == 0) {  // every group empty: row_splits of zeros
+    HIP_TRY(hipMemsetAsync(out_row_splits, 0, (size_t)n_splits * 8, st));
+    *n_out = 0;
+    return NANN_OK;
+  }
+  if (!scratch) return fail(NANN_ERR_BAD_ARGUMENT, "nann_group_gather_unique: null scratch");
+  ResultBuf* rb;
+  int rc = get_result_buf(&rb);
+  if (rc) return rc;
+  const uint64_t slots = ggu_table_slots(n_values);
+  unsigned long long* table = static_cast<unsigned long long*>(scratch);
+  uint32_t* grp = reinterpret_cast<uint32_t*>(table + slots);
+  long long* counts = reinterpret_cast<long long*>(reinterpret_cast<unsigned char*>(grp) + (((uint64_t)n_values * 4 + 255) & ~255ull));
+  const uint32_t mask = (uint32_t)(slots - 1);
+  HIP_TRY(hipMemsetAsync(table, 0xff, slots * 8, st));
+  const unsigned gblocks = (unsigned)std::min<long long>(n_groups, 4096);
+  const unsigned pblocks = (unsigned)std::min<long long>((n_values + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_ggu_groups, dim3(gblocks), dim3(256), 0, st, row_splits, n_groups, grp);
+  hipLaunchKernelGGL(k_ggu_insert, dim3(pblocks), dim3(256), 0, st, values, (long long)n_values, grp, table, mask);
+  hipLaunchKernelGGL(k_ggu_count, dim3(gblocks), dim3(256), 0, st, values, row_splits, n_groups, grp, table, mask, counts);
+  hipLaunchKernelGGL(k_ggu_scan, dim3(1), dim3(kNT), 0, st, counts, n_groups, out_row_splits, rb->dev);
+  hipLaunchKernelGGL(k_ggu_emit, dim3(gblocks), dim3(256), 0, st, values, row_splits, n_groups, grp, table, mask,
+                     out_row_splits, out_values);
+  HIP_TRY(hipGetLastError());
+  rc = fetch_result(rb, st);
+  if (rc) return rc;
+  *n_out = rb->host->n_out;
   return NANN_OK;
 }
 

@@ -84,11 +84,10 @@ def group_gather(params_values, params_row_splits, indices_values, indices_row_s
     group of `indices`, concatenate the CSR rows params[i] in order, duplicates
     kept.  Returns (ret_values int32, ret_row_splits int64).
 
-    unique=True selects the reference's unordered_set path (:91-131), whose
-    output order is implementation-defined; the serving graph never uses it
-    (build_opt_graph.py:48) and it is not implemented here."""
-    if unique:
-        raise UnimplementedError(102, "GroupGather unique=True is not used by the serving graph")
+    unique=True is the reference's per-group unordered_set path (:91-131): a group's
+    row holds its distinct values.  The reference writes them in the set's iteration
+    order (implementation-defined: any order is its answer); this op emits them in
+    first-occurrence order.  The serving graph never sets it (build_opt_graph.py:48)."""
     pv = _dev(params_values, torch.int32)
     prs = _dev(params_row_splits, torch.int64)
     iv = _dev(indices_values, torch.int64)
@@ -106,7 +105,19 @@ def group_gather(params_values, params_row_splits, indices_values, indices_row_s
         st = lib().nann_group_gather_fill(_ptr(pv), _ptr(prs), _ptr(iv), C.c_int64(iv.numel()),
                                           _ptr(offsets), _ptr(ret_values), _stream())
         _check(st, "GroupGather")
-    return ret_values, ret_rs[: n_rs.value]
+    ret_rs = ret_rs[: n_rs.value]
+    if not unique or n_rs.value <= 1:
+        return ret_values, ret_rs
+    nbytes = C.c_int64(0)
+    _check(lib().nann_group_gather_unique_scratch_bytes(C.c_int64(n_ret.value), C.c_int64(n_rs.value), C.byref(nbytes)), "GroupGather")
+    scratch = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=pv.device)
+    out = torch.empty(max(n_ret.value, 1), dtype=torch.int32, device=pv.device)
+    out_rs = torch.empty(n_rs.value, dtype=torch.int64, device=pv.device)
+    n_out = C.c_int64(0)
+    st = lib().nann_group_gather_unique(_ptr(ret_values), C.c_int64(n_ret.value), _ptr(ret_rs), C.c_int64(n_rs.value),
+                                        _ptr(scratch), _ptr(out), _ptr(out_rs), C.byref(n_out), _stream())
+    _check(st, "GroupGather")
+    return out[: n_out.value], out_rs
 
 
 # ---- a2: BitmapRefDifference ---------------------------------------------------

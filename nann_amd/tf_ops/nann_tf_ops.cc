@@ -162,10 +162,9 @@ template <typename T>
 class GroupGatherHip : public OpKernel {
  public:
   explicit GroupGatherHip(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    // unique=true (GroupGather_kernel.cc:91-131): a group's distinct values; the reference's order is its
+    // unordered_set's, this kernel's is first-occurrence order -- one of the orders the reference may produce
     OP_REQUIRES_OK(ctx, ctx->GetAttr("unique", &unique_));
-    OP_REQUIRES(ctx, !unique_, errors::Unimplemented(
-        "GroupGather unique=true has implementation-defined order in the reference and is "
-        "unused by the serving graph (build_opt_graph.py:48)"));
   }
 
   void Compute(OpKernelContext* ctx) override {
@@ -203,26 +202,45 @@ class GroupGatherHip : public OpKernel {
       OP_REQUIRES(ctx, false, errors::InvalidArgument("Invalid RaggedTensor input1 indices, code: ", code));
     }
     OP_REQUIRES_OK(ctx, ToStatus(st, "GroupGather"));
-    Tensor* out_values = nullptr;
-    Tensor* out_rs = nullptr;
-    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({n_ret}), &out_values));
-    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({n_ret_splits}), &out_rs));
     if (n_ret > 0) {
       OP_REQUIRES_OK(ctx, d_out.Alloc(n_ret * 4));
       OP_REQUIRES_OK(ctx, ToStatus(nann_group_gather_fill(d_pv.as<int32_t>(), d_prs.as<int64_t>(),
                                                           d_iv.as<int64_t>(), n_iv, d_off.as<int64_t>(),
                                                           d_out.as<int32_t>(), nullptr),
                                    "GroupGather"));
+    }
+    DeviceBuffer d_uniq, d_uniq_rs, d_scratch;
+    DeviceBuffer* values = &d_out;
+    DeviceBuffer* splits = &d_rs;
+    if (unique_ && n_ret > 0 && n_ret_splits > 1) {  // the set of every group of that list (:91-131)
+      int64_t scratch_bytes = 0, n_unique = 0;
+      OP_REQUIRES_OK(ctx, ToStatus(nann_group_gather_unique_scratch_bytes(n_ret, n_ret_splits, &scratch_bytes), "GroupGather"));
+      OP_REQUIRES_OK(ctx, d_scratch.Alloc(scratch_bytes));
+      OP_REQUIRES_OK(ctx, d_uniq.Alloc(n_ret * 4));
+      OP_REQUIRES_OK(ctx, d_uniq_rs.Alloc(n_ret_splits * 8));
+      OP_REQUIRES_OK(ctx, ToStatus(nann_group_gather_unique(d_out.as<int32_t>(), n_ret, d_rs.as<int64_t>(), n_ret_splits,
+                                                            d_scratch.as<void>(), d_uniq.as<int32_t>(),
+                                                            d_uniq_rs.as<int64_t>(), &n_unique, nullptr),
+                                   "GroupGather"));
+      n_ret = n_unique;
+      values = &d_uniq;
+      splits = &d_uniq_rs;
+    }
+    Tensor* out_values = nullptr;
+    Tensor* out_rs = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({n_ret}), &out_values));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({n_ret_splits}), &out_rs));
+    if (n_ret > 0) {
       if (std::is_same<T, int32>::value) {
-        OP_REQUIRES_OK(ctx, d_out.Download(out_values->flat<T>().data(), n_ret * 4));
+        OP_REQUIRES_OK(ctx, values->Download(out_values->flat<T>().data(), n_ret * 4));
       } else {
         std::vector<int32_t> host((size_t)n_ret);
-        OP_REQUIRES_OK(ctx, d_out.Download(host.data(), n_ret * 4));
+        OP_REQUIRES_OK(ctx, values->Download(host.data(), n_ret * 4));
         T* o = out_values->flat<T>().data();
         for (int64_t i = 0; i < n_ret; ++i) o[i] = (T)host[(size_t)i];
       }
     }
-    OP_REQUIRES_OK(ctx, d_rs.Download(out_rs->flat<int64>().data(), n_ret_splits * 8));
+    OP_REQUIRES_OK(ctx, splits->Download(out_rs->flat<int64>().data(), n_ret_splits * 8));
   }
 
  private:

@@ -51,6 +51,74 @@ int oracle_validate_ragged(int64_t n_values, const int64_t* row_splits,
 }
 
 /* ------------------------------------------------------------------------ */
+/* GroupGather, unique=true: GroupGather_kernel.cc:91-131.  Per group, the SET of the values of the gathered rows
+ * (`std::unordered_set<T>` filled row by row, :98-106), its size the group's row length (:110-114), its members
+ * written in the set's iteration order (:121-124) -- which the C++ standard leaves to the library, so any order of
+ * a group's distinct values is an answer of the reference.  This restatement (and the HIP op) emits FIRST-OCCURRENCE
+ * order: value v precedes w iff v's first copy in the unique=false list precedes w's.  Parity = ret_row_splits equal
+ * and every group's values equal as a set; first-occurrence order is the build's own, tested against this function.
+ * Validation and the void-input path are the shared head of Compute (:62-77).  */
+int oracle_group_gather_unique_i32(const int32_t* pv, int64_t n_pv, const int64_t* prs,
+                                   int64_t n_prs, const int64_t* iv, int64_t n_iv,
+                                   const int64_t* irs, int64_t n_irs, int32_t* out_values,
+                                   int64_t out_cap, int64_t* out_rs, int64_t* n_out,
+                                   int64_t* n_out_splits, int* ragged_code) {
+  int code = oracle_validate_ragged(n_pv, prs, n_prs);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_PARAMS; /* :62-64 */
+  code = oracle_validate_ragged(n_iv, irs, n_irs);
+  if (ragged_code) *ragged_code = code;
+  if (code) return ORACLE_ERR_INVALID_RAGGED_INDICES; /* :65-67 */
+  if (n_prs == 1 || n_irs == 1) { /* :69-77 */
+    out_rs[0] = 0;
+    *n_out = 0;
+    *n_out_splits = 1;
+    return ORACLE_OK;
+  }
+  const int64_t num_groups = n_irs - 1, n_rows = n_prs - 1;
+  out_rs[0] = 0;
+  *n_out_splits = n_irs;
+  int64_t sum = 0;
+  for (int64_t i = 0; i < num_groups; ++i) {
+    /* the group's list as unique=false would emit it, then an open-addressing set over it */
+    int64_t len = 0;
+    for (int64_t j = irs[i]; j < irs[i + 1]; ++j) {
+      const int64_t idx = iv[j];
+      if (idx < 0 || idx >= n_rows) return ORACLE_ERR_INDEX_OUT_OF_RANGE; /* UB in the reference */
+      len += prs[idx + 1] - prs[idx];
+    }
+    uint64_t cap = 16;
+    while (cap < 2 * (uint64_t)len) cap <<= 1;
+    int32_t* keys = (int32_t*)malloc(cap * 4);
+    unsigned char* used = (unsigned char*)calloc(cap, 1);
+    if (!keys || !used) { free(keys); free(used); return ORACLE_ERR_BAD_ARGUMENT; }
+    int64_t w = sum;
+    for (int64_t j = irs[i]; j < irs[i + 1]; ++j) {
+      const int64_t g = iv[j];
+      for (int64_t k = prs[g]; k < prs[g + 1]; ++k) {
+        const int32_t v = pv[k];
+        uint64_t h = ((uint64_t)(uint32_t)v * 0x9E3779B97F4A7C15ull) >> 20 & (cap - 1);
+        while (used[h] && keys[h] != v) h = (h + 1) & (cap - 1);
+        if (used[h]) continue; /* a later copy: the set already holds v (:103-104) */
+        used[h] = 1;
+        keys[h] = v;
+        if (out_values) {
+          if (w >= out_cap) { free(keys); free(used); return ORACLE_ERR_BAD_ARGUMENT; }
+          out_values[w] = v;
+        }
+        ++w;
+      }
+    }
+    free(keys);
+    free(used);
+    sum = w;
+    out_rs[i + 1] = sum; /* :110-114 */
+  }
+  *n_out = sum;
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------ */
 /* GroupGather, unique=false: GroupGather_kernel.cc:136-170                  */
 int oracle_group_gather_i32(const int32_t* pv, int64_t n_pv, const int64_t* prs,
                             int64_t n_prs, const int64_t* iv, int64_t n_iv,

@@ -71,6 +71,17 @@ int oracle_group_gather_i32(const int32_t* params_values, int64_t n_params_value
                             int64_t* out_row_splits, int64_t* n_out,
                             int64_t* n_out_splits, int* ragged_code);
 
+/* GroupGather<int32>, unique=true path (GroupGather_kernel.cc:91-131): per group the set of the gathered values,
+ * emitted in first-occurrence order (the reference's order is the unordered_set's: any order is its answer).
+ * Same argument meaning as oracle_group_gather_i32. */
+int oracle_group_gather_unique_i32(const int32_t* params_values, int64_t n_params_values,
+                                   const int64_t* params_row_splits, int64_t n_params_splits,
+                                   const int64_t* indices_values, int64_t n_indices_values,
+                                   const int64_t* indices_row_splits, int64_t n_indices_splits,
+                                   int32_t* out_values, int64_t out_cap,
+                                   int64_t* out_row_splits, int64_t* n_out,
+                                   int64_t* n_out_splits, int* ragged_code);
+
 /* BitmapRefDifference<int32> (bitmap_ops.cc:175-257).  bitmap is mutated in
  * place (Ref semantics).  n_bitmap_words is used for the bounds check the
  * reference omits (Appendix C) -> ORACLE_ERR_INDEX_OUT_OF_RANGE. */

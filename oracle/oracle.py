@@ -94,13 +94,14 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
-def group_gather(params_values, params_row_splits, indices_values, indices_row_splits):
-    """-> (status, ragged_code, ret_values int32, ret_row_splits int64)"""
+def group_gather(params_values, params_row_splits, indices_values, indices_row_splits, unique=False):
+    """-> (status, ragged_code, ret_values int32, ret_row_splits int64); unique=True: per group the set of the
+    gathered values in first-occurrence order (GroupGather_kernel.cc:91-131)"""
     pv = _c(params_values, np.int32); prs = _c(params_row_splits, np.int64)
     iv = _c(indices_values, np.int64); irs = _c(indices_row_splits, np.int64)
     ors = np.zeros(max(len(irs), 1), np.int64)
     n_out = C.c_int64(0); n_os = C.c_int64(0); code = C.c_int(0)
-    f = lib().oracle_group_gather_i32
+    f = lib().oracle_group_gather_unique_i32 if unique else lib().oracle_group_gather_i32
     args = [_p(pv), C.c_int64(len(pv)), _p(prs), C.c_int64(len(prs)), _p(iv), C.c_int64(len(iv)),
             _p(irs), C.c_int64(len(irs))]
     rc = f(*args, None, C.c_int64(0), _p(ors), C.byref(n_out), C.byref(n_os), C.byref(code))

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_the_abi():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.nann_abi_version() == 4
+    assert L.nann_abi_version() == 5
     assert isinstance(_lib.last_error(), str)
     assert L.nann_device_count() >= 0
 

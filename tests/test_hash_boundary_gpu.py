@@ -1,0 +1,113 @@
+"""-m gpu: the visited set at its direct <-> tag boundary (bitmap_ops.cc:224-232).
+
+A hash-set entry is (tag << 12) | position-in-piece with pieces of 4095 ids; up to 2^20 - 1 items the tag is the id
+itself, from 2^20 items on it is cut from a bijection of the id space (nann_device.h, vis_key; plan_search's
+bit_length(n_items)).  ADVICE r3's bug lived exactly here: id 2^20 - 1 at piece position 4095 encoded as the empty
+value.  These tests put the LAST id of a shard of 2^20 - 1, 2^20 and 2^20 + 1 items at the last position of a full
+piece of a level-0 round, copies of it at the head and the tail of the pieces behind, other boundary ids around it, and
+require every plan to answer like the oracle's serial scan bit for bit (ids, scores, per-round counters)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import MODES, bits, cuda, require_gpu, traversal_mode
+
+pytestmark = pytest.mark.gpu
+
+PIECE = 4095
+D = 64
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    require_gpu()
+
+
+def _crafted_index(n, seed):
+    """n items; nodes 0..15 are the 'core' (x = ((i + 1) / 256, 0, ...): with q[0] = 0 node i beats node i + 1), the rest
+    the bulk (random rows far from the origin).  Level 1 leads entry nodes 0..3 to 8..12; the level-0 rows of the
+    first frontier [0, 1, 2, 3, 8, 9, 10, 11] concatenate to a crafted list of 3 pieces + 100 ids; every other node
+    has four pseudo-random neighbours."""
+    rng = np.random.default_rng(seed)
+    embs = (rng.standard_normal((n, D)) * 0.3).astype(np.float16)
+    embs[:16] = 0
+    embs[:16, 0] = (np.arange(16) + 1) / 256.0
+    item_ids = (rng.permutation(n) + 1).astype(np.int64)
+    # level 1: rows of the entry nodes only
+    rows1 = {0: [8, 9], 1: [10, 11], 3: [12]}
+    len1 = np.zeros(n, np.int64)
+    for k, v in rows1.items():
+        len1[k] = len(v)
+    rs1 = np.concatenate([[0], np.cumsum(len1)]).astype(np.int64)
+    nb1 = np.array([x for k in sorted(rows1) for x in rows1[k]], np.int32)
+    # the crafted list of the first level-0 round
+    total = 3 * PIECE + 100
+    bulk = rng.integers(16, n, size=total).astype(np.int64)
+    dup = rng.random(total) < 0.3                       # copies of earlier list entries
+    src = (rng.random(total) * np.maximum(np.arange(total), 1)).astype(np.int64)
+    for i in np.nonzero(dup)[0]:
+        bulk[i] = bulk[src[i]]
+    visited = rng.random(total) < 0.02                  # ids the marks already hold
+    bulk[visited] = rng.choice([0, 1, 2, 3, 8, 9, 10, 11], size=int(visited.sum()))
+    last = n - 1
+    L = bulk
+    L[PIECE - 1] = last            # the last position of a full piece: (tag << 12) | 4095
+    L[PIECE] = last                # its copy heads the next piece ("visited before this piece")
+    L[PIECE - 2] = n - 2
+    L[PIECE + 1] = n - 2
+    L[2 * PIECE - 1] = last        # and again at the last position of piece 1
+    L[2 * PIECE] = n - 3
+    L[2 * PIECE - 2] = (1 << 20) - 1 if n > (1 << 20) - 1 else n - 4   # id 2^20 - 1 where the shard has it
+    L[total - 1] = last
+    L[0] = n - 5
+    cuts = [0, 1000, 4000, 4095, 4097, 8097, 8190, 10000, total]       # eight rows, two of them across piece seams
+    frontier = [0, 1, 2, 3, 8, 9, 10, 11]
+    len0 = np.full(n, 4, np.int64)
+    for j, node in enumerate(frontier):
+        len0[node] = cuts[j + 1] - cuts[j]
+    rs0 = np.concatenate([[0], np.cumsum(len0)]).astype(np.int64)
+    nb0 = np.empty(int(rs0[-1]), np.int32)
+    i = np.arange(n, dtype=np.int64)
+    default = np.stack([(i * 7 + 1) % n, (i * 13 + 5) % n, (i * 101 + 17) % n, (i * 31 + 3) % n], 1).astype(np.int32)
+    plain = len0 == 4
+    pos = rs0[:-1][plain]
+    nb0[(pos[:, None] + np.arange(4)[None, :]).ravel()] = default[plain].ravel()
+    for j, node in enumerate(frontier):
+        nb0[rs0[node]:rs0[node + 1]] = L[cuts[j]:cuts[j + 1]]
+    enter = np.arange(8, dtype=np.int32)
+    return dict(item_embs=embs, item_ids=item_ids, nb_values=[nb0, nb1], nb_row_splits=[rs0, rs1], enter_points=enter,
+                crafted=L.copy())
+
+
+@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1])
+def test_last_id_at_the_last_position_of_a_full_piece(oracle, n):
+    from nann_amd import ops, retrieval
+    g = _crafted_index(n, seed=n & 0xffff)
+    oix = oracle.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    dix = retrieval.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    rng = np.random.default_rng(3)
+    q = (rng.standard_normal((6, D)) * 0.05).astype(np.float32)
+    q[:, 0] = 0.0  # the core nodes keep their order
+    topn = [4, 8, 8, 8, 8, 10]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", D, oracle.EMB_F16), q, topn)
+    assert (exp[0] == 0).all(), exp[0]
+    ctr = exp[4].reshape(len(q), 3, -1)
+    # round 2 (the first level-0 round) walked the crafted list: 8 rows, 3 pieces + 100 gathered ids
+    assert (ctr[:, 0, 2] == 8).all() and (ctr[:, 1, 2] == 3 * PIECE + 100).all(), ctr[0]
+    # what the serial scan keeps of it, from the stand-alone oracle op on the same list and marks
+    bm = np.zeros((n + 31) // 32, np.int32)
+    for m in (0, 1, 2, 3, 8, 9, 10, 11):
+        bm[m >> 5] |= np.int32(1 << (m & 31)) if (m & 31) < 31 else np.int32(-(1 << 31))
+    rc, _, kept, _ = oracle.bitmap_ref_difference(g["crafted"].astype(np.int32), [0, len(g["crafted"])], bm)
+    assert rc == 0 and (ctr[:, 2, 2] == len(kept)).all()
+    assert (n - 1) in kept.tolist() and kept.tolist().count(n - 1) == 1
+    sc = ops.Scorer("l2", D, torch.float16)
+    for mode in MODES + ["auto"]:
+        with traversal_mode(mode):
+            r = retrieval.search(dix, sc, cuda(q), topn)
+            torch.cuda.synchronize()
+        assert (r.status.cpu().numpy() == 0).all(), (mode, r.status.cpu().numpy())
+        assert (r.index.cpu().numpy() == exp[3]).all(), mode
+        assert (r.item_ids.cpu().numpy() == exp[1]).all(), mode
+        assert (bits(r.scores.cpu().numpy()) == bits(exp[2])).all(), mode
+        assert (r.counters.cpu().numpy() == exp[4]).all(), mode

@@ -65,8 +65,66 @@ def test_group_gather_errors():
     with pytest.raises(ops.InvalidArgumentError) as e:  # row index out of range (UB in the reference)
         ops.group_gather([1, 2], [0, 2], [1], [0, 1])
     assert e.value.status == 5
-    with pytest.raises(ops.UnimplementedError):
-        ops.group_gather([1, 2], [0, 2], [0], [0, 1], unique=True)
+
+
+def _first_occurrence(values):
+    seen, out = set(), []
+    for v in values:
+        if v not in seen:
+            seen.add(v)
+            out.append(v)
+    return out
+
+
+def test_group_gather_unique(oracle, ref_ops):
+    """unique=true (GroupGather_kernel.cc:91-131): a group's row is the SET of its gathered values -- the reference
+    writes its unordered_set's iteration order, so parity is per-group set equality + equal ret_row_splits; the HIP
+    op's own order is first occurrence, equal to the oracle's restatement element for element."""
+    from nann_amd import ops
+    # the reference script's inputs (group_gather_test.py:18-26), unique=True as its commented line :20 would run them
+    for case in ref_ops["group_gather"]:
+        args = (case["params_values"], case["params_row_splits"], case["indices_values"], case["indices_row_splits"])
+        if case["status"]:
+            with pytest.raises(ops.InvalidArgumentError) as e:
+                ops.group_gather(*args, unique=True)
+            assert e.value.status == case["status"], case["name"]
+            continue
+        v, rs = ops.group_gather(*args, unique=True)
+        v, rs = v.cpu().tolist(), rs.cpu().tolist()
+        plain, prs_ = case["ret_values"], case["ret_row_splits"]
+        exp_rs, exp_v = [0], []
+        for g in range(len(prs_) - 1):
+            exp_v += _first_occurrence(plain[prs_[g]:prs_[g + 1]])
+            exp_rs.append(len(exp_v))
+        if len(prs_) == 1:
+            exp_rs = [0]
+        assert rs == exp_rs and v == exp_v, case["name"]
+        rc, _, ov, ors = oracle.group_gather(*args, unique=True)
+        assert rc == 0 and ov.tolist() == v and ors.tolist() == rs, case["name"]
+    rng = np.random.default_rng(11)
+    # random ragged input: heavy duplication inside and across groups, negative and extreme values, empty groups
+    for n_rows, n_groups, max_len, lo, hi in [(50, 1, 70, 0, 40), (3000, 7, 200, 0, 5000), (20000, 3, 64, -(1 << 31), (1 << 31) - 1),
+                                               (100, 40, 0, 0, 10), (500, 25, 30, -3, 3), (4000, 2, 64, (1 << 31) - 5, (1 << 31) - 1)]:
+        lens = rng.integers(0, max_len + 1, size=n_rows)
+        lens[rng.random(n_rows) < 0.3] = 0
+        prs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pv = rng.integers(lo, hi + 1, size=int(prs[-1]), dtype=np.int64).astype(np.int32)
+        glen = rng.integers(0, 300, size=n_groups)
+        glen[rng.random(n_groups) < 0.2] = 0
+        irs = np.concatenate([[0], np.cumsum(glen)]).astype(np.int64)
+        iv = rng.integers(0, n_rows, size=int(irs[-1])).astype(np.int64)
+        rc, _, ev, ers = oracle.group_gather(pv, prs, iv, irs, unique=True)
+        assert rc == 0
+        v, rs = ops.group_gather(pv, prs, iv, irs, unique=True)
+        v, rs = v.cpu().numpy(), rs.cpu().numpy()
+        assert (rs == ers).all() and (v == ev).all()
+        # and against the definition: per group the set of the unique=false list
+        pl, plrs = ops.group_gather(pv, prs, iv, irs)
+        pl, plrs = pl.cpu().numpy(), plrs.cpu().numpy()
+        for g in range(n_groups):
+            mine = v[rs[g]:rs[g + 1]]
+            assert len(set(mine.tolist())) == len(mine)
+            assert set(mine.tolist()) == set(pl[plrs[g]:plrs[g + 1]].tolist())
 
 
 # ---------------------------------------------------------------- BitmapRefDifference

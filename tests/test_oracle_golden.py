@@ -170,3 +170,25 @@ def test_sibling_ops(oracle, ref_ops):
     rc, out, fnew = oracle.bitmap_difference([4, 40, 40, 6, 41], flags)
     assert rc == 0 and out.tolist() == [40, 41] and flags.tolist() == [32254, 0, 0, 0]
     assert fnew.tolist() == [32254, 768, 0, 0]
+
+
+def test_group_gather_unique_is_the_per_group_set(oracle, ref_ops):
+    """GroupGather_kernel.cc:91-131: unique=true = per group the set of the gathered values (any order is the
+    reference's answer: unordered_set); the restatement emits first-occurrence order."""
+    for case in ref_ops["group_gather"]:
+        if case["status"]:
+            continue
+        args = (case["params_values"], case["params_row_splits"], case["indices_values"], case["indices_row_splits"])
+        rc, _, v, rs = oracle.group_gather(*args, unique=True)
+        assert rc == 0
+        plain, prs = case["ret_values"], case["ret_row_splits"]
+        assert len(rs) == len(prs)
+        for g in range(len(prs) - 1):
+            mine = v[rs[g]:rs[g + 1]].tolist()
+            ref = plain[prs[g]:prs[g + 1]]
+            assert set(mine) == set(ref) and len(set(mine)) == len(mine)
+            assert mine == list(dict.fromkeys(ref))  # first-occurrence order
+    # the docstring example (group_gather_test.py:7-10): rows [[0,1,1,2,3,4],[3,4,5,5,6],[7,8,8,9],[10,11,12]], groups [[0,1],[3]]
+    rc, _, v, rs = oracle.group_gather([0, 1, 1, 2, 3, 4, 3, 4, 5, 5, 6, 7, 8, 8, 9, 10, 11, 12], [0, 6, 11, 15, 18], [0, 1, 3], [0, 2, 3],
+                                       unique=True)
+    assert rc == 0 and v.tolist() == [0, 1, 2, 3, 4, 5, 6, 10, 11, 12] and rs.tolist() == [0, 7, 10]
