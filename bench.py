@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--topk", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
-    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "hnsw_cpu", "synth", "knn"],
+    ap.add_argument("--graph", default="hnsw", choices=["hnsw", "hnsw_dense", "hnsw_cpu", "synth", "knn"],
                     help="hnsw = the shipped HNSW builder ON THE DEVICE (default since round 3: 1M x 128-d in ~0.6 s); "
+                         "hnsw_dense = the same with the heuristic's keepPrunedConnections (rows filled to their cap: mean level-0 degree ~55); "
                          "hnsw_cpu = the same algorithm by the host-side C++ builder (rounds 1-2: 16-30 s); synth = exact-search "
                          "insertion graph built with torch (round-1 default, ~2 min at 1M); knn = full-degree exact k-NN rows")
     ap.add_argument("--noise", type=float, default=1.0)
@@ -191,18 +192,20 @@ def make_index(items, dim, ef, graph, noise, dtype, rank, dev, n_threads, cache_
                     "nb_values": [z["nb_values_0"], z["nb_values_1"]],
                     "nb_row_splits": [z["nb_row_splits_0"], z["nb_row_splits_1"]],
                     "enter_points": z["enter_points"]}
-    if graph in ("hnsw", "hnsw_cpu"):
+    if graph in ("hnsw", "hnsw_dense", "hnsw_cpu"):
         import torch
         embs, _ = synth.make_corpus(items, dim, n_clusters=ncl, noise=noise, seed=1234, item_seed=1234 + 100 + 1000 * rank)
         x32 = embs.astype(np.float32)  # the builder sees exactly the values the index stores (f16-exact)
         if dtype == "bf16":
             bits = to_bf16_bits(x32)
             x32 = (bits.astype(np.uint32) << 16).view(np.float32)
-        if graph == "hnsw":  # HNSW construction on the device (csrc/nann_hnsw_build.hip): 1M x 128-d in ~0.6 s
+        if graph in ("hnsw", "hnsw_dense"):  # HNSW construction on the device (csrc/nann_hnsw_build.hip): 1M x 128-d in ~0.6 s
+            # hnsw_dense: the same builder with the heuristic's keepPrunedConnections on -- rows fill up to their cap
             with torch.cuda.device(dev):
                 rows = (torch.as_tensor(bits.view(np.int16)).to(dev).view(torch.bfloat16) if dtype == "bf16"
                         else torch.as_tensor(embs).to(dev))
-                ex = index_build.build_hnsw_gpu(rows, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank)
+                ex = index_build.build_hnsw_gpu(rows, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank,
+                                                keep_pruned=graph == "hnsw_dense")
                 del rows
         else:  # the host-side builder (csrc/host/hnsw_build.cpp), multi-threaded
             raw = index_build.build_hnsw(x32, num_neighbors=32, ef_construction=40, seed=1236 + 1000 * rank,
@@ -698,6 +701,7 @@ def main():
     qps = prim["qps_end_to_end"]
     desc = (f"{args.items} items/GPU x {args.dim}-d {args.dtype}, M=32 graph from "
             + {"hnsw": "the shipped HNSW builder on the device (efConstruction=40)",
+               "hnsw_dense": "the shipped HNSW builder on the device (efConstruction=40, keepPrunedConnections: rows filled to their cap)",
                "hnsw_cpu": "the shipped host-side HNSW builder (efConstruction=40)", "synth": "synth.py (exact-search insertion)",
                "knn": "exact k-NN rows"}[args.graph]
             + f", ef_search={args.ef}, top-{args.topk}, "

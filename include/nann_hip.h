@@ -489,6 +489,13 @@ int nann_hnsw_draw_levels(int64_t n_items, int32_t M, uint64_t seed, int32_t* le
 int nann_hnsw_build_device(const void* item_embs, int64_t n_items, int32_t d, int32_t emb_dtype, int32_t M,
                            int32_t ef_construction, const int32_t* levels /*[host]*/, int32_t* adj0, int32_t* up_row,
                            int32_t* adj_up, nann_stream_t stream);
+/* The same with alg. 4's keepPrunedConnections switch (keep_pruned != 0: a row's free slots are filled with the nearest
+ * candidates the heuristic discarded -- Faiss and hence the reference leave it off): rows fill up to their cap, mean level-0
+ * degree ~55 of 64 instead of ~17.  The dense-graph family SURVEY.md 8's gather bound (L0 gathered <= ef * 64) is about;
+ * bench.py --graph hnsw_dense and the planner tests run on it. */
+int nann_hnsw_build_device_ex(const void* item_embs, int64_t n_items, int32_t d, int32_t emb_dtype, int32_t M,
+                              int32_t ef_construction, int32_t keep_pruned, const int32_t* levels /*[host]*/, int32_t* adj0,
+                              int32_t* up_row, int32_t* adj_up, nann_stream_t stream);
 
 /* ---- 8(f2): the reference's own scorer model behind the BlazeXlaOp contract -------------
  * NANN_impls/nann/model/model.py:189-233 + model_util.py:70-97: softmax attention of the candidate

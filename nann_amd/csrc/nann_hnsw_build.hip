@@ -67,6 +67,7 @@ struct HbGraph {
   int32_t* adj_up;      // [rows, M]
   int32_t* cnt_up;      // [rows]
   int n_items, d, M;
+  int keep_pruned;      // alg. 4's keepPrunedConnections: fill a row's free slots with the nearest candidates the heuristic discarded
 };
 
 __device__ __forceinline__ int32_t* hb_row(const HbGraph& g, int node, int level, int* cap, int32_t** cnt) {
@@ -211,6 +212,19 @@ __device__ __forceinline__ uint64_t wave_select(const HbGraph& g, unsigned long 
       }
     }
     if (!dominated) { kept |= 1ull << c; ++n_kept; }
+  }
+  if (g.keep_pruned && n_kept < cap) {
+    // keepPrunedConnections (Malkov & Yashunin alg. 4, lines 15-17): the discarded candidates, nearest first, until the row
+    // is full.  Faiss leaves this off (so do the reference's graphs and this builder's default); with it rows fill up to the
+    // cap -- the dense-graph case of SURVEY.md 8's gather bound (L0 gathered <= ef * 64).
+    const int n_all = min(n, 64);
+    uint64_t rest = ~kept & (n_all >= 64 ? ~0ull : ((1ull << n_all) - 1ull));
+    while (rest && n_kept < cap) {
+      const int c = __ffsll((unsigned long long)rest) - 1;
+      kept |= 1ull << c;
+      rest &= rest - 1;
+      ++n_kept;
+    }
   }
   return kept;
 }
@@ -481,6 +495,12 @@ int nann_hnsw_draw_levels(int64_t n_items, int32_t M, uint64_t seed, int32_t* le
 int nann_hnsw_build_device(const void* item_embs, int64_t n_items, int32_t d, int32_t emb_dtype, int32_t M,
                            int32_t ef_construction, const int32_t* levels, int32_t* adj0, int32_t* up_row,
                            int32_t* adj_up, nann_stream_t stream) {
+  return nann_hnsw_build_device_ex(item_embs, n_items, d, emb_dtype, M, ef_construction, 0, levels, adj0, up_row, adj_up, stream);
+}
+
+int nann_hnsw_build_device_ex(const void* item_embs, int64_t n_items, int32_t d, int32_t emb_dtype, int32_t M,
+                              int32_t ef_construction, int32_t keep_pruned, const int32_t* levels, int32_t* adj0,
+                              int32_t* up_row, int32_t* adj_up, nann_stream_t stream) {
   if (!item_embs || !levels || !adj0 || !up_row || n_items <= 0)
     return fail(NANN_ERR_BAD_ARGUMENT, "nann_hnsw_build_device: null argument");
   if (n_items > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "nann_hnsw_build_device: more than 2^31 - 1 items");
@@ -545,7 +565,7 @@ int nann_hnsw_build_device(const void* item_embs, int64_t n_items, int32_t d, in
 
   HbGraph g;
   g.emb = item_embs; g.adj0 = adj0; g.cnt0 = d_cnt0; g.up_row = up_row; g.adj_up = adj_up; g.cnt_up = d_cnt_up;
-  g.n_items = N; g.d = d; g.M = M;
+  g.n_items = N; g.d = d; g.M = M; g.keep_pruned = keep_pruned ? 1 : 0;
   const int global_entry = order[0], top = levels[order[0]] - 1;  // level index of the entry point
   std::vector<int32_t> h_entry((size_t)max_batch, global_entry);
 

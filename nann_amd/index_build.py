@@ -103,11 +103,14 @@ def build_and_save_index(embeddings, start_level, num_neighbors, output_dir, see
 
 
 # ---- construction on the device (csrc/nann_hnsw_build.hip) -----------------------------------------------------
-def build_hnsw_gpu(item_embs, num_neighbors=32, ef_construction=40, seed=0, start_level=2, want_raw=False):
+def build_hnsw_gpu(item_embs, num_neighbors=32, ef_construction=40, seed=0, start_level=2, want_raw=False,
+                   keep_pruned=False):
     """HNSW(M) over the rows of `item_embs` (CUDA tensor f16 | bf16 [N, d], or a numpy f16 array) built ON THE GPU
     (nann_hnsw_build_device).  Returns the export of build_hnsw_index.py:41-66 -- {"enter_points", "nb_values"
     [start_level], "nb_row_splits"[start_level], "levels"} as numpy arrays (values int64 on disk) -- assembled with
-    torch on the device; with want_raw also the Faiss-shaped raw arrays of build_hnsw()."""
+    torch on the device; with want_raw also the Faiss-shaped raw arrays of build_hnsw().  keep_pruned: the selection
+    heuristic's keepPrunedConnections switch (off in Faiss, hence in the reference's graphs): rows fill up to their cap --
+    the dense-graph family (mean level-0 degree ~55 of 64 instead of ~17)."""
     import torch
     from . import _lib
     from .ops import _check, _ptr, _stream, _DT
@@ -124,9 +127,10 @@ def build_hnsw_gpu(item_embs, num_neighbors=32, ef_construction=40, seed=0, star
     up_row = torch.empty(n, dtype=torch.int32, device=x.device)
     adj_up = torch.empty((max(n_up.value, 1), m), dtype=torch.int32, device=x.device)
     torch.cuda.synchronize()
-    _check(L.nann_hnsw_build_device(_ptr(x), C.c_int64(n), C.c_int32(d), C.c_int32(_DT[x.dtype]), C.c_int32(m),
-                                    C.c_int32(ef_construction), levels.ctypes.data_as(C.c_void_p), _ptr(adj0), _ptr(up_row),
-                                    _ptr(adj_up), _stream()), "hnsw build")
+    _check(L.nann_hnsw_build_device_ex(_ptr(x), C.c_int64(n), C.c_int32(d), C.c_int32(_DT[x.dtype]), C.c_int32(m),
+                                       C.c_int32(ef_construction), C.c_int32(1 if keep_pruned else 0),
+                                       levels.ctypes.data_as(C.c_void_p), _ptr(adj0), _ptr(up_row), _ptr(adj_up), _stream()),
+           "hnsw build")
     lev = torch.as_tensor(levels, device=x.device)
     out = {"levels": levels, "enter_points": np.nonzero(levels > start_level)[0],  # build_hnsw_index.py:45
            "nb_values": [], "nb_row_splits": []}
