@@ -282,12 +282,16 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     retrieval.set_traversal_mode(cfg.get("traversal", "auto"))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # per-call options (nann_search_options): a sharded run that overlaps its exchanges leaves RCCL a few workgroup slots
+    sopt = sharded.search_options(overlap=cfg.get("overlap_exchange", False)) if sharded is not None else None
+    if cfg.get("mlp_form"):
+        sopt = retrieval.search_options(mlp_form=cfg["mlp_form"])
 
     def step(j, i=None):
         q = ops.user_seq_mean(seqs[j % n_batches])
         if i is not None:
             ev[i][0].record()
-        r = retrieval.search(index, scorer, q, topn, want_counters=True)
+        r = retrieval.search(index, scorer, q, topn, want_counters=True, options=sopt)
         if i is not None:
             ev[i][1].record()
         if sharded is not None:
@@ -346,8 +350,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         roofline["traffic_source"] = pmc["source"]
     if scorer_kind == "mlp":
         # What the traversal EXECUTES on the matrix cores per scored row (round 4: both precisions run on the table of
-        # pre-projected item halves with layer 2 resident in LDS, nann_mlp5.h; NANN_MLP_MAPPING / NANN_PREPROJECT=0
-        # select the older forms, priced by their own counts):
+        # pre-projected item halves with layer 2 resident in LDS, nann_mlp5.h; without a table -- NANN_PREPROJECT=0, no room in
+        # HBM -- the forms that read the embedding rows run, priced by their own counts):
         #   split-f16  layer 2 only, 3 f16 products per f32 MAC: 3 * 2*256*128 = 196 608 flop = 6 MFMAs of 32x32x16 per
         #              (32 rows x 32 outputs x 16 k); forms that still run layer 1 add 2 * 2*d*256
         #   exact f32  layer 2 only: 2*256*128 = 65 536 flop = 16 MFMAs of 32x32x2 per (32 rows x 32 outputs x 32 k); the
@@ -356,13 +360,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         # row -- which counts the hoisted query half and the looked-up item half of layer 1 as if they were computed per
         # candidate -- is the second figure.  The issued count is cross-checked against SQ_INSTS_MFMA of the committed
         # rocprofv3 pass (profiles/pmc_latest.json).
-        mapping = os.environ.get("NANN_MLP_MAPPING", "6")
-        table_form = os.environ.get("NANN_PREPROJECT", "1") != "0" and (mapping in "567" or (precision == "split" and mapping in "34"))
-        # the pipeline of phases runs where it pays (nann_hip.hip plan_search: beams that fit the 16K-slot set; exact at every
-        # batch size, split-f16 at <= 160 queries) -- the label follows the same rule
-        # (wide beams -- a level's visited ids beyond the 16K-slot set, ef = 256 here -- always: the stages run the 32K-slot plan)
-        phased = (table_form and cfg.get("traversal", "auto") == "auto" and
-                  (mapping == "7" or (mapping == "6" and (precision == "exact" or batch <= 160 or ef > 160))))
+        # which form ran: the planner's own answer for the timed calls (nann_search_plan: table read? pipeline of phases?)
+        table_form = bool(r.plan["table"])
+        phased = bool(r.plan["phased"])
         nominal = rows * 2.0 * (2 * dim * 256 + 256 * 128 + 128)
         if precision == "split":
             per_row = 3 * 2.0 * 256 * 128 + (0 if table_form else 2 * 2.0 * dim * 256)
@@ -382,7 +382,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         tot_b2, _ = algorithmic_bytes(counters[ok], row_bytes // 2, 2, len(g["enter_points"]), topk)
         kernel_label = ("pipeline of phases (nann_mlp6.h): k_mlp_phase_score<%s> x 5 rounds [dominant] + k_search<phase> x 6; "
                         "kernel_ms = the whole call" % precision) if phased else (
-                        "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form and mapping == "5" else ""))
+                        "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form else ""))
         roofline = {"bound": "mfma", "kernel": kernel_label,
                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                     "traffic": None, "kernel_ms": round(kern_ms, 4),
@@ -410,7 +410,12 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
             roofline["traffic_source"] = pmc["source"]
 
     qps = batch * steps / elapsed
+    try:  # the planner's choice for the timed calls and how many queries of the last one were rerun on the bitmap kernel
+        plan_info, reruns = dict(r.plan), int(r.reruns())
+    except Exception:
+        plan_info, reruns = None, None
     res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "plan": plan_info, "reruns_last_step": reruns,
            "batch": batch, "steps": steps, "valid_queries": n_valid, "setup_s": round(setup_s, 1),
            # host time to ENQUEUE each step (no sync inside the loop): a value near ms_per_step = the host blocked
            "host_enqueue_ms": host_enqueue_ms[:8],
@@ -732,7 +737,7 @@ def main():
     }
     if world > 1 and exchange_note:
         result["exchange_note"] = exchange_note
-    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "roofline", "batch_latency_ms",
+    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "plan", "reruns_last_step", "roofline", "batch_latency_ms",
               "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown", "host_enqueue_ms"):
         if k in prim:
             result[k] = prim[k]

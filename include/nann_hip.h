@@ -224,7 +224,8 @@ void nann_scorer_destroy(nann_scorer* s);
  * nann_index_destroy only RETIRE a table: it is freed by a later call once every launch that reads it has completed
  * (an event per stream behind each search), so no call synchronises the device and a concurrent search on another
  * thread never loses its table.  Thread-safe.
- * nann_set_preprojection(0) switches the tables off process-wide (NANN_PREPROJECT=0 in the environment: the same). */
+ * nann_search_options.preprojection = 0 runs a call without tables; nann_set_preprojection(0) makes that the process
+ * default (NANN_PREPROJECT=0 in the environment: the same). */
 int nann_scorer_prepare(const nann_scorer* scorer, const nann_index* ix, nann_stream_t stream);
 int nann_scorer_release(const nann_scorer* scorer, const nann_index* ix);
 int nann_scorer_table_bytes(const nann_scorer* scorer, const nann_index* ix, int64_t* table_bytes,
@@ -318,7 +319,8 @@ int nann_index_info(const nann_index* ix, int64_t out[6]);
  * a query whose set could overflow is rerun on a bitmap kernel inside the same call.  Otherwise
  * (matrix-core scorers with wide beams, larger shards) LDS_BITMAP when ceil(N/32) words fit the CU's
  * LDS next to the phase buffers, else HBM_BITMAP.  Results are identical in every mode (tested);
- * the knob exists for tests and tuning.  Process-wide, thread-safe. */
+ * the knob exists for tests and tuning.  Per call: nann_search_options.traversal_mode; nann_set_traversal_mode stores the
+ * process default of that field.  Thread-safe. */
 enum nann_traversal_mode { NANN_TRAVERSAL_AUTO = 0, NANN_TRAVERSAL_LDS_BITMAP = 1,
                            NANN_TRAVERSAL_HBM_BITMAP = 2, NANN_TRAVERSAL_LDS_HASH = 3,
                            NANN_TRAVERSAL_LDS_HASH32 = 4 };
@@ -326,7 +328,8 @@ int nann_set_traversal_mode(int32_t mode);
 /* Workgroup slots the persistent traversal grid leaves free on the device (default 0: it takes every CU, two
  * workgroups each for the L2 plan).  A host that runs other kernels NEXT TO a search -- the exchange of batch i on its
  * own stream while batch i + 1 is searched (8(e), nann_sharded_topk) -- reserves a few: without them those kernels
- * only start when the first traversal workgroups exit (measured, profiles/r4_overlap_*.json).  Process-wide. */
+ * only start when the first traversal workgroups exit (measured, profiles/r4_overlap_*.json).  Per call:
+ * nann_search_options.slot_reserve; this setter stores the process default of that field. */
 int nann_set_search_reserve(int32_t workgroups);
 
 /* Workspace bytes nann_search needs for (index, level_topn, n_queries), any scorer. */
@@ -381,6 +384,47 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
                    int32_t* out_index, int32_t* status, int32_t* counters, int64_t* phase_ticks,
                    nann_stream_t stream);
 
+/* ---- options of a search call (round 5; ABI v5) -----------------------------------------------------------------
+ * Every knob of the planner travels WITH THE CALL, so threads that share an index / scorer handle do not share a plan
+ * (rounds 1-4 had three process-global setters beside an ABI that promises re-entrancy).  A field left at -1 takes the
+ * process default: what the matching nann_set_* call stored, else the built-in value (AUTO, 0, 1, AUTO).
+ *   traversal_mode  enum nann_traversal_mode: where a query's visited set lives
+ *   slot_reserve    workgroup slots the persistent grids leave free for kernels of other streams (the exchange of a
+ *                   sharded search that overlaps the next batch); the MLP's pipeline of phases honours it too
+ *   preprojection   1: MLP / attention scorers read their per-(scorer, index) tables; 0: the kernels that read the
+ *                   embedding rows (a host with no HBM to spare)
+ *   mlp_form        enum nann_mlp_form: the fused kernel or the pipeline of phases for an MLP traversal on its table;
+ *                   AUTO = the planner's measured rule (exact f32: phased; split-f16: phased up to 160 queries and for
+ *                   wide beams)
+ * nann_search_plan ([host], optional) receives what the planner chose; the number of queries the hash-set kernel handed
+ * back to the bitmap kernel is read from the workspace afterwards (nann_search_reruns: synchronises `stream`). */
+enum nann_mlp_form { NANN_MLP_FORM_AUTO = 0, NANN_MLP_FORM_FUSED = 1, NANN_MLP_FORM_PHASED = 2 };
+typedef struct {
+  int32_t struct_bytes;   /* sizeof(nann_search_options) of the caller's header (nann_search_options_init sets it) */
+  int32_t traversal_mode;
+  int32_t slot_reserve;
+  int32_t preprojection;
+  int32_t mlp_form;
+} nann_search_options;
+typedef struct {
+  int32_t visited_set;           /* enum nann_traversal_mode of the main launch (of the traversal stages when phased) */
+  int32_t fallback_visited_set;  /* ... of the rerun of handed-back queries */
+  int32_t threads;               /* per workgroup */
+  int32_t workgroups;            /* resident workgroups (= queries in flight) */
+  int32_t phased;                /* 1: the MLP's pipeline of phases */
+  int32_t table;                 /* 1: a pre-projected table is read */
+  float est_visited;             /* the planner's estimate of a level's visited ids (hash-set capacity: 16K / 32K slots) */
+  float worst_visited;           /* the bound from the index's maximum degrees */
+} nann_search_plan;
+void nann_search_options_init(nann_search_options* o);
+/* nann_search_v + phase_ticks (uniform level_topn only) + options + plan.  level_topn == NULL: level_topn_max for all. */
+int nann_search_opt(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                    const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace, int64_t workspace_bytes,
+                    int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status, int32_t* counters,
+                    int64_t* phase_ticks, const nann_search_options* options, nann_search_plan* plan, nann_stream_t stream);
+/* queries of the LAST search on `workspace` that were rerun on the bitmap kernel (phased MLP: of its last chunk) */
+int nann_search_reruns(const void* workspace, int64_t* n_rerun, nann_stream_t stream);
+
 /* The serving signature in one call (build_opt_graph.py:151-159): comm_seq f16[n_queries, seq_len, E]
  * + level_topn -> top_k, scored by whatever model the BlazeXlaOp nodes of the graph name.  l2 / mlp:
  * nann_user_seq_mean + nann_search.  attention: the per-user projection once per request
@@ -399,6 +443,12 @@ int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* c
                         const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
                         int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
                         int32_t* status, int32_t* counters, nann_stream_t stream);
+/* ... with per-call options and the planner's choice (see nann_search_opt) */
+int nann_search_model_opt(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                          const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
+                          int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                          int32_t* status, int32_t* counters, const nann_search_options* options, nann_search_plan* plan,
+                          nann_stream_t stream);
 int nann_model_prepare(const nann_model* m, const nann_index* ix, nann_stream_t stream);
 int nann_model_release(const nann_model* m, const nann_index* ix);
 int nann_model_table_bytes(const nann_model* m, const nann_index* ix, int64_t* table_bytes, int64_t* resident_bytes);

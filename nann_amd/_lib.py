@@ -34,7 +34,7 @@ SYMBOLS = [
     "nann_group_gather_fill", "nann_group_gather_unique_scratch_bytes", "nann_group_gather_unique", "nann_bitmap_ref_difference", "nann_bloom_filter_difference", "nann_gather_rows", "nann_topk",
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
     "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
-    "nann_search", "nann_search_v", "nann_search_ex", "nann_set_traversal_mode", "nann_set_search_reserve", "nann_search_model_workspace_bytes",
+    "nann_search", "nann_search_v", "nann_search_ex", "nann_search_opt", "nann_search_options_init", "nann_search_reruns", "nann_search_model_opt", "nann_set_traversal_mode", "nann_set_search_reserve", "nann_search_model_workspace_bytes",
     "nann_search_model", "nann_search_model_v",
     "nann_scorer_prepare", "nann_scorer_release", "nann_scorer_table_bytes", "nann_set_preprojection",
     "nann_model_prepare", "nann_model_release", "nann_model_table_bytes", "nann_search_eval_workspace_bytes", "nann_search_eval", "nann_search_eval_model",
@@ -44,6 +44,19 @@ SYMBOLS = [
     "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_sharded_topk_workspace_bytes",
     "nann_sharded_topk", "nann_hnsw_draw_levels", "nann_hnsw_build_device", "nann_hnsw_build_device_ex",
 ]
+
+
+class SearchOptions(C.Structure):
+    """nann_search_options (include/nann_hip.h): -1 = the process default of the field"""
+    _fields_ = [("struct_bytes", C.c_int32), ("traversal_mode", C.c_int32), ("slot_reserve", C.c_int32),
+                ("preprojection", C.c_int32), ("mlp_form", C.c_int32)]
+
+
+class SearchPlan(C.Structure):
+    """nann_search_plan: what the planner chose for a call"""
+    _fields_ = [("visited_set", C.c_int32), ("fallback_visited_set", C.c_int32), ("threads", C.c_int32),
+                ("workgroups", C.c_int32), ("phased", C.c_int32), ("table", C.c_int32),
+                ("est_visited", C.c_float), ("worst_visited", C.c_float)]
 
 
 class ScorerDesc(C.Structure):

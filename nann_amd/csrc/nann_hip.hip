@@ -697,15 +697,55 @@ struct HipProjBackend {
 };
 typedef nann::ProjCacheT<HipProjBackend> ProjCache;
 typedef nann::ProjTableT<HipProjBackend> ProjTable;
-static std::atomic<int> g_preproject{-1};  // -1: NANN_PREPROJECT from the environment (default on), 0 off, 1 on
-static bool preproject_enabled() {
-  int v = g_preproject.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = std::getenv("NANN_PREPROJECT");
-    v = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
-    g_preproject.store(v, std::memory_order_relaxed);
+// ---- options of a search call -------------------------------------------------------------------------------------
+// Every knob of the planner is a field of nann_search_options (include/nann_hip.h, round 5); a field left at -1 takes the
+// PROCESS DEFAULT: what nann_set_traversal_mode / nann_set_search_reserve / nann_set_preprojection last stored, else the
+// environment read ONCE below (A/B tooling: NANN_PREPROJECT=0, NANN_SEARCH_SLOT_RESERVE=n, NANN_MLP_FORM=fused|phased,
+// NANN_PHASE_SMALL32=0), else the built-in value.  plan_search and the launchers only ever see the resolved struct.
+struct SearchOpt {
+  int mode;        // nann_traversal_mode
+  int reserve;     // workgroup slots the persistent grids leave free
+  int preproject;  // 1: the MLP / attention scorers read their pre-projected tables
+  int mlp_form;    // nann_mlp_form
+  int small32;     // 1: at most one query per CU -> one 1024-thread workgroup per CU for the traversal (stages)
+};
+static std::atomic<int> g_traversal_mode{-1}, g_slot_reserve{-1}, g_preproject{-1};
+static const SearchOpt& env_defaults() {
+  static const SearchOpt d = [] {
+    SearchOpt o{NANN_TRAVERSAL_AUTO, 0, 1, NANN_MLP_FORM_AUTO, 1};
+    if (const char* e = std::getenv("NANN_PREPROJECT")) o.preproject = !(e[0] == '0' && e[1] == 0);
+    if (const char* e = std::getenv("NANN_SEARCH_SLOT_RESERVE")) o.reserve = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("NANN_MLP_FORM")) o.mlp_form = std::string(e) == "fused" ? NANN_MLP_FORM_FUSED : std::string(e) == "phased" ? NANN_MLP_FORM_PHASED : NANN_MLP_FORM_AUTO;
+    if (const char* e = std::getenv("NANN_PHASE_SMALL32")) o.small32 = !(e[0] == '0');
+    return o;
+  }();
+  return d;
+}
+static SearchOpt resolve_options(const nann_search_options* u) {
+  SearchOpt o = env_defaults();
+  const int gm = g_traversal_mode.load(std::memory_order_relaxed), gr = g_slot_reserve.load(std::memory_order_relaxed),
+            gp = g_preproject.load(std::memory_order_relaxed);
+  if (gm >= 0) o.mode = gm;
+  if (gr >= 0) o.reserve = gr;
+  if (gp >= 0) o.preproject = gp;
+  if (u) {
+    // struct_bytes: a caller built against an older header passes a shorter struct; fields behind it keep their defaults
+    const size_t nb = u->struct_bytes > 0 ? (size_t)u->struct_bytes : sizeof(*u);
+    auto has = [&](const int32_t* f) { return (size_t)(reinterpret_cast<const char*>(f) - reinterpret_cast<const char*>(u)) + 4 <= nb; };
+    if (has(&u->traversal_mode) && u->traversal_mode >= 0) o.mode = u->traversal_mode;
+    if (has(&u->slot_reserve) && u->slot_reserve >= 0) o.reserve = u->slot_reserve;
+    if (has(&u->preprojection) && u->preprojection >= 0) o.preproject = u->preprojection != 0;
+    if (has(&u->mlp_form) && u->mlp_form >= 0) o.mlp_form = u->mlp_form;
   }
-  return v != 0;
+  return o;
+}
+static int check_options(const nann_search_options* u) {
+  if (!u) return NANN_OK;
+  if (u->struct_bytes < 0 || (u->struct_bytes > 0 && u->struct_bytes < 8)) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_options: struct_bytes");
+  const SearchOpt o = resolve_options(u);
+  if (o.mode < NANN_TRAVERSAL_AUTO || o.mode > NANN_TRAVERSAL_LDS_HASH32) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_options: unknown traversal_mode");
+  if (o.mlp_form < NANN_MLP_FORM_AUTO || o.mlp_form > NANN_MLP_FORM_PHASED) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_options: unknown mlp_form");
+  return NANN_OK;
 }
 
 struct nann_scorer {
@@ -1929,21 +1969,10 @@ int nann_index_info(const nann_index* ix, int64_t out[6]) {
 }
 
 // ---- fused search -----------------------------------------------------------------------
-static std::atomic<int> g_traversal_mode{NANN_TRAVERSAL_AUTO};
 constexpr int64_t kPhaseTail = 8192;  // behind the slots: reserved (round 4's first pipeline of phases kept its block prefix here)
-// workgroup slots the persistent traversal grid leaves FREE (nann_set_search_reserve): a host that overlaps another
-// stream's kernels with the search -- the exchange step of a sharded search, DESIGN.md 7 -- keeps a few for them; the
-// grid otherwise owns every CU's LDS until its first workgroups exit.  -1: NANN_SEARCH_SLOT_RESERVE from the environment.
-static std::atomic<int> g_slot_reserve{-1};
-static int slot_reserve() {
-  int v = g_slot_reserve.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = std::getenv("NANN_SEARCH_SLOT_RESERVE");
-    v = e ? std::max(0, std::atoi(e)) : 0;
-    g_slot_reserve.store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
+// (SearchOpt::reserve: workgroup slots the persistent traversal grid leaves FREE -- a host that overlaps another stream's
+// kernels with the search, the exchange step of a sharded search, DESIGN.md 7, keeps a few for them; the grid otherwise
+// owns every CU's LDS until its first workgroups exit.)
 
 static int bit_length(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
@@ -1952,7 +1981,8 @@ constexpr int kKindMlpSplit = 3;  //   the MLP scorer in split-f16 form (two sli
 constexpr int kKindMlpRes = 4;    //   the MLP scorer, either precision, on the pre-projected table with layer 2 resident in LDS
                                   //   (nann_mlp5.h): 16K-slot set under the weights, or the HBM bitmap
 // kind: scorer kind of the call, or -1 = "any" (workspace sizing: the largest plan)
-static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p, bool mlp_exact_hint = false) {
+static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queries, int kind, SearchPlan* p, const SearchOpt& opt,
+                       bool mlp_exact_hint = false) {
   for (int i = 0; i < 6; ++i)
     if (t[i] < 0 || t[i] > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "level_topn entries must be in [0, 1024]");
   DeviceInfo di;
@@ -1978,7 +2008,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
                             : res ? (size_t)kMlpResBytes
                             : kind < 0 ? big_scratch : (size_t)kPhaseScratch;
   const bool bitmap_fits = !res && bm_bytes + bm_scratch + tail <= di.lds_max;  // resident layer 2 owns the LDS: HBM bitmap
-  const int mode = g_traversal_mode.load(std::memory_order_relaxed);
+  const int mode = opt.mode;
   // the bitmap plan: what MLP traversals run, what oversized shards run, and the fallback of the hash plan
   const int bm_vis = (bitmap_fits && mode != NANN_TRAVERSAL_HBM_BITMAP) ? VIS_LDS_BITMAP : VIS_HBM_BITMAP;
   const size_t bm_lds = bm_scratch + tail + (bm_vis == VIS_LDS_BITMAP ? bm_bytes : 0);
@@ -2059,13 +2089,12 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // batch size (batch 32: 3.4x -- the scoring launch spreads 32 queries' rows over the chip, the fused kernel holds 32 CUs --,
   // 128: 1.7x, >= 256: +3..8 %); split-f16 below ~160 queries (batch 32: 1.64x).  Above that the fused split-f16 kernel, which
   // runs the same software-pipelined block loop, is level with it or ahead: 256-512 queries +8..19 % (one query per CU finishes
-  // sooner than 12 launches), 1024: within 2 % either way box to box, 4096: +2.7 %.  NANN_MLP_MAPPING=7: always, =5: never.
+  // sooner than 12 launches), 1024: within 2 % either way box to box, 4096: +2.7 %.  nann_search_options.mlp_form forces either.
   const bool exact_form = mlp_exact_hint;
   const bool pays = exact_form || n_queries <= 160;
   const bool no_forced_bitmap = mode != NANN_TRAVERSAL_LDS_BITMAP && mode != NANN_TRAVERSAL_HBM_BITMAP;
-  const int mapping_now = mlp_mapping_choice();
-  p->phased = res && own_hash_plan && no_forced_bitmap && 2 * hash16_lds <= di.lds_max &&
-              (mapping_now >= 7 || (mapping_now == 6 && pays));
+  const bool want_phased = opt.mlp_form == NANN_MLP_FORM_PHASED || (opt.mlp_form == NANN_MLP_FORM_AUTO && pays);
+  p->phased = res && own_hash_plan && no_forced_bitmap && 2 * hash16_lds <= di.lds_max && want_phased;
   p->phase_vis = VIS_LDS_HASH;
   p->phase_per_cu = 2;
   p->phase_lds_bytes = hash16_lds;
@@ -2074,7 +2103,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // plan (one 1024-thread workgroup per CU).  Both precisions, every batch size (profiles/r5g_*).
   const bool fits32 = worst_visited <= 32704.0 || est_visited <= 24000.0;
   if (res && !own_hash_plan && tag_fits && fits32 && no_forced_bitmap && mode != NANN_TRAVERSAL_LDS_HASH && hash32_lds <= di.lds_max &&
-      mapping_now >= 6) {
+      opt.mlp_form != NANN_MLP_FORM_FUSED) {
     p->phased = true;
     p->phase_vis = VIS_LDS_HASH32;
     p->phase_per_cu = 1;
@@ -2084,8 +2113,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   }
   // few queries (at most one per CU): a query's stages run faster on ONE 1024-thread workgroup per CU than on one of two
   // 512-thread workgroups that has no partner to overlap with (the L2 kernel's small-batch rule, above)
-  static const bool small32 = [] { const char* e = std::getenv("NANN_PHASE_SMALL32"); return !(e && e[0] == '0'); }();
-  if (p->phased && p->phase_vis == VIS_LDS_HASH && small32 && n_queries <= (int64_t)di.cus && tag_fits && hash32_lds <= di.lds_max) {
+  if (p->phased && p->phase_vis == VIS_LDS_HASH && opt.small32 && n_queries <= (int64_t)di.cus && tag_fits && hash32_lds <= di.lds_max) {
     p->phase_vis = VIS_LDS_HASH32;
     p->phase_per_cu = 1;
     p->phase_lds_bytes = hash32_lds;
@@ -2093,21 +2121,36 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
     p->slot_bytes = slot_layout(p->max_cand, p->max_raw, p->pool_cap, gbm_words, off);
   }
   p->phase_slots = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), (int64_t)di.cus * p->phase_per_cu));
+  p->phase_score_wgs = di.cus;
+  p->est_visited = (float)est_visited;
+  p->worst_visited = (float)worst_visited;
   if (kind < 0)  // sizing: the widest plan (two workgroups per CU, or one slot per query of a phased chunk)
     p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, std::max<int64_t>((int64_t)di.cus * 2, kPhaseChunk)));
-  else if (const int reserve = slot_reserve()) {  // leave workgroup slots to kernels of other streams (nann_set_search_reserve)
+  else if (const int reserve = opt.reserve) {  // leave workgroup slots to kernels of other streams (nann_search_options.slot_reserve)
     const int per_cu = p->vis == VIS_LDS_HASH && p->nt == 512 && !res && kind != kKindAttn && kind != kKindMlpSplit ? 2
                        : p->vis == VIS_HBM_BITMAP && !res ? 2 : 1;
     p->slots = std::max(1, std::min(p->slots, di.cus * per_cu - reserve));
     p->fb_slots = std::max(1, std::min(p->fb_slots, di.cus * bm_per_cu - reserve));
+    // the pipeline of phases keeps the same promise (it ignored the reserve): its traversal stages leave `reserve`
+    // slots, its scoring launches -- one workgroup owns a CU's LDS -- the CUs those slots stand for
+    p->phase_slots = std::max(1, std::min(p->phase_slots, di.cus * p->phase_per_cu - reserve));
+    p->phase_score_wgs = std::max(1, di.cus - (reserve + 1) / 2);
   }
   return NANN_OK;
 }
 
+// The three setters are PROCESS DEFAULTS of the fields of nann_search_options that a call leaves at -1 (round 5: the knobs
+// themselves travel with the call -- nann_search_opt --, so two threads sharing a handle no longer share a plan).
 int nann_set_search_reserve(int32_t workgroups) {
   if (workgroups < 0) return fail(NANN_ERR_BAD_ARGUMENT, "nann_set_search_reserve: negative");
   g_slot_reserve.store(workgroups, std::memory_order_relaxed);
   return NANN_OK;
+}
+
+void nann_search_options_init(nann_search_options* o) {
+  if (!o) return;
+  o->struct_bytes = (int32_t)sizeof(*o);
+  o->traversal_mode = o->slot_reserve = o->preprojection = o->mlp_form = -1;
 }
 
 int nann_set_traversal_mode(int32_t mode) {
@@ -2121,7 +2164,7 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
                                 int64_t* nbytes) {
   if (!ix || !level_topn || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_workspace_bytes: null argument");
   SearchPlan p;
-  const int rc = plan_search(ix, level_topn, n_queries, -1, &p);
+  const int rc = plan_search(ix, level_topn, n_queries, -1, &p, resolve_options(nullptr));  // (kind "any": the widest plan, whatever the options)
   if (rc) return rc;
   *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots) + kPhaseTail);
   return NANN_OK;
@@ -2129,25 +2172,16 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
 
 }  // extern "C"
 
-namespace nann {
-int mlp_mapping_choice() {
-  static const int choice = [] {
-    const char* e = std::getenv("NANN_MLP_MAPPING");
-    return (e && e[0] >= '1' && e[0] <= '7' && e[1] == 0) ? e[0] - '0' : 6;
-  }();
-  return choice;
-}
-}  // namespace nann
 
 // The pre-projected table of (scorer, index): found, or built on `st` by `build(table)` (a one-time wait per pair,
 // ~10-20 ms per million items: nann_*_prepare moves it ahead of traffic).  *out stays null -- with NANN_OK -- when there
 // is to be no table: pre-projection switched off, or no room for it in HBM (the caller then runs the kernels that
 // read the embedding rows; ADVICE r3: a failed hipMalloc must not fail the search).  pin: count a prepare call.
 template <typename Build>
-static int projection_for(ProjCache& c, const nann_index* ix, int width, hipStream_t st, Build build, bool pin,
+static int projection_for(ProjCache& c, const nann_index* ix, int width, hipStream_t st, Build build, bool pin, bool enabled,
                           std::shared_ptr<ProjTable>* out) {
   const size_t bytes = (size_t)ix->desc.n_items * (size_t)width * 4;
-  return c.acquire(ix->uid, bytes, preproject_enabled(), pin, [&](float* t) -> int {
+  return c.acquire(ix->uid, bytes, enabled, pin, [&](float* t) -> int {
     const int rc = build(t);
     if (rc) return rc;
     // the table becomes visible to searches on OTHER streams when acquire() returns: it must be complete by then
@@ -2164,16 +2198,16 @@ static int projection_release(ProjCache& c, const nann_index* ix) {
   return fail(NANN_ERR_BAD_ARGUMENT, "release: no pre-projected table of this index");
 }
 
-static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, bool pin, std::shared_ptr<ProjTable>* out) {
+static int mlp_projection(const nann_scorer* sc, const nann_index* ix, hipStream_t st, bool pin, bool enabled, std::shared_ptr<ProjTable>* out) {
   return projection_for(sc->proj, ix, kMlpProjWidth, st, [&](float* t) {
     return launch_mlp_preproject(ix->desc.emb_dtype, ix->desc.item_embs, (long long)ix->desc.n_items, ix->desc.d, sc->mlp.w1, t, st);
-  }, pin, out);
+  }, pin, enabled, out);
 }
 
-static int attn_projection(const nann_attn_scorer* sc, const nann_index* ix, hipStream_t st, bool pin, std::shared_ptr<ProjTable>* out) {
+static int attn_projection(const nann_attn_scorer* sc, const nann_index* ix, hipStream_t st, bool pin, bool enabled, std::shared_ptr<ProjTable>* out) {
   return projection_for(sc->proj, ix, kAttnProjWidth, st, [&](float* t) {
     return launch_attn_preproject(ix->desc.emb_dtype, sc->P, ix->desc.item_embs, (long long)ix->desc.n_items, t, st);
-  }, pin, out);
+  }, pin, enabled, out);
 }
 
 // L2 instantiations live in nann_l2_inst.hip (one object per row dtype), MLP ones in
@@ -2210,29 +2244,44 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
                        const float* q, const float* kt, const float* upad, int64_t n_queries,
                        const int32_t level_topn[6], const int32_t* tq, void* workspace, int64_t workspace_bytes,
                        int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
-                       int32_t* counters, int64_t* phase_ticks, hipStream_t st) {
+                       int32_t* counters, int64_t* phase_ticks, const nann_search_options* options, nann_search_plan* plan_out,
+                       hipStream_t st) {
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
+  int rc = check_options(options);
+  if (rc) return rc;
+  const SearchOpt opt = resolve_options(options);
   const int kind = attn ? kKindAttn : scorer->desc.kind;
   const bool mlp = !attn && kind == NANN_SCORER_MLP;
   const bool mlp_split = mlp && scorer->desc.precision == NANN_MLP_SPLIT_F16;
-  const int mapping = mlp_mapping_choice();
   // the item-only part of the scorer, pre-projected per (scorer, index): found or built here (nann_*_prepare does it
   // ahead of traffic); without a table -- switched off, or no room in HBM -- the kernels that read the embedding rows run
   std::shared_ptr<ProjTable> tab;
   ProjCache* cache = nullptr;
-  int rc = NANN_OK;
-  if (attn && mapping >= 3) {  // both precisions run on the table of item-only layers (nann_attn_proj.h; nann_attn_kernels.h PROJ)
+  if (attn) {  // both precisions run on the table of item-only layers (nann_attn_proj.h; nann_attn_kernels.h PROJ)
     cache = &attn->proj;
-    rc = attn_projection(attn, ix, st, false, &tab);
-  } else if (mlp && (mapping >= 5 || (mlp_split && mapping >= 3))) {
+    rc = attn_projection(attn, ix, st, false, opt.preproject != 0, &tab);
+  } else if (mlp) {
     cache = &scorer->proj;
-    rc = mlp_projection(scorer, ix, st, false, &tab);
+    rc = mlp_projection(scorer, ix, st, false, opt.preproject != 0, &tab);
   }
   if (rc) return rc;
-  const bool mlp_res = mlp && tab && mapping >= 5;  // layer 2 resident in LDS, either precision (nann_mlp5.h)
+  const bool mlp_res = mlp && tab;  // layer 2 resident in LDS, either precision (nann_mlp5.h)
   SearchPlan p;
-  rc = plan_search(ix, level_topn, n_queries, mlp_res ? kKindMlpRes : mlp_split ? kKindMlpSplit : kind, &p, mlp && !mlp_split);
+  rc = plan_search(ix, level_topn, n_queries, mlp_res ? kKindMlpRes : mlp_split ? kKindMlpSplit : kind, &p, opt, mlp && !mlp_split);
   if (rc) return rc;
+  if (plan_out) {  // what this call runs (host-side facts; the number of reruns lives in the workspace: nann_search_reruns)
+    const bool ph = mlp_res && p.phased;
+    const int v = ph ? p.phase_vis : p.vis;
+    plan_out->visited_set = v == VIS_LDS_HASH ? NANN_TRAVERSAL_LDS_HASH : v == VIS_LDS_HASH32 ? NANN_TRAVERSAL_LDS_HASH32
+                            : v == VIS_LDS_BITMAP ? NANN_TRAVERSAL_LDS_BITMAP : NANN_TRAVERSAL_HBM_BITMAP;
+    plan_out->fallback_visited_set = p.fb_vis == VIS_LDS_BITMAP ? NANN_TRAVERSAL_LDS_BITMAP : NANN_TRAVERSAL_HBM_BITMAP;
+    plan_out->threads = ph ? (p.phase_vis == VIS_LDS_HASH32 ? kNT : 512) : ((mlp || attn) && p.nt == kNT ? 512 : p.nt);
+    plan_out->workgroups = ph ? p.phase_slots : p.slots;
+    plan_out->phased = ph ? 1 : 0;
+    plan_out->table = tab ? 1 : 0;
+    plan_out->est_visited = p.est_visited;
+    plan_out->worst_visited = p.worst_visited;
+  }
   const int64_t need_slots = p.phased ? std::max<int64_t>(std::min<int64_t>(n_queries, kPhaseChunk), p.fb_slots) : std::max(p.slots, p.fb_slots);
   if (!workspace || workspace_bytes < (int64_t)(256 + p.slot_bytes * (unsigned long long)need_slots + (p.phased ? kPhaseTail : 0)))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_workspace_bytes()");
@@ -2280,9 +2329,9 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
     a.attn = attn->P;
     if (tab) {  // the default form: q_ and the e rows of DNN layer 1 pre-projected per (model, index) (nann_attn_proj.h)
       auto launch = attn->precision == NANN_MLP_SPLIT_F16 ? launch_search_attn_proj : launch_search_attn_xproj;
-      // split-f16 on the 16K-slot plan: the form with keys and weights resident for a scoring call (NANN_MLP_MAPPING <= 4:
-      // the slice-ring form, which the bitmap plans and the overflow rerun keep)
-      const bool resident = attn->precision == NANN_MLP_SPLIT_F16 && mapping >= 5;
+      // split-f16 on the 16K-slot plan: the form with keys and weights resident for a scoring call (the bitmap plans and the
+      // overflow rerun keep the slice-ring form)
+      const bool resident = attn->precision == NANN_MLP_SPLIT_F16;
       return both([&](int vis, int, int slots, size_t lds) {
         if (resident && vis == VIS_LDS_HASH && !a.redo) return launch_search_attn_res(slots, lds, a, st);
         return launch(vis, slots, lds, a, st);
@@ -2314,12 +2363,12 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
       if (counters) c.counters = counters + (size_t)c0 * 3 * NANN_NUM_ROUNDS;
       if (phase_ticks) c.phase_ticks = reinterpret_cast<long long*>(phase_ticks) + (size_t)c0 * NANN_NUM_PHASES;
       if (c0) HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
-      const int slots = (int)std::min<int64_t>(c.n_queries, (int64_t)di.cus * p.phase_per_cu);
+      const int slots = (int)std::min<int64_t>(c.n_queries, (int64_t)p.phase_slots);
       for (int ph = 0; ph <= NANN_NUM_ROUNDS && !rc; ++ph) {
         c.phase = ph;
         rc = launch_search_mlp_phase(p.phase_vis, slots, p.phase_lds_bytes, c, st);
         if (!rc && ph < NANN_NUM_ROUNDS) {
-          rc = launch_mlp_phase_score(exact, c, ph, di.cus, st);
+          rc = launch_mlp_phase_score(exact, c, ph, p.phase_score_wgs, st);
         }
       }
       if (!rc) {
@@ -2335,8 +2384,6 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
     return both([&](int vis, int, int slots, size_t lds) {
       return launch_search_mlp_res(exact, vis, slots, lds, a, st);
     });
-  if (mlp_split && tab)  // round 3's form (NANN_MLP_MAPPING=3|4): the table, layer-2 slices streamed per pass (nann_mlp3.h)
-    return both([&](int vis, int, int slots, size_t lds) { return launch_search_mlp_proj(vis, slots, lds, a, st); });
   return both([&](int vis, int nt, int slots, size_t lds) {
     return launch_search_any(ix->desc.d / 8, dt, kind, mlp_split, vis, nt, slots, lds, a, st);
   });
@@ -2354,7 +2401,30 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
   if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
     return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
   return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, nullptr, workspace, workspace_bytes,
-                     out_item_ids, out_scores, out_index, status, counters, phase_ticks, as_stream(stream));
+                     out_item_ids, out_scores, out_index, status, counters, phase_ticks, nullptr, nullptr, as_stream(stream));
+}
+
+int nann_search_opt(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                    const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace, int64_t workspace_bytes,
+                    int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status, int32_t* counters,
+                    int64_t* phase_ticks, const nann_search_options* options, nann_search_plan* plan, nann_stream_t stream) {
+  if (!ix || !scorer || !level_topn_max || !out_item_ids || !status)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_opt: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  if (level_topn && phase_ticks) return fail(NANN_ERR_UNSUPPORTED, "nann_search_opt: phase ticks with a uniform level_topn only");
+  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn_max, level_topn, workspace, workspace_bytes,
+                     out_item_ids, out_scores, out_index, status, counters, phase_ticks, options, plan, as_stream(stream));
+}
+
+int nann_search_reruns(const void* workspace, int64_t* n_rerun, nann_stream_t stream) {
+  if (!workspace || !n_rerun) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_reruns: null argument");
+  unsigned int v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, static_cast<const unsigned char*>(workspace) + offsetof(WsHeader, n_redo), 4, hipMemcpyDeviceToHost, as_stream(stream)));
+  HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  *n_rerun = v;
+  return NANN_OK;
 }
 
 int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
@@ -2367,7 +2437,7 @@ int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* 
   if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
     return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
   return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn_max, level_topn, workspace,
-                     workspace_bytes, out_item_ids, out_scores, out_index, status, counters, nullptr, as_stream(stream));
+                     workspace_bytes, out_item_ids, out_scores, out_index, status, counters, nullptr, nullptr, nullptr, as_stream(stream));
 }
 
 // ---- lifecycle of the pre-projected tables (ProjCache) -------------------------------------------------------
@@ -2385,7 +2455,8 @@ static int prepare_impl(const nann_scorer* s, const nann_attn_scorer* at, const 
   const int d = at ? at->P.d : s->desc.d, dt = at ? at->emb_dtype : s->desc.emb_dtype;
   if (d != ix->desc.d || dt != ix->desc.emb_dtype) return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
   std::shared_ptr<ProjTable> tab;
-  const int rc = at ? attn_projection(at, ix, st, true, &tab) : mlp_projection(s, ix, st, true, &tab);
+  const bool enabled = resolve_options(nullptr).preproject != 0;
+  const int rc = at ? attn_projection(at, ix, st, true, enabled, &tab) : mlp_projection(s, ix, st, true, enabled, &tab);
   if (rc) return rc;
   if (!tab) return fail(NANN_ERR_CAPACITY, "no room in HBM for the pre-projected table (or pre-projection is switched off): "
                                            "searches of this pair will read the embedding table");
@@ -2426,7 +2497,7 @@ int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m,
                                       int64_t n_queries, int64_t* nbytes) {
   if (!ix || !m || !level_topn || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_model_workspace_bytes: null argument");
   SearchPlan p;
-  const int rc = plan_search(ix, level_topn, n_queries, m->kind == NANN_MODEL_ATTENTION ? kKindAttn : -1, &p);
+  const int rc = plan_search(ix, level_topn, n_queries, m->kind == NANN_MODEL_ATTENTION ? kKindAttn : -1, &p, resolve_options(nullptr));
   if (rc) return rc;
   *nbytes = (int64_t)(256 + p.slot_bytes * (unsigned long long)std::max(p.slots, p.fb_slots) + kPhaseTail + 256 +
                       model_query_bytes(m, n_queries));
@@ -2436,7 +2507,7 @@ int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m,
 static int search_model_impl(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
                              const int32_t level_topn[6], const int32_t* tq, void* workspace, int64_t workspace_bytes,
                              int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
-                             int32_t* counters, nann_stream_t stream) {
+                             int32_t* counters, const nann_search_options* options, nann_search_plan* plan, nann_stream_t stream) {
   if (!ix || !m || !comm_seq_f16 || !level_topn || !out_item_ids || !status || !workspace)
     return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_model: null argument");
   if (n_queries <= 0) return NANN_OK;
@@ -2456,13 +2527,13 @@ static int search_model_impl(const nann_index* ix, const nann_model* m, const vo
     rc = nann_attn_prepare(m->attn, comm_seq_f16, n_queries, kt, upad, stream);
     if (rc) return rc;
     return search_impl(ix, nullptr, m->attn, nullptr, kt, upad, n_queries, level_topn, tq, workspace, search_bytes,
-                       out_item_ids, out_scores, out_index, status, counters, nullptr, st);
+                       out_item_ids, out_scores, out_index, status, counters, nullptr, options, plan, st);
   }
   float* q = reinterpret_cast<float*>(qbuf);
   rc = nann_user_seq_mean(comm_seq_f16, n_queries, m->seq_len, m->d, q, stream);
   if (rc) return rc;
   return search_impl(ix, m->scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, tq, workspace, search_bytes,
-                     out_item_ids, out_scores, out_index, status, counters, nullptr, st);
+                     out_item_ids, out_scores, out_index, status, counters, nullptr, options, plan, st);
 }
 
 int nann_search_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
@@ -2470,7 +2541,7 @@ int nann_search_model(const nann_index* ix, const nann_model* m, const void* com
                       int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                       int32_t* counters, nann_stream_t stream) {
   return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn, nullptr, workspace, workspace_bytes, out_item_ids,
-                           out_scores, out_index, status, counters, stream);
+                           out_scores, out_index, status, counters, nullptr, nullptr, stream);
 }
 
 int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
@@ -2478,7 +2549,16 @@ int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* c
                         int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
                         int32_t* status, int32_t* counters, nann_stream_t stream) {
   return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn_max, level_topn, workspace, workspace_bytes,
-                           out_item_ids, out_scores, out_index, status, counters, stream);
+                           out_item_ids, out_scores, out_index, status, counters, nullptr, nullptr, stream);
+}
+
+int nann_search_model_opt(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
+                          const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
+                          int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
+                          int32_t* status, int32_t* counters, const nann_search_options* options, nann_search_plan* plan,
+                          nann_stream_t stream) {
+  return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn_max, level_topn, workspace, workspace_bytes,
+                           out_item_ids, out_scores, out_index, status, counters, options, plan, stream);
 }
 
 int nann_model_prepare(const nann_model* m, const nann_index* ix, nann_stream_t stream) {

@@ -30,10 +30,6 @@
 
 #include "nann_mlp3.h"
 
-#ifndef NANN_RES_SKEW
-#define NANN_RES_SKEW 0    // s_sleep units (64 cycles) the second wavefront of every SIMD starts late; measured (r4c): 0 / 6 / 12 / 24
-                           // make no difference to the split-f16 form
-#endif
 #ifndef NANN_RES_XSKEW
 #define NANN_RES_XSKEW 32  // the same for the exact form (a tile = 64 f32 MFMAs of 64 cycles)
 #endif
@@ -120,31 +116,6 @@ __device__ __forceinline__ void wg_mlp_res_leave(uint4* lds, const uint4* park, 
 // the next tile's).  For the unrolled body to keep its registers the LDS addresses are formed from THREE opaque bases
 // (weights below / above the 64 KB an instruction's offset field reaches, and the vectors) + immediate offsets; left to
 // itself the compiler hoists ~60 address registers out of the block loop and spills them into it.
-#ifndef NANN_RES_ROLLED
-#define NANN_RES_ROLLED 0
-#endif
-#ifndef NANN_PIPE_MT_MAJOR
-#define NANN_PIPE_MT_MAJOR 0  // A/B build of the pipeline: products ordered output tile by output tile (see there)
-#endif
-#ifndef NANN_PIPE_ASM
-#define NANN_PIPE_ASM 0  // 1: the pipeline's PReLU as hand-written packed-f32 asm -- fewer instructions (7 instead of ~9 per pair) and SLOWER
-                        // (379 k against 388 k queries/s, profiles/r4x_*: asm statements pin the order hipcc would otherwise choose)
-#endif
-#ifndef NANN_PIPE_NOPK
-#define NANN_PIPE_NOPK 0  // 1: the pipeline's PReLU as scalar f32 instructions pinned by asm (no v_pk_fma_f32 in the MFMAs' shadow)
-#endif
-#ifndef NANN_PIPE_PRIO
-#define NANN_PIPE_PRIO 0  // n > 0: s_setprio n for wavefronts 4-7 of the workgroup over the whole pipeline (MI355X_MICROARCH.md, static priority)
-#endif
-#ifndef NANN_PIPE_AGPR
-#define NANN_PIPE_AGPR 0  // 1: one inline-asm "a" operand in the pipeline: hipcc then selects the AGPR form of every MFMA of the kernel
-#endif
-#ifndef NANN_RES_PIPE
-#define NANN_RES_PIPE 1  // the software-pipelined block loop (wave_mlp_split_pipeline); 0: the tile-phased loop of r4a-r4j
-#endif
-#ifndef NANN_RES_WF16
-#define NANN_RES_WF16 0  // 1: all sixteen A fragments of a tile read at its top (32 more live registers) instead of 8 + 8
-#endif
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4v* lds_u4_ptr;
@@ -183,12 +154,6 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
   constexpr int H1T = 8, H2T = 4;
   constexpr int kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
   const uint32_t w_lo = L.w_lo, w_hi = L.w_hi, v_at = L.v_at, u_at = L.u_at;
-#if NANN_PIPE_AGPR
-  { int z = 0; asm volatile("; accumulators in AGPRs" : "+a"(z)); }
-#endif
-#if NANN_PIPE_PRIO
-  if (__builtin_amdgcn_workitem_id_x() & 256) __builtin_amdgcn_s_setprio(NANN_PIPE_PRIO);  // the younger half of a 512-thread workgroup
-#endif
   auto vec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(v_at + 4 * float_index); };
   auto uvec4 = [&](int float_index) -> f32x4v { return *reinterpret_cast<lds_f4_ptr>(u_at + 4 * float_index); };
   auto fragt = [&](int t, int k) -> f16x8 {
@@ -218,26 +183,9 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
     const f32x2 bp = (p & 1) ? f32x2{be.z, be.w} : f32x2{be.x, be.y};
     // packed f32 forms by hand (left to itself hipcc scalarises about half of them; the vector pipe's issue slots
     // are what bounds this loop): x + u, min(., 0) per half (there is no packed f32 min), (alpha - 1) min + (x + u)
-#if NANN_PIPE_ASM
-    f32x2 xs, h;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(xs) : "v"(xp), "v"(up));
-    f32x2 m;
-    asm("v_min_f32 %0, 0, %1" : "=v"(m.x) : "v"(xs.x));
-    asm("v_min_f32 %0, 0, %1" : "=v"(m.y) : "v"(xs.y));
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(h) : "v"(m), "v"(bp), "v"(xs));
-    return h;
-#elif NANN_PIPE_NOPK
-    // scalar f32 forms (MI355X_MICROARCH.md: a packed-f32 instruction beside MFMAs costs +11..22 cycles over its two scalar halves)
-    f32x2 h;
-    const float x0 = xp.x + up.x, x1 = xp.y + up.y;
-    h.x = __builtin_fmaf(__builtin_fminf(x0, 0.0f), bp.x, x0);
-    h.y = __builtin_fmaf(__builtin_fminf(x1, 0.0f), bp.y, x1);
-    return h;
-#else
     const f32x2 xs = xp + up;
     const f32x2 m = __builtin_elementwise_min(xs, f32x2{0.0f, 0.0f});
     return __builtin_elementwise_fma(m, bp, xs);
-#endif
   };
   // ... and its f16 halves: hi = rtz(a), lo = a - hi (prelu_split_pair_pk's arithmetic, nann_mlp2.h)
   auto convert_b = [&](f32x2 h, uint32_t& hi, uint32_t& lo) {
@@ -283,29 +231,6 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
         if (t == H1T - 2 && q == 1 && change) lds_write_u(u_next);
         const f16x8 bh = as_f16x8(uint4{Bh[cbuf][q][0], Bh[cbuf][q][1], Bh[cbuf][q][2], Bh[cbuf][q][3]});
         const f16x8 bl = as_f16x8(uint4{Bl[cbuf][q][0], Bl[cbuf][q][1], Bl[cbuf][q][2], Bl[cbuf][q][3]});
-#if NANN_PIPE_MT_MAJOR
-        // (A/B build: the three products of an output tile back to back on one accumulator, each with its shadow)
-#pragma unroll
-        for (int mt = 0; mt < H2T; ++mt) {
-          f32x2 hvm = {};
-          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bh, acc[mt], 0, 0, 0);
-          if (!(VAR & 4)) hvm = convert_a(x[nbuf], q, mt);
-          __builtin_amdgcn_sched_barrier(0);
-          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt], bl, acc[mt], 0, 0, 0);
-          if (!(VAR & 2)) Wf[2 * mt] = fragt(nt, nq * 2 * H2T + 2 * mt);
-          if (!(VAR & 4)) convert_b(hvm, Bh[nbuf][q][mt], Bl[nbuf][q][mt]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (!(VAR & 8)) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[2 * mt + 1], bh, acc[mt], 0, 0, 0);
-          if (!(VAR & 2)) Wf[2 * mt + 1] = fragt(nt, nq * 2 * H2T + 2 * mt + 1);
-          if (q == 0 && !(VAR & 1))
-            x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!(VAR & 4)) {  // u / beta of the next step's conversion (this step's conversions are done)
-          cu[0] = uvec4(32 * ct + 8 * (2 * nq)); cu[1] = uvec4(32 * ct + 8 * (2 * nq + 1));
-          cb[0] = vec4(kBeta1 + 32 * ct + 8 * (2 * nq)); cb[1] = vec4(kBeta1 + 32 * ct + 8 * (2 * nq + 1));
-        }
-#else
         f32x2 hv[H2T] = {};
 #pragma unroll
         for (int mt = 0; mt < H2T; ++mt) {
@@ -332,7 +257,6 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
             x[cbuf][mt] = *reinterpret_cast<const f32x4v*>((t + 2 >= H1T ? next : row) + 32 * ((t + 2) & (H1T - 1)) + 8 * mt);
           __builtin_amdgcn_sched_barrier(0);
         }
-#endif
       }
     }
     // PReLU of layer 2 and the bias-free output layer
@@ -388,7 +312,6 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
   const int cand = lane & 31, g = lane >> 5;
   const int nblk = (n + 31) >> 5;
   if (wave >= nblk) return;
-  if (NANN_RES_SKEW > 0 && wave >= NW / 2) __builtin_amdgcn_s_sleep(NANN_RES_SKEW);  // (see NANN_RES_SKEW)
   auto row_ptr = [&](int i) -> const float* {
     const int ic = min(i, n - 1);
     const uint32_t rid = ids ? (uint32_t)ids[ic] : (uint32_t)ic;
@@ -416,8 +339,7 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
   constexpr int kU = 0, kBeta1 = 256, kB2 = 512, kBeta2 = 640, kW3 = 768;  // Mlp2Vectors, in floats
   static_assert(offsetof(Mlp2Vectors, beta1) == 4 * kBeta1 && offsetof(Mlp2Vectors, b2) == 4 * kB2 &&
                 offsetof(Mlp2Vectors, beta2) == 4 * kBeta2 && offsetof(Mlp2Vectors, w3) == 4 * kW3, "Mlp2Vectors layout");
-#if NANN_RES_PIPE
-  {  // round 4, second half: the software pipeline (NANN_RES_PIPE=0: the loop below, the form of r4a-r4j)
+  {  // the software pipeline (round 4, second half; the tile-phased loop of r4a-r4j: tools/rejected/nann_mlp5_tile_phased_loop.h)
     SplitPipeLds L;
     L.w_lo = w_lo; L.w_hi = w_hi; L.v_at = v_at; L.u_at = v_at; L.u_wr = 0u;  // (kU = 0: the query's u heads the vectors)
     int i_cur = 0;
@@ -432,105 +354,6 @@ __device__ __forceinline__ void wg_score_mlp_res(const float* __restrict__ proj,
           if (g == 0 && i_cur < n) scores[i_cur] = score;
         });
     return;
-  }
-#endif
-  const float* row = row_ptr(wave * 32 + cand);
-  // gathers run two tiles ahead of their use
-  float4 x[2][4];
-  load_tile(row, 0, x[0]);
-  load_tile(row, 1, x[1]);
-  for (int b = wave; b < nblk; b += NW) {
-    const int i = b * 32 + cand;
-    const float* next = (b + NW < nblk) ? row_ptr(i + NW * 32) : row;
-    f32x16 a2[H2T];
-#pragma unroll
-    for (int mt = 0; mt < H2T; ++mt)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
-        a2[mt][4 * rr] = v.x; a2[mt][4 * rr + 1] = v.y; a2[mt][4 * rr + 2] = v.z; a2[mt][4 * rr + 3] = v.w;
-      }
-    auto tile = [&](int t, float4 (&xt)[4]) {
-      // everything the tile reads from LDS leaves in one burst: the A fragments of its first 16-deep step and the
-      // query's part / slopes of its 16 hidden units
-      f16x8 Wf[(NANN_RES_WF16 ? 4 : 2) * H2T];
-#pragma unroll
-      for (int k = 0; k < (NANN_RES_WF16 ? 4 : 2) * H2T; ++k) Wf[k] = frag(t, k);
-      f32x4v ub[8];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) { ub[rr] = vec4(kU + 32 * t + 8 * rr); ub[4 + rr] = vec4(kBeta1 + 32 * t + 8 * rr); }
-      __builtin_amdgcn_sched_barrier(0);
-      f16x8 bh[2], bl[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        uint4 h, l;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int rr = 2 * q + half;
-          const f32x4v u = ub[rr], be = ub[4 + rr];
-          uint32_t h0, l0, h1, l1;
-#if (NANN_RES_VAR & 1)  // timing build: no PReLU / operand split arithmetic
-          h0 = __float_as_uint(xt[rr].x + u.x); l0 = __float_as_uint(xt[rr].y + be.x); h1 = __float_as_uint(xt[rr].z); l1 = __float_as_uint(xt[rr].w);
-#else
-          prelu_split_pair_pk(f32x2{xt[rr].x, xt[rr].y}, f32x2{u.x, u.y}, f32x2{be.x, be.y}, h0, l0);
-          prelu_split_pair_pk(f32x2{xt[rr].z, xt[rr].w}, f32x2{u.z, u.w}, f32x2{be.z, be.w}, h1, l1);
-#endif
-          if (half == 0) { h.x = h0; h.y = h1; l.x = l0; l.y = l1; } else { h.z = h0; h.w = h1; l.z = l0; l.w = l1; }
-        }
-        bh[q] = as_f16x8(h); bl[q] = as_f16x8(l);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#if !(NANN_RES_VAR & 2)  // (timing build bit 1: no gathers after the first tiles)
-      load_tile(t + 2 >= H1T ? next : row, (t + 2) & (H1T - 1), xt);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int mt = 0; mt < H2T; ++mt) {
-          const int fo = NANN_RES_WF16 ? q * 2 * H2T : 0;
-          const f16x8 wh = Wf[fo + mt * 2], wl = Wf[fo + mt * 2 + 1];
-          a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[q], a2[mt], 0, 0, 0);
-          a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl[q], a2[mt], 0, 0, 0);
-          a2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[q], a2[mt], 0, 0, 0);
-          if (q == 0 && !NANN_RES_WF16) {  // the second step's fragments travel underneath the first step's MFMAs
-            Wf[mt * 2] = frag(t, 2 * H2T + mt * 2);
-            Wf[mt * 2 + 1] = frag(t, 2 * H2T + mt * 2 + 1);
-          }
-        }
-      }
-    };
-#if NANN_RES_ROLLED
-#pragma unroll 1
-    for (int t = 0; t < H1T; t += 2) {  // (runtime t: frag / vec4 fall back to computed addresses)
-      tile(t, x[0]);
-      tile(t + 1, x[1]);
-    }
-#else
-#pragma unroll
-    for (int t = 0; t < H1T; t += 2) {
-      tile(t, x[0]);
-      tile(t + 1, x[1]);
-    }
-#endif
-    row = next;
-    float part = 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < H2T; ++mt)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const f32x4v be = vec4(kBeta2 + 32 * mt + 8 * rr);
-        const f32x4v w3 = vec4(kW3 + 32 * mt + 8 * rr);
-        const float bes[4] = {be.x, be.y, be.z, be.w}, w3s[4] = {w3.x, w3.y, w3.z, w3.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xa = a2[mt][4 * rr + e];
-          part = __builtin_fmaf(__builtin_fmaf(neg_part(xa), bes[e], xa), w3s[e], part);
-        }
-      }
-    const float other = __shfl_xor(part, 32);
-    constexpr float kUnscale = 1.0f / (kSplit2Scale * kSplit2Scale);
-    if (g == 0 && i < n) scores[i] = (part + other) * kUnscale;
   }
 }
 

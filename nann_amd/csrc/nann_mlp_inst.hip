@@ -1,8 +1,6 @@
 // nann_mlp_inst.hip -- MLP-scorer instantiations of the fused traversal and of the
 // stand-alone scorer for ONE embedding dim (-DNANN_MLP_D=64|128|256), so that the three
 // heavy objects (1024 unrolled MFMAs each) compile in parallel.
-#include <cstdlib>
-
 #include "nann_eval.h"
 
 #ifndef NANN_MLP_D
@@ -13,21 +11,7 @@
 
 namespace nann {
 
-static bool first_mapping_forced() { return mlp_mapping_choice() == 1; }
-
 #if NANN_MLP_D == 128
-int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
-  // 512 threads: one 32-row block per wavefront, two wavefronts per SIMD; NANN_MLP_MAPPING=4: the 256-thread form.
-  // The scorer never reads the embedding table, so the <16, f16> instance serves every d and row dtype.
-  if (vis == VIS_LDS_HASH) {
-    if (mlp_mapping_choice() == 4) return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, kMlp2NT>(slots, lds_bytes, a, st);
-    return launch_search_as<16, DT_F16, VIS_LDS_HASH, kScorerMlpProj, 512>(slots, lds_bytes, a, st);
-  }
-  // wide beams (the 16K-slot set would overflow), forced bitmap modes, and the rerun of queries the set handed back
-  if (vis != VIS_LDS_BITMAP && vis != VIS_HBM_BITMAP) return fail(NANN_ERR_UNSUPPORTED, "MLP traversal: no kernel for this plan");
-  return launch_search_bitmap<16, DT_F16, kScorerMlpProj, 512>(vis, slots, lds_bytes, a, st);
-}
-
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st) {
   if (dt != NANN_F16 && dt != NANN_BF16) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: item rows must be f16 or bf16");
   if (d > 256 || d % 4) return fail(NANN_ERR_UNSUPPORTED, "MLP scorer: d <= 256");
@@ -46,12 +30,8 @@ int NANN_CAT(launch_search_mlp_d, NANN_MLP_D)(int dt, int split, int vis, int sl
   if (split && vis == VIS_LDS_HASH) {  // one workgroup per CU: 16K-slot set + the weight-slice buffers
 #if NANN_MLP_D <= 128
     // second mapping (nann_mlp2.h): 256 threads, 64 rows per wavefront at one wavefront per SIMD
-    if (!first_mapping_forced()) {
-      if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlp2NT>(slots, lds_bytes, a, st);
-      return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlp2NT>(slots, lds_bytes, a, st);
-    }
-    if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
-    return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
+    if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlp2NT>(slots, lds_bytes, a, st);
+    return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlp2NT>(slots, lds_bytes, a, st);
 #else
     if (dt == NANN_F16) return launch_search_as<LPR, DT_F16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
     return launch_search_as<LPR, DT_BF16, VIS_LDS_HASH, kScorerMlpSplit, kMlpNT>(slots, lds_bytes, a, st);
@@ -85,8 +65,8 @@ int NANN_CAT(launch_score_mlp_d, NANN_MLP_D)(int dt, int split, unsigned blocks,
 #define NANN_LAUNCH_SCORE2(DT_)                                                                               \
   hipLaunchKernelGGL((k_score_mlp2<NANN_MLP_D, DT_>), dim3(blocks), dim3(kMlp2NT), 0, st, P, table, n_table_rows, \
                      indices, n, q, out, res)
-  if (split && !first_mapping_forced() && dt == NANN_F16) NANN_LAUNCH_SCORE2(DT_F16);
-  else if (split && !first_mapping_forced() && dt == NANN_BF16) NANN_LAUNCH_SCORE2(DT_BF16);
+  if (split && dt == NANN_F16) NANN_LAUNCH_SCORE2(DT_F16);
+  else if (split && dt == NANN_BF16) NANN_LAUNCH_SCORE2(DT_BF16);
   else
 #undef NANN_LAUNCH_SCORE2
 #endif

@@ -169,7 +169,7 @@ __host__ __device__ inline unsigned long long slot_layout(int max_cand, int max_
 constexpr int kScorerMlpSplit = 2;
 constexpr int kScorerAttn = 3;  // the reference's attention + DNN model (nann_attn.h); "query" = kt / upad of the user
 constexpr int kScorerAttnSplit = 4;  //   the same on the 16-bit MFMA with split operands (nann_attn_split.h)
-constexpr int kScorerMlpProj = 5;    // split-f16 MLP with the item half of layer 1 pre-projected per (scorer, index) (nann_mlp3.h)
+// (5 was round 3's split-f16 MLP on the table with layer 2 streamed per pass: retired in round 5, tools/rejected/nann_mlp3_streamed_layer2.h)
 constexpr int kScorerAttnProj = 6;   // split-f16 attention model with its item-only layers pre-projected per (model, index) (nann_attn_proj.h)
 constexpr int kScorerMlpRes = 7;     // split-f16 MLP on the pre-projected table with ALL of layer 2 resident in LDS (nann_mlp5.h)
 constexpr int kScorerMlpXRes = 8;    // exact f32 MLP on the pre-projected table, layer 2 resident in LDS: bit-identical to the oracle
@@ -214,7 +214,7 @@ constexpr int phase_scratch() {
   //   HBM-bitmap plan  the (larger) phase scratch of the bitmap filter lies over W2's first 32 KB: 32 KB reloaded per call
   if (is_mlp_res(SC)) return hash ? base : kMlpResBytes;
   if (is_attn(SC) && base < kAttnScratch) return kAttnScratch;
-  if ((SC == kScorerMlpSplit || SC == kScorerMlpProj) && base < kMlpSplitScratch) return kMlpSplitScratch;
+  if (SC == kScorerMlpSplit && base < kMlpSplitScratch) return kMlpSplitScratch;
   return base;
 }
 
@@ -256,7 +256,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
   __syncthreads();
   constexpr int H1T = 8, H2T = 4;  // 256-128-1 (BASELINE configs 3-5)
   float mlp_u = 0.0f;              // MLP: thread j's per-query part of hidden unit j, once per query
-  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit || SC == kScorerMlpProj || is_mlp_res(SC)) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
+  if constexpr (SC == NANN_SCORER_MLP || SC == kScorerMlpSplit || is_mlp_res(SC)) mlp_u = wg_mlp_query_u<NT>(a.mlp, qv);
   constexpr bool PHASED = SC == kScorerMlpPhase;
   bool resumed = false;  // PHASED, stage > 0: this launch starts BEHIND the scoring call of round a.phase - 1
   if constexpr (PHASED) {
@@ -497,13 +497,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
         wg_mlp_res_leave<NT>(lds0, park, SLOTS / 4);
       } else {
         // (the phase scratch was reused since the last stage)
-        if constexpr (SC == kScorerMlpProj) {  // item half of layer 1 pre-projected: gather P rows, layer 2 on the matrix cores
-          static_assert(NT == kMlp2NT || NT == 512, "the pre-projected scorer: 256 threads (two blocks per wavefront) or 512 (one)");
-          Mlp3Scratch* M = reinterpret_cast<Mlp3Scratch*>(scratch);
-          wg_mlp2_stage_setup<NT>(a.mlp, mlp_u, &M->v);
-          if constexpr (NT == 512) wg_score_mlp_proj1(a.mlp, a.proj, a.n_items, sc_ids, sc_n, M, sc_out);
-          else wg_score_mlp_proj(a.mlp, a.proj, a.n_items, sc_ids, sc_n, M, sc_out);
-        } else if constexpr (SC == kScorerMlpSplit && NT == kMlp2NT) {  // second mapping: 4 wavefronts x 64 rows (nann_mlp2.h)
+        if constexpr (SC == kScorerMlpSplit && NT == kMlp2NT) {  // second mapping: 4 wavefronts x 64 rows (nann_mlp2.h)
           Mlp2Scratch<LPR * 8>* M = reinterpret_cast<Mlp2Scratch<LPR * 8>*>(scratch);
           wg_mlp2_stage_setup<NT>(a.mlp, mlp_u, &M->v);
           wg_score_mlp_split2<LPR * 8, DT>(a.mlp, a.emb, a.n_items, sc_ids, sc_n, M, sc_out);
@@ -682,6 +676,8 @@ struct SearchPlan {
   size_t phase_lds_bytes;
   int phase_slots;
   int phase_vis, phase_per_cu;  // VIS_LDS_HASH (two 512-thread workgroups per CU) | VIS_LDS_HASH32 (one of 1024: wide beams)
+  int phase_score_wgs;          // workgroups of a scoring launch (one per CU, fewer with a slot reserve)
+  float est_visited, worst_visited;  // the planner's estimate of a level's visited ids / the bound from max degrees
 };
 
 template <int LPR, int DT, int VIS, int SC, int NT>
@@ -711,19 +707,13 @@ int launch_search_l2_f32(int lpr, int vis, int nt, int slots, size_t lds_bytes, 
 int launch_search_mlp_d64(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d128(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_search_mlp_d256(int dt, int split, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
-// the pre-projected form (nann_mlp3.h): ONE instantiation for every d / row dtype (it never reads the embedding table);
-// lives in the d = 128 object.  launch_mlp_preproject fills the table.
-int launch_search_mlp_proj(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
+// launch_mlp_preproject fills the table of pre-projected item halves of layer 1 (nann_mlp3.h); lives in the d = 128 object
 // layer 2 resident in LDS (nann_mlp5.h), split-f16 (exact = 0) or exact f32 (exact = 1); vis in {VIS_LDS_HASH, VIS_HBM_BITMAP}
 int launch_search_mlp_res(int exact, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 // the pipeline of phases (nann_mlp6.h): a traversal stage (a.phase), a round's scoring launch
 int launch_search_mlp_phase(int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);
 int launch_mlp_phase_score(int exact, const SearchArgs& a, int round, int workgroups, hipStream_t st);
 int launch_mlp_preproject(int dt, const void* emb, long long n_rows, int d, const float* w1, float* proj, hipStream_t st);
-// which form of the MLP the traversal runs: 5 = pre-projected + layer 2 resident in LDS (default, both precisions),
-// split-f16 only: 3 = pre-projected with streamed slices (round 3), 4 = its 256-thread form, 2 = second mapping, 1 = first
-// (NANN_MLP_MAPPING in the environment: A/B measurements on one build, not a product knob)
-int mlp_mapping_choice();
 // attention-scorer instantiations live in nann_attn_inst.hip: (vis, 512 threads) for vis in
 // {VIS_LDS_HASH (one workgroup per CU), VIS_LDS_BITMAP, VIS_HBM_BITMAP}
 int launch_search_attn(int d, int dt, int vis, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st);

@@ -116,38 +116,61 @@ TRAVERSAL_MODES = {"auto": 0, "lds_bitmap": 1, "hbm_bitmap": 2, "lds_hash": 3, "
 def set_traversal_mode(mode="auto"):
     """Where nann_search keeps a query's visited set (include/nann_hip.h, nann_traversal_mode):
     "auto" | "lds_bitmap" | "hbm_bitmap" | "lds_hash" | "lds_hash32".  Results are identical in every mode; the
-    knob exists for the parity tests and for tuning.  Process-wide."""
+    knob exists for the parity tests and for tuning.  The process default of search_options(traversal=...)."""
     _check(lib().nann_set_traversal_mode(C.c_int32(TRAVERSAL_MODES[mode])), "traversal mode")
 
 
-class SearchResult:
-    __slots__ = ("item_ids", "scores", "index", "status", "counters", "phase_ticks")
+MLP_FORMS = {"auto": 0, "fused": 1, "phased": 2}
 
-    def __init__(self, item_ids, scores, index, status, counters, phase_ticks=None):
+
+def search_options(traversal=None, slot_reserve=None, preprojection=None, mlp_form=None):
+    """nann_search_options for one call; None = the process default of the field (nann_set_* / built-in)."""
+    o = _lib.SearchOptions()
+    lib().nann_search_options_init(C.byref(o))
+    if traversal is not None:
+        o.traversal_mode = TRAVERSAL_MODES[traversal]
+    if slot_reserve is not None:
+        o.slot_reserve = int(slot_reserve)
+    if preprojection is not None:
+        o.preprojection = 1 if preprojection else 0
+    if mlp_form is not None:
+        o.mlp_form = MLP_FORMS[mlp_form]
+    return o
+
+
+class SearchResult:
+    __slots__ = ("item_ids", "scores", "index", "status", "counters", "phase_ticks", "plan", "_ws")
+
+    def __init__(self, item_ids, scores, index, status, counters, phase_ticks=None, plan=None, ws=None):
         self.item_ids, self.scores, self.index, self.status, self.counters = (
             item_ids, scores, index, status, counters)
         self.phase_ticks = phase_ticks
+        self.plan = plan  # dict: what the planner chose (nann_search_plan)
+        self._ws = ws
+
+    def reruns(self):
+        """queries of this call that the hash-set kernel handed back to the bitmap kernel (synchronises the stream;
+        read it before the next search on the same index reuses the workspace)"""
+        n = C.c_int64(0)
+        _check(lib().nann_search_reruns(_ptr(self._ws), C.byref(n), _stream()), "reruns")
+        return n.value
 
 
-def _level_topn_args(level_topn, b, dev):
-    """level_topn as the C ABI takes it: uniform i32[6] -> (maxima, NULL); per query [B, 6] (the reference feeds
-    `level_topn` per request, build_opt_graph.py:75,151-159) -> (column maxima [host], device i32[B, 6])."""
-    lt = np.asarray(level_topn.cpu() if isinstance(level_topn, torch.Tensor) else level_topn, dtype=np.int64)
-    if lt.ndim == 1:
-        assert lt.shape[0] == 6
-        return (C.c_int32 * 6)(*[int(x) for x in lt]), None, int(lt[5])
-    assert lt.shape == (b, 6), "per-query level_topn: [n_queries, 6]"
-    mx = np.maximum(lt.max(axis=0), 0)
-    tq = torch.as_tensor(lt.astype(np.int32)).to(dev).contiguous()
-    return (C.c_int32 * 6)(*[int(x) for x in mx]), tq, int(mx[5])
+_VIS_NAMES = {v: k for k, v in TRAVERSAL_MODES.items()}
 
 
-def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=False):
+def _plan_dict(p):
+    return {"visited_set": _VIS_NAMES.get(p.visited_set, p.visited_set), "fallback_visited_set": _VIS_NAMES.get(p.fallback_visited_set),
+            "threads": p.threads, "workgroups": p.workgroups, "phased": bool(p.phased), "table": bool(p.table),
+            "est_visited": round(float(p.est_visited), 1), "worst_visited": round(float(p.worst_visited), 1)}
+
+
+def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=False, options=None):
     """Fused execution of build_model()'s schedule for a batch of queries.
     q: f32[B, d] CUDA tensor (ops.user_seq_mean of `comm_seq`).  level_topn: i32[6] for the whole batch, or
     [B, 6] per query (nann_search_v; rows of the outputs are level_topn.max(0)[5] wide, zero behind a query's
-    own k).  Asynchronous: the returned tensors are valid once the current stream reaches them.
-    status[b] != 0 marks a request the reference would have failed."""
+    own k).  options: search_options(...) for this call (nann_search_opt).  Asynchronous: the returned tensors are valid
+    once the current stream reaches them.  status[b] != 0 marks a request the reference would have failed."""
     q = q.to(device=index.device, dtype=torch.float32).contiguous()
     b = q.shape[0]
     dev = index.device
@@ -160,25 +183,21 @@ def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=Fa
     ticks = (torch.zeros((b, _lib.NUM_PHASES), dtype=torch.int64, device=dev)
              if want_phase_ticks else None)
     ws = index.workspace(list(t), b)
+    plan = _lib.SearchPlan()
+    assert not (want_phase_ticks and tq is not None), "phase ticks: uniform level_topn only"
     with torch.cuda.device(dev):
-        if tq is None:
-            _check(lib().nann_search_ex(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(ws),
-                                        C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores),
-                                        _ptr(out_index), _ptr(status), _ptr(counters), _ptr(ticks),
-                                        _stream()), "search")
-        else:
-            assert not want_phase_ticks, "phase ticks: uniform level_topn only"
-            _check(lib().nann_search_v(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(tq), _ptr(ws),
-                                       C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores),
-                                       _ptr(out_index), _ptr(status), _ptr(counters), _stream()), "search")
-    return SearchResult(out_ids, out_scores, out_index, status, counters, ticks)
+        _check(lib().nann_search_opt(index.handle, scorer.handle, _ptr(q), C.c_int64(b), t, _ptr(tq), _ptr(ws),
+                                     C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
+                                     _ptr(status), _ptr(counters), _ptr(ticks),
+                                     C.byref(options) if options is not None else None, C.byref(plan), _stream()), "search")
+    return SearchResult(out_ids, out_scores, out_index, status, counters, ticks, _plan_dict(plan), ws)
 
 
-def search_model(index, model, comm_seq, level_topn, want_counters=True):
+def search_model(index, model, comm_seq, level_topn, want_counters=True, options=None):
     """The serving signature (build_opt_graph.py:151-159) for a batch: comm_seq f16[B, seq_len, E] +
     level_topn (i32[6], or [B, 6] per request) -> SearchResult, scored by `model` (ops.Model: l2 / mlp / the
     reference's attention + DNN model -- the per-user projection runs once per request, then the fused traversal;
-    nann_search_model / nann_search_model_v)."""
+    nann_search_model_opt)."""
     seq = comm_seq.to(device=index.device, dtype=torch.float16).contiguous()
     b = seq.shape[0]
     dev = index.device
@@ -191,11 +210,13 @@ def search_model(index, model, comm_seq, level_topn, want_counters=True):
     nbytes = C.c_int64(0)
     _check(lib().nann_search_model_workspace_bytes(index.handle, model.handle, t, C.c_int64(b), C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+    plan = _lib.SearchPlan()
     with torch.cuda.device(dev):
-        _check(lib().nann_search_model_v(index.handle, model.handle, _ptr(seq), C.c_int64(b), t, _ptr(tq), _ptr(ws),
-                                         C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
-                                         _ptr(status), _ptr(counters), _stream()), "search")
-    return SearchResult(out_ids, out_scores, out_index, status, counters, None)
+        _check(lib().nann_search_model_opt(index.handle, model.handle, _ptr(seq), C.c_int64(b), t, _ptr(tq), _ptr(ws),
+                                           C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
+                                           _ptr(status), _ptr(counters),
+                                           C.byref(options) if options is not None else None, C.byref(plan), _stream()), "search")
+    return SearchResult(out_ids, out_scores, out_index, status, counters, None, _plan_dict(plan), ws)
 
 
 def prepare(index, scorer):

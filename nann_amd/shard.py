@@ -125,6 +125,18 @@ class ShardedSearch:
         self._ws = None
         self._comm_stream = None
 
+    def search_options(self, overlap=True, reserve=None):
+        """nann_search_options for the searches whose exchanges this object overlaps (pass to retrieval.search).  The
+        persistent traversal grid owns every CU's LDS until its first workgroups exit; RCCL's kernels need a few
+        workgroup slots of their own to run NEXT TO it (measured on one GPU, profiles/r4g_overlap.txt: 16 slots of 512
+        cost the search ~3 %, an exchange that only starts when the grid drains costs the whole overlap).  Per call
+        since round 5 (the process-wide setter was never restored and taxed unrelated searches)."""
+        from . import retrieval
+        real = self.transport == "rccl" and self.world > 1 and not getattr(self.comm, "is_loopback", False)
+        if reserve is None:
+            reserve = self.RESERVED_SLOTS if (overlap and real) else 0
+        return retrieval.search_options(slot_reserve=reserve)
+
     def _exchange(self, result):
         """pack + ncclAllGather + merge on the CURRENT stream (nann_sharded_topk)"""
         nq, k = result.scores.shape
@@ -160,12 +172,6 @@ class ShardedSearch:
             cur = torch.cuda.current_stream(dev)
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=dev)
-                if self.world > 1 and not getattr(self.comm, "is_loopback", False):
-                    # the persistent traversal grid owns every CU's LDS until its first workgroups exit; RCCL's kernels
-                    # need a few workgroup slots of their own to run NEXT TO it (nann_set_search_reserve; measured on
-                    # one GPU, profiles/r4g_overlap.txt: 16 slots of 512 cost the search ~3 %, an exchange that only
-                    # starts when the grid drains costs the whole overlap)
-                    _check(lib().nann_set_search_reserve(C.c_int32(self.RESERVED_SLOTS)), "search reserve")
             cs = self._comm_stream
             cs.wait_stream(cur)  # the search that wrote `result`
             with torch.cuda.stream(cs):

@@ -895,3 +895,57 @@ def test_search_without_preprojection_matches(oracle):
         assert kinds.count("diverged") <= 1, kinds
     finally:
         _lib.lib().nann_set_preprojection(1)
+
+
+def test_search_options_travel_with_the_call(oracle):
+    """nann_search_options (round 5): the planner's knobs are fields of the call, not process state.  Every plan forced
+    per call answers like the oracle and reports itself in nann_search_plan; the process default (set_traversal_mode)
+    is untouched by a call's options; two threads sharing the index and the scorer run DIFFERENT plans concurrently."""
+    import threading
+    from nann_amd import ops, retrieval
+    g, oix, dix = synth_index(20000, 64, 32)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 200, seed=31)])
+    topn = [32] * 5 + [20]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", 64, oracle.EMB_F16), q, topn, n_threads=8)
+    sc = ops.Scorer("l2", 64, torch.float16)
+
+    def run(mode, qq=q):
+        r = retrieval.search(dix, sc, cuda(qq), topn, options=retrieval.search_options(traversal=mode) if mode else None)
+        torch.cuda.synchronize()
+        return r, (r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy(),
+                   r.counters.cpu().numpy())
+
+    for mode in MODES:
+        r, got = run(mode)
+        assert r.plan["visited_set"] == mode, r.plan
+        _assert_same(got, exp)
+    r, got = run(None)  # defaults: the planner's own choice, and no trace of the forced calls above
+    assert r.plan["visited_set"] in ("lds_hash", "lds_hash32") and r.reruns() == 0
+    _assert_same(got, exp)
+    r1, _ = run(None, q[:1])
+    assert r1.plan["visited_set"] == "lds_hash32" and r1.plan["workgroups"] == 1  # at most one query per CU: one 1024-thread workgroup
+    out, errs = {}, []
+
+    def worker(mode):
+        try:
+            for _ in range(6):
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    r, got = run(mode)
+                    assert r.plan["visited_set"] == mode
+                    _assert_same(got, exp)
+            out[mode] = True
+        except Exception as e:  # noqa: BLE001
+            errs.append((mode, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(m,)) for m in ("lds_hash", "hbm_bitmap", "lds_hash32")]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs and len(out) == 3, errs
+    # a reserve leaves workgroup slots free without changing an answer
+    r, got = run(None)
+    full = r.plan["workgroups"]
+    r2 = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(slot_reserve=16))
+    torch.cuda.synchronize()
+    assert r2.plan["workgroups"] == full - 16 if full > 16 else True
+    assert (r2.item_ids.cpu().numpy() == got[1]).all()

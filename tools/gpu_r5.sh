@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 GPU session runner (through gpurun).  New steps live here; every other step name is handed to tools/gpu_r4.sh.
 # usage: tools/gpu_r5.sh <tag> <deadline_s> <step> [<step> ...]
-#   steps: tests_r5 mlp_vars (VARS='name ...', MAPS='6 7') seqmean dense_graph ... + gpu_r4.sh's
+#   steps: tests_r5 mlp_vars (VARS='name ...', FORMS='auto phased') seqmean dense ... + gpu_r4.sh's
 set -u
 TAG=$1; DEADLINE=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -35,10 +35,10 @@ for STEP in "$@"; do
       for L in $R/nann_amd/_build/libnann_hip.so $R/nann_amd/_build/var_*/libnann_hip.so; do
         V=$(basename $(dirname $L)); [ "$V" = "_build" ] && V=shipped
         if [ -n "${VARS:-}" ] && ! echo " $VARS shipped " | grep -q " ${V#var_} "; then continue; fi
-        for M in ${MAPS:-6 7}; do
+        for M in ${FORMS:-auto phased}; do
           if [ $(left) -lt 60 ]; then echo "SKIP $V $M"; continue; fi
-          NANN_MLP_MAPPING=$M NANN_HIP_LIB=$L timeout 200 $BENCH --scorer mlp --batch ${VAR_BATCH:-1024} --steps ${VAR_STEPS:-150} --warmup ${VAR_WARMUP:-100} --no-secondary --no-cpu-baseline > $OUT/mlpvar_${V}_m${M}_$TAG.json 2> $OUT/mlpvar_${V}_m${M}_$TAG.err
-          line $OUT/mlpvar_${V}_m${M}_$TAG.json "VAR ${V#var_} mapping $M"
+          NANN_MLP_FORM=$M NANN_HIP_LIB=$L timeout 200 $BENCH --scorer mlp --batch ${VAR_BATCH:-1024} --steps ${VAR_STEPS:-150} --warmup ${VAR_WARMUP:-100} --no-secondary --no-cpu-baseline > $OUT/mlpvar_${V}_m${M}_$TAG.json 2> $OUT/mlpvar_${V}_m${M}_$TAG.err
+          line $OUT/mlpvar_${V}_m${M}_$TAG.json "VAR ${V#var_} form $M"
         done
       done ;;
     seqmean)  # the headline step with the new k_user_seq_mean: step - kernel, then the kernel's own duration under rocprofv3
@@ -48,6 +48,20 @@ for STEP in "$@"; do
       ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt_l2 -o kt -- $BENCH --steps 10 --warmup 2 --no-secondary --no-cpu-baseline > $OUT/prof_kt_l2_$TAG.log 2>&1 )
       find /tmp/prof/kt_l2 -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_l2_$TAG.csv \;
       grep -E "k_search|k_user_seq" $OUT/kernel_stats_l2_$TAG.csv | cut -c1-200 ;;
+    dense)  # configs[1] on the dense graph family (keepPrunedConnections): plan, reruns, rate, roofline, parity
+      timeout 400 $BENCH --graph hnsw_dense --no-secondary --no-cpu-baseline --steps 10 > $OUT/bench_dense_$TAG.json 2> $OUT/bench_dense_$TAG.err
+      line $OUT/bench_dense_$TAG.json "L2 dense graph"
+      python - <<PY
+import json
+d = json.loads(open('$OUT/bench_dense_$TAG.json').read().strip().splitlines()[-1])
+print('   mean_degree_l0', d.get('mean_degree_l0'), 'plan', d.get('plan'), 'reruns', d.get('reruns_last_step'), 'recall', d.get('recall_at_k_vs_bruteforce'),
+      'rows/q', d['roofline'].get('rows_scored_per_query'), 'gathered/q', d['roofline'].get('gathered_per_query'))
+PY
+      for M in lds_hash lds_hash32; do
+        timeout 300 $BENCH --graph hnsw_dense --no-secondary --no-cpu-baseline --steps 10 --traversal $M > $OUT/bench_dense_${M}_$TAG.json 2> $OUT/bench_dense_${M}_$TAG.err
+        line $OUT/bench_dense_${M}_$TAG.json "L2 dense graph $M"
+        python -c "import json;d=json.loads(open('$OUT/bench_dense_${M}_$TAG.json').read().strip().splitlines()[-1]);print('   plan',d.get('plan'),'reruns',d.get('reruns_last_step'))"
+      done ;;
     *)
       bash $R/tools/gpu_r4.sh $TAG $(left) $STEP ;;
   esac

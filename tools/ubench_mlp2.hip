@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../nann_amd/csrc/nann_mlp3.h"
+#include "rejected/nann_mlp3_streamed_layer2.h"
 
 using namespace nann;
 
