@@ -156,6 +156,19 @@ class SearchResult:
         return n.value
 
 
+def _level_topn_args(level_topn, b, dev):
+    """level_topn as the C ABI takes it: uniform i32[6] -> (maxima, NULL); per query [B, 6] (the reference feeds
+    `level_topn` per request, build_opt_graph.py:75,151-159) -> (column maxima [host], device i32[B, 6])."""
+    lt = np.asarray(level_topn.cpu() if isinstance(level_topn, torch.Tensor) else level_topn, dtype=np.int64)
+    if lt.ndim == 1:
+        assert lt.shape[0] == 6
+        return (C.c_int32 * 6)(*[int(x) for x in lt]), None, int(lt[5])
+    assert lt.shape == (b, 6), "per-query level_topn: [n_queries, 6]"
+    mx = np.maximum(lt.max(axis=0), 0)
+    tq = torch.as_tensor(lt.astype(np.int32)).to(dev).contiguous()
+    return (C.c_int32 * 6)(*[int(x) for x in mx]), tq, int(mx[5])
+
+
 _VIS_NAMES = {v: k for k, v in TRAVERSAL_MODES.items()}
 
 

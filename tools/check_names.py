@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Poor man's pyflakes (none in the image): names loaded but never bound in a module.  usage: tools/check_names.py files..."""
+import ast
+import builtins
+import sys
+
+
+def check(path):
+    tree = ast.parse(open(path).read())
+    defined = set(dir(builtins)) | {"__file__", "__name__"}
+    for n in ast.walk(tree):
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+            defined.add(n.name)
+        elif isinstance(n, ast.Import):
+            defined.update((a.asname or a.name).split(".")[0] for a in n.names)
+        elif isinstance(n, ast.ImportFrom):
+            defined.update(a.asname or a.name for a in n.names)
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+            defined.add(n.id)
+        elif isinstance(n, ast.arg):
+            defined.add(n.arg)
+        elif isinstance(n, ast.ExceptHandler) and n.name:
+            defined.add(n.name)
+        elif isinstance(n, (ast.Global, ast.Nonlocal)):
+            defined.update(n.names)
+    return sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in defined})
+
+
+bad = 0
+for f in sys.argv[1:]:
+    m = check(f)
+    if m:
+        bad += 1
+        print(f, "undefined:", m)
+sys.exit(1 if bad else 0)
