@@ -415,7 +415,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     except Exception:
         plan_info, reruns = None, None
     res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "plan": plan_info, "reruns_last_step": reruns,
+           "plan": plan_info, "reruns_last_step": reruns, "index_probe": index.probe,
            "batch": batch, "steps": steps, "valid_queries": n_valid, "setup_s": round(setup_s, 1),
            # host time to ENQUEUE each step (no sync inside the loop): a value near ms_per_step = the host blocked
            "host_enqueue_ms": host_enqueue_ms[:8],
@@ -737,7 +737,7 @@ def main():
     }
     if world > 1 and exchange_note:
         result["exchange_note"] = exchange_note
-    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "plan", "reruns_last_step", "roofline", "batch_latency_ms",
+    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "plan", "reruns_last_step", "index_probe", "roofline", "batch_latency_ms",
               "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown", "host_enqueue_ms"):
         if k in prim:
             result[k] = prim[k]

@@ -33,7 +33,7 @@ SYMBOLS = [
     "nann_host_free", "nann_huge_const_load", "nann_group_gather_count",
     "nann_group_gather_fill", "nann_group_gather_unique_scratch_bytes", "nann_group_gather_unique", "nann_bitmap_ref_difference", "nann_bloom_filter_difference", "nann_gather_rows", "nann_topk",
     "nann_scorer_create", "nann_scorer_destroy", "nann_user_seq_mean", "nann_score",
-    "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_search_workspace_bytes",
+    "nann_index_create", "nann_index_destroy", "nann_index_info", "nann_index_probe_info", "nann_search_workspace_bytes",
     "nann_search", "nann_search_v", "nann_search_ex", "nann_search_opt", "nann_search_options_init", "nann_search_reruns", "nann_search_model_opt", "nann_set_traversal_mode", "nann_set_search_reserve", "nann_search_model_workspace_bytes",
     "nann_search_model", "nann_search_model_v",
     "nann_scorer_prepare", "nann_scorer_release", "nann_scorer_table_bytes", "nann_set_preprojection",

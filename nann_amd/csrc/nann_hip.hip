@@ -773,7 +773,12 @@ struct nann_index {
   std::vector<void*> owned;
   int64_t max_deg[2] = {0, 0};
   uint32_t bm_words = 0;  // ceil(N/32) padded to a multiple of 4
+  // the probe launch of nann_index_create (round 5): new level-0 nodes per frontier row, measured on THIS graph
+  bool probe_valid = false;
+  int probe_ef = 0, probe_queries = 0;
+  float probe_new_per_row_mean = 0.0f, probe_new_per_row_max = 0.0f;
 };
+static void probe_index(nann_index* ix);  // (defined behind search_impl)
 
 extern "C" {
 
@@ -1950,6 +1955,7 @@ int nann_index_create(const nann_index_desc* desc, nann_index** out) {
     ix->owns = true;
     dd.on_device = 1;
   }
+  probe_index(ix);  // what a beam visits on this graph: 64 queries, one small launch (never fails the creation)
   *out = ix;
   return NANN_OK;
 }
@@ -1959,6 +1965,15 @@ void nann_index_destroy(nann_index* ix) {
   ProjCache::drop_index(ix->uid);  // the scorers' pre-projected tables of this index go with it (retired, then freed)
   for (void* p : ix->owned) (void)hipFree(p);
   delete ix;
+}
+
+int nann_index_probe_info(const nann_index* ix, float out[4]) {
+  if (!ix || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_index_probe_info: null argument");
+  out[0] = ix->probe_valid ? (float)ix->probe_queries : 0.0f;
+  out[1] = (float)ix->probe_ef;
+  out[2] = ix->probe_new_per_row_mean;
+  out[3] = ix->probe_new_per_row_max;
+  return NANN_OK;
 }
 
 int nann_index_info(const nann_index* ix, int64_t out[6]) {
@@ -2027,7 +2042,19 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   const bool tag_fits = id_bits <= 27;
   const double mean_deg0 = (double)ix->desc.nb_nnz[0] / (double)std::max<int64_t>(ix->desc.n_items, 1);
   const double walk_deg = std::min<double>((double)ix->max_deg[0], 2.75 * mean_deg0);
-  const double est_visited = t[1] + 0.45 * walk_deg * ((double)t[1] + t[2] + t[3]);
+  // Round 5: the estimate is MEASURED per index where it can be (probe_index: 64 queries at nann_index_create, the new nodes a
+  // level-0 round finds per frontier row; the largest of the probe's queries, so the estimate sits on the tail).  Rounds 1-4
+  // guessed it from the mean degree (2.75 x mean degree walked, 45 % new: fitted to the device builder's graphs, mean degree
+  // ~17) and sent a dense graph (keepPrunedConnections, mean degree 52) to the one-workgroup-per-CU 32K plan at 0.67 of the
+  // roofline, where the 16K plan holds its ~8 k visited ids at 0.84 with no rerun (profiles/r5b_dense_graph.txt).  The ratio
+  // falls as the beam widens (neighbourhoods overlap more), so a probe at ef <= 64 overestimates wider beams: safe side.
+  const double rows_walked = (double)t[1] + t[2] + t[3];
+  const double est_guess = t[1] + 0.45 * walk_deg * rows_walked;
+  const double est_visited = ix->probe_valid ? std::min(t[1] + (double)ix->probe_new_per_row_max * rows_walked,
+                                                        t[1] + (double)ix->max_deg[0] * rows_walked)
+                                             : est_guess;
+  // the 16K / 32K-slot set holds 16320 / 32704 ids; a measured estimate may come closer to that than a guessed one
+  const double fit16 = ix->probe_valid ? 13500.0 : 11000.0, fit32 = ix->probe_valid ? 28000.0 : 24000.0;
   const double worst_visited = t[1] + (double)ix->max_deg[0] * ((double)t[1] + t[2] + t[3]);
   const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512, 16384>() + tail;
   const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT, 32768>() + tail;
@@ -2037,8 +2064,8 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   if (mode == NANN_TRAVERSAL_LDS_HASH) hash_vis = VIS_LDS_HASH;
   else if (mode == NANN_TRAVERSAL_LDS_HASH32) hash_vis = VIS_LDS_HASH32;
   else if (mode == NANN_TRAVERSAL_AUTO && (kind == NANN_SCORER_L2 || kind < 0)) {
-    if (worst_visited <= 16320.0 || est_visited <= 11000.0) hash_vis = VIS_LDS_HASH;
-    else if (worst_visited <= 32704.0 || est_visited <= 24000.0) hash_vis = VIS_LDS_HASH32;
+    if (worst_visited <= 16320.0 || est_visited <= fit16) hash_vis = VIS_LDS_HASH;
+    else if (worst_visited <= 32704.0 || est_visited <= fit32) hash_vis = VIS_LDS_HASH32;
     // small batches: with at most one query per CU the second 512-thread workgroup of the 16K-slot plan has nothing to
     // overlap with, and a query is served faster by ONE 1024-thread workgroup owning the CU (measured at configs[1]:
     // B = 1 0.196 -> 0.160 ms, B = 64 0.206 -> 0.165 ms; profiles/r3d_*)
@@ -2046,7 +2073,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   }
   // attention model / split-f16 MLP: 16K slots, one workgroup per CU -- when the level's visited ids are expected to fit
   // (a beam too wide for the set would send nearly every query through both kernels)
-  const bool fits16 = worst_visited <= 16320.0 || est_visited <= 11000.0 || mode == NANN_TRAVERSAL_LDS_HASH;
+  const bool fits16 = worst_visited <= 16320.0 || est_visited <= fit16 || mode == NANN_TRAVERSAL_LDS_HASH;
   const bool own_hash_plan = (kind == kKindAttn || kind == kKindMlpSplit || res) && tag_fits && fits16;
   if ((mode == NANN_TRAVERSAL_LDS_HASH || mode == NANN_TRAVERSAL_LDS_HASH32) && !hash_ok && kind >= 0 &&
       !(own_hash_plan && mode == NANN_TRAVERSAL_LDS_HASH))
@@ -2101,7 +2128,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // Wide beams (ef = 256: a level's visited ids need the 32K-slot set): the fused kernel keeps its bitmap in HBM because the
   // resident weights leave no room for a set; the pipeline's traversal stages own the LDS and run the L2 kernel's 32K-slot
   // plan (one 1024-thread workgroup per CU).  Both precisions, every batch size (profiles/r5g_*).
-  const bool fits32 = worst_visited <= 32704.0 || est_visited <= 24000.0;
+  const bool fits32 = worst_visited <= 32704.0 || est_visited <= fit32;
   if (res && !own_hash_plan && tag_fits && fits32 && no_forced_bitmap && mode != NANN_TRAVERSAL_LDS_HASH && hash32_lds <= di.lds_max &&
       opt.mlp_form != NANN_MLP_FORM_FUSED) {
     p->phased = true;
@@ -2387,6 +2414,83 @@ static int search_impl(const nann_index* ix, const nann_scorer* scorer, const na
   return both([&](int vis, int nt, int slots, size_t lds) {
     return launch_search_any(ix->desc.d / 8, dt, kind, mlp_split, vis, nt, slots, lds, a, st);
   });
+}
+
+// ---- the probe of nann_index_create ---------------------------------------------------------------------------------
+// plan_search has to know how many ids a level's visited set will hold BEFORE it launches (16K-slot set, two workgroups per
+// CU; 32K-slot set, one; bitmap).  That is a property of the graph -- degrees, and how much the neighbourhoods of a beam's
+// rows overlap -- which no formula over the mean degree captures for every builder.  So the index
+// measures it once: 64 of its own rows as queries, ef = min(64, #enter points), L2 scorer, on the HBM-bitmap plan (which
+// cannot overflow); from the kernel's per-round counters, new nodes found per frontier row over the three level-0 rounds.
+__global__ void k_probe_queries(const void* emb, int dt, int d, long long n_items, int nq, float* q) {
+  const int j = blockIdx.x;
+  const long long row = (long long)j * (n_items / nq);
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
+    float v;
+    if (dt == NANN_F32) v = static_cast<const float*>(emb)[row * d + k];
+    else {
+      const uint32_t h = static_cast<const uint16_t*>(emb)[row * d + k];
+      v = dt == NANN_F16 ? half_bits_to_float(h) : bf16_bits_to_float(h);
+    }
+    q[(size_t)j * d + k] = v;
+  }
+}
+
+static void probe_index(nann_index* ix) {
+  ix->probe_valid = false;
+  const int d = ix->desc.d;
+  const int64_t E = ix->desc.n_enter, N = ix->desc.n_items;
+  if (E < 8 || N < 4096) return;  // (toy indices: the degree-based guess)
+  const int nq = 64, e = (int)std::min<int64_t>(64, E);
+  const int32_t t[6] = {e, e, e, e, e, std::min(e, 10)};
+  nann_scorer_desc sd{};
+  sd.kind = NANN_SCORER_L2; sd.d = d; sd.emb_dtype = ix->desc.emb_dtype;
+  nann_scorer* sc = nullptr;
+  if (nann_scorer_create(&sd, &sc) != NANN_OK) return;
+  nann_search_options o;
+  nann_search_options_init(&o);
+  o.traversal_mode = NANN_TRAVERSAL_HBM_BITMAP;
+  o.slot_reserve = 0;
+  int64_t ws_bytes = 0;
+  const size_t n_ctr = (size_t)nq * 3 * NANN_NUM_ROUNDS;
+  unsigned char* buf = nullptr;
+  std::vector<int32_t> h_ctr(n_ctr), h_st((size_t)nq);
+  bool ok = nann_search_workspace_bytes(ix, t, nq, &ws_bytes) == NANN_OK;
+  const size_t off_q = ((size_t)ws_bytes + 255) & ~(size_t)255, off_ids = off_q + (size_t)nq * d * 4,
+               off_st = off_ids + (size_t)nq * t[5] * 8, off_ctr = off_st + (size_t)nq * 4, total = off_ctr + n_ctr * 4;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&buf), total) == hipSuccess;
+  if (ok) {
+    hipStream_t st = nullptr;
+    hipLaunchKernelGGL(k_probe_queries, dim3(nq), dim3(128), 0, st, ix->desc.item_embs, ix->desc.emb_dtype, d, (long long)N, nq,
+                       reinterpret_cast<float*>(buf + off_q));
+    ok = search_impl(ix, sc, nullptr, reinterpret_cast<const float*>(buf + off_q), nullptr, nullptr, nq, t, nullptr, buf, ws_bytes,
+                     reinterpret_cast<int64_t*>(buf + off_ids), nullptr, nullptr, reinterpret_cast<int32_t*>(buf + off_st),
+                     reinterpret_cast<int32_t*>(buf + off_ctr), nullptr, &o, nullptr, st) == NANN_OK;
+    ok = ok && hipMemcpy(h_ctr.data(), buf + off_ctr, n_ctr * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(h_st.data(), buf + off_st, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (buf) (void)hipFree(buf);
+  nann_scorer_destroy(sc);
+  (void)hipGetLastError();
+  if (!ok) return;
+  double sum = 0.0, mx = 0.0;
+  int n_valid = 0;
+  for (int j = 0; j < nq; ++j) {
+    if (h_st[(size_t)j] != NANN_OK) continue;
+    const int32_t* c = h_ctr.data() + (size_t)j * 3 * NANN_NUM_ROUNDS;  // [F | G | S][round]
+    double rows = 0.0, fresh = 0.0;
+    for (int r = 2; r <= 4; ++r) { rows += c[0 * NANN_NUM_ROUNDS + r]; fresh += c[2 * NANN_NUM_ROUNDS + r]; }
+    if (rows <= 0.0) continue;
+    const double ratio = fresh / rows;
+    sum += ratio; mx = std::max(mx, ratio);
+    ++n_valid;
+  }
+  if (n_valid < 8) return;  // (a corpus whose clusters a beam exhausts: nothing to learn from failed requests)
+  ix->probe_valid = true;
+  ix->probe_ef = e;
+  ix->probe_queries = n_valid;
+  ix->probe_new_per_row_mean = (float)(sum / n_valid);
+  ix->probe_new_per_row_max = (float)mx;
 }
 
 extern "C" {

@@ -93,3 +93,49 @@ def test_device_builder_graph_quality_matches_the_host_builder(oracle):
             assert (r.status.cpu().numpy()[:16] == st).all() and (r.index.cpu().numpy()[:16][ok] == eidx[ok]).all()
     assert out["gpu"][0] >= out["cpu"][0] - 0.02, out
     assert abs(out["gpu"][1] - out["cpu"][1]) / out["cpu"][1] < 0.1, out
+
+
+def test_dense_graph_family_and_the_measured_planner(oracle):
+    """VERDICT r4 next 4.  The builder's keepPrunedConnections switch (alg. 4; off in Faiss and the reference) fills rows
+    to their cap: mean level-0 degree >= 40 of 64 -- the graph family SURVEY.md 8's gather bound (L0 gathered <= ef * 64)
+    is about.  On it: (1) the traversal still answers like the oracle bit for bit, (2) the index's probe launch
+    (nann_index_create) measures what a beam visits on THIS graph and the planner, which used to guess from the mean
+    degree and sent this graph to the one-workgroup-per-CU 32K plan, keeps the two-workgroups-per-CU 16K-slot plan,
+    (3) with < 1 % of the queries handed back to the bitmap kernel."""
+    from nann_amd import index_build, ops, retrieval, synth
+    n, d, ef = 300_000, 128, 128
+    embs, _ = synth.make_corpus(n, d, n_clusters=78, noise=1.0)
+    ids = synth.make_item_ids(n)
+    seqs = torch.as_tensor(synth.make_queries_from_centres(d, 600, n_clusters=78, noise=1.0)).cuda()
+    q = ops.user_seq_mean(seqs)
+    sc = ops.Scorer("l2", d)
+    topn = [ef] * 5 + [200]
+    deg, plans = {}, {}
+    for name, keep in (("dense", True), ("heuristic", False)):
+        ex = index_build.build_hnsw_gpu(cuda(embs), 32, 40, seed=9, keep_pruned=keep)
+        _check_export(ex, n, 32)
+        g = {"item_embs": embs, "item_ids": ids, "nb_values": [v.astype(np.int32) for v in ex["nb_values"]],
+             "nb_row_splits": ex["nb_row_splits"], "enter_points": ex["enter_points"].astype(np.int32)}
+        deg[name] = len(g["nb_values"][0]) / n
+        dix = retrieval.Index.from_dict(g)
+        assert dix.probe is not None and dix.probe["queries"] >= 32 and dix.probe["ef"] == 64, dix.probe
+        r = retrieval.search(dix, sc, q, topn)
+        torch.cuda.synchronize()
+        plans[name] = (r.plan, dix.probe, r.reruns())
+        st = r.status.cpu().numpy()
+        assert (st == 0).mean() >= 0.95
+        # the probe's ratio is the measured form of "new level-0 nodes per frontier row": the real calls stay under it
+        ctr = r.counters.cpu().numpy().astype(np.int64)[st == 0]
+        ratio = ctr[:, 2, 2:5].sum(1) / ctr[:, 0, 2:5].sum(1)
+        assert np.quantile(ratio, 0.99) <= dix.probe["new_per_row_max"] * 1.05, (np.quantile(ratio, 0.99), dix.probe)
+        assert r.plan["visited_set"] == "lds_hash" and r.plan["threads"] == 512 and r.plan["workgroups"] == 512, r.plan
+        assert r.reruns() <= 0.01 * len(st), r.reruns()
+        oix = oracle.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+        est, eids, esc, eidx, ectr = oracle.search_batch(oix, oracle.Scorer("l2", d, oracle.EMB_F16), q[:24].cpu().numpy(), topn, n_threads=8)
+        ok = est == 0
+        assert (st[:24] == est).all()
+        assert (r.index.cpu().numpy()[:24][ok] == eidx[ok]).all() and (r.item_ids.cpu().numpy()[:24][ok] == eids[ok]).all()
+        assert (r.scores.cpu().numpy()[:24][ok].view(np.uint32) == esc[ok].view(np.uint32)).all()
+        assert (r.counters.cpu().numpy()[:24][ok] == ectr[ok]).all()
+    print("dense-graph planner:", deg, plans)
+    assert deg["dense"] >= 40 and deg["heuristic"] < 25, deg

@@ -942,10 +942,11 @@ def test_search_options_travel_with_the_call(oracle):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not errs and len(out) == 3, errs
-    # a reserve leaves workgroup slots free without changing an answer
-    r, got = run(None)
+    # a reserve leaves workgroup slots free without changing an answer (600 queries: every slot of the plan is taken)
+    q3 = np.concatenate([q, q, q])
+    r, got = run(None, q3)
     full = r.plan["workgroups"]
-    r2 = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(slot_reserve=16))
+    r2 = retrieval.search(dix, sc, cuda(q3), topn, options=retrieval.search_options(slot_reserve=16))
     torch.cuda.synchronize()
-    assert r2.plan["workgroups"] == full - 16 if full > 16 else True
+    assert full > 16 and r2.plan["workgroups"] == full - 16, (r.plan, r2.plan)
     assert (r2.item_ids.cpu().numpy() == got[1]).all()
