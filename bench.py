@@ -84,7 +84,8 @@ def parse():
                          "random = random-init weights of the architecture (rounds 1-2)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "lds_bitmap", "hbm_bitmap", "lds_hash", "lds_hash32"])
     ap.add_argument("--index-cache", default=None, help="directory to cache built indices in")
-    ap.add_argument("--stress-items", type=int, default=2_000_000)
+    ap.add_argument("--stress-items", type=int, default=4_000_000,
+                    help="items of the HBM-honest secondary workload: configs[4]'s shard at its own size (4M x 256-d bf16, ef=256)")
     ap.add_argument("--phase-ticks", action="store_true",
                     help="one extra instrumented launch: per-phase time attribution")
     return ap.parse_args()
@@ -133,19 +134,21 @@ def load_pmc_counters(tag):
     p = _pmc_entry(tag)
     if p is None or "SQ_VALU_MFMA_BUSY_CYCLES" not in p:
         return None
-    out = {"mfma_busy_source": "profiles/pmc_latest.json (%s)" % p.get("kernel_version", "?")}
+    # (PMC counters cannot be read from inside the timed process: these are the COMMITTED rocprofv3 passes of the same bench
+    # command -- hence "_committed" in every name; `source` names the file and the kernel version they were taken on)
+    out = {"source": "profiles/pmc_latest.json (%s)" % p.get("kernel_version", "?")}
     # SQ_VALU_MFMA_BUSY_CYCLES sums, over the SIMDs, the cycles their matrix pipe was busy; SQ_BUSY_CYCLES the cycles
     # an SQ (one per XCD ... summed over SEs) had waves: busy fraction = MFMA cycles / (4 SIMDs x CU-cycles the kernel ran)
     if p.get("GRBM_GUI_ACTIVE"):
         cu_cycles = p["GRBM_GUI_ACTIVE"] / 8.0 * 256  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-        out["mfma_busy_frac"] = round(p["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu_cycles), 4)
+        out["mfma_busy_frac_committed"] = round(p["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu_cycles), 4)
     for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE",
               "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
         if k in p:
-            out[k] = p[k]
+            out[k + "_committed"] = p[k]
     sc = p.get("by_kernel", {}).get("k_mlp_phase_score")
     if sc:  # the pipeline of phases: the scoring launches on their own (their share of the call: profiles/r4*_phase_trace_*.txt)
-        out["scoring_launches"] = {k: sc[k] for k in ("mfma_busy_frac", "shader_clock_GHz_in_pass", "SQ_INSTS_MFMA", "FETCH_SIZE_KiB") if k in sc}
+        out["scoring_launches_committed"] = {k: sc[k] for k in ("mfma_busy_frac", "shader_clock_GHz_in_pass", "SQ_INSTS_MFMA", "FETCH_SIZE_KiB") if k in sc}
     return out
 
 
@@ -276,7 +279,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                  else synth.make_mlp_weights_metric(dim, rows))
     precision = cfg.get("mlp_precision", "exact") if scorer_kind == "mlp" else "exact"
     scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w, precision=precision)
-    n_batches = min(steps + warmup, 24)
+    n_batches = min(steps + warmup, 40)  # (the driver's 3 + 20 steps: every step its own batch; long matrix-core warm-ups wrap around)
     seqs = make_query_batches(dim, batch, n_batches, args.noise, dev, n_clusters=n_clusters_for(items, ef))
     setup_s = time.time() - t0
     retrieval.set_traversal_mode(cfg.get("traversal", "auto"))
@@ -284,6 +287,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     # per-call options (nann_search_options): a sharded run that overlaps its exchanges leaves RCCL a few workgroup slots
     sopt = sharded.search_options(overlap=cfg.get("overlap_exchange", False)) if sharded is not None else None
+    timed_comm = sharded is not None and sharded.transport == "rccl" and sharded.comm is not None
+    if timed_comm:
+        sharded.comm.set_timing(True)  # HIP events around pack | all-gather | merge of every exchange, on the exchange's stream
     if cfg.get("mlp_form"):
         sopt = retrieval.search_options(mlp_form=cfg["mlp_form"])
 
@@ -327,6 +333,24 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     # ---- roofline of the traversal kernel (rank-local launch, HIP events on its stream)
     kern_all = np.asarray([a.elapsed_time(b) for a, b in ev], np.float64)
     kern_ms = float(kern_all.mean())
+    breakdown = None
+    if sharded is not None:
+        # what one step costs on THIS rank, part by part (HIP events on the streams the parts run on): the search launch,
+        # and -- last exchange of the run -- pack, all-gather, merge.  Gathered from every rank below: an efficiency
+        # number from an 8-GPU node then explains itself (step = max(search, exchange) when the exchange overlaps the
+        # next search, their sum otherwise).
+        mine = {"rank": rank, "search": round(kern_ms, 4)}
+        if timed_comm:
+            try:
+                mine.update(sharded.comm.last_breakdown())
+                mine["shards"], mine["rccl_ranks"] = sharded.comm.ranks()
+            except Exception as e:  # noqa: BLE001
+                mine["error"] = repr(e)
+        else:
+            mine["note"] = "torch.distributed transport: exchange parts are not timed separately"
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        breakdown = box
     status = r.status.cpu().numpy()
     counters = r.counters.cpu().numpy().astype(np.int64)
     ok = status == 0
@@ -380,11 +404,24 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         # bytes the scorer gathers per row: the 1 KB row of the table (f32 x 256) instead of the d x 2 B embedding row
         row_bytes = 1024 if table_form else dim * 2
         tot_b2, _ = algorithmic_bytes(counters[ok], row_bytes // 2, 2, len(g["enter_points"]), topk)
+        # (why the MLP lines run batch 1024 where the headline runs 4096: the rate is flat from 1024 up -- 396 k at 4096 against
+        # 383-388 k at 1024, profiles/r4g_bench_mlp_split_b*.json -- and a chunk of the pipeline of phases is 1024 queries)
         kernel_label = ("pipeline of phases (nann_mlp6.h): k_mlp_phase_score<%s> x 5 rounds [dominant] + k_search<phase> x 6; "
                         "kernel_ms = the whole call" % precision) if phased else (
                         "k_search (MLP scorer, %s%s)" % (precision, ", layer 2 resident in LDS" if table_form else ""))
-        roofline = {"bound": "mfma", "kernel": kernel_label,
-                    "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+        # BOTH rooflines: executed matrix-core flops against the MFMA peak of the operand type, and the bytes
+        # the scorer gathers (1 KB table rows) + the traversal's adjacency / id traffic against HBM; `bound` = the one the
+        # kernel sits closer to, and achieved / peak / unit / frac are that one's
+        hbm_gbps = float(tot_b2.sum()) / (kern_ms * 1e-3) / 1e9
+        frac_mfma, frac_hbm = tf / peak, hbm_gbps / HBM_PEAK_GBS
+        bound = "hbm" if frac_hbm > frac_mfma else "mfma"
+        roofline = {"bound": bound, "kernel": kernel_label,
+                    "achieved": round(hbm_gbps, 1) if bound == "hbm" else round(tf, 2),
+                    "peak": HBM_PEAK_GBS if bound == "hbm" else peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                    "frac": round(max(frac_mfma, frac_hbm), 4),
+                    "frac_mfma": round(frac_mfma, 4), "frac_hbm": round(frac_hbm, 4),
+                    "mfma_achieved_TFLOPs": round(tf, 2), "mfma_peak_TFLOPs": peak,
+                    "algorithmic_bytes_per_launch": float(tot_b2.sum()),
                     "traffic": None, "kernel_ms": round(kern_ms, 4),
                     "flops": "EXECUTED matrix-core flops per scored row x rows scored: " + flops_note,
                     "executed_flops_per_row": per_row, "executed_flops_per_launch": executed,
@@ -400,10 +437,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
         pmc = load_pmc_counters(name)
         if pmc is not None:
-            roofline.update(pmc)
-            if pmc.get("SQ_INSTS_MFMA"):
-                roofline["mfma_instructions_per_launch_pmc"] = pmc["SQ_INSTS_MFMA"]
-                roofline["executed_over_pmc_instructions"] = round(executed / flop_per_mfma / pmc["SQ_INSTS_MFMA"], 4)
+            roofline["pmc_committed"] = pmc
+            if pmc.get("SQ_INSTS_MFMA_committed"):
+                roofline["executed_over_committed_pmc_instructions"] = round(executed / flop_per_mfma / pmc["SQ_INSTS_MFMA_committed"], 4)
         pmc = load_pmc_traffic(name)
         if pmc is not None:
             roofline["traffic"] = pmc["bytes_per_launch"]
@@ -415,6 +451,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     except Exception:
         plan_info, reruns = None, None
     res = {"workload": name, "qps_end_to_end": round(qps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+           **({"exchange_breakdown_ms": breakdown,
+               "rccl_ranks_seen": max([b.get("rccl_ranks", 0) for b in breakdown] + [0])} if breakdown else {}),
            "plan": plan_info, "reruns_last_step": reruns, "index_probe": index.probe,
            "batch": batch, "steps": steps, "valid_queries": n_valid, "setup_s": round(setup_s, 1),
            # host time to ENQUEUE each step (no sync inside the loop): a value near ms_per_step = the host blocked
@@ -546,8 +584,18 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     return res
 
 
-def batch_sweep(handles, topn, sizes):
-    """smaller request batches (B in {1, 64, 1024}): latency and QPS of one launch"""
+def hbm_roofline(bytes_per_launch, ms, kernel, **extra):
+    """the `roofline` block of an HBM-bound line: algorithmic bytes of ONE launch / its duration against 8 TB/s"""
+    ach = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": float(bytes_per_launch), **extra}
+
+
+def batch_sweep(handles, topn, sizes, dim, n_enter):
+    """smaller request batches (B in {1, 64, 1024}): latency and QPS of one launch, each with its roofline
+    (the launch's own counters through 8(d)'s byte formula / its median duration: a batch that fills 1 or 64 of 256 CUs is
+    priced against the whole chip's 8 TB/s all the same -- that is what the line is there to show)"""
     import torch
     from nann_amd import ops, retrieval
     index, scorer, seqs = handles
@@ -558,21 +606,30 @@ def batch_sweep(handles, topn, sizes):
         for it in range(3 + 10):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            retrieval.search(index, scorer, qb, topn, want_counters=False)
+            r = retrieval.search(index, scorer, qb, topn, want_counters=it == 0)
             e1.record()
             torch.cuda.synchronize()
+            if it == 0:
+                okb = r.status.cpu().numpy() == 0
+                tot_b, _ = algorithmic_bytes(r.counters.cpu().numpy().astype(np.int64)[okb], dim, 2, n_enter, topn[5])
+                plan = r.plan
             if it >= 3:
                 ts.append(e0.elapsed_time(e1))
         ts = np.asarray(ts)
-        sweep.append({"batch": bsz, "ms_p50": round(float(np.percentile(ts, 50)), 4),
+        p50 = float(np.percentile(ts, 50))
+        sweep.append({"batch": bsz, "ms_p50": round(p50, 4),
                       "ms_max": round(float(ts.max()), 4),
-                      "qps": round(bsz / (float(np.percentile(ts, 50)) * 1e-3), 1)})
+                      "qps": round(bsz / (p50 * 1e-3), 1),
+                      "plan": "%s, %d threads x %d workgroups" % (plan["visited_set"], plan["threads"], plan["workgroups"]),
+                      "roofline": hbm_roofline(float(tot_b.sum()), p50, "k_search (one launch of %d queries)" % bsz)})
     return sweep
 
 
-def eval_graph_rate(handles, n_users=1024):
+def eval_graph_rate(handles, dim, n_enter, n_users=1024):
     """f3: users/s of the evaluation graph's traversal in one kernel (nann_search_eval): the reference's defaults
-    (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned) and a wide setting above the serving kernels' 1024"""
+    (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned) and a wide setting above the serving kernels' 1024.
+    roofline: SURVEY.md 8(d)'s byte formula over the kernel's OWN counters (nann_search_eval_ex: rows walked F, neighbours
+    gathered G, rows scored S per user; pinned to the op-by-op spelling by test_fused_eval_graph_counters_...)."""
     import torch
     from nann_amd import ops, retrieval
     index, scorer, seqs = handles
@@ -583,14 +640,20 @@ def eval_graph_rate(handles, n_users=1024):
         for it in range(1 + 3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = retrieval.search_eval(index, scorer, q, *cfg)
+            r = retrieval.search_eval(index, scorer, q, *cfg, want_counters=it == 0)
             e1.record()
             torch.cuda.synchronize()
+            if it == 0:
+                c = r.counters.cpu().numpy().astype(np.int64)[r.status.cpu().numpy() == 0]
+                F, G, S = c[:, 0], c[:, 1], c[:, 2]
+                bytes_launch = float((S * dim * 2 + G * 4 + F * 16 + G * 8).sum() + len(c) * (n_enter * 4 + cfg[2] * 12))
             if it >= 1:
                 ts.append(e0.elapsed_time(e1))
         ms = float(np.median(ts))
         res = {"users": int(q.shape[0]), "ms": round(ms, 3), "users_per_s": round(q.shape[0] / (ms * 1e-3), 1),
-               "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1)}
+               "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1),
+               "rows_scored_per_user": round(float(S.mean()), 1), "gathered_per_user": round(float(G.mean()), 1),
+               "roofline": hbm_roofline(bytes_launch, ms, "k_search_eval")}
         if name == "defaults":
             out.update(res)
         else:
@@ -616,21 +679,47 @@ def attention_model_rate(handles, dim, topn, precision, n_users=512):
     for it in range(n_warm + 8):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = retrieval.search_model(index, model, seq, topn, want_counters=False)
+        r = retrieval.search_model(index, model, seq, topn, want_counters=it == 0)
         e1.record()
+        if it == 0:
+            torch.cuda.synchronize()
+            okq = r.status.cpu().numpy() == 0
+            ctr = r.counters.cpu().numpy().astype(np.int64)[okq]
+            plan = r.plan
         if it >= n_warm:
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
     ms = float(np.median(ts))
     out = {"users": n_users, "precision": precision, "ms": round(ms, 3),
            "queries_per_s": round(n_users / (ms * 1e-3), 1), "failed": int((r.status != 0).sum())}
+    # roofline (VERDICT r4 missing 5): what the traversal EXECUTES per scored row on the pre-projected table
+    #   split-f16  220 x v_mfma_f32_32x32x16_f16 per 32 rows (attention logits, softmax-weighted sum, DNN 128-64-32-1 attention half)
+    #   f32 form   608 x v_mfma_f32_32x32x2_f32 per 32 rows
+    # and the bytes it gathers: the table row is 384 f32 = 1 536 B (q_ 256 + e W1e 128) instead of the 2 d-byte embedding row
+    rows = float(ctr[:, 2, :].sum())
+    mfma_per_32, flop_per_mfma, peak = (220, 32 * 32 * 16 * 2, F16_MFMA_PEAK_TF) if precision == "split" else (608, 32 * 32 * 2 * 2, F32_MFMA_PEAK_TF)
+    row_bytes = 1536 if plan["table"] else dim * 2
+    executed = rows / 32.0 * mfma_per_32 * flop_per_mfma
+    tf = executed / (ms * 1e-3) / 1e12
+    tot_b, _ = algorithmic_bytes(ctr, row_bytes // 2, 2, int(index.enter_points.numel()), topn[5])
+    gbps = float(tot_b.sum()) / (ms * 1e-3) / 1e9
+    frac_mfma, frac_hbm = tf / peak, gbps / HBM_PEAK_GBS
+    bound = "hbm" if frac_hbm > frac_mfma else "mfma"
+    out["roofline"] = {"bound": bound, "kernel": "k_search<attention model, %s> + the per-user projection (kernel_ms = the whole nann_search_model call)" % precision,
+                       "achieved": round(gbps, 1) if bound == "hbm" else round(tf, 2), "peak": HBM_PEAK_GBS if bound == "hbm" else peak,
+                       "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(max(frac_mfma, frac_hbm), 4),
+                       "frac_mfma": round(frac_mfma, 4), "frac_hbm": round(frac_hbm, 4), "traffic": None, "kernel_ms": round(ms, 4),
+                       "executed_flops_per_launch": executed, "mfma_instructions_per_32_rows": mfma_per_32,
+                       "algorithmic_bytes_per_launch": float(tot_b.sum()), "hbm_bytes_gathered_per_row": row_bytes,
+                       "rows_scored_per_query": round(rows / max(len(ctr), 1), 1),
+                       "note": "only valid when the table form ran (plan.table): %s" % bool(plan["table"])}
     out["form"] = ("item-only layers pre-projected per (model, index), keys and weights resident in LDS per scoring call: "
                    "nann_attn_proj.h wg_score_attn_res" if precision == "split" else
                    "f32 MFMA on the same pre-projected table: nann_attn_kernels.h wg_score_attn<PROJ>")
     if precision == "split":
         pmc = load_pmc_counters("attention_model_f2_split")
         if pmc is not None:
-            out["counters"] = pmc
+            out["roofline"]["pmc_committed"] = pmc
     return out
 
 
@@ -737,7 +826,8 @@ def main():
     }
     if world > 1 and exchange_note:
         result["exchange_note"] = exchange_note
-    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "plan", "reruns_last_step", "index_probe", "roofline", "batch_latency_ms",
+    for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "plan", "reruns_last_step", "index_probe",
+              "exchange_breakdown_ms", "rccl_ranks_seen", "roofline", "batch_latency_ms",
               "cpu_baseline", "parity", "recall_at_k_vs_bruteforce", "phase_breakdown", "host_enqueue_ms"):
         if k in prim:
             result[k] = prim[k]
@@ -745,11 +835,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and args.scorer == "l2":
         sec = {}
         try:
-            sec["batch_sweep"] = batch_sweep(prim["_handles"], [args.ef] * 5 + [args.topk], [1, 64, 1024])
+            sec["batch_sweep"] = batch_sweep(prim["_handles"], [args.ef] * 5 + [args.topk], [1, 64, 1024], args.dim, prim["n_enter"])
         except Exception as e:  # a failing extra must not take the headline line with it
             sec["batch_sweep"] = {"error": repr(e)}
         try:
-            sec["eval_graph_f3"] = eval_graph_rate(prim["_handles"])
+            sec["eval_graph_f3"] = eval_graph_rate(prim["_handles"], args.dim, prim["n_enter"])
         except Exception as e:
             sec["eval_graph_f3"] = {"error": repr(e)}
         for prec in ("split", "exact"):
@@ -773,6 +863,18 @@ def main():
         prim.pop("_handles", None)
         prim.pop("_index", None)
         torch.cuda.empty_cache()
+        try:  # degree sensitivity: configs[1] on the DENSE graph family -- the same corpus, the same builder with
+            # the heuristic's keepPrunedConnections on (rows filled to their cap: mean level-0 degree ~52 of 64 instead of ~17)
+            cfg = dict(primary_cfg, graph="hnsw_dense", steps=10, warmup=3, cpu_seconds=min(args.cpu_seconds, 4.0))
+            dense = run_workload(tag.replace("_" + args.graph, "_hnsw_dense"), args, dev, rank, world, cfg,
+                                 want_cpu=not args.no_cpu_baseline, want_parity=True, want_recall=True)
+            dense.pop("_handles", None)
+            dense.pop("_index", None)
+            sec["dense_graph"] = strip(dense)
+            del dense
+            torch.cuda.empty_cache()
+        except Exception as e:
+            sec["dense_graph"] = {"error": repr(e)}
         try:  # HBM-honest: config 5's shard shape (256-d bf16, ef=256) at a size whose table is 4x the Infinity Cache
             cfg = {"items": args.stress_items, "dim": 256, "ef": 256, "topk": 200, "batch": 2048, "steps": 5,
                    "warmup": 2, "scorer": "l2", "dtype": "bf16", "graph": "hnsw", "traversal": "auto"}

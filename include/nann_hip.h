@@ -478,6 +478,13 @@ int nann_search_eval(const nann_index* ix, const nann_scorer* scorer, const floa
                      int32_t topk_eval, void* workspace, int64_t workspace_bytes, int64_t* out_item_ids,
                      float* out_scores, int32_t* out_index, int32_t* n_out, int32_t* status,
                      nann_stream_t stream);
+/* nann_search_eval + counters i32[n_queries, 3] (device, or NULL): rows walked F, neighbours gathered G, rows scored S (the
+ * enter points included), summed over a user's rounds -- what SURVEY.md 8(d)'s byte formula is evaluated on (bench.py's
+ * roofline of the f3 line); a user whose request failed keeps zeros. */
+int nann_search_eval_ex(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                        const int32_t num_scoring_per_level[3], const int32_t top_k_per_level[3], int32_t topk_eval,
+                        void* workspace, int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
+                        int32_t* out_index, int32_t* n_out, int32_t* status, int32_t* counters, nann_stream_t stream);
 int nann_search_eval_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16,
                            int64_t n_queries, const int32_t num_scoring_per_level[3],
                            const int32_t top_k_per_level[3], int32_t topk_eval, void* workspace,
@@ -520,6 +527,16 @@ typedef struct nann_comm nann_comm;
 int nann_comm_get_unique_id(void* id /*[host] NANN_COMM_ID_BYTES*/);
 int nann_comm_create(int32_t world, int32_t rank, const void* id /*[host]*/, nann_comm** out);
 void nann_comm_destroy(nann_comm* c);
+/* *world = shards of this communicator; *rccl_ranks = ncclCommCount of the RCCL communicator behind it (0: none -- a
+ * loopback, or a one-shard communicator created without an id): what a multi-GPU bench line states so that "N ranks
+ * exchanged over RCCL" is a measured fact. */
+int nann_comm_ranks(const nann_comm* c, int32_t* world, int32_t* rccl_ranks);
+/* enabled: HIP events around the three parts of every later nann_sharded_topk call on its stream;
+ * nann_comm_last_breakdown -> ms[3] = {pack, all-gather, merge} of the LAST call (waits for it).  loopback_repeat (loopback
+ * communicators only, >= 1): the device copies that stand in for the all-gather are issued this many times -- an exchange
+ * as long as 8 GPUs' over xGMI on one GPU, for the overlap / slot-reserve measurements (tools/overlap_bench.py). */
+int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat);
+int nann_comm_last_breakdown(nann_comm* c, float ms[3]);
 int nann_sharded_topk_workspace_bytes(int32_t world, int64_t n_queries, int32_t k_in, int64_t* nbytes);
 int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, const int32_t* status,
                       int64_t n_queries, int32_t k_in, int32_t k_out, void* workspace,

@@ -37,11 +37,11 @@ SYMBOLS = [
     "nann_search", "nann_search_v", "nann_search_ex", "nann_search_opt", "nann_search_options_init", "nann_search_reruns", "nann_search_model_opt", "nann_set_traversal_mode", "nann_set_search_reserve", "nann_search_model_workspace_bytes",
     "nann_search_model", "nann_search_model_v",
     "nann_scorer_prepare", "nann_scorer_release", "nann_scorer_table_bytes", "nann_set_preprojection",
-    "nann_model_prepare", "nann_model_release", "nann_model_table_bytes", "nann_search_eval_workspace_bytes", "nann_search_eval", "nann_search_eval_model",
+    "nann_model_prepare", "nann_model_release", "nann_model_table_bytes", "nann_search_eval_workspace_bytes", "nann_search_eval", "nann_search_eval_ex", "nann_search_eval_model",
     "nann_merge_topk", "nann_merge_topk_host",
     "nann_attn_scorer_create", "nann_attn_scorer_destroy", "nann_attn_prepare", "nann_attn_score",
     "nann_model_load", "nann_model_destroy", "nann_model_kind", "nann_model_scorer", "nann_model_workspace_bytes", "nann_model_forward",
-    "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_sharded_topk_workspace_bytes",
+    "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_comm_ranks", "nann_comm_set_timing", "nann_comm_last_breakdown", "nann_sharded_topk_workspace_bytes",
     "nann_sharded_topk", "nann_hnsw_draw_levels", "nann_hnsw_build_device", "nann_hnsw_build_device_ex",
 ]
 

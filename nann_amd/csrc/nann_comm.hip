@@ -28,6 +28,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string where;
 };
@@ -50,6 +51,7 @@ int load_rccl(Rccl** out) {
     R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.handle, "ncclCommDestroy"));
     R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.handle, "ncclAllGather"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.handle, "ncclGetErrorString"));
+    R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.handle, "ncclCommCount"));
     if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) {
       R.handle = nullptr;
       return fail(NANN_ERR_UNSUPPORTED, "RCCL library lacks the ncclAllGather entry points");
@@ -115,7 +117,12 @@ struct nann_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool loopback = false;
+  int loopback_repeat = 1;  // test facility: the loopback's device copies issued this many times (an exchange as long as xGMI's)
   Rccl* R = nullptr;
+  // nann_comm_set_timing: four events around the three parts of every nann_sharded_topk call (pack | all-gather | merge)
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool timed_once = false;
 };
 
 extern "C" {
@@ -156,7 +163,39 @@ int nann_comm_create(int32_t world, int32_t rank, const void* id, nann_comm** ou
 void nann_comm_destroy(nann_comm* c) {
   if (!c) return;
   if (c->comm) (void)c->R->CommDestroy(c->comm);
+  for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
   delete c;
+}
+
+int nann_comm_ranks(const nann_comm* c, int32_t* world, int32_t* rccl_ranks) {
+  if (!c || !world || !rccl_ranks) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_ranks: null argument");
+  *world = c->world;
+  *rccl_ranks = 0;  // (no RCCL communicator behind this object: a loopback, or a one-shard communicator without an id)
+  if (c->comm && c->R->CommCount) {
+    int n = 0;
+    RCCL_TRY(c->R, c->R->CommCount(c->comm, &n));
+    *rccl_ranks = n;
+  }
+  return NANN_OK;
+}
+
+int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat) {
+  if (!c) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_set_timing: null communicator");
+  if (enabled)
+    for (hipEvent_t& e : c->ev)
+      if (!e) NANN_HIP_TRY(hipEventCreate(&e));
+  c->timing = enabled != 0;
+  c->timed_once = false;
+  c->loopback_repeat = std::max(1, (int)loopback_repeat);
+  return NANN_OK;
+}
+
+int nann_comm_last_breakdown(nann_comm* c, float ms[3]) {
+  if (!c || !ms) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_last_breakdown: null argument");
+  if (!c->timing || !c->timed_once) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_last_breakdown: no timed exchange yet (nann_comm_set_timing)");
+  NANN_HIP_TRY(hipEventSynchronize(c->ev[3]));
+  for (int i = 0; i < 3; ++i) NANN_HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  return NANN_OK;
 }
 
 int nann_sharded_topk_workspace_bytes(int32_t world, int64_t n_queries, int32_t k_in, int64_t* nbytes) {
@@ -182,17 +221,21 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
   unsigned char* send = static_cast<unsigned char*>(workspace);
   unsigned char* recv = send + rb;
   const long long n = n_queries * k_in;
+  if (c->timing) NANN_HIP_TRY(hipEventRecord(c->ev[0], st));
   hipLaunchKernelGGL(k_pack_record, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st,
                      scores, ids, status, (long long)n_queries, (int)k_in, (world > 1 || c->comm) ? send : recv);
   NANN_HIP_TRY(hipGetLastError());
+  if (c->timing) NANN_HIP_TRY(hipEventRecord(c->ev[1], st));
   if (world > 1 && c->loopback) {
-    for (int r = 0; r < world; ++r)
-      NANN_HIP_TRY(hipMemcpyAsync(recv + (size_t)r * rb, send, rb, hipMemcpyDeviceToDevice, st));
+    for (int rep = 0; rep < c->loopback_repeat; ++rep)
+      for (int r = 0; r < world; ++r)
+        NANN_HIP_TRY(hipMemcpyAsync(recv + (size_t)r * rb, send, rb, hipMemcpyDeviceToDevice, st));
   } else if (c->comm) {
     RCCL_TRY(c->R, c->R->AllGather(send, recv, rb, ncclChar, c->comm, st));
   } else if (world > 1) {
     return fail(NANN_ERR_BAD_ARGUMENT, "nann_sharded_topk: communicator without RCCL state");
   }
+  if (c->timing) NANN_HIP_TRY(hipEventRecord(c->ev[2], st));
   const size_t lds = (size_t)n_in * 4;
   if (lds > 48 * 1024)
     NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_records),
@@ -200,6 +243,7 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
   hipLaunchKernelGGL(k_merge_records, dim3((unsigned)n_queries), dim3(kNT), lds, st, recv, (unsigned long long)rb,
                      world, (long long)n_queries, (int)k_in, (int)k_out, out_scores, out_ids);
   NANN_HIP_TRY(hipGetLastError());
+  if (c->timing) { NANN_HIP_TRY(hipEventRecord(c->ev[3], st)); c->timed_once = true; }
   return NANN_OK;
 }
 

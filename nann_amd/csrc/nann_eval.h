@@ -46,6 +46,8 @@ struct EvalArgs {
   int32_t* out_index;
   int32_t* n_out;      // [n_queries] rows that are valid (min(topk_eval, results))
   int32_t* status;
+  int32_t* counters;   // [n_queries, 3] or NULL: rows walked (F), neighbours gathered (G), rows scored (S), summed over a user's
+                       // rounds (S includes the enter points): what SURVEY.md 8(d)'s byte formula is evaluated on
   MlpParams mlp;
   AttnParams attn;
   const float* kt;
@@ -133,6 +135,8 @@ template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
 __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
                                                unsigned char* scratch, float* qv, int* n_result) {
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  int ctr_f = 0, ctr_s = 0;  // (uniform)
+  int ctr_g = 0;             // this lane's share: row lengths it fetched (lanes 0-7 of every wavefront)
   constexpr int NW = NT / 64;
   EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
   if constexpr (SC != kScorerAttn) {
@@ -161,6 +165,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   const int E = a.n_enter;
   if (E <= 0) return NANN_ERR_EMPTY_SCORE_BATCH;
   eval_score<LPR, DT, SC, NT>(a, qi, a.enter, E, sv.cat_sc, scratch, qv, mlp_u);
+  ctr_s += E;
   int n_res = min(a.top_k[2], E);
   int st = wg_topk<NT, kEvalMaxK>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr, scratch);
   if (st) return st;
@@ -193,6 +198,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
     const int64_t* __restrict__ rs = a.nbrs[level];
     for (int it = 0; it < a.num_scoring[level]; ++it) {
       // ---- neighbours of the candidates -> bits of `seen`: eight rows per wavefront and trip
+      ctr_f += n_cand;
       {
         int bad = 0;
         for (int base = wave * 8; base < n_cand; base += NW * 8) {
@@ -200,6 +206,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
           if (lane < 8 && base + lane < n_cand) {
             const int32_t c = sv.cand[base + lane];
             s = rs[c]; e = rs[c + 1];
+            ctr_g += (int)(e - s);
           }
           int32_t v[8];
           long long sr[8], er[8];
@@ -242,6 +249,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
         total += t;
       }
       const int n_next = (int)total;
+      ctr_s += n_next;
       if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
       // ---- ... and written out in word order = ascending ids (:316-319); visited |= new (:321), seen = 0
       {
@@ -305,6 +313,10 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
     }
   }
   *n_result = n_res;
+  if (a.counters) {  // (the kernel zeroed the user's three words before the call)
+    if (tid == 0) { atomicAdd(&a.counters[(size_t)qi * 3 + 0], ctr_f); atomicAdd(&a.counters[(size_t)qi * 3 + 2], ctr_s); }
+    if (ctr_g) atomicAdd(&a.counters[(size_t)qi * 3 + 1], ctr_g);
+  }
   return NANN_OK;
 }
 
@@ -337,6 +349,7 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
     __syncthreads();
     const int qi = misc[0];
     if (qi >= a.n_queries) break;
+    if (a.counters && threadIdx.x < 3) a.counters[(size_t)qi * 3 + threadIdx.x] = 0;
     int n_res = 0;
     int st;
     if constexpr (SEEN_LDS) st = search_eval_one<LPR, DT, SC, NT, true>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res);

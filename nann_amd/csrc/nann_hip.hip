@@ -2709,7 +2709,7 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
                      const float* kt, const float* upad, int64_t n_queries, const int32_t num_scoring[3],
                      const int32_t top_k[3], int32_t topk_eval, void* workspace, int64_t workspace_bytes,
                      int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* n_out, int32_t* status,
-                     hipStream_t st) {
+                     hipStream_t st, int32_t* counters = nullptr) {
   if (n_queries > 0x7fffffffll) return fail(NANN_ERR_UNSUPPORTED, "too many queries in one call");
   if (num_scoring[2] != 1) return fail(NANN_ERR_BAD_ARGUMENT, "num_scoring_per_level[2] must be 1 (model.py:347)");
   for (int l = 0; l < 3; ++l)
@@ -2737,6 +2737,7 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   a.ws = static_cast<unsigned char*>(workspace);
   a.bm_words = ix->bm_words;
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index; a.n_out = n_out; a.status = status;
+  a.counters = counters;
   a.mlp = MlpParams{};
   a.attn = AttnParams{};
   a.kt = kt; a.upad = upad;
@@ -2779,6 +2780,19 @@ int nann_search_eval(const nann_index* ix, const nann_scorer* scorer, const floa
     return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
   return eval_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, num_scoring_per_level, top_k_per_level, topk_eval,
                    workspace, workspace_bytes, out_item_ids, out_scores, out_index, n_out, status, as_stream(stream));
+}
+
+int nann_search_eval_ex(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
+                        const int32_t num_scoring_per_level[3], const int32_t top_k_per_level[3], int32_t topk_eval,
+                        void* workspace, int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
+                        int32_t* out_index, int32_t* n_out, int32_t* status, int32_t* counters, nann_stream_t stream) {
+  if (!ix || !scorer || !q || !num_scoring_per_level || !top_k_per_level || !out_item_ids || !n_out || !status)
+    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_eval_ex: null argument");
+  if (n_queries <= 0) return NANN_OK;
+  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
+    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
+  return eval_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, num_scoring_per_level, top_k_per_level, topk_eval,
+                   workspace, workspace_bytes, out_item_ids, out_scores, out_index, n_out, status, as_stream(stream), counters);
 }
 
 int nann_search_eval_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,

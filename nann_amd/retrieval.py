@@ -271,7 +271,7 @@ class EvalResult:
         self.item_ids, self.scores, self.index, self.n_out, self.status = item_ids, scores, index, n_out, status
 
 
-def search_eval(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 200, 100), topk_eval=200):
+def search_eval(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 200, 100), topk_eval=200, want_counters=False):
     """Model.retrieval() (model.py:299-362) for a batch of users in ONE kernel (nann_search_eval /
     nann_search_eval_model).  `scorer`: ops.Scorer with q f32[B, d], or ops.Model with q = comm_seq
     f16[B, seq_len, E].  Same results as search_eval_per_op, user by user."""
@@ -290,12 +290,21 @@ def search_eval(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 2
     _check(lib().nann_search_eval_workspace_bytes(index.handle, scorer.handle if is_model else None, C.c_int64(b),
                                                   C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
-    fn = lib().nann_search_eval_model if is_model else lib().nann_search_eval
+    counters = None
     with torch.cuda.device(dev):
-        _check(fn(index.handle, scorer.handle, _ptr(q), C.c_int64(b), ns, tk, C.c_int32(k), _ptr(ws),
-                  C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index), _ptr(n_out), _ptr(status),
-                  _stream()), "search_eval")
-    return EvalResult(out_ids, out_scores, out_index, n_out, status)
+        if want_counters and not is_model:  # F, G, S per user (nann_search_eval_ex)
+            counters = torch.zeros((b, 3), dtype=torch.int32, device=dev)
+            _check(lib().nann_search_eval_ex(index.handle, scorer.handle, _ptr(q), C.c_int64(b), ns, tk, C.c_int32(k), _ptr(ws),
+                                             C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
+                                             _ptr(n_out), _ptr(status), _ptr(counters), _stream()), "search_eval")
+        else:
+            fn = lib().nann_search_eval_model if is_model else lib().nann_search_eval
+            _check(fn(index.handle, scorer.handle, _ptr(q), C.c_int64(b), ns, tk, C.c_int32(k), _ptr(ws),
+                      C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index), _ptr(n_out), _ptr(status),
+                      _stream()), "search_eval")
+    res = EvalResult(out_ids, out_scores, out_index, n_out, status)
+    res.counters = counters
+    return res
 
 
 # -----------------------------------------------------------------------------
@@ -372,14 +381,17 @@ def search_per_op(index, scorer, q, level_topn):
 # that score at least the worst kept result), in the min(k, n) guard of its top_k (model.py:268)
 # and in visiting neighbours as an ascending set (tf.unique + tf.sets, :316-321).
 def search_eval_per_op(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=(400, 200, 100),
-                       topk_eval=200, backend=None):
+                       topk_eval=200, backend=None, stats=None):
     """One query through Model.retrieval().  num_scoring / top_k_per_level are indexed by level
     (0, 1, start level 2), as config.py:50-58 lists them.  Returns
     (item_ids i64[<=topk_eval], scores f32, internal index i32).  `backend`: the module providing
     group_gather / bitmap_ref_difference / blaze_score / top_k / gather (default: nann_amd.ops, the
-    HIP kernels; the CPU tests pass a stand-in to check this host logic against the oracle)."""
+    HIP kernels; the CPU tests pass a stand-in to check this host logic against the oracle).  `stats`: a dict that
+    receives F / G / S (rows walked, neighbours gathered, rows scored incl. the enter points: the fused kernel's counters)."""
     B = ops if backend is None else backend
     assert int(num_scoring[2]) == 1                                          # model.py:347
+    n_f = n_g = 0
+    n_s = int(index.enter_points.numel())
     q = q.reshape(-1)
 
     def get_scores(idx):                                                     # :240-262
@@ -404,7 +416,10 @@ def search_eval_per_op(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=
             nxt, _ = B.group_gather(index.nb_values[level], index.nb_row_splits[level],
                                     idx_candidate.to(torch.int64), _fake_row_splits(idx_candidate),
                                     unique=False)                            # :316
+            n_f += int(idx_candidate.numel())
+            n_g += int(nxt.numel())
             nxt, _, flags = B.bitmap_ref_difference(nxt, _fake_row_splits(nxt), flags)   # unique, minus visited, visited |= (:317-321)
+            n_s += int(nxt.numel())
             idx_next = torch.sort(nxt).values                                # tf.sets results are ascending
             scores_next = get_scores(idx_next)                               # :323
             idx_result, scores_result = top_k(torch.cat([idx_result, idx_next]),
@@ -413,6 +428,8 @@ def search_eval_per_op(index, scorer, q, num_scoring=(3, 1, 1), top_k_per_level=
             mask = scores_next >= scores_result[-1]                          # :330
             idx_candidate = idx_next[mask]                                   # :331
         results, scores = idx_result, scores_result
+    if stats is not None:
+        stats.update(F=n_f, G=n_g, S=n_s)
     results, scores = results[:topk_eval], scores[:topk_eval]                # :358
     item_ids = B.gather(index.item_ids.view(torch.int32).reshape(-1, 2), results)   # :360
     return item_ids.reshape(-1).view(torch.int64), scores, results

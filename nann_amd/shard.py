@@ -105,6 +105,23 @@ class Comm:
         _check(lib().nann_comm_create(C.c_int32(world), C.c_int32(0), None, C.byref(self.handle)), "comm create")
         return self
 
+    def ranks(self):
+        """(shards, ranks of the RCCL communicator behind this object: ncclCommCount; 0 = none, e.g. a loopback)"""
+        w, r = C.c_int32(0), C.c_int32(0)
+        _check(lib().nann_comm_ranks(self.handle, C.byref(w), C.byref(r)), "comm ranks")
+        return w.value, r.value
+
+    def set_timing(self, enabled=True, loopback_repeat=1):
+        """HIP events around pack | all-gather | merge of every later exchange (nann_comm_set_timing); loopback_repeat:
+        the loopback's stand-in copies issued that many times (an exchange as long as xGMI's, on one GPU)"""
+        _check(lib().nann_comm_set_timing(self.handle, C.c_int32(1 if enabled else 0), C.c_int32(loopback_repeat)), "comm timing")
+
+    def last_breakdown(self):
+        """{pack, all_gather, merge} ms of the last exchange (waits for it)"""
+        ms = (C.c_float * 3)()
+        _check(lib().nann_comm_last_breakdown(self.handle, ms), "comm breakdown")
+        return {"pack": round(ms[0], 4), "all_gather": round(ms[1], 4), "merge": round(ms[2], 4)}
+
     def __del__(self):
         try:  # at interpreter shutdown the module globals may already be gone
             if getattr(self, "handle", None) and self.handle.value:

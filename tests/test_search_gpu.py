@@ -511,6 +511,26 @@ def test_fused_eval_graph_tiny_graph_and_per_op_agree(oracle):
         assert (idx.cpu().numpy() == eidx).all() and (bits(s.cpu().numpy()) == bits(r.scores[b, :n].cpu().numpy())).all()
 
 
+def test_fused_eval_graph_counters_equal_the_per_op_spelling(oracle):
+    """nann_search_eval_ex's counters (rows walked F, neighbours gathered G, rows scored S: what bench.py's f3 roofline is
+    priced on) against the same quantities counted in the op-by-op spelling of Model.retrieval, whose every op is pinned
+    to the oracle; results with and without counters are the same bits."""
+    from nann_amd import ops, retrieval
+    g, oix, dix = synth_index(20000, 64, 32)
+    sc = ops.Scorer("l2", 64)
+    qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 24, seed=6)])
+    for cfg in (((3, 1, 1), (400, 200, 100), 200), ((2, 2, 1), (64, 300, 50), 40)):
+        r = retrieval.search_eval(dix, sc, cuda(qs), *cfg, want_counters=True)
+        r0 = retrieval.search_eval(dix, sc, cuda(qs), *cfg)
+        torch.cuda.synchronize()
+        assert (r.index.cpu().numpy() == r0.index.cpu().numpy()).all() and (bits(r.scores.cpu().numpy()) == bits(r0.scores.cpu().numpy())).all()
+        ctr = r.counters.cpu().numpy()
+        for b in range(0, 24, 3):
+            st = {}
+            retrieval.search_eval_per_op(dix, sc, cuda(qs[b]), *cfg, stats=st)
+            assert int(r.status[b]) == 0 and ctr[b].tolist() == [st["F"], st["G"], st["S"]], (b, ctr[b], st)
+
+
 def test_fused_eval_graph_with_the_attention_model(oracle, tmp_path):
     """nann_search_eval_model: comm_seq in, the reference's attention + DNN model as the scorer; scores within
     1e-5 of the oracle's, ids tie-aware (the tolerance the attention scorer is held to everywhere)."""
