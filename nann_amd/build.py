@@ -7,20 +7,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libnann_hip.so")
-# (source, extra flags, object name): compiled in parallel, then linked
-UNITS = [("nann_hip.hip", [], "nann_hip.o"),
-         ("nann_l2_inst.hip", ["-DNANN_L2_DT=0", "-DNANN_L2_NAME=f16"], "nann_l2_f16.o"),
-         ("nann_l2_inst.hip", ["-DNANN_L2_DT=1", "-DNANN_L2_NAME=bf16"], "nann_l2_bf16.o"),
-         ("nann_l2_inst.hip", ["-DNANN_L2_DT=2", "-DNANN_L2_NAME=f32"], "nann_l2_f32.o"),
-         ("nann_mlp_inst.hip", ["-DNANN_MLP_D=64"], "nann_mlp_d64.o"),
-         ("nann_mlp_inst.hip", ["-DNANN_MLP_D=128"], "nann_mlp_d128.o"),
-         ("nann_mlp_inst.hip", ["-DNANN_MLP_D=256"], "nann_mlp_d256.o"),
-         ("nann_mlp_res_inst.hip", [], "nann_mlp_res.o"),
-         ("nann_attn_inst.hip", [], "nann_attn.o"),
-         ("nann_attn_split_inst.hip", [], "nann_attn_split.o"),
-         ("nann_eval_inst.hip", [], "nann_eval.o"),
-         ("nann_comm.hip", [], "nann_comm.o"),
-         ("nann_hnsw_build.hip", [], "nann_hnsw_build.o")]
+# translation units: (object name, [(source, {macro: value} defined around its #include), ...]) -- compiled in parallel, then
+# linked.  A unit of several sources is compiled through a generated wrapper (_build/<obj>.d/unit.hip) that includes them
+# one after the other.  Round 5: 13 units -> 9: the three small host-facing files share one object, the
+# bf16 and f32 L2 instances another, the resident-layer-2 MLP kernels ride with the d = 64 MLP instances; the longest unit
+# (nann_eval: ~140 s) still bounds the wall time of a full build, ~160 s on 8 cores.
+UNITS = [("nann_core.o", [("nann_hip.hip", {}), ("nann_comm.hip", {}), ("nann_hnsw_build.hip", {})]),
+         ("nann_l2_f16.o", [("nann_l2_inst.hip", {"NANN_L2_DT": "0", "NANN_L2_NAME": "f16"})]),
+         ("nann_l2_bf16_f32.o", [("nann_l2_inst.hip", {"NANN_L2_DT": "1", "NANN_L2_NAME": "bf16"}),
+                                 ("nann_l2_inst.hip", {"NANN_L2_DT": "2", "NANN_L2_NAME": "f32"})]),
+         ("nann_mlp_d64_res.o", [("nann_mlp_inst.hip", {"NANN_MLP_D": "64"}), ("nann_mlp_res_inst.hip", {})]),
+         ("nann_mlp_d128.o", [("nann_mlp_inst.hip", {"NANN_MLP_D": "128"})]),
+         ("nann_mlp_d256.o", [("nann_mlp_inst.hip", {"NANN_MLP_D": "256"})]),
+         ("nann_attn.o", [("nann_attn_inst.hip", {})]),
+         ("nann_attn_split.o", [("nann_attn_split_inst.hip", {})]),
+         ("nann_eval.o", [("nann_eval_inst.hip", {})])]
 DEPS = ["nann_hip.hip", "nann_mlp_inst.hip", "nann_mlp_res_inst.hip", "nann_mlp5.h", "nann_mlp6.h", "nann_l2_inst.hip", "nann_attn_inst.hip", "nann_attn_split_inst.hip", "nann_attn_split.h", "nann_attn_proj.h", "nann_eval_inst.hip", "nann_eval.h", "nann_comm.hip", "nann_hnsw_build.hip", "nann_device.h", "nann_mlp.h", "nann_mlp2.h", "nann_mlp3.h",
         "nann_attn.h", "nann_attn_kernels.h", "nann_search.h", os.path.join("host", "nann_graphdef.h"), os.path.join("host", "nann_graphdef_text.h"), os.path.join("host", "nann_projcache.h"),
         os.path.join("..", "..", "include", "nann_hip.h")]
@@ -97,15 +98,28 @@ def _check_occupancy(log_path):
             raise RuntimeError(f"{name}: occupancy {m.group(1)} waves/SIMD, the hash-set kernel needs 4")
 
 
+def unit_command(obj, parts, odir, extra_flags=(), save_temps=True):
+    """Write the wrapper of a translation unit into `odir` and return the hipcc command that compiles it to odir/obj."""
+    unit = os.path.join(odir, "unit.hip")
+    with open(unit, "w") as f:
+        for src, macros in parts:
+            for k, v in macros.items():
+                f.write("#define %s %s\n" % (k, v))
+            f.write('#include "%s"\n' % os.path.join(SRC_DIR, src))
+            for k in macros:
+                f.write("#undef %s\n" % k)
+    return [_hipcc()] + FLAGS + list(extra_flags) + ["-I", SRC_DIR] + (["--save-temps=obj"] if save_temps else []) + \
+           ["-Rpass-analysis=kernel-resource-usage", "-c", unit, "-o", os.path.join(odir, obj)]
+
+
 def _build_into(OUT_DIR, LIB, extra_flags, verbose):
     os.makedirs(OUT_DIR, exist_ok=True)
     procs = []
-    for src, extra, obj in UNITS:
+    for obj, parts in UNITS:
         # one directory per object: --save-temps keeps the device assembly for the audit below
         odir = os.path.join(OUT_DIR, obj[:-2] + ".d")
         os.makedirs(odir, exist_ok=True)
-        cmd = [_hipcc()] + FLAGS + list(extra_flags) + extra + ["--save-temps=obj", "-Rpass-analysis=kernel-resource-usage",
-                                            "-c", os.path.join(SRC_DIR, src), "-o", os.path.join(odir, obj)]
+        cmd = unit_command(obj, parts, odir, extra_flags)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         log = open(os.path.join(odir, "compile.log"), "w")
@@ -128,7 +142,7 @@ def _build_into(OUT_DIR, LIB, extra_flags, verbose):
             if not f.endswith(".o") and f != "compile.log" and not os.environ.get("NANN_KEEP_TEMPS"):
                 os.remove(os.path.join(odir, f))  # preprocessed sources, bitcode, assembly: ~15 MB per object
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + \
-           [os.path.join(OUT_DIR, obj[:-2] + ".d", obj) for _, _, obj in UNITS] + ["-ldl"]
+           [os.path.join(OUT_DIR, obj[:-2] + ".d", obj) for obj, _ in UNITS] + ["-ldl"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)

@@ -11,8 +11,9 @@
 
 namespace nann {
 
+#define NANN_LAUNCH_L2 NANN_CAT(launch_l2_as_, NANN_L2_NAME)  // (one name per row dtype: two dtypes may share a translation unit)
 template <int LPR>
-static int launch_l2(int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
+static int NANN_LAUNCH_L2(int vis, int nt, int slots, size_t lds_bytes, const SearchArgs& a, hipStream_t st) {
   if (vis == VIS_LDS_HASH && nt == 512)  // two queries per CU
     return launch_search_as<LPR, NANN_L2_DT, VIS_LDS_HASH, NANN_SCORER_L2, 512>(slots, lds_bytes, a, st);
   if (vis == VIS_LDS_HASH32 && nt == kNT)  // wide beams: one query per CU, 32K-slot set
@@ -25,11 +26,13 @@ static int launch_l2(int vis, int nt, int slots, size_t lds_bytes, const SearchA
 int NANN_CAT(launch_search_l2_, NANN_L2_NAME)(int lpr, int vis, int nt, int slots, size_t lds_bytes,
                                               const SearchArgs& a, hipStream_t st) {
   switch (lpr) {
-    case 8: return launch_l2<8>(vis, nt, slots, lds_bytes, a, st);
-    case 16: return launch_l2<16>(vis, nt, slots, lds_bytes, a, st);
-    case 32: return launch_l2<32>(vis, nt, slots, lds_bytes, a, st);
-    default: return launch_l2<64>(vis, nt, slots, lds_bytes, a, st);
+    case 8: return NANN_LAUNCH_L2<8>(vis, nt, slots, lds_bytes, a, st);
+    case 16: return NANN_LAUNCH_L2<16>(vis, nt, slots, lds_bytes, a, st);
+    case 32: return NANN_LAUNCH_L2<32>(vis, nt, slots, lds_bytes, a, st);
+    default: return NANN_LAUNCH_L2<64>(vis, nt, slots, lds_bytes, a, st);
   }
 }
+
+#undef NANN_LAUNCH_L2
 
 }  // namespace nann

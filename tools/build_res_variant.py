@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing / tuning builds of the resident-layer-2 MLP traversal (nann_amd/csrc/nann_mlp5.h): recompiles ONLY
-nann_mlp_res_inst.hip with extra -D flags and links it with the objects of the shipped build into
+the translation unit nann_mlp_res_inst.hip lives in with extra -D flags and links it with the objects of the shipped build into
 nann_amd/_build/var_<name>/libnann_hip.so (load with NANN_HIP_LIB=...).  ~20 s per variant instead of a full rebuild.
 usage: tools/build_res_variant.py <name> [-DNANN_RES_PF=2] [-DNANN_RES_VAR=1] ..."""
 import os
@@ -17,13 +17,13 @@ def main():
     B.build()  # the shipped objects must exist
     out = os.path.join(B.OUT_DIR, "var_" + name)
     os.makedirs(out, exist_ok=True)
-    obj = os.path.join(out, "nann_mlp_res.o")
+    unit = next(u for u in B.UNITS if any(src == "nann_mlp_res_inst.hip" for src, _ in u[1]))  # the object the kernels live in
+    obj = os.path.join(out, unit[0])
     log = os.path.join(out, "compile.log")
-    cmd = [B._hipcc()] + B.FLAGS + flags + ["-Rpass-analysis=kernel-resource-usage", "-c",
-                                            os.path.join(B.SRC_DIR, "nann_mlp_res_inst.hip"), "-o", obj]
+    cmd = B.unit_command(unit[0], unit[1], out, flags, save_temps=False)
     with open(log, "w") as f:
         subprocess.check_call(cmd, stderr=f, stdout=f)
-    objs = [obj if o == "nann_mlp_res.o" else os.path.join(B.OUT_DIR, o[:-2] + ".d", o) for _, _, o in B.UNITS]
+    objs = [obj if o == unit[0] else os.path.join(B.OUT_DIR, o[:-2] + ".d", o) for o, _ in B.UNITS]
     lib = os.path.join(out, "libnann_hip.so")
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
     import re

@@ -16,11 +16,9 @@ from nann_amd import build  # noqa: E402
 
 
 def one(unit):
-    src, extra, obj = unit
+    obj, parts = unit
     d = tempfile.mkdtemp(prefix="isa_")
-    cmd = [build._hipcc()] + build.FLAGS + extra + ["--save-temps=obj", "-c", os.path.join(build.SRC_DIR, src),
-                                                     "-o", os.path.join(d, obj)]
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    subprocess.check_call(build.unit_command(obj, parts, d), stderr=subprocess.DEVNULL)
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
         if f.endswith(".s") and "amdgcn" in f:
