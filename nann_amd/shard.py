@@ -62,6 +62,35 @@ def all_gather_topk(scores, ids, world, group=None):
             gi.view(world, nq, k).permute(1, 0, 2).contiguous().to(dev))
 
 
+def record_bytes(n_queries, k):
+    """bytes of one rank's packed record (nann_comm.hip rec_bytes): f32[B, k] scores, then i64[B, k] ids, padded to 256"""
+    return (n_queries * k * 12 + 255) & ~255
+
+
+def pack_record_host(scores, ids, status):
+    """Host stand-in of k_pack_record (nann_comm.hip): the record a rank contributes to the all-gather -- scores f32[B, k]
+    followed by item ids i64[B, k]; a query that failed on this shard (status != 0) contributes (-inf, 0)."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    ids = np.ascontiguousarray(ids, np.int64)
+    b, k = scores.shape
+    bad = np.asarray(status) != 0 if status is not None else np.zeros(b, bool)
+    rec = np.zeros(record_bytes(b, k), np.uint8)
+    rec[: b * k * 4] = np.where(bad[:, None], np.float32(-np.inf), scores).astype(np.float32).view(np.uint8).ravel()
+    rec[b * k * 4: b * k * 12] = np.where(bad[:, None], 0, ids).astype(np.int64).view(np.uint8).ravel()
+    return rec
+
+
+def merge_records_host(recv, n_queries, k_in, k_out):
+    """Host stand-in of k_merge_records: recv uint8[world, record_bytes] (rank-major, as ncclAllGather leaves it) ->
+    (scores f32[B, k_out], ids i64[B, k_out]) in TopKV2's order over the shard-major concatenation (score descending,
+    ties -> lower shard, then lower local rank), read straight from the records without a transposition."""
+    world = recv.shape[0]
+    b, k = n_queries, k_in
+    sc = np.stack([recv[s, : b * k * 4].view(np.float32).reshape(b, k) for s in range(world)], 1)   # [B, world, k]
+    ii = np.stack([recv[s, b * k * 4: b * k * 12].view(np.int64).reshape(b, k) for s in range(world)], 1)
+    return merge_host(sc, ii, k_out)
+
+
 class Comm:
     """nann_comm: the library's own RCCL communicator.  Collective: every rank constructs it.
     The 128-byte id travels from rank 0 through the existing torch.distributed group (any
@@ -196,6 +225,16 @@ class ShardedSearch:
             for t in (result.scores, result.item_ids, result.status):
                 t.record_stream(cs)  # the caching allocator must not hand these out again before the exchange read them
             return out
+        if self.transport == "records":
+            # the device path's record layout and merge with host stand-ins for its kernels and a torch.distributed
+            # all-gather of the raw bytes (CPU tests of the N-rank flow: tests/test_shard_cpu.py)
+            nq, k = result.scores.shape
+            rec = torch.as_tensor(pack_record_host(result.scores.cpu().numpy(), result.item_ids.cpu().numpy(),
+                                                   result.status.cpu().numpy() if result.status is not None else None))
+            recv = torch.empty(self.world * rec.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(recv, rec, group=self.group)
+            s, i = merge_records_host(recv.view(self.world, rec.numel()).numpy(), nq, k, self.k)
+            return torch.as_tensor(i), torch.as_tensor(s)
         scores = result.scores
         bad = (result.status != 0)[:, None]
         scores = torch.where(bad, torch.full_like(scores, float("-inf")), scores)

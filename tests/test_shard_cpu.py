@@ -59,6 +59,72 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, tmp):
+    """8 ranks over gloo: the device path's RECORD layout (pack -> all-gather of raw bytes -> merge from the records,
+    nann_comm.hip) with host stand-ins for its two kernels; shard 3 fails every fifth query, shard 5 all of them."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from nann_amd import retrieval, shard, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d, ef, k, nq = 64, 16, 20, 20
+    topn = [ef] * 5 + [k]
+    seq = synth.make_queries_from_centres(d, nq, n_clusters=8, noise=1.0, seed=7)
+    q = np.stack([O.user_seq_mean(s) for s in seq])
+    g = synth.make_index(800, d, ef=ef, seed=7, noise=1.0, n_clusters=8, shard=rank)
+    ix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    st, ids, scores, idx, ctr = O.search_batch(ix, O.Scorer("l2", d, O.EMB_F16), q, topn)
+    st = st.copy()
+    if rank == 3:
+        st[::5] = 4   # (TopKV2 k > n on this shard: the reference's failure code)
+    if rank == 5:
+        st[:] = 6
+    local = retrieval.SearchResult(torch.as_tensor(ids), torch.as_tensor(scores), torch.as_tensor(idx), torch.as_tensor(st), None)
+    outs = {}
+    for transport, merge in (("records", "device"), ("torch", "host")):
+        mi, ms = shard.ShardedSearch(topn, world, rank, merge=merge, transport=transport).merge(local)
+        outs[transport + "/" + merge] = (mi.numpy(), ms.numpy())
+    box = [None] * world
+    dist.all_gather_object(box, (st, ids, scores))
+    if rank == 0:
+        exp_ids, exp_scores = [], []
+        for b in range(nq):
+            s = np.stack([np.where(p[0][b] == 0, p[2][b], -np.inf).astype(np.float32) for p in box])
+            i = np.stack([np.where(p[0][b] == 0, p[1][b], 0) for p in box])
+            rc, ms_, mi_ = O.merge_topk(s, i, k)
+            assert rc == 0
+            exp_ids.append(mi_); exp_scores.append(ms_)
+        exp_ids, exp_scores = np.stack(exp_ids), np.stack(exp_scores)
+        ok = all((v[0] == exp_ids).all() and (v[1].view(np.uint32) == exp_scores.view(np.uint32)).all() for v in outs.values())
+        # the failing shards' items never appear while six healthy shards hold candidates
+        lo5, hi5 = 5 * 800, 6 * 800
+        ok = ok and not ((exp_ids > lo5) & (exp_ids <= hi5)).any() and np.isfinite(exp_scores).all()
+        open(os.path.join(tmp, "ok8"), "w").write("1" if ok else "0 " + repr({k_: (v[0] == exp_ids).all() for k_, v in outs.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_merge_world8_with_failing_shards_and_the_record_layout(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert open(tmp_path / "ok8").read() == "1"
+
+
+def test_record_layout_of_a_failed_query():
+    from nann_amd import shard
+    sc = np.array([[3.0, 2.0], [1.0, 0.5]], np.float32)
+    ids = np.array([[7, 8], [9, 10]], np.int64)
+    rec = shard.pack_record_host(sc, ids, np.array([0, 5]))
+    assert rec.size == 256 and rec.size == shard.record_bytes(2, 2)
+    assert rec[:16].view(np.float32).tolist() == [3.0, 2.0, -np.inf, -np.inf] and rec[16:48].view(np.int64).tolist() == [7, 8, 0, 0]
+    s, i = shard.merge_records_host(np.stack([rec, shard.pack_record_host(sc - 0.25, ids + 100, None)]), 2, 2, 3)
+    assert i.tolist() == [[7, 107, 8], [109, 110, 0]] and s[0].tolist() == [3.0, 2.75, 2.0] and s[1][2] == -np.inf
+
+
 def test_sharded_merge_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -62,6 +62,15 @@ PY
         line $OUT/bench_dense_${M}_$TAG.json "L2 dense graph $M"
         python -c "import json;d=json.loads(open('$OUT/bench_dense_${M}_$TAG.json').read().strip().splitlines()[-1]);print('   plan',d.get('plan'),'reruns',d.get('reruns_last_step'))"
       done ;;
+    reserve_sweep)  # the slot reserve under an exchange as long as xGMI's (loopback copies x 15), one GPU
+      timeout 600 python tools/overlap_bench.py /tmp/idx 30 --repeat 15 --reserves 0,8,16,32 > $OUT/reserve_sweep_$TAG.jsonl 2> $OUT/reserve_sweep_$TAG.err
+      timeout 300 python tools/overlap_bench.py /tmp/idx 30 --repeat 1 --reserves 0,16 >> $OUT/reserve_sweep_$TAG.jsonl 2>> $OUT/reserve_sweep_$TAG.err
+      python - <<PY
+import json
+for l in open('$OUT/reserve_sweep_$TAG.jsonl'):
+    d = json.loads(l); print(d['summary'], d['exchange_parts_ms'])
+PY
+      tail -2 $OUT/reserve_sweep_$TAG.err | grep -v amdgpu.ids ;;
     *)
       bash $R/tools/gpu_r4.sh $TAG $(left) $STEP ;;
   esac
