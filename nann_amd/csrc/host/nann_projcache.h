@@ -23,6 +23,7 @@
 //   static bool event_done(Event);     static void event_wait(Event);
 #pragma once
 #include <algorithm>
+#include <condition_variable>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -40,6 +41,7 @@ struct ProjTableT {
   size_t bytes = 0;
   int pins = 0;           // prepare() calls not yet released
   uint64_t last_use = 0;  // LRU clock of the owning cache
+  bool building = false;  // a placeholder: one thread allocates and fills the table OUTSIDE the cache's mutex (round 5)
   std::vector<std::pair<typename B::Stream, typename B::Event>> events;
   bool idle() const {
     for (auto& e : events)
@@ -57,6 +59,7 @@ struct ProjCacheT {
   using Table = ProjTableT<B>;
   using Ref = std::shared_ptr<Table>;
   std::mutex mu;
+  std::condition_variable built;  // a placeholder became a table (or its build failed)
   std::vector<Ref> live;
   std::vector<Ref> retired;
   uint64_t tick = 0;
@@ -86,11 +89,12 @@ struct ProjCacheT {
     retired.push_back(live[i]);
     live.erase(live.begin() + (long)i);
   }
-  int unpinned_locked() const { int n = 0; for (auto& t : live) n += t->pins == 0; return n; }
+  // (a table under construction counts as pinned: its builder will publish it)
+  int unpinned_locked() const { int n = 0; for (auto& t : live) n += t->pins == 0 && !t->building; return n; }
   void retire_lru_locked() {
     size_t best = live.size();
     for (size_t i = 0; i < live.size(); ++i)
-      if (live[i]->pins == 0 && (best == live.size() || live[i]->last_use < live[best]->last_use)) best = i;
+      if (live[i]->pins == 0 && !live[i]->building && (best == live.size() || live[i]->last_use < live[best]->last_use)) best = i;
     if (best < live.size()) retire_locked(best);
   }
   size_t resident() {
@@ -105,41 +109,72 @@ struct ProjCacheT {
   // The table of index `uid`: found, or allocated and filled by build(table) -> 0 | error code (the builder waits for
   // its own stream: the table must be complete when it becomes visible to other threads).  *out stays empty, with 0
   // returned, when there is to be no table (enabled == false, or no room).  pin: count a prepare() call.
+  // Round 5: the mutex is NOT held across the allocation and the build (10-20 ms per million items: hipMalloc,
+  // the pre-projection kernel, a stream wait) -- the first search of a new pair used to stall every concurrent search on the
+  // scorer, hits on other indices' tables included.  The builder publishes a placeholder (`building`), drops the mutex,
+  // builds, and publishes the table; only callers that want THAT index wait (on `built`).
   template <class Build>
   int acquire(uint64_t uid, size_t bytes, bool enabled, bool pin, Build build, Ref* out) {
     out->reset();
-    std::lock_guard<std::mutex> lk(mu);
-    reap_locked();
-    for (auto& t : live)
-      if (t->index_uid == uid) {
-        t->last_use = ++tick;
-        if (pin) ++t->pins;
-        *out = t;
+    std::unique_lock<std::mutex> lk(mu);
+    Ref tab;
+    for (;;) {
+      reap_locked();
+      Ref hit;
+      for (auto& t : live)
+        if (t->index_uid == uid) { hit = t; break; }
+      if (hit && hit->building) {  // another thread is building this very table: wait for it, then look again
+        built.wait(lk, [&] { return !hit->building; });
+        continue;
+      }
+      if (hit) {
+        hit->last_use = ++tick;
+        if (pin) ++hit->pins;
+        *out = hit;
         return 0;
       }
-    if (!enabled) return 0;
-    while (unpinned_locked() >= kProjAuto) retire_lru_locked();  // the table used longest ago goes
-    reap_locked();
-    const size_t margin = (size_t)1 << 30;  // leave a GiB to the caller's workspaces
-    size_t free_b = 0;
-    if (!B::mem_info(&free_b)) free_b = ~(size_t)0;
-    if (bytes + margin > free_b && unpinned_locked() > 0) {  // make room: the unpinned tables of this scorer
-      while (unpinned_locked() > 0) retire_lru_locked();
+      if (!enabled) return 0;
+      while (unpinned_locked() >= kProjAuto) retire_lru_locked();  // the table used longest ago goes
       reap_locked();
+      const size_t margin = (size_t)1 << 30;  // leave a GiB to the caller's workspaces
+      size_t free_b = 0;
       if (!B::mem_info(&free_b)) free_b = ~(size_t)0;
+      if (bytes + margin > free_b && unpinned_locked() > 0) {  // make room: the unpinned tables of this scorer
+        while (unpinned_locked() > 0) retire_lru_locked();
+        reap_locked();
+        if (!B::mem_info(&free_b)) free_b = ~(size_t)0;
+      }
+      if (bytes + margin > free_b) return 0;  // no table: the embedding-table kernels serve this pair
+      tab = std::make_shared<Table>();
+      tab->index_uid = uid;
+      tab->bytes = bytes;
+      tab->building = true;
+      live.push_back(tab);
+      break;
     }
-    if (bytes + margin > free_b) return 0;  // no table: the embedding-table kernels serve this pair
+    lk.unlock();
     void* p = nullptr;
-    if (!B::malloc(&p, bytes)) return 0;
-    const int rc = build(static_cast<float*>(p));
-    if (rc) { B::free(p); return rc; }
-    auto tab = std::make_shared<Table>();
-    tab->index_uid = uid;
+    int rc = 0;
+    const bool have = B::malloc(&p, bytes);
+    if (have) {
+      rc = build(static_cast<float*>(p));
+      if (rc) { B::free(p); p = nullptr; }
+    }
+    lk.lock();
+    if (!p) {  // no memory after all, or the build failed: the placeholder goes, waiters look again
+      for (auto* v : {&live, &retired})
+        v->erase(std::remove(v->begin(), v->end(), tab), v->end());
+      tab->building = false;
+      built.notify_all();
+      return rc;
+    }
     tab->table = static_cast<float*>(p);
-    tab->bytes = bytes;
     tab->pins = pin ? 1 : 0;
     tab->last_use = ++tick;
-    live.push_back(tab);
+    tab->building = false;
+    built.notify_all();
+    // (an index destroyed while its table was built has moved the placeholder to `retired`: the caller still gets the
+    // table for its launch, and it is freed behind that launch like any retired table)
     *out = tab;
     return 0;
   }
@@ -175,6 +210,7 @@ struct ProjCacheT {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i < live.size(); ++i)
       if (live[i]->index_uid == uid) {
+        if (live[i]->building) return true;  // (nothing pinned yet: the builder publishes it unpinned or with its own pin)
         if (live[i]->pins > 0) --live[i]->pins;
         if (live[i]->pins == 0) retire_locked(i);  // released by its owner: do not wait for the LRU
         reap_locked();

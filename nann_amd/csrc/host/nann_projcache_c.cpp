@@ -186,4 +186,60 @@ int nann_projcache_stress(int32_t n_threads, int32_t n_indices, int32_t n_iters,
   return 0;
 }
 
+// acquire() held the cache's mutex across the allocation and the build, so the first search of a new pair
+// stalled every concurrent search on the scorer.  Here one thread builds the table of index 1 for `build_ms`; meanwhile a
+// second thread -- started once the build is under way -- hits the (already built) table of index 2 `n_hits` times and a
+// third asks for index 1 itself.  out[4] = {hits served while the build was still running, longest single hit in
+// microseconds, builds of index 1 (must be 1: the third thread waits for the first's), violations}.
+int nann_projcache_slow_build(int32_t build_ms, int32_t n_hits, int64_t out[4]) {
+  Device dev;
+  dev.capacity = (long long)3 << 20;
+  g_dev = &dev;
+  std::atomic<int> building{0}, done{0}, builds1{0};
+  std::atomic<long long> hits_during{0}, worst_us{0}, bad{0};
+  {
+    Cache cache;
+    Cache::Ref t2;
+    if (cache.acquire(2, 1 << 20, true, true, [&](float* t) { t[0] = 2.0f; return 0; }, &t2) || !t2) bad.fetch_add(1);
+    t2.reset();
+    std::thread builder([&] {
+      Cache::Ref t1;
+      const int rc = cache.acquire(1, 1 << 20, true, false, [&](float* t) {
+        builds1.fetch_add(1);
+        building.store(1);
+        std::this_thread::sleep_for(std::chrono::milliseconds(build_ms));
+        t[0] = 1.0f;
+        done.store(1);
+        return 0;
+      }, &t1);
+      if (rc || !t1 || t1->table[0] != 1.0f) bad.fetch_add(1);
+    });
+    while (!building.load()) std::this_thread::yield();
+    std::thread hitter([&] {
+      for (int i = 0; i < n_hits; ++i) {
+        const auto a = std::chrono::steady_clock::now();
+        Cache::Ref t;
+        if (cache.acquire(2, 1 << 20, true, false, [&](float*) { bad.fetch_add(1); return 0; }, &t) || !t || t->table[0] != 2.0f) bad.fetch_add(1);
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count();
+        long long w = worst_us.load();
+        while (us > w && !worst_us.compare_exchange_weak(w, us)) {}
+        if (!done.load()) hits_during.fetch_add(1);
+      }
+    });
+    std::thread same([&] {  // wants the table that is being built: waits for it, does not build a second one
+      Cache::Ref t;
+      if (cache.acquire(1, 1 << 20, true, false, [&](float* t_) { builds1.fetch_add(1); t_[0] = 1.0f; return 0; }, &t) || !t || t->table[0] != 1.0f)
+        bad.fetch_add(1);
+      if (!done.load()) bad.fetch_add(1);  // (it may only return once the build has finished)
+    });
+    builder.join(); hitter.join(); same.join();
+    cache.release(2);
+  }
+  out[0] = hits_during.load(); out[1] = worst_us.load(); out[2] = builds1.load(); out[3] = bad.load() + dev.violations.load() + (dev.used.load() != 0);
+  for (Block* b : dev.graveyard) delete b;
+  for (MockEvent* e : dev.events) delete e;
+  g_dev = nullptr;
+  return 0;
+}
+
 }  // extern "C"

@@ -44,3 +44,17 @@ def test_single_index_is_built_once():
 def test_more_indices_than_kept():
     r = _stress(6, 5, 800, 6, seed=3)
     assert r["violations"] == 0 and r["leaked_bytes"] == 0, r
+
+
+def test_a_slow_build_does_not_stall_the_other_tables():
+    """acquire() used to hold the cache's mutex across hipMalloc + the pre-projection kernel + a stream wait, so
+    the first search of a new (scorer, index) pair stalled hits on every other index's table.  One thread builds index 1
+    for 300 ms; hits on index 2 go on meanwhile (each well under the build's duration), and a second caller of index 1
+    waits for the first's table instead of building another."""
+    L = C.CDLL(index_build.build_host_lib())
+    out = (C.c_int64 * 4)()
+    assert L.nann_projcache_slow_build(C.c_int32(300), C.c_int32(2000), out) == 0
+    hits_during, worst_us, builds1, bad = list(out)
+    assert bad == 0 and builds1 == 1, list(out)
+    assert hits_during >= 100, list(out)          # (under the old lock: 0 -- the first hit would return after the build)
+    assert worst_us < 100_000, list(out)          # no hit waited for the 300 ms build

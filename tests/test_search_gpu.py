@@ -970,3 +970,40 @@ def test_search_options_travel_with_the_call(oracle):
     torch.cuda.synchronize()
     assert full > 16 and r2.plan["workgroups"] == full - 16, (r.plan, r2.plan)
     assert (r2.item_ids.cpu().numpy() == got[1]).all()
+
+
+@pytest.mark.parametrize("precision,form", [("exact", "auto"), ("split", "fused"), ("split", "phased")])
+def test_mlp_traversal_scores_against_float64_numpy(oracle, precision, form):
+    """the oracle's MLP order changed together with the kernels (a1 = u + P), so "bit-identical to the oracle"
+    cannot catch a mistake the two share.  This check does not touch the oracle's scorer: every score the traversal
+    returns -- fused kernel and pipeline of phases, both precisions, on the pre-projected table -- against a float64 numpy
+    evaluation of the reference's MLP, concat([q ; e]) W1 + b1 -> PReLU -> W2 + b2 -> PReLU -> w3 (model_util.py:9-11,
+    model.py:218-219), with per-unit PReLU slopes of both signs."""
+    from nann_amd import ops, retrieval, synth
+    g, oix, dix = synth_index(20000, 128, 32)
+    rng = np.random.default_rng(17)
+    w = synth.make_mlp_weights(128)
+    w["alpha1"] = rng.uniform(-0.3, 1.2, 256).astype(np.float32)
+    w["alpha2"] = rng.uniform(-0.3, 1.2, 128).astype(np.float32)
+    w["b1"] = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    w["b2"] = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 300, seed=41)])
+    topn = [32] * 5 + [20]
+    sc = ops.Scorer("mlp", 128, torch.float16, w, precision=precision)
+    r = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(mlp_form=form))
+    torch.cuda.synchronize()
+    assert r.plan["table"] and r.plan["phased"] == (form == "phased" or precision == "exact"), r.plan
+    st, idx, got = r.status.cpu().numpy(), r.index.cpu().numpy(), r.scores.cpu().numpy()
+    ok = np.nonzero(st == 0)[0]
+    assert len(ok) > 150
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    prelu = lambda z, a: np.maximum(z, 0) + a * np.minimum(z, 0)
+    worst = 0.0
+    for b in ok[:120]:
+        e = g["item_embs"][idx[b]].astype(np.float64)
+        x = np.concatenate([np.tile(q[b].astype(np.float64), (len(e), 1)), e], 1)
+        ref = prelu(prelu(x @ w64["w1"] + w64["b1"], w64["alpha1"]) @ w64["w2"] + w64["b2"], w64["alpha2"]) @ w64["w3"]
+        worst = max(worst, float(np.max(np.abs(got[b] - ref) / np.maximum(1.0, np.abs(ref)))))
+        assert (np.diff(got[b]) <= 0).all()  # sorted descending
+    # exact f32: fmaf chains of 256 + 256 + 128 terms; split-f16: north_star's 1e-5
+    assert worst <= (3e-6 if precision == "exact" else 1e-5), worst
