@@ -532,10 +532,11 @@ void nann_comm_destroy(nann_comm* c);
  * exchanged over RCCL" is a measured fact. */
 int nann_comm_ranks(const nann_comm* c, int32_t* world, int32_t* rccl_ranks);
 /* enabled: HIP events around the three parts of every later nann_sharded_topk call on its stream;
- * nann_comm_last_breakdown -> ms[3] = {pack, all-gather, merge} of the LAST call (waits for it).  loopback_repeat (loopback
- * communicators only, >= 1): the device copies that stand in for the all-gather are issued this many times -- an exchange
- * as long as 8 GPUs' over xGMI on one GPU, for the overlap / slot-reserve measurements (tools/overlap_bench.py). */
-int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat);
+ * nann_comm_last_breakdown -> ms[3] = {pack, all-gather, merge} of the LAST call (waits for it).  Loopback communicators
+ * only (one-GPU measurements of the overlap and the slot reserve, tools/overlap_bench.py): loopback_wait_us > 0 puts a
+ * kernel of 16 waiting workgroups in front of the stand-in copies -- an exchange that holds its slots and its stream as long
+ * as 8 GPUs' all-gather over xGMI would (~1.5 ms at configs[3]) --, loopback_repeat >= 1 issues the copies that many times. */
+int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat, int32_t loopback_wait_us);
 int nann_comm_last_breakdown(nann_comm* c, float ms[3]);
 int nann_sharded_topk_workspace_bytes(int32_t world, int64_t n_queries, int32_t k_in, int64_t* nbytes);
 int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, const int32_t* status,

@@ -113,11 +113,22 @@ __global__ __launch_bounds__(kNT) void k_merge_records(const unsigned char* recv
   }
 }
 
+// Loopback stand-in for the time an all-gather over xGMI takes: what RCCL's ring kernels mostly do is WAIT for the peers'
+// bytes while holding one workgroup slot per channel.  16 workgroups of 256 threads sleep until `us` microseconds have
+// passed (bounded: 20 ms), so the exchange of a one-GPU measurement occupies the slots and the stream for as long as
+// eight GPUs' would, without the memory traffic that repeating the device copies adds (profiles/r5f_reserve_sweep_*).
+__global__ __launch_bounds__(256) void k_loopback_wait(unsigned int us) {
+  const long long t0 = wall_clock64();  // constant 100 MHz
+  const long long ticks = (long long)(us > 20000u ? 20000u : us) * 100ll;
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 struct nann_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool loopback = false;
-  int loopback_repeat = 1;  // test facility: the loopback's device copies issued this many times (an exchange as long as xGMI's)
+  int loopback_repeat = 1;  // test facility: the loopback's device copies issued this many times
+  int loopback_wait_us = 0; //   ... and a kernel of 16 waiting workgroups in front of them (an exchange as LONG as xGMI's)
   Rccl* R = nullptr;
   // nann_comm_set_timing: four events around the three parts of every nann_sharded_topk call (pack | all-gather | merge)
   bool timing = false;
@@ -179,7 +190,7 @@ int nann_comm_ranks(const nann_comm* c, int32_t* world, int32_t* rccl_ranks) {
   return NANN_OK;
 }
 
-int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat) {
+int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat, int32_t loopback_wait_us) {
   if (!c) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_set_timing: null communicator");
   if (enabled)
     for (hipEvent_t& e : c->ev)
@@ -187,6 +198,7 @@ int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat)
   c->timing = enabled != 0;
   c->timed_once = false;
   c->loopback_repeat = std::max(1, (int)loopback_repeat);
+  c->loopback_wait_us = std::max(0, (int)loopback_wait_us);
   return NANN_OK;
 }
 
@@ -227,6 +239,7 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
   NANN_HIP_TRY(hipGetLastError());
   if (c->timing) NANN_HIP_TRY(hipEventRecord(c->ev[1], st));
   if (world > 1 && c->loopback) {
+    if (c->loopback_wait_us > 0) hipLaunchKernelGGL(k_loopback_wait, dim3(16), dim3(256), 0, st, (unsigned int)c->loopback_wait_us);
     for (int rep = 0; rep < c->loopback_repeat; ++rep)
       for (int r = 0; r < world; ++r)
         NANN_HIP_TRY(hipMemcpyAsync(recv + (size_t)r * rb, send, rb, hipMemcpyDeviceToDevice, st));

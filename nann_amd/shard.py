@@ -140,10 +140,12 @@ class Comm:
         _check(lib().nann_comm_ranks(self.handle, C.byref(w), C.byref(r)), "comm ranks")
         return w.value, r.value
 
-    def set_timing(self, enabled=True, loopback_repeat=1):
-        """HIP events around pack | all-gather | merge of every later exchange (nann_comm_set_timing); loopback_repeat:
-        the loopback's stand-in copies issued that many times (an exchange as long as xGMI's, on one GPU)"""
-        _check(lib().nann_comm_set_timing(self.handle, C.c_int32(1 if enabled else 0), C.c_int32(loopback_repeat)), "comm timing")
+    def set_timing(self, enabled=True, loopback_repeat=1, loopback_wait_us=0):
+        """HIP events around pack | all-gather | merge of every later exchange (nann_comm_set_timing).  Loopback only:
+        loopback_wait_us puts 16 waiting workgroups in front of the stand-in copies (an exchange as long as xGMI's, on one
+        GPU), loopback_repeat issues the copies that many times"""
+        _check(lib().nann_comm_set_timing(self.handle, C.c_int32(1 if enabled else 0), C.c_int32(loopback_repeat),
+                                          C.c_int32(loopback_wait_us)), "comm timing")
 
     def last_breakdown(self):
         """{pack, all_gather, merge} ms of the last exchange (waits for it)"""

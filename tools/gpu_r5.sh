@@ -63,7 +63,7 @@ PY
         python -c "import json;d=json.loads(open('$OUT/bench_dense_${M}_$TAG.json').read().strip().splitlines()[-1]);print('   plan',d.get('plan'),'reruns',d.get('reruns_last_step'))"
       done ;;
     reserve_sweep)  # the slot reserve under an exchange as long as xGMI's (loopback copies x 15), one GPU
-      timeout 600 python tools/overlap_bench.py /tmp/idx 30 --repeat ${SWEEP_REPEAT:-50} --reserves 0,8,16,32,64 > $OUT/reserve_sweep_$TAG.jsonl 2> $OUT/reserve_sweep_$TAG.err
+      timeout 600 python tools/overlap_bench.py /tmp/idx 30 --wait-us ${SWEEP_WAIT_US:-1400} --reserves 0,8,16,32,64 > $OUT/reserve_sweep_$TAG.jsonl 2> $OUT/reserve_sweep_$TAG.err
       timeout 300 python tools/overlap_bench.py /tmp/idx 30 --repeat 1 --reserves 0,16 >> $OUT/reserve_sweep_$TAG.jsonl 2>> $OUT/reserve_sweep_$TAG.err
       python - <<PY
 import json

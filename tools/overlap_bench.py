@@ -15,7 +15,9 @@ batch 4096 on the 1M x 128-d index, a different query batch per step.  Three ord
 and the same with the traversal grid leaving n workgroup slots free for the exchange's kernels (per call:
 nann_search_options.slot_reserve).  Round 5: `--repeat R` issues the loopback's device copies R times
 (nann_comm_set_timing's loopback_repeat), so that the stand-in exchange lasts as long as 8 GPUs' all-gather over xGMI
-(~1.5 ms at R = 15), and `--reserves 0,8,16,32` sweeps the reserve in one run.  Prints one JSON line per reserve.  Under
+-- but ALSO 50 x its memory traffic, which is what then slows the search: profiles/r5f_reserve_sweep_copies_x50.jsonl --,
+`--wait-us T` instead puts 16 workgroups in front of the copies that WAIT for T microseconds (what RCCL's ring kernels do
+while the peers' bytes cross xGMI: hold a slot per channel), and `--reserves 0,8,16,32` sweeps the reserve in one run.  Prints one JSON line per reserve.  Under
 `rocprofv3 --kernel-trace` the start / end stamps of k_merge_records against k_search show the same thing kernel by
 kernel (tools/gpu_r4.sh overlap)."""
 import json
@@ -38,6 +40,7 @@ def main():
     ap.add_argument("cache", nargs="?", default=None)
     ap.add_argument("steps", nargs="?", type=int, default=30)
     ap.add_argument("--repeat", type=int, default=1, help="loopback copies issued this many times (15 ~ xGMI's 1.5 ms)")
+    ap.add_argument("--wait-us", type=int, default=0, help="16 waiting workgroups in front of the copies: the exchange lasts this long")
     ap.add_argument("--reserves", default=os.environ.get("NANN_SEARCH_SLOT_RESERVE", "0"))
     a = ap.parse_args()
     cache, steps = a.cache, a.steps
@@ -53,7 +56,7 @@ def main():
 
     def make_sharded():
         ss = shard.ShardedSearch(topn, shards, 0, transport="rccl", comm=shard.Comm.loopback(shards))
-        ss.comm.set_timing(True, loopback_repeat=a.repeat)
+        ss.comm.set_timing(True, loopback_repeat=a.repeat, loopback_wait_us=a.wait_us)
         return ss
 
     def run(mode, reserve):
@@ -105,7 +108,7 @@ def main():
         res["summary"] = {"search_ms": s_, "exchange_ms": e, "serial_ms": min(res["serial"]), "overlapped_ms": min(res["overlapped"]),
                           "ideal_overlap_ms": round(max(s_, e), 4), "sum_ms": round(s_ + e, 4),
                           "hidden_fraction_of_exchange": round((min(res["serial"]) - min(res["overlapped"])) / e, 3) if e else None,
-                          "slot_reserve": reserve, "loopback_repeat": a.repeat}
+                          "slot_reserve": reserve, "loopback_repeat": a.repeat, "loopback_wait_us": a.wait_us}
         print(json.dumps({"workload": "1M x 128-d f16, ef=128, L2, batch 4096, 8-shard loopback exchange (9.8 MB record x 8 x %d)" % a.repeat, **res}), flush=True)
 
 
