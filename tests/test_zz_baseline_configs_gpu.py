@@ -1,7 +1,8 @@
 """-m gpu: the fused traversal at BASELINE.json's config shapes ("every config is exercised at
-toy size only").  Indices come from the shipped builder (nann_amd/index_build.py -> hnsw_build.cpp, what
-the reference gets from faiss.IndexHNSWFlat) on the seeded synthetic corpus bench.py uses; collected last
-(file name) because it builds million-item graphs on the host (~1 min on the GPU box's 16 cores).
+toy size only").  Indices come from the shipped DEVICE builder (nann_amd/index_build.build_hnsw_gpu ->
+csrc/nann_hnsw_build.hip: HNSW M=32, efConstruction=40 -- what the reference gets from faiss.IndexHNSWFlat; 1M x 128-d in
+0.6 s, 4M x 256-d in 9 s) on the seeded synthetic corpus bench.py uses; collected last (file name) because its
+million-item corpora take the most memory and time of the suite.
 
   configs[0]  100k x 64-d,  ef=64,  top-200, L2   (the reference's CPU-runnable case): oracle-exact
   configs[1]  1M   x 128-d, ef=128, top-200, L2   oracle-exact on a sample + properties on 4096 queries
