@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kNT) void k_merge_records(const unsigned char* recv
 // Loopback stand-in for the time an all-gather over xGMI takes: what RCCL's ring kernels mostly do is WAIT for the peers'
 // bytes while holding one workgroup slot per channel.  16 workgroups of 256 threads sleep until `us` microseconds have
 // passed (bounded: 20 ms), so the exchange of a one-GPU measurement occupies the slots and the stream for as long as
-// eight GPUs' would, without the memory traffic that repeating the device copies adds (profiles/r5f_reserve_sweep_*).
+// eight GPUs' would, without the memory traffic that repeating the device copies adds (profiles/rd5f_reserve_sweep_*).
 __global__ __launch_bounds__(256) void k_loopback_wait(unsigned int us) {
   const long long t0 = wall_clock64();  // constant 100 MHz
   const long long ticks = (long long)(us > 20000u ? 20000u : us) * 100ll;

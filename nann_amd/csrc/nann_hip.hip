@@ -2046,7 +2046,7 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // level-0 round finds per frontier row; the largest of the probe's queries, so the estimate sits on the tail).  Rounds 1-4
   // guessed it from the mean degree (2.75 x mean degree walked, 45 % new: fitted to the device builder's graphs, mean degree
   // ~17) and sent a dense graph (keepPrunedConnections, mean degree 52) to the one-workgroup-per-CU 32K plan at 0.67 of the
-  // roofline, where the 16K plan holds its ~8 k visited ids at 0.84 with no rerun (profiles/r5b_dense_graph.txt).  The ratio
+  // roofline, where the 16K plan holds its ~8 k visited ids at 0.84 with no rerun (profiles/rd5c_dense_graph.txt).  The ratio
   // falls as the beam widens (neighbourhoods overlap more), so a probe at ef <= 64 overestimates wider beams: safe side.
   const double rows_walked = (double)t[1] + t[2] + t[3];
   const double est_guess = t[1] + 0.45 * walk_deg * rows_walked;

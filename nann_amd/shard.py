@@ -164,7 +164,7 @@ class Comm:
 
 class ShardedSearch:
     """Exchange + merge for one rank of a sharded search."""
-    RESERVED_SLOTS = 32  # workgroup slots kept free for the exchange's kernels when it overlaps the next search (profiles/r5e_reserve_sweep.txt)
+    RESERVED_SLOTS = 32  # workgroup slots kept free for the exchange's kernels when it overlaps the next search (profiles/rd5e_reserve_sweep.txt)
 
     def __init__(self, level_topn, world, rank=0, merge="device", group=None, transport="torch", comm=None):
         self.world, self.k, self.merge_kind, self.group = world, int(level_topn[5]), merge, group

@@ -15,7 +15,7 @@ batch 4096 on the 1M x 128-d index, a different query batch per step.  Three ord
 and the same with the traversal grid leaving n workgroup slots free for the exchange's kernels (per call:
 nann_search_options.slot_reserve).  Round 5: `--repeat R` issues the loopback's device copies R times
 (nann_comm_set_timing's loopback_repeat), so that the stand-in exchange lasts as long as 8 GPUs' all-gather over xGMI
--- but ALSO 50 x its memory traffic, which is what then slows the search: profiles/r5f_reserve_sweep_copies_x50.jsonl --,
+-- but ALSO 50 x its memory traffic, which is what then slows the search: profiles/rd5f_reserve_sweep_copies_x50.jsonl --,
 `--wait-us T` instead puts 16 workgroups in front of the copies that WAIT for T microseconds (what RCCL's ring kernels do
 while the peers' bytes cross xGMI: hold a slot per channel), and `--reserves 0,8,16,32` sweeps the reserve in one run.  Prints one JSON line per reserve.  Under
 `rocprofv3 --kernel-trace` the start / end stamps of k_merge_records against k_search show the same thing kernel by

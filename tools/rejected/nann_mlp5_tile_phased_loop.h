@@ -10,7 +10,7 @@
 //   NANN_PIPE_NOPK      PReLU as scalar f32 instructions (no v_pk_fma_f32)           409.5 k against 408.4 k (r5a)
 //   NANN_PIPE_PRIO      s_setprio 1 for wavefronts 4-7 over the pipeline             410.4 k against 408.4 k (r5a)
 //   NANN_PIPE_AGPR      AGPR form of every MFMA (one asm "a" operand in the kernel)  395.7 k against 408.4 k (r5a)
-// (profiles/r5a_mlp_loop_variants.txt; git show a8e9c1e:nann_amd/csrc/nann_mlp5.h has the switches.)
+// (profiles/rd5a_mlp_loop_variants.txt; git show a8e9c1e:nann_amd/csrc/nann_mlp5.h has the switches.)
 // The fragment below continues wg_score_mlp_res after its LDS bases and lambdas (row_ptr, load_tile, frag, vec4) are set up.
 #if 0
   const float* row = row_ptr(wave * 32 + cand);
