@@ -599,7 +599,24 @@ def test_rccl_binding_one_rank_communicator(oracle):
     for b in range(0, nq, 7):
         rc, es, ei = oracle.merge_topk(s_in[b][None], i_in[b][None], k_out)
         assert rc == 0 and (mi[b].cpu().numpy() == ei).all() and (bits(ms[b].cpu().numpy()) == bits(es)).all()
-    del ss, comm
+    # round 5: what a --gpus N bench line reports about its exchange -- the communicator's own events around pack |
+    # all-gather | merge, and ncclCommCount of the RCCL communicator behind it
+    assert comm.ranks() == (1, 1)
+    comm.set_timing(True)
+    mi2, _ = ss.merge(local)
+    parts = comm.last_breakdown()
+    assert set(parts) == {"pack", "all_gather", "merge"} and all(0.0 <= v < 50.0 for v in parts.values()), parts
+    assert (mi2.cpu().numpy() == pi.cpu().numpy()).all()
+    lb = shard.Comm.loopback(8)
+    assert lb.ranks() == (8, 0)          # a loopback has no RCCL communicator behind it
+    with pytest.raises(Exception):       # no timed exchange yet
+        lb.last_breakdown()
+    lb.set_timing(True, loopback_wait_us=300)
+    ss8 = shard.ShardedSearch([0, 0, 0, 0, 0, k_out], 8, 0, transport="rccl", comm=lb)
+    ss8.merge(local)
+    parts8 = lb.last_breakdown()
+    assert 0.25 <= parts8["all_gather"] < 5.0, parts8   # the waiting stand-in holds the stream for ~0.3 ms
+    del ss, comm, ss8, lb
 
 
 @pytest.mark.parametrize("world", [1, 3, 8])
