@@ -1,5 +1,8 @@
 #!/bin/bash
 # Round-4 GPU session runner (through gpurun): named steps, each skipped once the deadline has passed.
+# (Round 5 retired NANN_MLP_MAPPING -- the steps below that set it now compare a form with itself; NANN_MLP_FORM=fused|phased
+#  is what is left of it, tools/gpu_r5.sh mlp_vars.  The generic steps -- tests_full, smoke, bench_full, prof_default, dry8,
+#  serve, eval_bench ... -- are what tools/gpu_r5.sh still hands over to this file.)
 # usage: tools/gpu_r4.sh <tag> <deadline_s> <step> [<step> ...]
 #   steps: tests_full tests_mlp tests_new tests_k (TESTS_K='<-k expr>') smoke bench_full bench_l2 bench_mlp bench_mlp_ab bench_mlp_maps
 #          bench_mlp_wide mlp_exact_diag bench_attn b1 b1modes phase_4m rate_mlp serve prof_l2 prof_mlp prof_attn prof_stress prof_4m
