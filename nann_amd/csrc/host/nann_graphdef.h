@@ -69,8 +69,8 @@ struct Node {
   std::string name, op, device;
   std::vector<std::string> inputs;
   std::map<std::string, Attr> attrs;
-  bool has_value = false;
-  Tensor value;  // attr["value"] of a Const
+  bool has_value = false;  // attr["value"] holds a tensor (a Const's payload: kept ONCE, in the attr -- ADVICE r4)
+  const Tensor& value() const { return attrs.at("value").tensor; }
 };
 
 struct Graph {
@@ -336,7 +336,7 @@ inline bool parse_node(Cursor c, Node* n) {
       if (!e.ok) return false;
       Attr a;
       if (have_val && !parse_attr(val, &a)) return false;
-      if (k == "value" && a.kind == 'T') { n->value = a.tensor; n->has_value = true; }
+      if (k == "value" && a.kind == 'T') n->has_value = true;
       n->attrs[k] = std::move(a);
     } else c.skip(wire);
   }
@@ -424,7 +424,7 @@ inline bool eval(const Graph& g, const std::string& input, Tensor* out, int dept
   if (it == g.by_name.end()) return false;
   const Node& n = g.nodes[(size_t)it->second];
   auto data_inputs = [&]() { std::vector<std::string> v; for (const auto& s : n.inputs) if (s.empty() || s[0] != '^') v.push_back(s); return v; };
-  if (n.op == "Const") { if (!n.has_value) return false; *out = n.value; return true; }
+  if (n.op == "Const") { if (!n.has_value) return false; *out = n.value(); return true; }
   const std::vector<std::string> in = data_inputs();
   if (n.op == "Identity" || n.op == "StopGradient" || n.op == "Snapshot") return in.size() >= 1 && eval(g, in[0], out, depth + 1);
   if (n.op == "Cast") {  // the payload is f32 already; integer -> float casts do not occur on these operands
@@ -494,14 +494,14 @@ inline bool operand_of(const Graph& g, const std::string& op_tail, int which, Te
 
 // a variable by its own name: Const `V`, or what folding made of `V/read`
 inline bool variable(const Graph& g, const std::string& var, Tensor* out) {
-  if (const Node* n = find_by_tail(g, var)) if (n->op == "Const" && n->has_value) { *out = n->value; return true; }
+  if (const Node* n = find_by_tail(g, var)) if (n->op == "Const" && n->has_value) { *out = n->value(); return true; }
   const std::string pre = var + "/read";
   for (const Node& n : g.nodes) {
     if (n.op != "Const" || !n.has_value) continue;
     const size_t at = n.name.find(pre);
     if (at == std::string::npos || (at > 0 && n.name[at - 1] != '/')) continue;
     const size_t after = at + pre.size();
-    if (after == n.name.size() || n.name[after] == '/') { *out = n.value; return true; }
+    if (after == n.name.size() || n.name[after] == '/') { *out = n.value(); return true; }
   }
   return false;
 }

@@ -261,7 +261,7 @@ inline bool graph_from_text(const TMsg& gd, Graph* g, std::string* err) {
         if (!k) continue;
         Attr a;
         if (v && v->is_msg && !text_attr(*v->msg, &a)) { *err = "malformed attr '" + k->scalar + "' of node '" + n.name + "'"; return false; }
-        if (k->scalar == "value" && a.kind == 'T') { n.value = a.tensor; n.has_value = true; }
+        if (k->scalar == "value" && a.kind == 'T') n.has_value = true;
         n.attrs[k->scalar] = std::move(a);
       }
     }
