@@ -10,7 +10,9 @@
 //   NANN_PIPE_NOPK      PReLU as scalar f32 instructions (no v_pk_fma_f32)           409.5 k against 408.4 k (r5a)
 //   NANN_PIPE_PRIO      s_setprio 1 for wavefronts 4-7 over the pipeline             410.4 k against 408.4 k (r5a)
 //   NANN_PIPE_AGPR      AGPR form of every MFMA (one asm "a" operand in the kernel)  395.7 k against 408.4 k (r5a)
-// (profiles/rd5a_mlp_loop_variants.txt; git show a8e9c1e:nann_amd/csrc/nann_mlp5.h has the switches.)
+//   NANN_PIPE_MASK_SPLIT  the operand split without VOP3P instructions (hi by v_and 0xffffe000, lo by v_sub, two       405.6-407.8 k against 405.0 k (r5l):
+//                       v_cvt_pkrtz per pair, scalar PReLU): 86 -> 28 unhidden cycles per step by tools/ubench_mfma5's prices   the chip is power-bound, cycles come back as clock
+// (profiles/rd5a_mlp_loop_variants.txt, rd5l_mlp_mask_split_ab.txt; git show a8e9c1e:nann_amd/csrc/nann_mlp5.h has the first five switches.)
 // The fragment below continues wg_score_mlp_res after its LDS bases and lambdas (row_ptr, load_tile, frag, vec4) are set up.
 #if 0
   const float* row = row_ptr(wave * 32 + cand);

@@ -1,0 +1,165 @@
+// ubench_mfma5 (round 5): does ANY filler hide under a v_mfma_f32_32x32x16_f16 on gfx950, and does it depend on where the
+// accumulators live (VGPR vs AGPR form) or on the filler's encoding?  MI355X_MICROARCH.md states <= 5 single-issue fillers
+// per MFMA gap are free with one wavefront per SIMD; ubench_mfma3 (round 3: accumulators in VGPRs, v_fmaak with a literal)
+// measured +2.4 cycles per filler.  Every instruction here is `asm volatile` in program order: 32 MFMAs per iteration over
+// four accumulators, NV fillers of one KIND behind each MFMA.  Prints shader cycles per MFMA.
+// build: hipcc -O3 --offload-arch=gfx950 tools/ubench_mfma5.hip -o tools/_build/ubench_mfma5
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// KIND: 0 v_fma_f32 (register operands)  1 v_add_f32  2 v_pk_fma_f32  3 v_cvt_pkrtz_f16_f32  4 v_fma_f32 with a literal (v_fmaak)
+//       5 v_min_f32 + v_fma (PReLU pair)  6 ds_read_b128 (no wait)   7 s_nop 0   8 v_fma_mixlo_f16   9 v_fma_mixlo + v_fma_mixhi (one
+//       packed lo pair: what the scorer's operand split issues)  10 global_load_dwordx4 (L2-resident, no wait)  11 v_cvt_f32_f16
+//       12 the scorer's REAL mix: NV = instructions per MFMA gap taken round-robin from one step's 42 (8 add, 8 min, 6 fma, 2 pk_fma,
+//       4 cvt_pkrtz, 8 fma_mix, 12 ds_read_b128 -- less the 4 gathers)
+template <int AGPR, int NV, int KIND, int NT>
+__global__ __launch_bounds__(NT) void k_pat(int iters, const uint4* data, float* out, long long* ticks) {
+  __shared__ uint4 lds[16 * 64];
+  for (int i = threadIdx.x; i < 16 * 64; i += NT) lds[i] = data[i];
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+  f16x8 x[4], y[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    union { uint4 u; f16x8 h; } cx, cy;
+    cx.u = data[(2 * s) * 1024 + (threadIdx.x & 1023)];
+    cy.u = data[(2 * s + 1) * 1024 + (threadIdx.x & 1023)];
+    x[s] = cx.h; y[s] = cy.h;
+  }
+  float v[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v[i] = (float)(threadIdx.x + i) * 1e-3f;
+  float c1 = 1.0001f, c2 = 0.5f;
+  asm volatile("" : "+v"(c1), "+v"(c2));
+  uint4 ring[2] = {lds[lane], lds[64 + lane]};
+  uint32_t hbits = 0x3c003800u + (uint32_t)lane, sink = 0;
+  asm volatile("" : "+v"(hbits));
+  uint32_t lds_at = (uint32_t)(size_t)(&lds[lane]);
+  asm volatile("" : "+v"(lds_at));
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      if (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[u % 4]) : "v"(x[u % 4]), "v"(y[(u / 4) % 4]));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[u % 4]) : "v"(x[u % 4]), "v"(y[(u / 4) % 4]));
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int j = (u * NV + k) % 12;
+        if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(c1), "v"(c2));
+        if (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(c2));
+        if (KIND == 2) { f32x2 p = {v[j & ~1], v[j | 1]}; asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(p)); v[j & ~1] = p.x; v[j | 1] = p.y; }
+        if (KIND == 3) { uint32_t h; asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v[j]), "v"(v[(j + 1) % 12])); v[j] = __uint_as_float(h | 0x3c003c00u); }
+        if (KIND == 4) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f000000" : "+v"(v[j]) : "v"(c1));
+        if (KIND == 5) { float m; asm volatile("v_min_f32 %0, 0, %1\n\tv_fma_f32 %1, %0, %2, %1" : "=&v"(m), "+v"(v[j]) : "v"(c2)); }
+        if (KIND == 6) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k & 1]) : "v"(lds_at), "n"(1024));
+        if (KIND == 7) asm volatile("s_nop 0");
+        if (KIND == 8) { uint32_t l = __float_as_uint(v[j]); asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hbits), "v"(v[(j + 1) % 12])); v[j] = __uint_as_float(l | 0x3c000000u); }
+        if (KIND == 9) { uint32_t l; asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(hbits), "v"(v[j]), "v"(v[(j + 1) % 12])); sink ^= l; }
+        if (KIND == 10) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ring[k & 1]) : "v"(data + (threadIdx.x & 1023)));
+        if (KIND == 11) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(v[j]) : "v"(hbits));
+        if (KIND == 12) {
+          // one step of the shipped pipeline = 12 gaps; 42 non-gather instructions in its order of kinds
+          static constexpr int mix[42] = {1, 1, 1, 1, 5, 5, 2,  5, 5, 0, 0,  1, 1, 1, 1, 5, 5, 2,  5, 5, 0, 0,   // hi.hi shadows: add x4, min x2, pk_fma | min x2, fma x2 | ...
+                                          6, 6, 3, 9,  6, 6, 3, 9,  6, 6, 3, 9,  6, 6, 3, 9,                 // hi.lo shadows: 2 ds_read, cvt_pkrtz, mixlo + mixhi
+                                          6, 6, 6, 6};                                                         // lo.hi shadows: 1 ds_read each
+          const int what = mix[(u * NV + k) % 42];
+          if (what == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(c1), "v"(c2));
+          if (what == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(c2));
+          if (what == 2) { f32x2 p = {v[j & ~1], v[j | 1]}; asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(p)); v[j & ~1] = p.x; v[j | 1] = p.y; }
+          if (what == 3) { uint32_t h; asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v[j]), "v"(v[(j + 1) % 12])); sink ^= h; }
+          if (what == 5) asm volatile("v_min_f32 %0, 0, %0" : "+v"(v[j]));
+          if (what == 6) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[k & 1]) : "v"(lds_at), "n"(1024));
+          if (what == 9) { uint32_t l; asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(hbits), "v"(v[j]), "v"(v[(j + 1) % 12])); sink ^= l; }
+        }
+      }
+    }
+    if (KIND == 6 || KIND == 12) asm volatile("s_waitcnt lgkmcnt(0)");
+    if (KIND == 10) asm volatile("s_waitcnt vmcnt(0)");
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  float s = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[a][r];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += v[i];
+  s += (float)(ring[0].x + ring[1].y + sink);
+  out[blockIdx.x * NT + threadIdx.x] = s;
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
+static uint16_t f2h(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  int e = (int)((x >> 23) & 0xff) - 127 + 15;
+  uint32_t m = x & 0x7fffffu;
+  if (e <= 0) return (uint16_t)sign;
+  if (e >= 31) return (uint16_t)(sign | 0x7bffu);
+  return (uint16_t)(sign | ((uint32_t)e << 10) | (m >> 13));
+}
+
+template <int AGPR, int NV, int KIND, int NT>
+static void run(const char* name, const uint4* data, float* out, long long* ticks) {
+  const int iters = 600, blocks = 256;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_pat<AGPR, NV, KIND, NT>), dim3(blocks), dim3(NT), 0, 0, 30, data, out, ticks);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_pat<AGPR, NV, KIND, NT>), dim3(blocks), dim3(NT), 0, 0, iters, data, out, ticks);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  long long h[256]; hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost);
+  double mean = 0; for (int i = 0; i < blocks; ++i) mean += (double)h[i]; mean /= blocks;
+  const double n = (double)iters * 32;
+  // with NT = 512 two wavefronts share a SIMD: cycles per MFMA of the SIMD = ticks per MFMA of one wavefront / 2
+  // ns per MFMA of a SIMD from the launch's duration (every SIMD of the chip runs NT / 256 wavefronts x iters x 32 MFMAs)
+  printf("%s waves/SIMD=%d fillers/MFMA=%d %-26s %6.1f ticks/MFMA per wavefront (counter at %.2f GHz)   %6.2f ns per SIMD-MFMA\n",
+         AGPR ? "AGPR" : "VGPR", NT / 256, NV, name, mean / n, mean / (ms * 1e6), ms * 1e6 / n / (NT / 256));
+}
+
+#define ROW(KIND, NAME)                                                                  \
+  run<0, 2, KIND, 256>(NAME, data, out, ticks); run<1, 2, KIND, 256>(NAME, data, out, ticks); \
+  run<0, 4, KIND, 256>(NAME, data, out, ticks); run<1, 4, KIND, 256>(NAME, data, out, ticks); \
+  run<0, 6, KIND, 256>(NAME, data, out, ticks); run<1, 6, KIND, 256>(NAME, data, out, ticks); \
+  run<0, 4, KIND, 512>(NAME, data, out, ticks); run<1, 4, KIND, 512>(NAME, data, out, ticks);
+
+int main() {
+  float* out; long long* ticks; uint4* data;
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&ticks, 256 * 8);
+  const size_t n16 = 16 * 1024 * 8;
+  std::vector<uint16_t> h(n16);
+  srand(7);
+  for (auto& v : h) { float s = 0; for (int i = 0; i < 12; ++i) s += (float)rand() / RAND_MAX; v = f2h(s - 6.0f); }
+  hipMalloc(&data, n16 * 2); hipMemcpy(data, h.data(), n16 * 2, hipMemcpyHostToDevice);
+  run<0, 0, 0, 256>("(bare)", data, out, ticks); run<1, 0, 0, 256>("(bare)", data, out, ticks);
+  run<0, 0, 0, 512>("(bare)", data, out, ticks); run<1, 0, 0, 512>("(bare)", data, out, ticks);
+  ROW(0, "v_fma_f32 regs")
+  ROW(1, "v_add_f32")
+  ROW(2, "v_pk_fma_f32")
+  ROW(3, "v_cvt_pkrtz_f16_f32")
+  ROW(4, "v_fmaak_f32 literal")
+  ROW(5, "v_min + v_fma (x2 instr)")
+  ROW(6, "ds_read_b128")
+  ROW(7, "s_nop 0")
+  ROW(8, "v_fma_mixlo_f16")
+  ROW(9, "v_fma_mixlo + mixhi (x2)")
+  ROW(10, "global_load_dwordx4")
+  ROW(11, "v_cvt_f32_f16")
+  run<0, 3, 12, 256>("REAL MIX 3/gap", data, out, ticks); run<0, 4, 12, 256>("REAL MIX 4/gap", data, out, ticks);
+  run<0, 3, 12, 512>("REAL MIX 3/gap", data, out, ticks); run<0, 4, 12, 512>("REAL MIX 4/gap", data, out, ticks);
+  run<1, 4, 12, 512>("REAL MIX 4/gap", data, out, ticks);
+  return 0;
+}
