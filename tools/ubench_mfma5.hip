@@ -144,6 +144,23 @@ int main() {
   srand(7);
   for (auto& v : h) { float s = 0; for (int i = 0; i < 12; ++i) s += (float)rand() / RAND_MAX; v = f2h(s - 6.0f); }
   hipMalloc(&data, n16 * 2); hipMemcpy(data, h.data(), n16 * 2, hipMemcpyHostToDevice);
+  if (getenv("UBENCH_OPERANDS")) {
+    // does the matrix pipe's power (hence the clock under a saturated pipe) depend on how many mantissa bits its operands carry?
+    // (the lo halves of the split-f16 scorer need ~6 significant bits, not 11)
+    struct { const char* name; uint16_t mask_a, mask_b; } pats[] = {
+        {"A, B random (11 significant bits)", 0xffff, 0xffff}, {"B: low 5 mantissa bits zero", 0xffff, 0xffe0},
+        {"A, B: low 5 mantissa bits zero", 0xffe0, 0xffe0},   {"B: low 8 mantissa bits zero", 0xffff, 0xff00},
+        {"A, B: low 8 mantissa bits zero", 0xff00, 0xff00},   {"B = 0", 0xffff, 0x0000}, {"A = B = 0", 0x0000, 0x0000}};
+    std::vector<uint16_t> m(n16);
+    for (auto& pt : pats) {
+      // k_pat loads x[s] from data[(2 s) * 1024 + tid] (A) and y[s] from data[(2 s + 1) * 1024 + tid] (B): blocks of 8192 halves
+      for (size_t i = 0; i < n16; ++i) m[i] = h[i] & (((i / 8192) & 1) ? pt.mask_b : pt.mask_a);
+      hipMemcpy(data, m.data(), n16 * 2, hipMemcpyHostToDevice);
+      run<0, 0, 0, 256>(pt.name, data, out, ticks);
+      run<0, 0, 0, 512>(pt.name, data, out, ticks);
+    }
+    return 0;
+  }
   run<0, 0, 0, 256>("(bare)", data, out, ticks); run<1, 0, 0, 256>("(bare)", data, out, ticks);
   run<0, 0, 0, 512>("(bare)", data, out, ticks); run<1, 0, 0, 512>("(bare)", data, out, ticks);
   ROW(0, "v_fma_f32 regs")
