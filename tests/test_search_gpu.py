@@ -915,6 +915,17 @@ def test_search_without_preprojection_matches(oracle):
         assert kinds.count("diverged") <= 1, kinds
     finally:
         _lib.lib().nann_set_preprojection(1)
+    # round 5: the same per CALL (nann_search_options.preprojection), next to a call on the same scorer that does use a table
+    sc = ops.Scorer("mlp", 64, torch.float16, w, precision="exact")
+    r0 = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(preprojection=False))
+    torch.cuda.synchronize()
+    assert not r0.plan["table"] and retrieval.table_bytes(dix, sc)[1] == 0
+    r1 = retrieval.search(dix, sc, cuda(q), topn)
+    torch.cuda.synchronize()
+    assert r1.plan["table"] and retrieval.table_bytes(dix, sc)[1] > 0
+    for r in (r0, r1):
+        _assert_same((r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
+                      r.index.cpu().numpy(), r.counters.cpu().numpy()), exp)
 
 
 def test_search_options_travel_with_the_call(oracle):
