@@ -312,9 +312,10 @@ int nann_index_info(const nann_index* ix, int64_t out[6]);
 /* The probe nann_index_create runs on every index of >= 4096 items (round 5): 64 of its own rows as queries, ef = min(64,
  * #enter points), L2 scorer, one small launch -- how many NEW nodes a level-0 round finds per frontier row on THIS graph,
  * which is what sizes a query's visited set (16K-slot hash set, two workgroups per CU; 32K slots, one; bitmap).  The planner
- * uses the measurement in place of rounds 1-4's guess from the mean degree.  out[4] = {valid queries of the probe (0: none,
- * the planner falls back to the guess), ef, mean, max}. */
-int nann_index_probe_info(const nann_index* ix, float out[4]);
+ * uses the measurement in place of rounds 1-4's guess from the mean degree: 1.15 x the 90th percentile of the probe's queries
+ * (a query in the tail beyond it is rerun on the bitmap kernel like any query whose set would overflow).  out[5] = {valid
+ * queries of the probe (0: none, the planner falls back to the guess), ef, mean, 90th percentile, max}. */
+int nann_index_probe_info(const nann_index* ix, float out[5]);
 
 #define NANN_NUM_ROUNDS 5
 /* Where a query's visited set lives (the reference: a TemporaryVariable bitmap of N/32 words,

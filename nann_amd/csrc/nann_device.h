@@ -629,7 +629,8 @@ __device__ __forceinline__ int wg_expand_walk(const int32_t* frontier, int n_fro
 // Every copy of an id walks the same sequence and slots are never vacated, so a copy finds its id at the same k.
 // A sequence longer than 62 steps hands the query to the bitmap kernel like a full set (probability ~load^63; step
 // 63 is never stored, so no entry equals the empty value 0xffffffff).
-// Capacity: the set must stay below SLOTS - 64 entries; a piece that could exceed it returns -2 and the host reruns
+// Capacity: the set must stay below SLOTS - 64 entries; a piece that could exceed it is cut to the room left, and with
+// less than kVisMinPiece of room returns -2 and the host reruns
 // that query on the bitmap kernel.
 constexpr uint32_t kVisEmpty = 0xffffffffu;
 constexpr int kVisPosBits = 12;   // position in the piece + 1 (0 = visited before the piece)
@@ -653,6 +654,7 @@ struct ExpandHashScratch {
 // bijections of [0, 2^B) in a row -- multiply by an odd constant, fold the high half onto the low half, multiply
 // again -- so that both halves of p depend on every bit of the id.
 constexpr int kVisTagBits = 14;
+constexpr int kVisMinPiece = 512;  // shortest piece the insert loop is run for when the set is nearly full
 constexpr int kVisDirectBits = 32 - kVisPosBits;  // id spaces of up to 20 bits: the entry holds the id itself (rounds 1-2)
 // -> home slot h0 and the entry's high part `hi` (everything but step and position)
 template <int SLOTS, bool TAG>
@@ -847,11 +849,22 @@ __device__ __forceinline__ int wg_expand_hash_impl(const int32_t* frontier, int 
   bool bad = false;
   int32_t x[PER], xn[PER];
   if (G > 0) fetch(0, min(PL, G), x);
-  for (int c0 = 0; c0 < G; c0 += PL) {
-    const int n_c = min(PL, G - c0);
-    if (vis_count + n_c > SLOTS - 64) return -2;  // uniform
+  for (int c0 = 0; c0 < G;) {
+    // A piece may add as many ids as it has positions.  One that could pass the set's capacity is CUT to the room that is
+    // left (piece boundaries are free: a later piece finds the ids of an earlier one in the set) instead of giving the
+    // query up -- on graphs whose rows are all at the cap most of a piece is visited already, and the uncut test handed
+    // back queries whose sets ended at 12 k of 16 k entries (round 5: 39 of 4096 on the exact k-NN graph, each a serial
+    // tail on the bitmap kernel: profiles/rd5u_knn_graph.txt).  Less than kMinPiece of room: the bitmap kernel.
+    int n_c = min(PL, G - c0);
+    const int room = SLOTS - 64 - vis_count;
+    const bool cut = n_c > room;  // uniform
+    if (cut) {
+      if (room < kVisMinPiece) return -2;
+      n_c = room;
+    }
+    const int c_next = c0 + n_c;
     long long tw = pt.now();
-    if (c0 + PL < G) fetch(c0 + PL, min(PL, G - c0 - PL), xn);
+    if (!cut && c_next < G) fetch(c_next, min(PL, G - c_next), xn);
     pt.sub(PH_EX_LOOKUP, tw);
     // 1. test-and-insert: (tag << 12) | (position in piece + 1), tag = (t << 6) | probe step.  One CAS per
     //    probe step: an empty slot is claimed, a slot with the same tag (= the same id) is joined with ds_min (the
@@ -928,8 +941,13 @@ __device__ __forceinline__ int wg_expand_hash_impl(const int32_t* frontier, int 
     const int tot = (int)wave_total(inc);
     base += tot;
     vis_count += tot;
+    if (cut) {  // (rare) the piece behind a cut one starts where no prefetch looked
+      if (c_next < G) fetch(c_next, min(PL, G - c_next), x);
+    } else {
 #pragma unroll
-    for (int j = 0; j < PER; ++j) x[j] = xn[j];
+      for (int j = 0; j < PER; ++j) x[j] = xn[j];
+    }
+    c0 = c_next;
     pt.sub(PH_EX_RANK, tw);
   }
   pt.sub(PH_EX_LOOP, tsub);

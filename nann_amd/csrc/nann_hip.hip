@@ -776,7 +776,7 @@ struct nann_index {
   // the probe launch of nann_index_create (round 5): new level-0 nodes per frontier row, measured on THIS graph
   bool probe_valid = false;
   int probe_ef = 0, probe_queries = 0;
-  float probe_new_per_row_mean = 0.0f, probe_new_per_row_max = 0.0f;
+  float probe_new_per_row_mean = 0.0f, probe_new_per_row_q90 = 0.0f, probe_new_per_row_max = 0.0f;
 };
 static void probe_index(nann_index* ix);  // (defined behind search_impl)
 
@@ -1967,12 +1967,13 @@ void nann_index_destroy(nann_index* ix) {
   delete ix;
 }
 
-int nann_index_probe_info(const nann_index* ix, float out[4]) {
+int nann_index_probe_info(const nann_index* ix, float out[5]) {
   if (!ix || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_index_probe_info: null argument");
   out[0] = ix->probe_valid ? (float)ix->probe_queries : 0.0f;
   out[1] = (float)ix->probe_ef;
   out[2] = ix->probe_new_per_row_mean;
-  out[3] = ix->probe_new_per_row_max;
+  out[3] = ix->probe_new_per_row_q90;
+  out[4] = ix->probe_new_per_row_max;
   return NANN_OK;
 }
 
@@ -2043,14 +2044,18 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   const double mean_deg0 = (double)ix->desc.nb_nnz[0] / (double)std::max<int64_t>(ix->desc.n_items, 1);
   const double walk_deg = std::min<double>((double)ix->max_deg[0], 2.75 * mean_deg0);
   // Round 5: the estimate is MEASURED per index where it can be (probe_index: 64 queries at nann_index_create, the new nodes a
-  // level-0 round finds per frontier row; the largest of the probe's queries, so the estimate sits on the tail).  Rounds 1-4
+  // level-0 round finds per frontier row; a high quantile of the probe's queries, so the estimate sits on the tail).  Rounds 1-4
   // guessed it from the mean degree (2.75 x mean degree walked, 45 % new: fitted to the device builder's graphs, mean degree
   // ~17) and sent a dense graph (keepPrunedConnections, mean degree 52) to the one-workgroup-per-CU 32K plan at 0.67 of the
   // roofline, where the 16K plan holds its ~8 k visited ids at 0.84 with no rerun (profiles/rd5c_dense_graph.txt).  The ratio
   // falls as the beam widens (neighbourhoods overlap more), so a probe at ef <= 64 overestimates wider beams: safe side.
   const double rows_walked = (double)t[1] + t[2] + t[3];
   const double est_guess = t[1] + 0.45 * walk_deg * rows_walked;
-  const double est_visited = ix->probe_valid ? std::min(t[1] + (double)ix->probe_new_per_row_max * rows_walked,
+  // (the 90th percentile of the probe's queries x 1.15, not their maximum: on the exact k-NN graph -- every row at the cap -- one
+  // of 64 probe queries found 41 new nodes per row against a mean of 13.6 and a q90 of ~20, and planning on that outlier sent
+  // configs[1] to the 32K plan at 0.65 although the real sets hold ~8 k ids; a query in the tail is rerun on the bitmap kernel,
+  // which is what the rerun is for: profiles/rd5u_knn_graph.txt)
+  const double est_visited = ix->probe_valid ? std::min(t[1] + std::min(1.15 * (double)ix->probe_new_per_row_q90, (double)ix->probe_new_per_row_max) * rows_walked,
                                                         t[1] + (double)ix->max_deg[0] * rows_walked)
                                              : est_guess;
   // the 16K / 32K-slot set holds 16320 / 32704 ids; a measured estimate may come closer to that than a guessed one
@@ -2475,6 +2480,7 @@ static void probe_index(nann_index* ix) {
   if (!ok) return;
   double sum = 0.0, mx = 0.0;
   int n_valid = 0;
+  std::vector<double> ratios;
   for (int j = 0; j < nq; ++j) {
     if (h_st[(size_t)j] != NANN_OK) continue;
     const int32_t* c = h_ctr.data() + (size_t)j * 3 * NANN_NUM_ROUNDS;  // [F | G | S][round]
@@ -2483,13 +2489,16 @@ static void probe_index(nann_index* ix) {
     if (rows <= 0.0) continue;
     const double ratio = fresh / rows;
     sum += ratio; mx = std::max(mx, ratio);
+    ratios.push_back(ratio);
     ++n_valid;
   }
   if (n_valid < 8) return;  // (a corpus whose clusters a beam exhausts: nothing to learn from failed requests)
   ix->probe_valid = true;
   ix->probe_ef = e;
   ix->probe_queries = n_valid;
+  std::sort(ratios.begin(), ratios.end());
   ix->probe_new_per_row_mean = (float)(sum / n_valid);
+  ix->probe_new_per_row_q90 = (float)ratios[(size_t)(0.9 * (double)(n_valid - 1))];
   ix->probe_new_per_row_max = (float)mx;
 }
 

@@ -63,12 +63,12 @@ class Index:
         info = (C.c_int64 * 6)()
         _check(lib().nann_index_info(self.handle, info))
         self.max_deg = (int(info[3]), int(info[4]))
-        pr = (C.c_float * 4)()
+        pr = (C.c_float * 5)()
         _check(lib().nann_index_probe_info(self.handle, pr))
         # the probe launch of nann_index_create: new level-0 nodes per frontier row on this graph (what the planner sizes
         # a query's visited set with); None for toy indices / corpora whose probe requests all failed
         self.probe = ({"queries": int(pr[0]), "ef": int(pr[1]), "new_per_row_mean": round(float(pr[2]), 3),
-                       "new_per_row_max": round(float(pr[3]), 3)} if pr[0] > 0 else None)
+                       "new_per_row_q90": round(float(pr[3]), 3), "new_per_row_max": round(float(pr[4]), 3)} if pr[0] > 0 else None)
         self.bitmap_words = int(math.ceil(self.n_items / 32))  # build_opt_graph.py:114
         self.device = dev
         self._ws = None

@@ -111,3 +111,61 @@ def test_last_id_at_the_last_position_of_a_full_piece(oracle, n):
         assert (r.item_ids.cpu().numpy() == exp[1]).all(), mode
         assert (bits(r.scores.cpu().numpy()) == bits(exp[2])).all(), mode
         assert (r.counters.cpu().numpy() == exp[4]).all(), mode
+
+
+def _regular_random_index(n, degree, n_enter, seed):
+    """Every level-0 row holds `degree` random neighbours (so nearly every gathered id is new), level 1 leads each of
+    the n_enter entry nodes to 8 random nodes."""
+    rng = np.random.default_rng(seed)
+    embs = (rng.standard_normal((n, D)) * 0.3).astype(np.float16)
+    item_ids = (rng.permutation(n) + 1).astype(np.int64)
+    nb0 = rng.integers(0, n, size=n * degree).astype(np.int32)
+    rs0 = (np.arange(n + 1, dtype=np.int64) * degree)
+    len1 = np.zeros(n, np.int64)
+    len1[:n_enter] = 8
+    rs1 = np.concatenate([[0], np.cumsum(len1)]).astype(np.int64)
+    nb1 = rng.integers(0, n, size=int(rs1[-1])).astype(np.int32)
+    return dict(item_embs=embs, item_ids=item_ids, nb_values=[nb0, nb1], nb_row_splits=[rs0, rs1],
+                enter_points=np.arange(n_enter, dtype=np.int32))
+
+
+def test_a_set_that_fills_up_cuts_its_pieces(oracle):
+    """Round 5.  A piece of the insert loop may add as many ids as it has positions (4095); the test `count + piece >
+    slots - 64` therefore gave a query up with its set at 12.2 k of 16.3 k entries.  Now a piece that could pass the capacity
+    is cut to the room left.  On degree-64 random graphs small enough that a round's list repeats itself: (1) beams of 128
+    over 20 k items start the second full piece of the last round with ~12.6 k ids in the 16K-slot set and end at ~14.1 k:
+    no query is handed to the bitmap kernel, the answer is the oracle's bit for bit; (2) beams of 200 (~17.1 k ids) do
+    overflow: every query is rerun, same parity; (3, 4) the same on the 32K-slot set (31.4 k of 32.7 k; 43 k)."""
+    from nann_amd import ops, retrieval
+    rng = np.random.default_rng(5)
+    q = (rng.standard_normal((12, D)) * 0.3).astype(np.float32)
+    sc = ops.Scorer("l2", D, torch.float16)
+    for mode, n, ef, want_reruns in (("lds_hash", 20_000, 128, False), ("lds_hash", 20_000, 200, True),
+                                     ("lds_hash32", 40_000, 320, False), ("lds_hash32", 80_000, 320, True)):
+        g = _regular_random_index(n, 64, 320, seed=77)
+        oix = oracle.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+        dix = retrieval.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+        topn = [ef] * 5 + [100]
+        exp = oracle.search_batch(oix, oracle.Scorer("l2", D, oracle.EMB_F16), q, topn, n_threads=8)
+        assert (exp[0] == 0).all(), exp[0]
+        ctr = exp[4].reshape(len(q), 3, -1)
+        visited = ef + ctr[:, 2, 2:5].sum(1)  # marks of the level + new nodes of its three rounds
+        cap = (16384 if mode == "lds_hash" else 32768) - 64
+        if want_reruns:
+            assert (visited > cap).all(), (mode, ef, visited)
+        else:
+            # the last round's list is >= 2 full pieces and the set passes `capacity - a piece` before the last full one
+            assert (ctr[:, 1, 4] >= 2 * PIECE).all()
+            before_last_round = ef + ctr[:, 2, 2:4].sum(1)
+            n_full = ctr[:, 1, 4] // PIECE
+            at_last_full_piece = before_last_round + ctr[:, 2, 4] * (n_full - 1) * PIECE // ctr[:, 1, 4]  # (new ids spread evenly)
+            assert (at_last_full_piece > cap - PIECE + 100).all() and (visited < cap - 512).all(), (mode, ef, visited, at_last_full_piece)
+        r = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(traversal=mode))
+        torch.cuda.synchronize()
+        assert r.plan["visited_set"] == mode, r.plan
+        assert r.reruns() == (len(q) if want_reruns else 0), (mode, ef, r.reruns(), visited)
+        assert (r.status.cpu().numpy() == 0).all()
+        assert (r.index.cpu().numpy() == exp[3]).all(), (mode, ef)
+        assert (r.item_ids.cpu().numpy() == exp[1]).all(), (mode, ef)
+        assert (bits(r.scores.cpu().numpy()) == bits(exp[2])).all(), (mode, ef)
+        assert (r.counters.cpu().numpy() == exp[4]).all(), (mode, ef)

@@ -128,6 +128,8 @@ def test_dense_graph_family_and_the_measured_planner(oracle):
         ctr = r.counters.cpu().numpy().astype(np.int64)[st == 0]
         ratio = ctr[:, 2, 2:5].sum(1) / ctr[:, 0, 2:5].sum(1)
         assert np.quantile(ratio, 0.99) <= dix.probe["new_per_row_max"] * 1.05, (np.quantile(ratio, 0.99), dix.probe)
+        # ... and what the planner prices with -- 1.15 x the probe's 90th percentile -- covers the real calls' 90th percentile
+        assert np.quantile(ratio, 0.9) <= 1.15 * dix.probe["new_per_row_q90"] <= 1.15 * dix.probe["new_per_row_max"], (np.quantile(ratio, 0.9), dix.probe)
         assert r.plan["visited_set"] == "lds_hash" and r.plan["threads"] == 512 and r.plan["workgroups"] == 512, r.plan
         assert r.reruns() <= 0.01 * len(st), r.reruns()
         oix = oracle.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])

@@ -62,6 +62,12 @@ PY
         line $OUT/bench_dense_${M}_$TAG.json "L2 dense graph $M"
         python -c "import json;d=json.loads(open('$OUT/bench_dense_${M}_$TAG.json').read().strip().splitlines()[-1]);print('   plan',d.get('plan'),'reruns',d.get('reruns_last_step'))"
       done ;;
+    knn)  # configs[1] on the exact k-NN graph (every level-0 row at the cap of 64): plan, reruns, rate; then both hash plans forced
+      for M in auto lds_hash lds_hash32; do
+        timeout 300 $BENCH --graph knn --no-secondary --no-cpu-baseline --steps 10 --traversal $M > $OUT/bench_knn_${M}_$TAG.json 2> $OUT/bench_knn_${M}_$TAG.err
+        line $OUT/bench_knn_${M}_$TAG.json "L2 knn graph $M"
+        python -c "import json;d=json.loads(open('$OUT/bench_knn_${M}_$TAG.json').read().strip().splitlines()[-1]);print('   plan',d.get('plan'),'reruns',d.get('reruns_last_step'),'probe',d.get('index_probe'),'recall',d.get('recall_at_k_vs_bruteforce'),'rows/q',d['roofline'].get('rows_scored_per_query'))"
+      done ;;
     reserve_sweep)  # the slot reserve under an exchange as long as xGMI's (loopback copies x 15), one GPU
       timeout 600 python tools/overlap_bench.py /tmp/idx 30 --wait-us ${SWEEP_WAIT_US:-1400} --reserves 0,8,16,32,64 > $OUT/reserve_sweep_$TAG.jsonl 2> $OUT/reserve_sweep_$TAG.err
       timeout 300 python tools/overlap_bench.py /tmp/idx 30 --repeat 1 --reserves 0,16 >> $OUT/reserve_sweep_$TAG.jsonl 2>> $OUT/reserve_sweep_$TAG.err
