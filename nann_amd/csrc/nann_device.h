@@ -107,6 +107,25 @@ __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+template <int CTRL>
+__device__ __forceinline__ int32_t dpp_i32(int32_t v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// lanes with lane % LPR == U take `v`, the others keep `keep`: v_cndmask against a constant lane mask that two scalar moves
+// put into vcc on the spot (a comparison per use would cost the vector instruction this saves; as an "s" operand the
+// compiler hoists the eight masks out of the loop and, short of scalar registers, parks them in vector lanes)
+template <int LPR, int U>
+__device__ __forceinline__ float lane_pick(float keep, float v) {
+  constexpr unsigned long long one = LPR == 64 ? 1ull : LPR == 32 ? 0x0000000100000001ull : LPR == 16 ? 0x0001000100010001ull
+                                     : LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+  static_assert(U < LPR, "one lane of the row's group per value");
+  constexpr unsigned long long m = one << U;
+  float r;
+  asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc"
+      : "=v"(r) : "v"(keep), "v"(v), "i"((int)(uint32_t)(m & 0xffffffffull)), "i"((int)(uint32_t)(m >> 32)) : "vcc");
+  return r;
+}
+
 // ---------------------------------------------------------------------------
 // optional per-phase time attribution (thread 0 only; off unless a buffer is given)
 enum { PH_ZERO = 0, PH_WALK, PH_EXPAND, PH_SCORE, PH_TOPK, PH_OTHER,
@@ -1043,6 +1062,32 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
   return 0.0f - acc;
 }
 
+// The same score from the 16 bytes of an f16 row as they were loaded: t_k = q_k - x_k is ONE v_fma_mix_f32 (x_k * -1 + q_k with
+// the f16 operand widened inside the instruction: exact product, one rounding -- the bits of cvt + sub) instead of a
+// conversion and a subtraction.  Round 5: the scoring phase of a query spent ~60 % of its cycles ISSUING vector
+// instructions (~48 per row chunk: 8 cvt, 8 sub, 8 fma, the butterfly with its DPP wait states, a branchy store, and the
+// address arithmetic of the next id), not waiting for HBM.
+template <int LPR>
+__device__ __forceinline__ float l2_finish_f16(const float q[8], const uint4& a) {
+  const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t0, t1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(w[i]), "v"(q[2 * i]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(w[i]), "v"(q[2 * i + 1]));
+    acc = __fmaf_rn(t0, t0, acc);
+    acc = __fmaf_rn(t1, t1, acc);
+  }
+  acc = acc + dpp_f32<0xB1>(acc);
+  acc = acc + dpp_f32<0x4E>(acc);
+  if constexpr (LPR >= 8) acc = acc + dpp_f32<0x141>(acc);
+  if constexpr (LPR >= 16) acc = acc + dpp_f32<0x140>(acc);
+  if constexpr (LPR >= 32) acc = acc + __shfl_xor(acc, 16);
+  if constexpr (LPR >= 64) acc = acc + __shfl_xor(acc, 32);
+  return 0.0f - acc;
+}
+
 // 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per 1024-thread workgroup).
 // Measured on MI355X (profiles/r2a_variants.jsonl): 12 and 16 in flight, and a rolling window that
 // refills each slot as soon as it is reduced, are all slower (2.62 / 2.71 / 2.56 ms vs 2.56 ms).
@@ -1069,6 +1114,49 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
   float q[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
+  if constexpr (LPR == 16 && DT != DT_F32) {
+    // One DPP row per table row (round 5).  A batch's ids arrive in ONE load per lane -- lane `sub` of a row's group
+    // holds the id of load u = sub & (U - 1) -- and reach the group by row_newbcast; a batch's U scores leave in ONE
+    // store, lane u of the group with score u: no control flow inside a batch, so the U butterflies interleave and their
+    // DPP wait states fill with the neighbours' arithmetic.
+    const int mine_at = (sub & (U - 1)) * RPI + slot;
+    int32_t idv = ids[min(begin + mine_at, end - 1)];  // positions past `end` re-read candidate end-1, result dropped
+    for (int i0 = begin; i0 < end; i0 += RPI * U) {
+      RowChunk<DT> ch[U];
+      static_assert(U == 8, "eight broadcasts below");
+      ch[0] = load_chunk<DT>(table, (size_t)dpp_i32<0x150>(idv), d, sub);
+      ch[1] = load_chunk<DT>(table, (size_t)dpp_i32<0x151>(idv), d, sub);
+      ch[2] = load_chunk<DT>(table, (size_t)dpp_i32<0x152>(idv), d, sub);
+      ch[3] = load_chunk<DT>(table, (size_t)dpp_i32<0x153>(idv), d, sub);
+      ch[4] = load_chunk<DT>(table, (size_t)dpp_i32<0x154>(idv), d, sub);
+      ch[5] = load_chunk<DT>(table, (size_t)dpp_i32<0x155>(idv), d, sub);
+      ch[6] = load_chunk<DT>(table, (size_t)dpp_i32<0x156>(idv), d, sub);
+      ch[7] = load_chunk<DT>(table, (size_t)dpp_i32<0x157>(idv), d, sub);
+      idv = ids[min(i0 + RPI * U + mine_at, end - 1)];  // the next batch's, underneath the row loads
+      float s[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if constexpr (DT == DT_F16) {
+          s[u] = l2_finish_f16<LPR>(q, ch[u].a);
+        } else {
+          float x[8];
+          chunk_to_float<DT>(ch[u], x);
+          s[u] = l2_finish<LPR>(q, x);
+        }
+      }
+      float mine = s[0];
+      mine = lane_pick<LPR, 1>(mine, s[1]);
+      mine = lane_pick<LPR, 2>(mine, s[2]);
+      mine = lane_pick<LPR, 3>(mine, s[3]);
+      mine = lane_pick<LPR, 4>(mine, s[4]);
+      mine = lane_pick<LPR, 5>(mine, s[5]);
+      mine = lane_pick<LPR, 6>(mine, s[6]);
+      mine = lane_pick<LPR, 7>(mine, s[7]);
+      const int i = i0 + mine_at;
+      if (sub < U && i < end) scores[i] = mine;
+    }
+    return;
+  }
   // branch-free: positions past `end` re-read candidate end-1 and their result is dropped
   int32_t nxt[U];
 #pragma unroll
