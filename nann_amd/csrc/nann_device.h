@@ -11,6 +11,7 @@
 //   wg_score     GatherV2 + scorer             core/kernels/gather_functor.h:96-103 + BlazeXlaOp
 //   wg_topk      TopKV2 (+ Gather of ids)      core/kernels/topk_op.cc:104-205
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -1068,7 +1069,7 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 // instructions (~48 per row chunk: 8 cvt, 8 sub, 8 fma, the butterfly with its DPP wait states, a branchy store, and the
 // address arithmetic of the next id), not waiting for HBM.
 template <int LPR>
-__device__ __forceinline__ float l2_finish_f16(const float q[8], const uint4& a) {
+__device__ __forceinline__ float l2_sum_f16(const float q[8], const uint4& a) {  // ||q - x||^2 over the row (every lane)
   const uint32_t w[4] = {a.x, a.y, a.z, a.w};
   float acc = 0.0f;
 #pragma unroll
@@ -1085,7 +1086,26 @@ __device__ __forceinline__ float l2_finish_f16(const float q[8], const uint4& a)
   if constexpr (LPR >= 16) acc = acc + dpp_f32<0x140>(acc);
   if constexpr (LPR >= 32) acc = acc + __shfl_xor(acc, 16);
   if constexpr (LPR >= 64) acc = acc + __shfl_xor(acc, 32);
-  return 0.0f - acc;
+  return acc;
+}
+template <int LPR>
+__device__ __forceinline__ float l2_sum_bf16(const float q[8], const uint4& a) {
+  const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t0 = q[2 * i] - __uint_as_float(w[i] << 16);
+    const float t1 = q[2 * i + 1] - __uint_as_float(w[i] & 0xffff0000u);
+    acc = __fmaf_rn(t0, t0, acc);
+    acc = __fmaf_rn(t1, t1, acc);
+  }
+  acc = acc + dpp_f32<0xB1>(acc);
+  acc = acc + dpp_f32<0x4E>(acc);
+  if constexpr (LPR >= 8) acc = acc + dpp_f32<0x141>(acc);
+  if constexpr (LPR >= 16) acc = acc + dpp_f32<0x140>(acc);
+  if constexpr (LPR >= 32) acc = acc + __shfl_xor(acc, 16);
+  if constexpr (LPR >= 64) acc = acc + __shfl_xor(acc, 32);
+  return acc;
 }
 
 // 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per 1024-thread workgroup).
@@ -1103,7 +1123,7 @@ __device__ __forceinline__ float l2_finish_f16(const float q[8], const uint4& a)
 template <int LPR, int DT, int NWAVES>
 __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table, int d, const int32_t* ids,
                                                  int begin, int end, const float* qv, float* scores,
-                                                 int wave_rel) {
+                                                 int wave_rel, bool near = false) {
   constexpr int U = (DT == DT_F32) ? NANN_SCORE_U / 2 : NANN_SCORE_U;
   constexpr int GPW = 64 / LPR;      // rows per wavefront per load
   constexpr int RPI = NWAVES * GPW;  // rows per iteration of the participating wavefronts
@@ -1114,47 +1134,56 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
   float q[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) q[k] = qv[sub * 8 + k];
-  if constexpr (LPR == 16 && DT != DT_F32) {
-    // One DPP row per table row (round 5).  A batch's ids arrive in ONE load per lane -- lane `sub` of a row's group
-    // holds the id of load u = sub & (U - 1) -- and reach the group by row_newbcast; a batch's U scores leave in ONE
-    // store, lane u of the group with score u: no control flow inside a batch, so the U butterflies interleave and their
-    // DPP wait states fill with the neighbours' arithmetic.
+  if constexpr (LPR >= 16 && DT != DT_F32) {
+    // Rows of one or more DPP rows (round 5).  A batch's ids arrive in ONE load per lane -- lane `sub` of a row's group
+    // holds the id of load u = sub & (U - 1) -- and reach the group by row_newbcast (every 16-lane DPP row of a group has
+    // lane u at position u); a batch's U scores leave in ONE store, lane u of the group with score u: no control flow
+    // inside a batch, so the U butterflies interleave and their DPP wait states fill with the neighbours' arithmetic.
+    // `near` (uniform): every row starts below 4 GB and ids are below 2^24 -- the row's address is ONE v_mad_u32_u24 on
+    // top of the scalar base instead of a 64-bit multiply-add and a 64-bit shift-add.
+    static_assert(U == 8, "eight broadcasts below");
+    constexpr uint32_t kRowBytes = LPR * 16;
     const int mine_at = (sub & (U - 1)) * RPI + slot;
-    int32_t idv = ids[min(begin + mine_at, end - 1)];  // positions past `end` re-read candidate end-1, result dropped
-    for (int i0 = begin; i0 < end; i0 += RPI * U) {
-      RowChunk<DT> ch[U];
-      static_assert(U == 8, "eight broadcasts below");
-      ch[0] = load_chunk<DT>(table, (size_t)dpp_i32<0x150>(idv), d, sub);
-      ch[1] = load_chunk<DT>(table, (size_t)dpp_i32<0x151>(idv), d, sub);
-      ch[2] = load_chunk<DT>(table, (size_t)dpp_i32<0x152>(idv), d, sub);
-      ch[3] = load_chunk<DT>(table, (size_t)dpp_i32<0x153>(idv), d, sub);
-      ch[4] = load_chunk<DT>(table, (size_t)dpp_i32<0x154>(idv), d, sub);
-      ch[5] = load_chunk<DT>(table, (size_t)dpp_i32<0x155>(idv), d, sub);
-      ch[6] = load_chunk<DT>(table, (size_t)dpp_i32<0x156>(idv), d, sub);
-      ch[7] = load_chunk<DT>(table, (size_t)dpp_i32<0x157>(idv), d, sub);
-      idv = ids[min(i0 + RPI * U + mine_at, end - 1)];  // the next batch's, underneath the row loads
-      float s[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if constexpr (DT == DT_F16) {
-          s[u] = l2_finish_f16<LPR>(q, ch[u].a);
+    auto run = [&](auto near_c) {
+      constexpr bool NEAR = decltype(near_c)::value;
+      // (NEAR: the lane that holds an id holds its row's byte offset; the broadcast rides on the `or` with the lane's own
+      //  16 bytes of the row -- one vector instruction per row address)
+      auto row = [&](int32_t v) -> uint4 {
+        if constexpr (NEAR) {
+          return *reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(table) + ((uint32_t)v | ((uint32_t)sub * 16u)));
         } else {
-          float x[8];
-          chunk_to_float<DT>(ch[u], x);
-          s[u] = l2_finish<LPR>(q, x);
+          return load_chunk<DT>(table, (size_t)v, d, sub).a;
         }
+      };
+      auto widen = [&](int32_t id) -> int32_t { return NEAR ? (int32_t)__umul24((uint32_t)id, kRowBytes) : id; };
+      int32_t idv = widen(ids[min(begin + mine_at, end - 1)]);  // positions past `end` re-read candidate end-1, result dropped
+      for (int i0 = begin; i0 < end; i0 += RPI * U) {
+        uint4 ch[U];
+        ch[0] = row(dpp_i32<0x150>(idv));
+        ch[1] = row(dpp_i32<0x151>(idv));
+        ch[2] = row(dpp_i32<0x152>(idv));
+        ch[3] = row(dpp_i32<0x153>(idv));
+        ch[4] = row(dpp_i32<0x154>(idv));
+        ch[5] = row(dpp_i32<0x155>(idv));
+        ch[6] = row(dpp_i32<0x156>(idv));
+        ch[7] = row(dpp_i32<0x157>(idv));
+        idv = widen(ids[min(i0 + RPI * U + mine_at, end - 1)]);  // the next batch's, underneath the row loads
+        float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = DT == DT_F16 ? l2_sum_f16<LPR>(q, ch[u]) : l2_sum_bf16<LPR>(q, ch[u]);
+        float mine = s[0];
+        mine = lane_pick<LPR, 1>(mine, s[1]);
+        mine = lane_pick<LPR, 2>(mine, s[2]);
+        mine = lane_pick<LPR, 3>(mine, s[3]);
+        mine = lane_pick<LPR, 4>(mine, s[4]);
+        mine = lane_pick<LPR, 5>(mine, s[5]);
+        mine = lane_pick<LPR, 6>(mine, s[6]);
+        mine = lane_pick<LPR, 7>(mine, s[7]);
+        const int i = i0 + mine_at;
+        if (sub < U && i < end) scores[i] = 0.0f - mine;
       }
-      float mine = s[0];
-      mine = lane_pick<LPR, 1>(mine, s[1]);
-      mine = lane_pick<LPR, 2>(mine, s[2]);
-      mine = lane_pick<LPR, 3>(mine, s[3]);
-      mine = lane_pick<LPR, 4>(mine, s[4]);
-      mine = lane_pick<LPR, 5>(mine, s[5]);
-      mine = lane_pick<LPR, 6>(mine, s[6]);
-      mine = lane_pick<LPR, 7>(mine, s[7]);
-      const int i = i0 + mine_at;
-      if (sub < U && i < end) scores[i] = mine;
-    }
+    };
+    if (near) run(std::true_type{}); else run(std::false_type{});
     return;
   }
   // branch-free: positions past `end` re-read candidate end-1 and their result is dropped

@@ -118,7 +118,7 @@ __device__ __forceinline__ void eval_score(const EvalArgs& a, int qi, const int3
                                            unsigned char* scratch, const float* qv, float mlp_u) {
   const int tid = local_tid();
   if constexpr (SC == NANN_SCORER_L2) {
-    wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, ids, 0, n, qv, out, tid >> 6);
+    wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, ids, 0, n, qv, out, tid >> 6, (unsigned long long)a.n_items * (unsigned)(a.d * 2) <= 0xffffffffull && a.n_items <= (1u << 24));
   } else if constexpr (SC == kScorerAttn) {
     wg_score_attn<LPR * 8, DT, NT>(a.attn, a.kt + (size_t)qi * 256 * kAttnLP, a.upad + (size_t)qi * kAttnLP * kAttnE,
                                    a.emb, (long long)a.n_items, ids, (long long)n,

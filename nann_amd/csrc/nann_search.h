@@ -419,7 +419,7 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       }
       if constexpr (!PHASED) {
       if constexpr (SC == NANN_SCORER_L2) {
-        wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, 0, sc_n, qv, sc_out, tid >> 6);
+        wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, 0, sc_n, qv, sc_out, tid >> 6, (unsigned long long)a.n_items * (unsigned)(a.d * 2) <= 0xffffffffull && a.n_items <= (1u << 24));
         if (lds_scores != nullptr) {
           __syncthreads();
           for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
