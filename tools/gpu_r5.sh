@@ -103,7 +103,9 @@ PY
         case $W in
           l2) kst l2 -- $BENCH --no-secondary --no-cpu-baseline --steps 10 --warmup 2
               pm l2_f "$L2T" 4 "BASELINE configs[1]: 1M x 128-d f16, ef=128, top-200, L2, batch 4096" FETCH_SIZE -- $BENCH $Q
-              pm l2_w "$L2T" 4 "BASELINE configs[1]: 1M x 128-d f16, ef=128, top-200, L2, batch 4096" WRITE_SIZE -- $BENCH $Q ;;
+              pm l2_w "$L2T" 4 "BASELINE configs[1]: 1M x 128-d f16, ef=128, top-200, L2, batch 4096" WRITE_SIZE -- $BENCH $Q
+              pm l2_a "$L2T" 4 "BASELINE configs[1]: 1M x 128-d f16, ef=128, top-200, L2, batch 4096" SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -- $BENCH $Q
+              pm l2_b "$L2T" 4 "BASELINE configs[1]: 1M x 128-d f16, ef=128, top-200, L2, batch 4096" GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- $BENCH $Q ;;
           dense) kst dense -- $BENCH --graph hnsw_dense --no-secondary --no-cpu-baseline --steps 10 --warmup 2
               pm dense_f "${L2T}_dense" 4 "configs[1] on the dense graph family (keepPrunedConnections)" FETCH_SIZE -- $BENCH --graph hnsw_dense $Q
               pm dense_w "${L2T}_dense" 4 "configs[1] on the dense graph family (keepPrunedConnections)" WRITE_SIZE -- $BENCH --graph hnsw_dense $Q ;;
