@@ -1068,8 +1068,7 @@ __device__ __forceinline__ float l2_finish(const float q[8], const float x[8]) {
 // conversion and a subtraction.  Round 5: the scoring phase of a query spent ~60 % of its cycles ISSUING vector
 // instructions (~48 per row chunk: 8 cvt, 8 sub, 8 fma, the butterfly with its DPP wait states, a branchy store, and the
 // address arithmetic of the next id), not waiting for HBM.
-template <int LPR>
-__device__ __forceinline__ float l2_sum_f16(const float q[8], const uint4& a) {  // ||q - x||^2 over the row (every lane)
+__device__ __forceinline__ float l2_lane_f16(const float q[8], const uint4& a) {  // this lane's 8 terms of ||q - x||^2
   const uint32_t w[4] = {a.x, a.y, a.z, a.w};
   float acc = 0.0f;
 #pragma unroll
@@ -1080,16 +1079,9 @@ __device__ __forceinline__ float l2_sum_f16(const float q[8], const uint4& a) { 
     acc = __fmaf_rn(t0, t0, acc);
     acc = __fmaf_rn(t1, t1, acc);
   }
-  acc = acc + dpp_f32<0xB1>(acc);
-  acc = acc + dpp_f32<0x4E>(acc);
-  if constexpr (LPR >= 8) acc = acc + dpp_f32<0x141>(acc);
-  if constexpr (LPR >= 16) acc = acc + dpp_f32<0x140>(acc);
-  if constexpr (LPR >= 32) acc = acc + __shfl_xor(acc, 16);
-  if constexpr (LPR >= 64) acc = acc + __shfl_xor(acc, 32);
   return acc;
 }
-template <int LPR>
-__device__ __forceinline__ float l2_sum_bf16(const float q[8], const uint4& a) {
+__device__ __forceinline__ float l2_lane_bf16(const float q[8], const uint4& a) {
   const uint32_t w[4] = {a.x, a.y, a.z, a.w};
   float acc = 0.0f;
 #pragma unroll
@@ -1099,13 +1091,44 @@ __device__ __forceinline__ float l2_sum_bf16(const float q[8], const uint4& a) {
     acc = __fmaf_rn(t0, t0, acc);
     acc = __fmaf_rn(t1, t1, acc);
   }
-  acc = acc + dpp_f32<0xB1>(acc);
-  acc = acc + dpp_f32<0x4E>(acc);
-  if constexpr (LPR >= 8) acc = acc + dpp_f32<0x141>(acc);
-  if constexpr (LPR >= 16) acc = acc + dpp_f32<0x140>(acc);
-  if constexpr (LPR >= 32) acc = acc + __shfl_xor(acc, 16);
-  if constexpr (LPR >= 64) acc = acc + __shfl_xor(acc, 32);
   return acc;
+}
+// The xor butterfly of l2_finish over the 16 lanes of a DPP row for EIGHT rows at once, as a reduce-scatter: every stage
+// halves the values a lane carries (it keeps one of a pair and sends the other to the partner that keeps that one), so the
+// tree costs 4 x 3 + 2 x 3 + 3 + 1 = 22 vector instructions instead of 8 x 4 adds + 7 selects, and lane l ends with the
+// finished sum of row u(l) = (b2^b3, b1^b2, b0^b2) (bits of l & 15; lanes l and 15 - l hold the same row).  Every sum is
+// the same tree as l2_finish's -- ((p[l] + p[l^1]) + (the pair next to it)) + (the other quad) + (the other half) -- with
+// the operands of an addition possibly swapped, i.e. the same bits.  The keep rules are xors of lane bits because the
+// last two stages pair lanes by MIRROR (7 - l, 15 - l: the patterns DPP has for strides 4 and 8), whose partners count
+// their quads backwards.  One asm block: the selects read constant lane masks from vcc, and the DPP wait states
+// (2 between a vector write and a DPP read of it) are laid out by hand.
+__device__ __forceinline__ float l2_rows8_reduce_scatter(float (&a)[8]) {
+  float t0, t1, t2, t3;
+  asm("s_mov_b32 vcc_lo, 0x5a5a5a5a\n\ts_mov_b32 vcc_hi, 0x5a5a5a5a\n\t"  // lanes with b0 ^ b2: keep the odd row of a pair
+      "v_cndmask_b32_e32 %8, %0, %1, vcc\n\tv_cndmask_b32_e32 %0, %1, %0, vcc\n\t"
+      "v_cndmask_b32_e32 %9, %2, %3, vcc\n\tv_cndmask_b32_e32 %2, %3, %2, vcc\n\t"
+      "v_cndmask_b32_e32 %10, %4, %5, vcc\n\tv_cndmask_b32_e32 %4, %5, %4, vcc\n\t"
+      "v_cndmask_b32_e32 %11, %6, %7, vcc\n\tv_cndmask_b32_e32 %6, %7, %6, vcc\n\t"
+      "v_add_f32_dpp %8, %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %2, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %4, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %11, %6, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b32 vcc_lo, 0x3c3c3c3c\n\ts_mov_b32 vcc_hi, 0x3c3c3c3c\n\t"  // b1 ^ b2
+      "v_cndmask_b32_e32 %1, %9, %8, vcc\n\tv_cndmask_b32_e32 %3, %11, %10, vcc\n\t"   // sent
+      "v_cndmask_b32_e32 %0, %8, %9, vcc\n\tv_cndmask_b32_e32 %2, %10, %11, vcc\n\t"   // kept
+      "v_add_f32_dpp %0, %1, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %3, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b32 vcc_lo, 0x0ff00ff0\n\ts_mov_b32 vcc_hi, 0x0ff00ff0\n\t"  // b2 ^ b3
+      "v_cndmask_b32_e32 %8, %2, %0, vcc\n\tv_cndmask_b32_e32 %9, %0, %2, vcc\n\t"     // sent, kept
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %9, %8, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      :
+      : "vcc");
+  return t1;
 }
 
 // 16-byte row loads per lane in flight in the scoring phase (8 = 128 KB per 1024-thread workgroup).
@@ -1137,13 +1160,14 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
   if constexpr (LPR >= 16 && DT != DT_F32) {
     // Rows of one or more DPP rows (round 5).  A batch's ids arrive in ONE load per lane -- lane `sub` of a row's group
     // holds the id of load u = sub & (U - 1) -- and reach the group by row_newbcast (every 16-lane DPP row of a group has
-    // lane u at position u); a batch's U scores leave in ONE store, lane u of the group with score u: no control flow
-    // inside a batch, so the U butterflies interleave and their DPP wait states fill with the neighbours' arithmetic.
+    // lane u at position u); a batch's U scores leave in ONE store, lanes 0..7 of the group with the row sum the
+    // reduce-scatter butterfly left them (l2_rows8_reduce_scatter): no control flow inside a batch.
     // `near` (uniform): every row starts below 4 GB and ids are below 2^24 -- the row's address is ONE v_mad_u32_u24 on
     // top of the scalar base instead of a 64-bit multiply-add and a 64-bit shift-add.
     static_assert(U == 8, "eight broadcasts below");
     constexpr uint32_t kRowBytes = LPR * 16;
     const int mine_at = (sub & (U - 1)) * RPI + slot;
+    const int out_at = ((sub & 7) ^ ((sub & 4) ? 3 : 0)) * RPI + slot;  // the row whose sum the reduce-scatter leaves in this lane
     auto run = [&](auto near_c) {
       constexpr bool NEAR = decltype(near_c)::value;
       // (NEAR: the lane that holds an id holds its row's byte offset; the broadcast rides on the `or` with the lane's own
@@ -1170,16 +1194,11 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
         idv = widen(ids[min(i0 + RPI * U + mine_at, end - 1)]);  // the next batch's, underneath the row loads
         float s[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = DT == DT_F16 ? l2_sum_f16<LPR>(q, ch[u]) : l2_sum_bf16<LPR>(q, ch[u]);
-        float mine = s[0];
-        mine = lane_pick<LPR, 1>(mine, s[1]);
-        mine = lane_pick<LPR, 2>(mine, s[2]);
-        mine = lane_pick<LPR, 3>(mine, s[3]);
-        mine = lane_pick<LPR, 4>(mine, s[4]);
-        mine = lane_pick<LPR, 5>(mine, s[5]);
-        mine = lane_pick<LPR, 6>(mine, s[6]);
-        mine = lane_pick<LPR, 7>(mine, s[7]);
-        const int i = i0 + mine_at;
+        for (int u = 0; u < U; ++u) s[u] = DT == DT_F16 ? l2_lane_f16(q, ch[u]) : l2_lane_bf16(q, ch[u]);
+        float mine = l2_rows8_reduce_scatter(s);
+        if constexpr (LPR >= 32) mine = mine + __shfl_xor(mine, 16);
+        if constexpr (LPR >= 64) mine = mine + __shfl_xor(mine, 32);
+        const int i = i0 + out_at;
         if (sub < U && i < end) scores[i] = 0.0f - mine;
       }
     };
