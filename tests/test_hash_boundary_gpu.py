@@ -169,3 +169,55 @@ def test_a_set_that_fills_up_cuts_its_pieces(oracle):
         assert (r.item_ids.cpu().numpy() == exp[1]).all(), (mode, ef)
         assert (bits(r.scores.cpu().numpy()) == bits(exp[2])).all(), (mode, ef)
         assert (r.counters.cpu().numpy() == exp[4]).all(), (mode, ef)
+
+
+def test_table_beyond_4_gib_takes_the_wide_row_address(oracle):
+    """Round 5's scoring loop forms a row's address with 32-bit arithmetic on a scalar base when the whole table sits below
+    4 GiB and ids below 2^24; above, the 64-bit form runs.  9 M x 256-d f16 = 4.6 GB, of which only a subgraph of 20 k nodes
+    in ten runs over the whole id range -- 40 % of them behind the 4 GiB mark (id 8 388 608) -- has neighbours and non-zero rows
+    (the host copy is calloc'ed: untouched pages never become resident; the device copy is a zeroed tensor + those rows).
+    Every plan answers like the oracle bit for bit; the ids also need 24-bit tags in the hash set."""
+    from nann_amd import ops, retrieval
+    n, d, m = 9_000_000, 256, 20_000
+    rng = np.random.default_rng(11)
+    mark = (1 << 32) // (2 * d)  # the first row that starts at or behind 4 GiB
+    # ten runs of 2 000 consecutive ids (the host array's pages are 2 MB: scattered ids would touch all of them), one of
+    # them across the mark, four behind it
+    bases = [5_000, 1_000_000, 2_100_000, 4_200_000, 6_300_000, mark - 600, 8_500_000, 8_700_000, 8_900_000, n - 2_000]
+    nodes = np.concatenate([np.arange(b, b + m // len(bases)) for b in bases]).astype(np.int64)
+    assert len(nodes) == m and (nodes >= mark).sum() > m // 3
+    rows = (rng.standard_normal((m, d)) * 0.3).astype(np.float16)
+    embs = np.zeros((n, d), np.float16)
+    embs[nodes] = rows
+    dev_embs = torch.zeros((n, d), dtype=torch.float16, device="cuda")
+    dev_embs[torch.as_tensor(nodes).cuda()] = torch.as_tensor(rows).cuda()
+    item_ids = np.arange(1, n + 1, dtype=np.int64)
+    deg = 24
+    len0 = np.zeros(n, np.int64)
+    len0[nodes] = deg
+    rs0 = np.concatenate([[0], np.cumsum(len0)]).astype(np.int64)
+    nb0 = nodes[rng.integers(0, m, size=m * deg)].astype(np.int32)
+    n_enter = 64
+    len1 = np.zeros(n, np.int64)
+    len1[nodes[:n_enter]] = 8
+    rs1 = np.concatenate([[0], np.cumsum(len1)]).astype(np.int64)
+    nb1 = nodes[rng.integers(0, m, size=n_enter * 8)].astype(np.int32)
+    enter = nodes[:n_enter].astype(np.int32)
+    oix = oracle.Index(embs, item_ids, [nb0, nb1], [rs0, rs1], enter)
+    dix = retrieval.Index(dev_embs, item_ids, [nb0, nb1], [rs0, rs1], enter)
+    q = (rng.standard_normal((16, d)) * 0.3).astype(np.float32)
+    topn = [32] * 5 + [50]
+    exp = oracle.search_batch(oix, oracle.Scorer("l2", d, oracle.EMB_F16), q, topn, n_threads=8)
+    assert (exp[0] == 0).all(), exp[0]
+    assert (exp[3] >= mark).sum() > exp[3].size // 10  # results from behind the 4 GiB mark
+    sc = ops.Scorer("l2", d, torch.float16)
+    for mode in MODES + ["auto"]:
+        r = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(traversal=mode))
+        torch.cuda.synchronize()
+        assert (r.status.cpu().numpy() == 0).all(), (mode, r.status.cpu().numpy())
+        assert (r.index.cpu().numpy() == exp[3]).all(), mode
+        assert (r.item_ids.cpu().numpy() == exp[1]).all(), mode
+        assert (bits(r.scores.cpu().numpy()) == bits(exp[2])).all(), mode
+        assert (r.counters.cpu().numpy() == exp[4]).all(), mode
+    del dix, dev_embs
+    torch.cuda.empty_cache()
