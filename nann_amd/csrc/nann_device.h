@@ -1137,6 +1137,9 @@ __device__ __forceinline__ float l2_rows8_reduce_scatter(float (&a)[8]) {
 #ifndef NANN_SCORE_U
 #define NANN_SCORE_U 8
 #endif
+#ifndef NANN_SCORE_ROLL
+#define NANN_SCORE_ROLL 1  // 0: load a batch - wait - compute it (the loop up to the middle of round 5)
+#endif
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
 // inside, so a subset of the workgroup can run it.
@@ -1180,6 +1183,52 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
         }
       };
       auto widen = [&](int32_t id) -> int32_t { return NEAR ? (int32_t)__umul24((uint32_t)id, kRowBytes) : id; };
+#if NANN_SCORE_ROLL
+      // Rolling refill: a slot's next row is requested as soon as its 8 terms are summed, so a batch's loads travel
+      // underneath the rest of the previous batch's arithmetic, the reduce-scatter and the store instead of behind them (the
+      // loop used to be load 8 - wait - compute 8: with the lean arithmetic of round 5 the waiting was most of it).  ids are
+      // fetched two batches ahead; the last batch refills nothing.
+      auto ids_of = [&](int at) -> int32_t { return widen(ids[min(at + mine_at, end - 1)]); };  // past `end`: candidate end-1, dropped
+      int32_t idv = ids_of(begin);
+      uint4 ch[U];
+      ch[0] = row(dpp_i32<0x150>(idv));
+      ch[1] = row(dpp_i32<0x151>(idv));
+      ch[2] = row(dpp_i32<0x152>(idv));
+      ch[3] = row(dpp_i32<0x153>(idv));
+      ch[4] = row(dpp_i32<0x154>(idv));
+      ch[5] = row(dpp_i32<0x155>(idv));
+      ch[6] = row(dpp_i32<0x156>(idv));
+      ch[7] = row(dpp_i32<0x157>(idv));
+      idv = ids_of(begin + RPI * U);
+      auto lane_sum = [&](const uint4& c) -> float { return DT == DT_F16 ? l2_lane_f16(q, c) : l2_lane_bf16(q, c); };
+      auto finish = [&](float (&s)[U], int i0) {
+        float mine = l2_rows8_reduce_scatter(s);
+        if constexpr (LPR >= 32) mine = mine + __shfl_xor(mine, 16);
+        if constexpr (LPR >= 64) mine = mine + __shfl_xor(mine, 32);
+        const int i = i0 + out_at;
+        if (sub < U && i < end) scores[i] = 0.0f - mine;
+      };
+      int i0 = begin;
+      for (; i0 + RPI * U < end; i0 += RPI * U) {
+        const int32_t idn = ids_of(i0 + 2 * RPI * U);
+        float s[U];
+#define NANN_ROLL_SLOT(u, ctrl)                 \
+        s[u] = lane_sum(ch[u]);                     \
+        ch[u] = row(dpp_i32<ctrl>(idv));            \
+        __builtin_amdgcn_sched_barrier(0);
+        NANN_ROLL_SLOT(0, 0x150) NANN_ROLL_SLOT(1, 0x151) NANN_ROLL_SLOT(2, 0x152) NANN_ROLL_SLOT(3, 0x153)
+        NANN_ROLL_SLOT(4, 0x154) NANN_ROLL_SLOT(5, 0x155) NANN_ROLL_SLOT(6, 0x156) NANN_ROLL_SLOT(7, 0x157)
+#undef NANN_ROLL_SLOT
+        finish(s, i0);
+        idv = idn;
+      }
+      {
+        float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = lane_sum(ch[u]);
+        finish(s, i0);
+      }
+#else
       int32_t idv = widen(ids[min(begin + mine_at, end - 1)]);  // positions past `end` re-read candidate end-1, result dropped
       for (int i0 = begin; i0 < end; i0 += RPI * U) {
         uint4 ch[U];
@@ -1201,6 +1250,7 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
         const int i = i0 + out_at;
         if (sub < U && i < end) scores[i] = 0.0f - mine;
       }
+#endif
     };
     if (near) run(std::true_type{}); else run(std::false_type{});
     return;

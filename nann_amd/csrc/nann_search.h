@@ -2,6 +2,12 @@
 // helper, shared by the translation units that instantiate it (nann_hip.hip: L2 scorer;
 // nann_mlp_inst.hip: MLP scorer, one object per embedding dim so they compile in parallel).
 #pragma once
+#ifndef NANN_REPEAT_SCORE
+#define NANN_REPEAT_SCORE 0  // measurement builds only
+#endif
+#ifndef NANN_REPEAT_TOPK
+#define NANN_REPEAT_TOPK 0
+#endif
 #include <type_traits>
 #include "../../include/nann_hip.h"
 #include "nann_device.h"
@@ -420,6 +426,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       if constexpr (!PHASED) {
       if constexpr (SC == NANN_SCORER_L2) {
         wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, 0, sc_n, qv, sc_out, tid >> 6, (unsigned long long)a.n_items * (unsigned)(a.d * 2) <= 0xffffffffull && a.n_items <= (1u << 24));
+#if NANN_REPEAT_SCORE  // measurement builds (tools/build_res_variant.py --unit nann_l2_inst.hip): a phase run twice costs what it costs once
+        for (int rep = 0; rep < NANN_REPEAT_SCORE; ++rep) {
+          __syncthreads();
+          wg_score_l2_part<LPR, DT, NT / 64>(a.emb, a.d, sc_ids, 0, sc_n, qv, sc_out, tid >> 6, (unsigned long long)a.n_items * (unsigned)(a.d * 2) <= 0xffffffffull && a.n_items <= (1u << 24));
+        }
+#endif
         if (lds_scores != nullptr) {
           __syncthreads();
           for (int i = tid; i < sc_n && base_off + i < kLdsScores; i += NT)  // LDS mirror for the selection
@@ -535,6 +547,13 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
       tk_map = a.item_ids; tk_out_map = a.out_ids + (size_t)qi * k5;
     }
     mark(PH_OTHER);
+#if NANN_REPEAT_TOPK
+    for (int rep = 0; rep < NANN_REPEAT_TOPK; ++rep) {
+      (void)wg_topk<NT>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
+                        nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch, pt);
+      __syncthreads();
+    }
+#endif
     const int st = wg_topk<NT>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
                                nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch, pt);
     mark(PH_TOPK);
