@@ -1137,6 +1137,9 @@ __device__ __forceinline__ float l2_rows8_reduce_scatter(float (&a)[8]) {
 #ifndef NANN_SCORE_U
 #define NANN_SCORE_U 8
 #endif
+#ifndef NANN_SCORE_NT
+#define NANN_SCORE_NT 0
+#endif
 #ifndef NANN_SCORE_ROLL
 #define NANN_SCORE_ROLL 1  // 0: load a batch - wait - compute it (the loop up to the middle of round 5)
 #endif
@@ -1177,7 +1180,13 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
       //  16 bytes of the row -- one vector instruction per row address)
       auto row = [&](int32_t v) -> uint4 {
         if constexpr (NEAR) {
+#if NANN_SCORE_NT  // measurement builds: the rows as non-temporal loads (a row is read once per query)
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          const u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(static_cast<const unsigned char*>(table) + ((uint32_t)v | ((uint32_t)sub * 16u))));
+          return uint4{r.x, r.y, r.z, r.w};
+#else
           return *reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(table) + ((uint32_t)v | ((uint32_t)sub * 16u)));
+#endif
         } else {
           return load_chunk<DT>(table, (size_t)v, d, sub).a;
         }
