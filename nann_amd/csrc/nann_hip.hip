@@ -2059,7 +2059,10 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
                                                         t[1] + (double)ix->max_deg[0] * rows_walked)
                                              : est_guess;
   // the 16K / 32K-slot set holds 16320 / 32704 ids; a measured estimate may come closer to that than a guessed one
-  const double fit16 = ix->probe_valid ? 13500.0 : 11000.0, fit32 = ix->probe_valid ? 28000.0 : 24000.0;
+  // (measured estimate: up to ~92 % of the capacity a set really has since a filling set cuts its pieces -- 16 256 / 32 640
+  //  less the 512 below which a query is handed back; ef = 192 on the shipped graph, estimate 14.7 k: 1.72 M q/s on the 16K plan
+  //  with no rerun against 1.47 M on the 32K plan, profiles/rd5ag_planner_thresholds.txt)
+  const double fit16 = ix->probe_valid ? 15000.0 : 11000.0, fit32 = ix->probe_valid ? 30500.0 : 24000.0;
   const double worst_visited = t[1] + (double)ix->max_deg[0] * ((double)t[1] + t[2] + t[3]);
   const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512, 16384>() + tail;
   const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT, 32768>() + tail;
