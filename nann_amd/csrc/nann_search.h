@@ -504,6 +504,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
           wg_mlp_res_vectors<NT>(a.mlp, mlp_u, V);
           __syncthreads();
           wg_score_mlp_res<NT>(a.proj, a.n_items, sc_ids, sc_n, lds0, V, sc_out);
+#if NANN_REPEAT_SCORE
+          for (int rep = 0; rep < NANN_REPEAT_SCORE; ++rep) {
+            __syncthreads();
+            wg_score_mlp_res<NT>(a.proj, a.n_items, sc_ids, sc_n, lds0, V, sc_out);
+          }
+#endif
         }
         __syncthreads();
         wg_mlp_res_leave<NT>(lds0, park, SLOTS / 4);
