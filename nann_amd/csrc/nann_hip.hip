@@ -2062,7 +2062,12 @@ static int plan_search(const nann_index* ix, const int32_t t[6], int64_t n_queri
   // (measured estimate: up to ~92 % of the capacity a set really has since a filling set cuts its pieces -- 16 256 / 32 640
   //  less the 512 below which a query is handed back; ef = 192 on the shipped graph, estimate 14.7 k: 1.72 M q/s on the 16K plan
   //  with no rerun against 1.47 M on the 32K plan, profiles/rd5ag_planner_thresholds.txt)
-  const double fit16 = ix->probe_valid ? 15000.0 : 11000.0, fit32 = ix->probe_valid ? 30500.0 : 24000.0;
+  // Beyond 2^20 items the entries are (tag, probe step) pairs and a probe sequence may be 62 steps long at most (longer: the
+  // query is rerun); at a load of 0.92 that is 0.5 % PER INSERT, at 0.80 below 1e-6 -- such shards plan with 0.80 of the set
+  // (test_a_set_that_fills_up_cuts_its_pieces: tag sets ending at 0.87 / 0.96 load rerun 1 / 12 of 12 queries).
+  const bool tag_entries = id_bits > 20;
+  const double fit16 = !ix->probe_valid ? 11000.0 : tag_entries ? 13000.0 : 15000.0;
+  const double fit32 = !ix->probe_valid ? 24000.0 : tag_entries ? 26000.0 : 30500.0;
   const double worst_visited = t[1] + (double)ix->max_deg[0] * ((double)t[1] + t[2] + t[3]);
   const size_t hash16_lds = (size_t)vis_slots(VIS_LDS_HASH) * 4 + hash_phase_scratch<512, 16384>() + tail;
   const size_t hash32_lds = (size_t)vis_slots(VIS_LDS_HASH32) * 4 + hash_phase_scratch<kNT, 32768>() + tail;
