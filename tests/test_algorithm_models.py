@@ -8,7 +8,9 @@ that a change to the device code's logic can be tried here first:
 * wg_expand_hash's positional hash set: the same scan with the visited set as an open-addressing
   table of (id << PB | position) entries, CAS to claim, ds_min to keep the first occurrence;
 * wg_topk_impl's radix search for the k-th largest key on key - min(key) (the shipped form) and on
-  raw keys with the common prefix skipped (the form it replaced)."""
+  raw keys with the common prefix skipped (the form it replaced);
+* l2_rows8_reduce_scatter -- the L2 scorer's xor butterfly over the 16 lanes of a DPP row for eight rows at once as a
+  reduce-scatter (round 5): instruction by instruction as the asm block issues them, against the butterfly, bit for bit."""
 import numpy as np
 import pytest
 
@@ -281,3 +283,70 @@ def test_hash_set_tag_is_a_bijection():
         for k in (0, 1, 5, 62):
             slot = (h + k * t.stride(r)) % t.slots
             assert t.decode(slot, (((r << t.sb) | k) << t.pb) | 3) == x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# l2_rows8_reduce_scatter (nann_device.h): v_cndmask_b32 dst = vcc ? src1 : src0; v_add_f32_dpp dst = dpp(src0) + src1.
+
+def _dpp(src, kind):
+    lanes = np.arange(len(src))
+    if kind == "xor1":
+        return src[(lanes & ~3) | np.array([1, 0, 3, 2])[lanes & 3]]
+    if kind == "xor2":
+        return src[(lanes & ~3) | np.array([2, 3, 0, 1])[lanes & 3]]
+    if kind == "half_mirror":
+        return src[(lanes & ~7) | (7 - (lanes & 7))]
+    if kind == "mirror":
+        return src[(lanes & ~15) | (15 - (lanes & 15))]
+    raise ValueError(kind)
+
+
+def _lane_mask(m32, n_lanes=64):
+    m = m32 | (m32 << 32)
+    return np.array([(m >> l) & 1 for l in range(n_lanes)], bool)
+
+
+def _butterfly(x):
+    for kind in ("xor1", "xor2", "half_mirror", "mirror"):
+        x = (x + _dpp(x, kind)).astype(np.float32)
+    return x
+
+
+def _rows8_reduce_scatter(p):
+    """p[u][lane]: the asm block of l2_rows8_reduce_scatter, one numpy statement per instruction."""
+    a = [p[u].copy() for u in range(8)]
+    t = [None] * 4
+    vcc = _lane_mask(0x5A5A5A5A)  # b0 ^ b2
+    for k in range(4):
+        t[k] = np.where(vcc, a[2 * k + 1], a[2 * k])          # v_cndmask t, a_even, a_odd   (kept)
+        a[2 * k] = np.where(vcc, a[2 * k], a[2 * k + 1])      # v_cndmask a_even, a_odd, a_even (sent)
+    for k in range(4):
+        t[k] = (_dpp(a[2 * k], "xor1") + t[k]).astype(np.float32)
+    vcc = _lane_mask(0x3C3C3C3C)  # b1 ^ b2
+    a[1] = np.where(vcc, t[0], t[1])
+    a[3] = np.where(vcc, t[2], t[3])
+    a[0] = np.where(vcc, t[1], t[0])
+    a[2] = np.where(vcc, t[3], t[2])
+    a[0] = (_dpp(a[1], "xor2") + a[0]).astype(np.float32)
+    a[2] = (_dpp(a[3], "xor2") + a[2]).astype(np.float32)
+    vcc = _lane_mask(0x0FF00FF0)  # b2 ^ b3
+    t[0] = np.where(vcc, a[0], a[2])
+    t[1] = np.where(vcc, a[2], a[0])
+    t[1] = (_dpp(t[0], "half_mirror") + t[1]).astype(np.float32)
+    return (_dpp(t[1], "mirror") + t[1]).astype(np.float32)
+
+
+def test_rows8_reduce_scatter_is_the_butterfly_bit_for_bit():
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        p = (rng.standard_normal((8, 64)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32) ** 2
+        got = _rows8_reduce_scatter(p)
+        ref = [_butterfly(p[u]) for u in range(8)]
+        for lane in range(64):
+            s = lane & 15
+            b0, b1, b2, b3 = s & 1, (s >> 1) & 1, (s >> 2) & 1, (s >> 3) & 1
+            u = ((b2 ^ b3) << 2) | ((b1 ^ b2) << 1) | (b0 ^ b2)
+            assert got[lane].view(np.uint32) == ref[u][lane].view(np.uint32), (trial, lane, u)
+            if s < 8:  # the lanes that store: wg_score_l2_part's out_at
+                assert u == (s & 7) ^ (3 if s & 4 else 0)
+        assert sorted(((l & 7) ^ (3 if l & 4 else 0)) for l in range(8)) == list(range(8))
