@@ -112,20 +112,6 @@ template <int CTRL>
 __device__ __forceinline__ int32_t dpp_i32(int32_t v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
-// lanes with lane % LPR == U take `v`, the others keep `keep`: v_cndmask against a constant lane mask that two scalar moves
-// put into vcc on the spot (a comparison per use would cost the vector instruction this saves; as an "s" operand the
-// compiler hoists the eight masks out of the loop and, short of scalar registers, parks them in vector lanes)
-template <int LPR, int U>
-__device__ __forceinline__ float lane_pick(float keep, float v) {
-  constexpr unsigned long long one = LPR == 64 ? 1ull : LPR == 32 ? 0x0000000100000001ull : LPR == 16 ? 0x0001000100010001ull
-                                     : LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
-  static_assert(U < LPR, "one lane of the row's group per value");
-  constexpr unsigned long long m = one << U;
-  float r;
-  asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc"
-      : "=v"(r) : "v"(keep), "v"(v), "i"((int)(uint32_t)(m & 0xffffffffull)), "i"((int)(uint32_t)(m >> 32)) : "vcc");
-  return r;
-}
 
 // ---------------------------------------------------------------------------
 // optional per-phase time attribution (thread 0 only; off unless a buffer is given)
@@ -1140,9 +1126,6 @@ __device__ __forceinline__ float l2_rows8_reduce_scatter(float (&a)[8]) {
 #ifndef NANN_SCORE_NT
 #define NANN_SCORE_NT 0
 #endif
-#ifndef NANN_SCORE_ROLL
-#define NANN_SCORE_ROLL 1  // 0: load a batch - wait - compute it (the loop up to the middle of round 5)
-#endif
 // wg_score_l2_part: scores[i] = -||q - table[ids[i]]||^2 for begin <= i < end, computed by
 // NWAVES wavefronts of the workgroup (this one is number wave_rel among them).  No barriers
 // inside, so a subset of the workgroup can run it.
@@ -1192,10 +1175,9 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
         }
       };
       auto widen = [&](int32_t id) -> int32_t { return NEAR ? (int32_t)__umul24((uint32_t)id, kRowBytes) : id; };
-#if NANN_SCORE_ROLL
       // Rolling refill: a slot's next row is requested as soon as its 8 terms are summed, so a batch's loads travel
       // underneath the rest of the previous batch's arithmetic, the reduce-scatter and the store instead of behind them (the
-      // loop used to be load 8 - wait - compute 8: with the lean arithmetic of round 5 the waiting was most of it).  ids are
+      // loop used to be load 8 - wait - compute 8; A/B on one box: +1.3 %, profiles/rd5ad_phase_repeat_and_rolling.txt).  ids are
       // fetched two batches ahead; the last batch refills nothing.
       auto ids_of = [&](int at) -> int32_t { return widen(ids[min(at + mine_at, end - 1)]); };  // past `end`: candidate end-1, dropped
       int32_t idv = ids_of(begin);
@@ -1237,29 +1219,6 @@ __device__ __forceinline__ void wg_score_l2_part(const void* __restrict__ table,
         for (int u = 0; u < U; ++u) s[u] = lane_sum(ch[u]);
         finish(s, i0);
       }
-#else
-      int32_t idv = widen(ids[min(begin + mine_at, end - 1)]);  // positions past `end` re-read candidate end-1, result dropped
-      for (int i0 = begin; i0 < end; i0 += RPI * U) {
-        uint4 ch[U];
-        ch[0] = row(dpp_i32<0x150>(idv));
-        ch[1] = row(dpp_i32<0x151>(idv));
-        ch[2] = row(dpp_i32<0x152>(idv));
-        ch[3] = row(dpp_i32<0x153>(idv));
-        ch[4] = row(dpp_i32<0x154>(idv));
-        ch[5] = row(dpp_i32<0x155>(idv));
-        ch[6] = row(dpp_i32<0x156>(idv));
-        ch[7] = row(dpp_i32<0x157>(idv));
-        idv = widen(ids[min(i0 + RPI * U + mine_at, end - 1)]);  // the next batch's, underneath the row loads
-        float s[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = DT == DT_F16 ? l2_lane_f16(q, ch[u]) : l2_lane_bf16(q, ch[u]);
-        float mine = l2_rows8_reduce_scatter(s);
-        if constexpr (LPR >= 32) mine = mine + __shfl_xor(mine, 16);
-        if constexpr (LPR >= 64) mine = mine + __shfl_xor(mine, 32);
-        const int i = i0 + out_at;
-        if (sub < U && i < end) scores[i] = 0.0f - mine;
-      }
-#endif
     };
     if (near) run(std::true_type{}); else run(std::false_type{});
     return;
