@@ -17,6 +17,12 @@
 //     together.
 // top_k_per_level / topk_eval up to kEvalMaxK = 2048 (the reference's are defaults, config.py:50-58).
 #pragma once
+#ifndef NANN_REPEAT_SCORE
+#define NANN_REPEAT_SCORE 0  // measurement builds only
+#endif
+#ifndef NANN_REPEAT_TOPK
+#define NANN_REPEAT_TOPK 0
+#endif
 #include "nann_search.h"
 
 namespace nann {
@@ -284,8 +290,16 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
         continue;
       }
       eval_score<LPR, DT, SC, NT>(a, qi, sv.cat_ids + n_res, n_next, sv.cat_sc + n_res, scratch, qv, mlp_u);  // :323
+#if NANN_REPEAT_SCORE  // measurement builds (tools/build_res_variant.py --unit nann_eval_inst.hip): a phase run twice costs what it costs once
+      eval_score<LPR, DT, SC, NT>(a, qi, sv.cat_ids + n_res, n_next, sv.cat_sc + n_res, scratch, qv, mlp_u);
+#endif
       const int n_cat = n_res + n_next;
       const int k = min(a.top_k[level], n_cat);
+#if NANN_REPEAT_TOPK
+      (void)wg_topk<NT, kEvalMaxK>(sv.cat_ids, sv.cat_sc, nullptr, n_cat, k, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr,
+                                  scratch);
+      __syncthreads();
+#endif
       st = wg_topk<NT, kEvalMaxK>(sv.cat_ids, sv.cat_sc, nullptr, n_cat, k, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr,
                                   scratch);  // :326-328
       if (st) return st;
