@@ -107,6 +107,8 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, EvalScanScratch* S,
   return base + inc - v;
 }
 
+constexpr int kEvalOwned = 32;  // words of a bitmap one thread owns when `seen` is in LDS (eval_plan: bm_words <= threads x this)
+
 __device__ __forceinline__ uint32_t ld_word(const uint32_t* p) {  // past the L1: the word is changed by atomics performed in L2
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -237,12 +239,31 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       __syncthreads();
       if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
       // ---- new = seen & ~visited, counted per owner ...
+      // (round 5) With `seen` in LDS a thread owns at most kEvalOwned words: its words of `visited` are fetched HERE, all at
+      // once, and serve both passes below.  The passes used to read visited[w] inside `if (s)`, one dependent L2 round trip
+      // per trip of a wavefront and pass -- 2 x 31 of them per round, which was most of this kernel's time.
+      uint32_t visw[kEvalOwned];
+      if constexpr (SEEN_LDS) {
+#pragma unroll
+        for (int j = 0; j < kEvalOwned; ++j) {
+          const uint32_t w = w0 + 64u * j;
+          visw[j] = (j < J && w < a.bm_words) ? sv.visited[w] : 0u;
+        }
+      }
       uint32_t cnt = 0;
-      for (int j = 0; j < J; ++j) {
-        const uint32_t w = w0 + 64u * j;
-        if (w < a.bm_words) {
-          const uint32_t s = seen_load(w);
-          if (s) cnt += (uint32_t)__popc(s & ~sv.visited[w]);
+      if constexpr (SEEN_LDS) {
+#pragma unroll
+        for (int j = 0; j < kEvalOwned; ++j) {
+          const uint32_t w = w0 + 64u * j;
+          if (j < J && w < a.bm_words) cnt += (uint32_t)__popc(seen[w] & ~visw[j]);
+        }
+      } else {
+        for (int j = 0; j < J; ++j) {
+          const uint32_t w = w0 + 64u * j;
+          if (w < a.bm_words) {
+            const uint32_t s = seen_load(w);
+            if (s) cnt += (uint32_t)__popc(s & ~sv.visited[w]);
+          }
         }
       }
       const uint32_t wtot = wave_total(wave_scan_add(cnt));
@@ -260,18 +281,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       // ---- ... and written out in word order = ascending ids (:316-319); visited |= new (:321), seen = 0
       {
         int32_t* dst = sv.cat_ids + n_res;
-        for (int j = 0; j < J; ++j) {
-          const uint32_t w = w0 + 64u * j;
-          uint32_t nw = 0;
-          if (w < a.bm_words) {
-            const uint32_t s = seen_load(w);
-            if (s) {
-              const uint32_t vis = sv.visited[w];
-              nw = s & ~vis;
-              sv.visited[w] = vis | s;
-              seen[w] = 0u;
-            }
-          }
+        auto emit_word = [&](uint32_t w, uint32_t nw) {
           const uint32_t c = (uint32_t)__popc(nw);
           const uint32_t inc = wave_scan_add(c);
           uint32_t at = run + inc - c;
@@ -281,6 +291,38 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
             dst[at++] = (int32_t)(w * 32u + (uint32_t)b);
           }
           run += wave_total(inc);
+        };
+        if constexpr (SEEN_LDS) {
+#pragma unroll
+          for (int j = 0; j < kEvalOwned; ++j) {
+            if (j >= J) break;  // (uniform)
+            const uint32_t w = w0 + 64u * j;
+            uint32_t nw = 0;
+            if (w < a.bm_words) {
+              const uint32_t s = seen[w];
+              if (s) {
+                nw = s & ~visw[j];
+                sv.visited[w] = visw[j] | s;
+                seen[w] = 0u;
+              }
+            }
+            emit_word(w, nw);
+          }
+        } else {
+          for (int j = 0; j < J; ++j) {
+            const uint32_t w = w0 + 64u * j;
+            uint32_t nw = 0;
+            if (w < a.bm_words) {
+              const uint32_t s = seen_load(w);
+              if (s) {
+                const uint32_t vis = sv.visited[w];
+                nw = s & ~vis;
+                sv.visited[w] = vis | s;
+                seen[w] = 0u;
+              }
+            }
+            emit_word(w, nw);
+          }
         }
       }
       __syncthreads();
