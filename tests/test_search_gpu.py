@@ -354,7 +354,7 @@ def test_cpp_serving_host_with_a_model(oracle, tmp_path, kind):
 
 @pytest.mark.parametrize("mode", ["lds_hash", "lds_bitmap"])
 @pytest.mark.parametrize("d,dtype,ef,k", [(256, "bf16", 64, 40), (64, "f32", 32, 20), (256, "f16", 48, 30),
-                                          (128, "bf16", 256, 200), (512, "f16", 32, 20), (512, "f32", 32, 20)])
+                                          (128, "bf16", 256, 200), (512, "f16", 32, 20), (512, "f32", 32, 20), (512, "bf16", 32, 20)])
 def test_search_row_dtypes_and_dims(oracle, d, dtype, ef, k, mode):
     """bf16 / f32 rows, 256-d (BASELINE configs[4] shape: 256-d bf16, ef_search=256) and the widest rows the library takes
     (512-d: 64 lanes per row) through the fused traversal."""
