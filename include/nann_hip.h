@@ -286,6 +286,25 @@ int nann_model_workspace_bytes(const nann_model* m, int64_t* nbytes);
 int nann_model_forward(const nann_model* m, const void* user_seq_f16, const void* item_emb, int64_t n,
                        float* logits, void* workspace, nann_stream_t stream);
 
+/* BlazeXlaOp's `blaze_option_path` attr as BlazeXlaOp::ParseAttr reads it (UO/blaze_op/blaze_xla_kernel.cc:156-167): first
+ * as the PATH of a text-format BlazeKernelOptions file (core/protobuf/config.proto:805-841; NANN_impls/nann/delivery/
+ * opt_default.conf is the one build_opt_graph.py:104 passes), then the attr STRING ITSELF as text format; neither ->
+ * NANN_ERR_IO "parse proto from ... failed" (the reference: errors::Internal).  A top-level field the message does not
+ * have fails the parse, as protobuf's TextFormat does.  What the MI355X op acts on: wait_ms (admission deadline,
+ * blaze_xla_kernel.cc:221-258) and run_mode (SKIP, :183-205); the rest is reported for the host's log.  attr [host]. */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t wait_ms;
+  int32_t run_mode;               /* 0 DEFAULT, 1 BENCHMARK, 2 SKIP */
+  int32_t xla_compilation;
+  int32_t auto_mixed_precision;
+  int32_t disable_output_padding;
+  int32_t n_warmup_batchsize;     /* entries of warmup_batchsize (no warm-up here: rows are scored as they come) */
+  int32_t max_warmup_batchsize;
+  int32_t from_file;              /* 1: the attr named a readable file; 0: the attr string was the message */
+} nann_blaze_options;
+int nann_blaze_options_parse(const char* attr, nann_blaze_options* out);
+
 /* ---- a6 + a7: resident index and the fused traversal -----------------------
  * The index is what the serving graph's HugeConst nodes hold
  * (build_opt_graph.py:83-90, 70): item_embs [N,d], item_ids i64[N], per level

@@ -6,6 +6,7 @@
 #include <iterator>
 
 #include "nann_graphdef_text.h"
+#include "nann_blaze_options.h"
 
 extern "C" {
 
@@ -59,6 +60,22 @@ int nann_graphdef_dump(const char* path, int32_t format, char* out, int64_t cap,
   const std::string js = nann_gd::graph_to_json(g);
   if (need) *need = (int64_t)js.size() + 1;
   if (out && cap >= (int64_t)js.size() + 1) std::memcpy(out, js.c_str(), js.size() + 1);
+  return 0;
+}
+
+// BlazeXlaOp's blaze_option_path attr (nann_blaze_options.h), as nann_blaze_options_parse of libnann_hip.so reads it.
+// out[8] = {wait_ms, run_mode, xla_compilation, auto_mixed_precision, disable_output_padding, n_warmup_batchsize,
+// max_warmup_batchsize, from_file}.  Returns 0, or 1 with a message in err.
+int nann_host_blaze_options(const char* attr, int32_t out[8], char* err, int32_t err_len) {
+  nann_gd::BlazeOptions o;
+  std::string msg;
+  if (!nann_gd::parse_blaze_options_attr(attr ? attr : "", &o, &msg)) {
+    if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", msg.c_str());
+    return 1;
+  }
+  const int32_t v[8] = {o.wait_ms, o.run_mode, o.xla_compilation, o.auto_mixed_precision, o.disable_output_padding,
+                        o.n_warmup_batchsize, o.max_warmup_batchsize, o.from_file};
+  std::memcpy(out, v, sizeof(v));
   return 0;
 }
 

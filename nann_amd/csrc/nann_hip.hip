@@ -4,6 +4,7 @@
 #include "nann_eval.h"
 #include "nann_attn.h"
 #include "host/nann_graphdef_text.h"
+#include "host/nann_blaze_options.h"
 #include "host/nann_projcache.h"
 
 #include <algorithm>
@@ -1842,6 +1843,22 @@ int nann_model_load(const char* dir, int32_t d, int32_t emb_dtype, int32_t seq_l
   }
   if (rc) { nann_model_destroy(m); return rc; }
   *out = m;
+  return NANN_OK;
+}
+
+// BlazeXlaOp.blaze_option_path as BlazeXlaOp::ParseAttr reads it (blaze_xla_kernel.cc:156-167): a text-format
+// BlazeKernelOptions file, else the attr string itself as text format (host/nann_blaze_options.h).
+int nann_blaze_options_parse(const char* attr, nann_blaze_options* out) {
+  if (!attr || !out) return fail(NANN_ERR_BAD_ARGUMENT, "nann_blaze_options_parse: null argument");
+  nann_gd::BlazeOptions o;
+  std::string msg;
+  if (!nann_gd::parse_blaze_options_attr(attr, &o, &msg)) return fail(NANN_ERR_IO, msg);
+  nann_blaze_options r = {};
+  r.struct_bytes = (int32_t)sizeof(nann_blaze_options);
+  r.wait_ms = o.wait_ms; r.run_mode = o.run_mode; r.xla_compilation = o.xla_compilation;
+  r.auto_mixed_precision = o.auto_mixed_precision; r.disable_output_padding = o.disable_output_padding;
+  r.n_warmup_batchsize = o.n_warmup_batchsize; r.max_warmup_batchsize = o.max_warmup_batchsize; r.from_file = o.from_file;
+  *out = r;
   return NANN_OK;
 }
 

@@ -22,7 +22,7 @@ _SRC = os.path.join(_HERE, "csrc", "host", "hnsw_build.cpp")
 _SRCS = [_SRC, os.path.join(_HERE, "csrc", "host", "nann_graphdef_c.cpp"),
          os.path.join(_HERE, "csrc", "host", "nann_projcache_c.cpp")]
 _DEPS = _SRCS + [os.path.join(_HERE, "csrc", "host", "nann_graphdef.h"), os.path.join(_HERE, "csrc", "host", "nann_graphdef_text.h"),
-                 os.path.join(_HERE, "csrc", "host", "nann_projcache.h")]
+                 os.path.join(_HERE, "csrc", "host", "nann_blaze_options.h"), os.path.join(_HERE, "csrc", "host", "nann_projcache.h")]
 _LIB_PATH = os.path.join(_HERE, "_build", "libnann_host.so")
 _LIB = None
 
