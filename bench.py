@@ -72,6 +72,10 @@ def parse():
                          "dry run of the multi-rank flow with every rank on cuda:0, exchange staged through the host)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: rccl = ncclAllGather issued by the C ABI; torch = torch.distributed collectives")
+    ap.add_argument("--replicas", action="store_true",
+                    help="--gpus N as N independent replicas of the single-GPU workload: every rank holds the whole index and "
+                         "answers its own query stream, no collective on the data path -- the reference's only multi-GPU mode "
+                         "(blaze-benchmark/benchmark/core/model.cc:192-235; SURVEY.md 8e 'Replicas')")
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1, rccl transport: run each batch's all-gather + merge on the search stream instead of "
                          "a stream of its own underneath the next batch's search")
@@ -101,6 +105,30 @@ def algorithmic_bytes(counters, d, emb_bytes, n_enter, k_out=200):
     F, G, S = c[..., 0, :], c[..., 1, :], c[..., 2, :]
     base = (S * d * emb_bytes + G * 4 + F * 16).sum(axis=-1) + n_enter * 4 + k_out * 12
     return base + (G * 8).sum(axis=-1), base
+
+
+INFINITY_CACHE_BYTES = 256 << 20
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md "HBM": 8 TB/s spec, ~6.3 TB/s achievable (float4 copy)
+
+
+def what_binds(table_bytes, row_bytes):
+    """Which resource a gather of random `row_bytes` rows out of a `table_bytes` table runs against.
+    Own measurement of that access pattern alone, tools/ubench_gather.hip (profiles/r2a_ubench_gather.txt: random 256-byte
+    rows, nothing else to do): 7.34 TB/s on a 256 MiB table (it lives in the 256 MiB Infinity Cache), 7.19 TB/s on 1 GiB,
+    6.40 TB/s on 4 GiB (HBM's stream rate, the guide's 6.3)."""
+    mib = table_bytes / float(1 << 20)
+    gather = 7339.0 if mib <= 256 else 7190.0 if mib <= 1024 else 6400.0
+    if table_bytes <= INFINITY_CACHE_BYTES:
+        binds = ("vector issue (the probe / scan / select phases and the DPP reductions of the scoring loop); the %.0f MiB row table is "
+                 "resident in the 256 MiB Infinity Cache and the entry rows hit L2, so the algorithmic bytes are served faster than "
+                 "HBM streams: `frac` is a fraction of the 8 TB/s table value, not HBM utilisation" % mib)
+    else:
+        binds = "HBM stream rate (the %.0f MiB row table is %.1fx the Infinity Cache)" % (mib, mib / 256.0)
+    return {"achievable_hbm_GBs": HBM_ACHIEVABLE_GBS,
+            "achievable_gather_GBs": gather,
+            "achievable_source": "MI355X_MICROARCH.md (6.3 TB/s float4 copy); tools/ubench_gather.hip, profiles/r2a_ubench_gather.txt "
+                                 "(random %d-byte rows alone on a table of this size class)" % 256,
+            "table_MiB": round(mib, 1), "table_in_infinity_cache": bool(table_bytes <= INFINITY_CACHE_BYTES), "binds": binds}
 
 
 def _pmc_entry(tag):
@@ -280,7 +308,8 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     precision = cfg.get("mlp_precision", "exact") if scorer_kind == "mlp" else "exact"
     scorer = ops.Scorer(scorer_kind, dim, tdt, weights=mlp_w, precision=precision)
     n_batches = min(steps + warmup, 40)  # (the driver's 3 + 20 steps: every step its own batch; long matrix-core warm-ups wrap around)
-    seqs = make_query_batches(dim, batch, n_batches, args.noise, dev, n_clusters=n_clusters_for(items, ef))
+    seqs = make_query_batches(dim, batch, n_batches, args.noise, dev, seed=cfg.get("query_seed", 4321),
+                              n_clusters=n_clusters_for(items, ef))
     setup_s = time.time() - t0
     retrieval.set_traversal_mode(cfg.get("traversal", "auto"))
 
@@ -290,8 +319,11 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
     timed_comm = sharded is not None and sharded.transport == "rccl" and sharded.comm is not None
     if timed_comm:
         sharded.comm.set_timing(True)  # HIP events around pack | all-gather | merge of every exchange, on the exchange's stream
-    if cfg.get("mlp_form"):
-        sopt = retrieval.search_options(mlp_form=cfg["mlp_form"])
+    if cfg.get("mlp_form"):  # on the options the sharded path made (its slot reserve stays)
+        if sopt is None:
+            sopt = retrieval.search_options(mlp_form=cfg["mlp_form"])
+        else:
+            sopt.mlp_form = retrieval.MLP_FORMS[cfg["mlp_form"]]
 
     def step(j, i=None):
         q = ops.user_seq_mean(seqs[j % n_batches])
@@ -368,10 +400,16 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                 "frac_without_visited_set_bytes": round(float(hbm_b.sum()) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "rows_scored_per_query": round(rows / max(n_valid, 1), 1),
                 "gathered_per_query": round(float(counters[ok][:, 1, :].sum()) / max(n_valid, 1), 1)}
+    roofline.update(what_binds(float(items) * dim * 2, dim * 2))
+    roofline["frac_of_achievable_hbm"] = round(achieved / HBM_ACHIEVABLE_GBS, 4)
     pmc = load_pmc_traffic(name)
     if pmc is not None:
         roofline["traffic"] = pmc["bytes_per_launch"]
         roofline["traffic_source"] = pmc["source"]
+        # fabric-side rate of the COMMITTED counter pass over THIS run's kernel time (the counters cannot be read in-process)
+        roofline["counter_traffic_GBs"] = round(pmc["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
+    else:
+        roofline["counter_traffic_GBs"] = None
     if scorer_kind == "mlp":
         # What the traversal EXECUTES on the matrix cores per scored row (round 4: both precisions run on the table of
         # pre-projected item halves with layer 2 resident in LDS, nann_mlp5.h; without a table -- NANN_PREPROJECT=0, no room in
@@ -435,6 +473,9 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                     "hbm_algorithmic_GBps": round(float(tot_b2.sum()) / (kern_ms * 1e-3) / 1e9, 1),
                     "hbm_bytes_gathered_per_row": row_bytes,
                     "rows_scored_per_query": roofline["rows_scored_per_query"]}
+        roofline.update(what_binds(float(items) * row_bytes, row_bytes))
+        roofline["binds"] = ("neither roofline: vector issue beside the MFMAs at the board's power limit (PReLU + hi/lo split of every "
+                             "activation: ~6 vector instructions per MFMA, DESIGN.md 4.2); " + roofline["binds"])
         pmc = load_pmc_counters(name)
         if pmc is not None:
             roofline["pmc_committed"] = pmc
@@ -444,6 +485,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
         if pmc is not None:
             roofline["traffic"] = pmc["bytes_per_launch"]
             roofline["traffic_source"] = pmc["source"]
+            roofline["counter_traffic_GBs"] = round(pmc["bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
 
     qps = batch * steps / elapsed
     try:  # the planner's choice for the timed calls and how many queries of the last one were rerun on the bitmap kernel
@@ -542,7 +584,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                              "ids_identical": kinds.count("exact"), "near_tie_only": kinds.count("near-tie"),
                              "diverged": kinds.count("diverged"),
                              "max_rel_score_err_on_identical": max(errs) if errs else None}
-        elif world == 1:
+        elif world == 1 or sharded is None:  # one GPU, or a replica (its own whole index): this rank's answers against the oracle
             gi, gs = out[0].cpu().numpy()[sel], out[1].cpu().numpy()[sel]
             okc = st == 0
             res["parity"] = {"queries_checked": int(len(sel)),
@@ -566,7 +608,7 @@ def run_workload(name, args, dev, rank, world, cfg, sharded=None, want_cpu=False
                                  "merged_ids_equal": bool((gi == np.stack(exp_i)).all()),
                                  "merged_scores_bitwise_equal": bool(
                                      (gs.view(np.uint32) == np.stack(exp_s).view(np.uint32)).all())}
-    if want_recall and world == 1:
+    if want_recall and (world == 1 or sharded is None):
         # recall@k of the traversal vs brute force under the same scorer (test_all, main.py:194-237):
         # score ALL items with the device scorer (parity-tested against the oracle) + TopKV2; 16 queries
         hits, nrec = 0, 0
@@ -756,7 +798,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = None
-    if world > 1:
+    replicas = bool(args.replicas) and world > 1
+    if replicas:  # the process group only carries the barriers and the max-over-ranks of the timed region
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("gloo" if args.dist_backend == "gloo" else "nccl", rank=rank, world_size=world,
+                                **({} if args.dist_backend == "gloo" else {"device_id": dev}))
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "gloo":
@@ -783,7 +831,8 @@ def main():
     primary_cfg = {"items": args.items, "dim": args.dim, "ef": args.ef, "topk": args.topk, "batch": args.batch,
                    "steps": args.steps, "warmup": args.warmup, "scorer": args.scorer, "dtype": args.dtype,
                    "graph": args.graph, "traversal": args.traversal, "mlp_precision": args.mlp_precision,
-                   "overlap_exchange": world > 1 and args.transport == "rccl" and not args.no_overlap_exchange}
+                   "overlap_exchange": world > 1 and not replicas and args.transport == "rccl" and not args.no_overlap_exchange,
+                   "query_seed": 4321 + (1000 * rank if replicas else 0)}  # replicas: every rank its own query stream
     is_headline = (args.items == 1_000_000 and args.dim == 128 and args.ef == 128 and args.topk == 200
                    and args.dtype == "f16")
     tag = f"{args.items}x{args.dim}{args.dtype}_ef{args.ef}_k{args.topk}_b{args.batch}_{args.scorer}_{args.graph}"
@@ -802,7 +851,8 @@ def main():
             + ("L2 scoring" if args.scorer == "l2" else "3-layer MLP 256-128-1 scorer on MFMA")
             + (" (BASELINE configs[1])" if is_headline and args.scorer == "l2" else
                " (BASELINE configs[2])" if is_headline else "")
-            + (f", sharded {world}-way as configs[3]" if world > 1 else ""))
+            + (f", {world} independent replicas (no collective)" if replicas else
+               f", sharded {world}-way as configs[3]" if world > 1 else ""))
     result = {
         "metric": "retrieval QPS @ recall@200 parity, 1M items/128-d",
         # whole-job throughput = the units ALL ranks processed per second.  The metric's unit is one query searched over a
@@ -811,7 +861,9 @@ def main():
         # unit only counts once its shard's list has been exchanged and merged into the complete answer (the timed region
         # ends behind the last merge).  Ideal weak scaling: value(N) = N x value(1); the complete answers per second over
         # the N x larger corpus (= value / N, flat under ideal scaling) are under `complete_answers_per_s`.
-        "value": round(qps * world, 1), "unit": "queries/s",
+        # Replicas (--replicas): every rank answers B complete queries per step over the whole index: N x B queries/s, plainly.
+        "value": round(qps * world, 1),
+        "unit": "queries/s" if world == 1 or replicas else "shard-queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": prim["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
@@ -819,16 +871,20 @@ def main():
         "data": "synthetic",
         "config": {"workload": desc, "level_topn": [args.ef] * 5 + [args.topk], "batch": args.batch,
                    "items_total": args.items * world,
-                   "parallelism": f"item-id shards x{world}" if world > 1 else "single GPU",
-                   **({"exchange_overlapped_with_next_search": primary_cfg["overlap_exchange"]} if world > 1 else {}),
-                   "exchange": (f"{args.transport} all-gather + {args.merge} merge" if world > 1 else None)},
+                   "parallelism": (f"replicas x{world} (independent query streams, no collective: the reference's mode, "
+                                   "blaze-benchmark/benchmark/core/model.cc:192-235)" if replicas else
+                                   f"item-id shards x{world}" if world > 1 else "single GPU"),
+                   **({"exchange_overlapped_with_next_search": primary_cfg["overlap_exchange"]} if world > 1 and not replicas else {}),
+                   "exchange": (f"{args.transport} all-gather + {args.merge} merge" if world > 1 and not replicas else None)},
         "qps_end_to_end": qps,
-        "complete_answers_per_s": qps,
-        "weak_scaling": {"units_per_step": args.batch * world, "unit": f"one query searched over one {args.items}-item shard (merged into its complete answer)",
-                         "complete_answers_per_s": qps,
-                         "efficiency_definition": "value(N) / (N x value(1)) = complete_answers_per_s(N) / value(1)"},
+        "complete_answers_per_s": qps * world if replicas else qps,
+        "weak_scaling": ({"units_per_step": args.batch * world, "unit": f"one query answered over the whole {args.items}-item index by one replica",
+                          "complete_answers_per_s": qps * world, "efficiency_definition": "value(N) / (N x value(1))"} if replicas else
+                         {"units_per_step": args.batch * world, "unit": f"one query searched over one {args.items}-item shard (merged into its complete answer)",
+                          "complete_answers_per_s": qps,
+                          "efficiency_definition": "value(N) / (N x value(1)) = complete_answers_per_s(N) / value(1)"}),
     }
-    if world > 1 and exchange_note:
+    if world > 1 and not replicas and exchange_note:
         result["exchange_note"] = exchange_note
     for k in ("valid_queries", "setup_s", "n_enter", "mean_degree_l0", "traversal", "plan", "reruns_last_step", "index_probe",
               "exchange_breakdown_ms", "rccl_ranks_seen", "roofline", "batch_latency_ms",
@@ -859,7 +915,10 @@ def main():
                 # profiles/r4e_power.txt), so these lines warm up for a few hundred ms before the timed steps
                 cfg = dict(primary_cfg, scorer="mlp", mlp_precision=prec, batch=min(args.batch, 1024),
                            steps=40 if prec == "split" else 20, warmup=100 if prec == "split" else 40, _index=prim["_index"])
-                sec[key] = strip(run_workload(tag + "_mlp_" + prec, args, dev, rank, world, cfg,
+                # the tag a direct `--scorer mlp --batch 1024` run has: real batch, real scorer (the PMC entries key on it)
+                mlp_tag = (f"{args.items}x{args.dim}{args.dtype}_ef{args.ef}_k{args.topk}_b{cfg['batch']}_mlp_{args.graph}"
+                           + ("_exact" if prec == "exact" else ""))
+                sec[key] = strip(run_workload(mlp_tag, args, dev, rank, world, cfg,
                                               want_cpu=prec == "split" and not args.no_cpu_baseline,
                                               want_parity=True, want_recall=prec == "split"))
             except Exception as e:

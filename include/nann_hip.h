@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NANN_ABI_VERSION 5
+#define NANN_ABI_VERSION 6
 
 /* status codes; 1..8 share the oracle's numbering (oracle/nann_oracle.h) and
  * map to the TF errors the reference raises at the cited lines */
@@ -328,7 +328,11 @@ int nann_index_create(const nann_index_desc* desc /*[host]*/, nann_index** out);
 void nann_index_destroy(nann_index* ix);
 /* [host] out: n_items, d, n_enter, max row length at level 0 / 1, bitmap words */
 int nann_index_info(const nann_index* ix, int64_t out[6]);
-/* The probe nann_index_create runs on every index of >= 4096 items (round 5): 64 of its own rows as queries, ef = min(64,
+/* nann_index_create note: the probe below makes the call SYNCHRONISE the device (a hipMalloc, one small launch on the NULL
+ * stream, two blocking copies, a hipFree): create indices at start-up, not next to traffic.  NANN_INDEX_PROBE=0 in the
+ * environment skips it (the planner falls back to its estimate from the mean degree).  A probe that fails never fails the
+ * creation and leaves nann_last_error as it found it.
+ * The probe nann_index_create runs on every index of >= 4096 items (round 5): 64 of its own rows as queries, ef = min(64,
  * #enter points), L2 scorer, one small launch -- how many NEW nodes a level-0 round finds per frontier row on THIS graph,
  * which is what sizes a query's visited set (16K-slot hash set, two workgroups per CU; 32K slots, one; bitmap).  The planner
  * uses the measurement in place of rounds 1-4's guess from the mean degree: 1.15 x the 90th percentile of the probe's queries
@@ -362,7 +366,16 @@ int nann_set_search_reserve(int32_t workgroups);
 int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6] /*[host]*/,
                                 int64_t n_queries, int64_t* nbytes);
 
-/* The whole schedule of build_model() (NANN_impls/nann/delivery/
+/* ONE search operation, ONE entry point per query form (ABI v6):
+ *     nann_search_opt        queries as vectors   q f32[n_queries, d]                 (l2 / mlp scorers)
+ *     nann_search_model_opt  queries as comm_seq  f16[n_queries, seq_len, E]          (any model a BlazeXlaOp node names)
+ * Both take per-launch maxima `level_topn_max`, an optional per-query `level_topn` table, per-call options and return the
+ * planner's choice.  The five older spellings below (nann_search, nann_search_v, nann_search_ex, nann_search_model,
+ * nann_search_model_v: rounds 1-5) are DEPRECATED THIN WRAPPERS -- each is one `return` of the canonical call with NULLs in
+ * the places it does not have (tests/test_abi.py asserts that) -- kept so that hosts built against v5 keep linking; new
+ * hosts (csrc/host/nann_serve.cpp, tf_ops/nann_tf_ops.cc, nann_amd/retrieval.py) call the canonical pair only.
+ *
+ * The whole schedule of build_model() (NANN_impls/nann/delivery/
  * build_opt_graph.py:109-149) for n_queries independent
  * queries, persistent workgroups that pull queries from a device-wide queue, visited set in LDS
  * (nann_traversal_mode).
@@ -379,6 +392,7 @@ int nann_search_workspace_bytes(const nann_index* ix, const int32_t level_topn[6
  *   counters     i32[n_queries, 3, NANN_NUM_ROUNDS] (F_r, G_r, S_r per round:
  *                rows walked, neighbours gathered, rows scored) or NULL
  * Asynchronous on `stream`. */
+/* deprecated: thin wrapper of nann_search_opt */
 int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
                 int64_t n_queries, const int32_t level_topn[6], void* workspace,
                 int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
@@ -392,6 +406,7 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
  * Query i returns its level_topn[i][5] results at the head of row i, zeros behind.  An entry outside
  * [0, level_topn_max[j]] fails THAT query with NANN_ERR_BAD_ARGUMENT in status[i]; k > n and the other failures of
  * the reference are per query as before.  Each query's result is bit-identical to a uniform launch with its values. */
+/* deprecated: thin wrapper of nann_search_opt */
 int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
                   const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
                   int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
@@ -404,6 +419,7 @@ int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* 
  * expand per piece: lookup + prefetch, id load wait, insert, barrier, check, rank + store}; NULL
  * disables the instrumentation (nann_search passes NULL). */
 #define NANN_NUM_PHASES 19
+/* deprecated: thin wrapper of nann_search_opt */
 int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float* q,
                    int64_t n_queries, const int32_t level_topn[6], void* workspace,
                    int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores,
@@ -459,12 +475,14 @@ int nann_search_reruns(const void* workspace, int64_t* n_rerun, nann_stream_t st
  * workspace: nann_search_model_workspace_bytes(); other arguments as nann_search. */
 int nann_search_model_workspace_bytes(const nann_index* ix, const nann_model* m, const int32_t level_topn[6],
                                       int64_t n_queries, int64_t* nbytes);
+/* deprecated: thin wrapper of nann_search_model_opt */
 int nann_search_model(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
                       const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
                       int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                       int32_t* counters, nann_stream_t stream);
 
 /* per-query level_topn (nann_search_v) and the table lifecycle (nann_scorer_prepare ...) for a model */
+/* deprecated: thin wrapper of nann_search_model_opt */
 int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
                         const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
                         int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
@@ -558,6 +576,17 @@ int nann_comm_ranks(const nann_comm* c, int32_t* world, int32_t* rccl_ranks);
  * as 8 GPUs' all-gather over xGMI would (~1.5 ms at configs[3]) --, loopback_repeat >= 1 issues the copies that many times. */
 int nann_comm_set_timing(nann_comm* c, int32_t enabled, int32_t loopback_repeat, int32_t loopback_wait_us);
 int nann_comm_last_breakdown(nann_comm* c, float ms[3]);
+/* A dead rank must not hang the node (round 6).  nann_sharded_topk only ENQUEUES; a host that then waits on the stream waits
+ * for ever when a peer never joins the all-gather.  Instead:
+ *   nann_comm_wait   bounded wait for the LAST exchange enqueued on this communicator: polls its completion event next to
+ *                    ncclCommGetAsyncError.  Done -> NANN_OK.  RCCL reports an asynchronous error, or timeout_ms (>= 0; < 0: no
+ *                    deadline) elapse -> the communicator is ABORTED (ncclCommAbort: RCCL's kernels see the flag and leave, so
+ *                    the stream drains) and NANN_ERR_HIP is returned with the reason in nann_last_error.
+ *   nann_comm_abort  the same abort on the host's own decision (a watchdog, a failed health check of a peer).
+ * An aborted communicator fails every later call with NANN_ERR_HIP; the host destroys it and creates a new one with the ranks
+ * that are left.  nann_sharded_topk itself refuses to enqueue on a communicator whose RCCL state already reports an error. */
+int nann_comm_wait(nann_comm* c, int32_t timeout_ms);
+int nann_comm_abort(nann_comm* c);
 int nann_sharded_topk_workspace_bytes(int32_t world, int64_t n_queries, int32_t k_in, int64_t* nbytes);
 int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, const int32_t* status,
                       int64_t n_queries, int32_t k_in, int32_t k_out, void* workspace,

@@ -41,7 +41,7 @@ SYMBOLS = [
     "nann_merge_topk", "nann_merge_topk_host",
     "nann_attn_scorer_create", "nann_attn_scorer_destroy", "nann_attn_prepare", "nann_attn_score",
     "nann_blaze_options_parse", "nann_model_load", "nann_model_destroy", "nann_model_kind", "nann_model_scorer", "nann_model_workspace_bytes", "nann_model_forward",
-    "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_comm_ranks", "nann_comm_set_timing", "nann_comm_last_breakdown", "nann_sharded_topk_workspace_bytes",
+    "nann_comm_get_unique_id", "nann_comm_create", "nann_comm_destroy", "nann_comm_ranks", "nann_comm_set_timing", "nann_comm_last_breakdown", "nann_comm_wait", "nann_comm_abort", "nann_sharded_topk_workspace_bytes",
     "nann_sharded_topk", "nann_hnsw_draw_levels", "nann_hnsw_build_device", "nann_hnsw_build_device_ex",
 ]
 

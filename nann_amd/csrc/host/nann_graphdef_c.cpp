@@ -7,6 +7,7 @@
 
 #include "nann_graphdef_text.h"
 #include "nann_blaze_options.h"
+#include "nann_npy.h"
 
 extern "C" {
 
@@ -76,6 +77,73 @@ int nann_host_blaze_options(const char* attr, int32_t out[8], char* err, int32_t
   const int32_t v[8] = {o.wait_ms, o.run_mode, o.xla_compilation, o.auto_mixed_precision, o.disable_output_padding,
                         o.n_warmup_batchsize, o.max_warmup_batchsize, o.from_file};
   std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+
+// ---- entry points of the parser fuzzers (tests/fuzz/fuzz_parsers.py; libnann_host_asan.so = this file under
+// -fsanitize=address,undefined).  Each runs ONE parser of external bytes on a memory image and everything built on its result,
+// and returns 0 (accepted) / 1 (rejected with a message); a crash, an out-of-bounds read or an overflow is the sanitizer's to report.
+
+// format: 0 = as BlazeXlaOp reads a graph_def (text first, then binary), 1 = binary GraphDef, 2 = binary SavedModel, 3 = text
+int nann_fuzz_graphdef(const uint8_t* data, int64_t n, int32_t format) {
+  nann_gd::Graph g;
+  std::string msg;
+  bool ok = false;
+  if (format == 0) ok = nann_gd::parse_graph_any(data, (size_t)n, &g, &msg);
+  else if (format == 1) ok = nann_gd::parse_graph(data, (size_t)n, &g, &msg);
+  else if (format == 2) ok = nann_gd::parse_saved_model(data, (size_t)n, &g, &msg);
+  else ok = nann_gd::parse_graph_text(reinterpret_cast<const char*>(data), (size_t)n, &g, &msg);
+  if (!ok) return 1;
+  nann_gd::AttnWeights w;
+  (void)nann_gd::extract_attention(g, &w, &msg);  // the weight extraction walks whatever graph was accepted
+  const std::string js = nann_gd::graph_to_json(g);
+  return js.empty() ? 1 : 0;
+}
+
+// the .npy decoder on a file image; *sum = a checksum over the decoded payload (every byte of it is read)
+int nann_fuzz_npy(const uint8_t* data, int64_t n, int32_t expect_dtype, int32_t allow_cast, const int64_t* expect_shape,
+                  int32_t expect_rank, uint64_t* sum, char* err, int32_t err_len) {
+  const unsigned char* payload = nullptr;
+  size_t bytes = 0;
+  std::vector<char> conv;
+  std::vector<int64_t> shape;
+  std::string msg;
+  const int rc = nann_npy::decode(data, (size_t)n, expect_dtype, expect_shape, expect_rank, allow_cast != 0, &payload, &bytes, &conv, &shape, &msg);
+  if (rc) {
+    if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", msg.c_str());
+    return rc;
+  }
+  uint64_t s = 1469598103934665603ull;
+  for (size_t i = 0; i < bytes; ++i) s = (s ^ payload[i]) * 1099511628211ull;
+  for (int64_t d : shape) s = (s ^ (uint64_t)d) * 1099511628211ull;
+  if (sum) *sum = s;
+  return 0;
+}
+
+int nann_fuzz_blaze_options(const char* data, int64_t n) {
+  nann_gd::BlazeOptions o;
+  std::string msg;
+  return nann_gd::parse_blaze_options_text(data, (size_t)n, &o, &msg) ? 0 : 1;
+}
+
+// what HugeConst's loader makes of a FILE (the CPU tests of npy 2.0 / Fortran order / truncation: no GPU needed).
+// shape[32], *rank, *payload_bytes; returns the nann_status nann_huge_const_load would return, message in err.
+int nann_host_npy_info(const char* path, int32_t expect_dtype, int32_t allow_cast, int64_t* shape, int32_t* rank,
+                       int64_t* payload_bytes, char* err, int32_t err_len) {
+  std::ifstream f(path, std::ifstream::binary);
+  if (!f) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "Fail to open file: %s", path); return nann_npy::kIo; }
+  const std::string image((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const unsigned char* payload = nullptr;
+  size_t bytes = 0;
+  std::vector<char> conv;
+  std::vector<int64_t> sh;
+  std::string msg;
+  const int rc = nann_npy::decode(reinterpret_cast<const unsigned char*>(image.data()), image.size(), expect_dtype, nullptr, 0, allow_cast != 0,
+                                  &payload, &bytes, &conv, &sh, &msg);
+  if (rc) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", msg.c_str()); return rc; }
+  if (rank) *rank = (int32_t)sh.size();
+  for (size_t i = 0; i < sh.size() && i < 32 && shape; ++i) shape[i] = sh[i];
+  if (payload_bytes) *payload_bytes = (int64_t)bytes;
   return 0;
 }
 

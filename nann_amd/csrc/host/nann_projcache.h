@@ -116,6 +116,10 @@ struct ProjCacheT {
   template <class Build>
   int acquire(uint64_t uid, size_t bytes, bool enabled, bool pin, Build build, Ref* out) {
     out->reset();
+    // a call that runs WITHOUT tables (nann_search_options.preprojection = 0) gets none, whatever is cached or pinned for the
+    // pair -- before the hit lookup and without touching pins or use order (it used to find a cached table and run
+    // on it, so the call's arithmetic depended on what earlier calls had left behind)
+    if (!enabled && !pin) return 0;
     std::unique_lock<std::mutex> lk(mu);
     Ref tab;
     for (;;) {

@@ -242,4 +242,33 @@ int nann_projcache_slow_build(int32_t build_ms, int32_t n_hits, int64_t out[4]) 
   return 0;
 }
 
+// a call that asks for NO table (nann_search_options.preprojection = 0) must not get the one an earlier call
+// cached for the pair.  A table for index 1 is built; a disabled acquire then returns none (and builds none), in either
+// order with enabled ones, which keep hitting the cached table.  out[3] = {builds (must be 1), tables a disabled call got
+// (must be 0), violations}.
+int nann_projcache_disabled_call(int64_t out[3]) {
+  Device dev;
+  dev.capacity = (long long)3 << 20;
+  g_dev = &dev;
+  long long builds = 0, got = 0, bad = 0;
+  {
+    Cache cache;
+    auto build = [&](float* t) { ++builds; t[0] = 1.0f; return 0; };
+    Cache::Ref t;
+    if (cache.acquire(1, 1 << 20, false, false, build, &t) || t) ++got;      // nothing cached yet: no table, no build
+    if (cache.acquire(1, 1 << 20, true, false, build, &t) || !t) ++bad;       // the pair's table
+    t.reset();
+    if (cache.acquire(1, 1 << 20, false, false, build, &t)) ++bad;            // cached now: a disabled call still gets none
+    if (t) ++got;
+    t.reset();
+    if (cache.acquire(1, 1 << 20, true, false, build, &t) || !t || t->table[0] != 1.0f) ++bad;  // and the cache still serves it
+    t.reset();
+  }
+  out[0] = builds; out[1] = got; out[2] = bad + dev.violations.load();
+  for (Block* b : dev.graveyard) delete b;
+  for (MockEvent* e : dev.events) delete e;
+  g_dev = nullptr;
+  return 0;
+}
+
 }  // extern "C"

@@ -343,7 +343,7 @@ int main(int argc, char** argv) {
                   (size_t)in_bytes);
     CHECK(nann_memcpy(ln.d_in, ln.h_in, (int64_t)b * in_bytes, 0, ln.stream));
     // level_topn is a per-request feed of the serving signature: a batch whose requests all ask for the server's values
-    // takes the uniform launch, a mixed one carries its [b, 6] table to the device (nann_search_v)
+    // takes the uniform launch, a mixed one carries its [b, 6] table to the device (the `level_topn` argument of nann_search_opt / nann_search_model_opt)
     bool uniform = true;
     for (int i = 0; i < b; ++i) {
       std::memcpy(ln.h_topn + (size_t)i * 6, batch[i]->level_topn, 6 * sizeof(int32_t));
@@ -355,12 +355,13 @@ int main(int argc, char** argv) {
       d_topn = static_cast<const int32_t*>(ln.d_topn);
     }
     if (attention) {
-      CHECK(nann_search_model_v(ix, model, ln.d_in, b, level_topn, d_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk),
-                                nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr, ln.stream));
+      CHECK(nann_search_model_opt(ix, model, ln.d_in, b, level_topn, d_topn, ln.ws, ws_bytes, static_cast<int64_t*>(ln.d_topk),
+                                  nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr, /*options*/ nullptr,
+                                  /*plan*/ nullptr, ln.stream));
     } else {
-      CHECK(nann_search_v(ix, scorer, static_cast<const float*>(ln.d_in), b, level_topn, d_topn, ln.ws, ws_bytes,
-                          static_cast<int64_t*>(ln.d_topk), nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr,
-                          ln.stream));
+      CHECK(nann_search_opt(ix, scorer, static_cast<const float*>(ln.d_in), b, level_topn, d_topn, ln.ws, ws_bytes,
+                            static_cast<int64_t*>(ln.d_topk), nullptr, nullptr, static_cast<int32_t*>(ln.d_status), nullptr,
+                            /*phase_ticks*/ nullptr, /*options*/ nullptr, /*plan*/ nullptr, ln.stream));
     }
     CHECK(nann_memcpy(ln.h_topk, ln.d_topk, (int64_t)b * topk * 8, 1, ln.stream));
     CHECK(nann_memcpy(ln.h_status, ln.d_status, (int64_t)b * 4, 1, ln.stream));

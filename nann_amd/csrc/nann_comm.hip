@@ -14,9 +14,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 using namespace nann;
 
@@ -29,6 +31,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string where;
 };
@@ -52,6 +56,8 @@ int load_rccl(Rccl** out) {
     R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.handle, "ncclAllGather"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.handle, "ncclGetErrorString"));
     R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.handle, "ncclCommCount"));
+    R.CommGetAsyncError = reinterpret_cast<decltype(R.CommGetAsyncError)>(dlsym(R.handle, "ncclCommGetAsyncError"));
+    R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(dlsym(R.handle, "ncclCommAbort"));
     if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) {
       R.handle = nullptr;
       return fail(NANN_ERR_UNSUPPORTED, "RCCL library lacks the ncclAllGather entry points");
@@ -134,7 +140,27 @@ struct nann_comm {
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed_once = false;
+  // round 6: a dead rank must not hang the node.  done_ev follows the merge of the LAST exchange on its stream; nann_comm_wait
+  // polls it with a deadline next to ncclCommGetAsyncError and aborts the communicator (ncclCommAbort: RCCL's kernels see the
+  // flag and leave) when either says the exchange will not finish
+  hipEvent_t done_ev = nullptr;
+  bool exchanged = false;
+  bool aborted = false;
 };
+
+// an asynchronous error of the RCCL communicator (a peer died, a link went down), as NANN_ERR_HIP; aborts the communicator
+static int check_async(nann_comm* c, const char* where) {
+  if (!c->comm || !c->R->CommGetAsyncError) return NANN_OK;
+  ncclResult_t async = ncclSuccess;
+  const ncclResult_t r = c->R->CommGetAsyncError(c->comm, &async);
+  if (r == ncclSuccess && (async == ncclSuccess || async == ncclInProgress)) return NANN_OK;
+  const ncclResult_t bad = r != ncclSuccess ? r : async;
+  const std::string msg = c->R->GetErrorString ? c->R->GetErrorString(bad) : "rccl error";
+  if (c->R->CommAbort) (void)c->R->CommAbort(c->comm);
+  c->comm = nullptr;
+  c->aborted = true;
+  return fail(NANN_ERR_HIP, std::string(where) + ": RCCL reports an asynchronous error (" + msg + "); communicator aborted");
+}
 
 extern "C" {
 
@@ -175,6 +201,7 @@ void nann_comm_destroy(nann_comm* c) {
   if (!c) return;
   if (c->comm) (void)c->R->CommDestroy(c->comm);
   for (hipEvent_t e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->done_ev) (void)hipEventDestroy(c->done_ev);
   delete c;
 }
 
@@ -220,6 +247,11 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
                       int64_t n_queries, int32_t k_in, int32_t k_out, void* workspace, int64_t workspace_bytes,
                       float* out_scores, int64_t* out_ids, nann_stream_t stream) {
   if (!c || !scores || !ids || !out_scores || !out_ids) return fail(NANN_ERR_BAD_ARGUMENT, "nann_sharded_topk: null argument");
+  if (c->aborted) return fail(NANN_ERR_HIP, "nann_sharded_topk: the communicator was aborted (nann_comm_wait / nann_comm_abort); create a new one");
+  {
+    const int rc = check_async(c, "nann_sharded_topk");
+    if (rc) return rc;
+  }
   const int world = c->world;
   const long long n_in = (long long)world * k_in;
   if (k_out < 0 || k_out > kMaxK) return fail(NANN_ERR_UNSUPPORTED, "k_out must be in [0, 1024]");
@@ -257,7 +289,43 @@ int nann_sharded_topk(nann_comm* c, const float* scores, const int64_t* ids, con
                      world, (long long)n_queries, (int)k_in, (int)k_out, out_scores, out_ids);
   NANN_HIP_TRY(hipGetLastError());
   if (c->timing) { NANN_HIP_TRY(hipEventRecord(c->ev[3], st)); c->timed_once = true; }
+  if (!c->done_ev) NANN_HIP_TRY(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
+  NANN_HIP_TRY(hipEventRecord(c->done_ev, st));
+  c->exchanged = true;
   return NANN_OK;
+}
+
+int nann_comm_abort(nann_comm* c) {
+  if (!c) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_abort: null communicator");
+  if (c->comm && c->R->CommAbort) (void)c->R->CommAbort(c->comm);
+  else if (c->comm) (void)c->R->CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->aborted = true;
+  return NANN_OK;
+}
+
+int nann_comm_wait(nann_comm* c, int32_t timeout_ms) {
+  if (!c) return fail(NANN_ERR_BAD_ARGUMENT, "nann_comm_wait: null communicator");
+  if (c->aborted) return fail(NANN_ERR_HIP, "nann_comm_wait: the communicator was aborted");
+  if (!c->exchanged) return NANN_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  int sleep_us = 20;
+  for (;;) {
+    const hipError_t e = hipEventQuery(c->done_ev);
+    if (e == hipSuccess) return NANN_OK;
+    if (e != hipErrorNotReady) return fail(NANN_ERR_HIP, std::string("nann_comm_wait: ") + hipGetErrorString(e));
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    const int rc = check_async(c, "nann_comm_wait");
+    if (rc) return rc;
+    const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (timeout_ms >= 0 && ms >= timeout_ms) {
+      (void)nann_comm_abort(c);
+      return fail(NANN_ERR_HIP, "nann_comm_wait: the exchange did not complete within " + std::to_string(timeout_ms) +
+                                    " ms (a rank that never joined the all-gather?); communicator aborted");
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+    sleep_us = std::min(1000, sleep_us * 2);
+  }
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include "nann_attn.h"
 #include "host/nann_graphdef_text.h"
 #include "host/nann_blaze_options.h"
+#include "host/nann_npy.h"
 #include "host/nann_projcache.h"
 
 #include <algorithm>
@@ -844,173 +845,58 @@ int nann_host_free(void* host_ptr) {
 }
 
 // ---- HugeConst -------------------------------------------------------------
-static const char* npy_descr(int dtype) {
-  switch (dtype) {
-    case NANN_F16: return "<f2";
-    case NANN_F32: return "<f4";
-    case NANN_F64: return "<f8";
-    case NANN_I32: return "<i4";
-    case NANN_I64: return "<i8";
-    default: return nullptr;
-  }
+// The .npy decoder is a host header of its own (host/nann_npy.h: every length checked, fuzzed under ASan in the CPU suite);
+// here: the file into memory, the decoder, the payload into HBM.
+static uint16_t f32_to_f16_rne(float f) { return nann_npy::f32_to_f16_rne(f); }
+
+static int read_whole_file(const char* path, std::vector<unsigned char>* out) {
+  std::ifstream f(path, std::ifstream::binary | std::ifstream::ate);
+  if (!f) return fail(NANN_ERR_IO, std::string("Fail to open file: ") + path);  // huge_const_op.cc:96-98
+  const std::streamoff size = f.tellg();
+  if (size < 0) return fail(NANN_ERR_IO, std::string("Fail to open file: ") + path);
+  out->resize((size_t)size);
+  f.seekg(0);
+  if (size > 0) f.read(reinterpret_cast<char*>(out->data()), size);
+  if (!f || f.gcount() != size) return fail(NANN_ERR_IO, std::string("short read of ") + path);
+  return NANN_OK;
 }
 
-// np.ndarray.astype for the casts the reference's wrapper performs
-static uint16_t f32_to_f16_rne(float f) {
-  uint32_t x;
-  std::memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
-  uint32_t man = x & 0x7fffffu;
-  if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
-  if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
-  if (exp <= 0) {
-    if (exp < -10) return (uint16_t)sign;
-    man |= 0x800000u;
-    const int shift = 14 - exp;
-    uint32_t hm = man >> shift;
-    const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
-    if (rem > half || (rem == half && (hm & 1))) ++hm;
-    return (uint16_t)(sign | hm);
-  }
-  uint32_t out = sign | ((uint32_t)exp << 10) | (man >> 13);
-  const uint32_t rem = man & 0x1fffu;
-  if (rem > 0x1000u || (rem == 0x1000u && (out & 1))) ++out;
-  return (uint16_t)out;
-}
-
-static bool cast_payload(const std::string& from, int to, const std::vector<char>& in, int64_t count,
-                         std::vector<char>* out) {
-  static const int esz[6] = {2, 2, 4, 4, 8, 8};
-  out->resize((size_t)std::max<int64_t>(count * esz[to], 1));
-  if (from == "<i8" && to == NANN_I32) {
-    const int64_t* a = reinterpret_cast<const int64_t*>(in.data());
-    int32_t* b = reinterpret_cast<int32_t*>(out->data());
-    for (int64_t i = 0; i < count; ++i) b[i] = (int32_t)a[i];
-    return true;
-  }
-  if (from == "<i4" && to == NANN_I64) {
-    const int32_t* a = reinterpret_cast<const int32_t*>(in.data());
-    int64_t* b = reinterpret_cast<int64_t*>(out->data());
-    for (int64_t i = 0; i < count; ++i) b[i] = a[i];
-    return true;
-  }
-  if ((from == "<f4" || from == "<f8") && to == NANN_F16) {
-    uint16_t* b = reinterpret_cast<uint16_t*>(out->data());
-    for (int64_t i = 0; i < count; ++i) {
-      const float v = from == "<f4" ? reinterpret_cast<const float*>(in.data())[i]
-                                     : (float)reinterpret_cast<const double*>(in.data())[i];
-      b[i] = f32_to_f16_rne(v);
-    }
-    return from == "<f4";  // f64 -> f16 through f32 would double-round: not offered
-  }
-  if (from == "<f8" && to == NANN_F32) {
-    float* b = reinterpret_cast<float*>(out->data());
-    for (int64_t i = 0; i < count; ++i) b[i] = (float)reinterpret_cast<const double*>(in.data())[i];
-    return true;
-  }
-  return false;
-}
-
-// .npy -> host bytes in `expect_dtype` (shared by HugeConst and the scorer-model loader)
+// .npy -> host bytes in `expect_dtype` (the scorer-model loader; HugeConst below copies straight from the file image)
 static int read_npy_host(const char* path, int expect_dtype, const int64_t* expect_shape, int expect_rank,
                          int allow_cast, std::vector<char>* out, std::vector<int64_t>* out_shape) {
-  std::ifstream f(path, std::ifstream::binary);
-  if (!f) return fail(NANN_ERR_IO, std::string("Fail to open file: ") + path);  // huge_const_op.cc:96-98
-  unsigned char head[12];
-  f.read(reinterpret_cast<char*>(head), 10);
-  if (!f || std::memcmp(head, "\x93NUMPY", 6) != 0) return fail(NANN_ERR_IO, "not an npy file");
-  const int major = head[6];
-  size_t hlen = 0;
-  if (major == 1) {
-    hlen = head[8] | (head[9] << 8);
-  } else if (major == 2) {  // npy.h:541-571 accepts 1.0 and 2.0
-    f.read(reinterpret_cast<char*>(head + 10), 2);
-    hlen = (size_t)head[8] | ((size_t)head[9] << 8) | ((size_t)head[10] << 16) | ((size_t)head[11] << 24);
-  } else {
-    return fail(NANN_ERR_IO, "unsupported npy version");
-  }
-  std::string hdr(hlen, '\0');
-  f.read(&hdr[0], (std::streamsize)hlen);
-  if (!f) return fail(NANN_ERR_IO, "truncated npy header");
-  auto find_val = [&](const char* key) -> size_t {
-    const size_t p = hdr.find(key);
-    if (p == std::string::npos) return p;
-    return hdr.find(':', p) + 1;
-  };
-  size_t p = find_val("'descr'");
-  if (p == std::string::npos) return fail(NANN_ERR_IO, "npy header without descr");
-  const size_t q0 = hdr.find('\'', p), q1 = hdr.find('\'', q0 + 1);
-  std::string descr = hdr.substr(q0 + 1, q1 - q0 - 1);
-  if (!descr.empty() && descr[0] == '|') descr[0] = '<';
-  p = find_val("'fortran_order'");
-  if (p == std::string::npos) return fail(NANN_ERR_IO, "npy header without fortran_order");
-  if (hdr.compare(hdr.find_first_not_of(' ', p), 4, "True") == 0)
-    return fail(NANN_ERR_UNSUPPORTED, "Fortran order NOT supported.");  // huge_const_op.cc:108-109
-  p = find_val("'shape'");
-  if (p == std::string::npos) return fail(NANN_ERR_IO, "npy header without shape");
-  const size_t s0 = hdr.find('(', p), s1 = hdr.find(')', s0);
-  std::vector<int64_t> shape;
-  {
-    const std::string body = hdr.substr(s0 + 1, s1 - s0 - 1);
-    size_t i = 0;
-    while (i < body.size()) {
-      while (i < body.size() && (body[i] == ' ' || body[i] == ',')) ++i;
-      if (i >= body.size()) break;
-      size_t j = i;
-      while (j < body.size() && body[j] >= '0' && body[j] <= '9') ++j;
-      if (j == i) return fail(NANN_ERR_IO, "bad npy shape");
-      shape.push_back(std::strtoll(body.substr(i, j - i).c_str(), nullptr, 10));
-      i = j;
-    }
-  }
-  const char* want = npy_descr(expect_dtype);
-  if (!want) return fail(NANN_ERR_UNSUPPORTED, "Unsupported DataType.");  // huge_const_op.cc:143-146
-  const bool need_cast = descr != want;
-  if (need_cast && !allow_cast)
-    return fail(NANN_ERR_DTYPE_MISMATCH, "DataType mismatch: " + descr + "!=" + want);  // :117-121
-  if (expect_shape) {
-    if ((int)shape.size() != expect_rank) return fail(NANN_ERR_SHAPE_MISMATCH, "rank mismatch");
-    for (int i = 0; i < expect_rank; ++i)
-      if (shape[i] != expect_shape[i])
-        return fail(NANN_ERR_SHAPE_MISMATCH,
-                    "attr_shape and np_shape NOT match in dim " + std::to_string(i));  // :111-115
-  }
-  static const int esz[6] = {2, 2, 4, 4, 8, 8};
-  int64_t count = 1;
-  for (int64_t v : shape) count *= v;
-  int file_esz = esz[expect_dtype];
-  if (need_cast) {
-    if (descr.size() != 3 || descr[0] != '<' || descr[2] < '1' || descr[2] > '8')
-      return fail(NANN_ERR_DTYPE_MISMATCH, "DataType mismatch: " + descr + "!=" + want);
-    file_esz = descr[2] - '0';
-  }
-  std::vector<char> host((size_t)std::max<int64_t>(count * file_esz, 1));
-  f.read(host.data(), (std::streamsize)(count * file_esz));
-  if (f.gcount() != (std::streamsize)(count * file_esz)) return fail(NANN_ERR_IO, "truncated npy payload");
-  if (need_cast) {
-    std::vector<char> conv;
-    if (!cast_payload(descr, expect_dtype, host, count, &conv))
-      return fail(NANN_ERR_DTYPE_MISMATCH, "no cast from " + descr + " to " + want);
-    host.swap(conv);
-  }
-  host.resize((size_t)(count * esz[expect_dtype]));
-  out->swap(host);
-  if (out_shape) *out_shape = shape;
+  std::vector<unsigned char> image;
+  int rc = read_whole_file(path, &image);
+  if (rc) return rc;
+  const unsigned char* payload = nullptr;
+  size_t bytes = 0;
+  std::vector<char> conv;
+  std::string err;
+  rc = nann_npy::decode(image.data(), image.size(), expect_dtype, expect_shape, expect_rank, allow_cast != 0, &payload, &bytes, &conv,
+                        out_shape, &err);
+  if (rc) return fail(rc, err);
+  if (!conv.empty() || bytes == 0) { conv.resize(bytes); out->swap(conv); }
+  else out->assign(reinterpret_cast<const char*>(payload), reinterpret_cast<const char*>(payload) + bytes);
   return NANN_OK;
 }
 
 int nann_huge_const_load(const char* path, int expect_dtype, const int64_t* expect_shape,
                          int expect_rank, int allow_cast, void** dev_ptr, int64_t* nbytes) {
   if (!path || !dev_ptr) return fail(NANN_ERR_BAD_ARGUMENT, "nann_huge_const_load: null argument");
-  std::vector<char> host;
-  const int rc = read_npy_host(path, expect_dtype, expect_shape, expect_rank, allow_cast, &host, nullptr);
+  std::vector<unsigned char> image;
+  int rc = read_whole_file(path, &image);
   if (rc) return rc;
-  const int64_t total = (int64_t)host.size();
+  const unsigned char* payload = nullptr;
+  size_t bytes = 0;
+  std::vector<char> conv;
+  std::string err;
+  rc = nann_npy::decode(image.data(), image.size(), expect_dtype, expect_shape, expect_rank, allow_cast != 0, &payload, &bytes, &conv,
+                        nullptr, &err);
+  if (rc) return fail(rc, err);
+  const int64_t total = (int64_t)bytes;
   void* d = nullptr;
   HIP_TRY(hipMalloc(&d, (size_t)std::max<int64_t>(total, 1)));
   if (total) {
-    const hipError_t e = hipMemcpy(d, host.data(), (size_t)total, hipMemcpyHostToDevice);
+    const hipError_t e = hipMemcpy(d, payload, (size_t)total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(d);  // do not leak the allocation on a failed copy
       return fail(NANN_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
@@ -2288,8 +2174,8 @@ int nann_search(const nann_index* ix, const nann_scorer* scorer, const float* q,
                 const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
                 int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                 int32_t* counters, nann_stream_t stream) {
-  return nann_search_ex(ix, scorer, q, n_queries, level_topn, workspace, workspace_bytes, out_item_ids,
-                        out_scores, out_index, status, counters, nullptr, stream);
+  return nann_search_opt(ix, scorer, q, n_queries, level_topn, nullptr, workspace, workspace_bytes, out_item_ids, out_scores,
+                         out_index, status, counters, nullptr, nullptr, nullptr, stream);  // deprecated: thin wrapper
 }
 
 }  // extern "C"
@@ -2468,6 +2354,12 @@ __global__ void k_probe_queries(const void* emb, int dt, int d, long long n_item
 
 static void probe_index(nann_index* ix) {
   ix->probe_valid = false;
+  // opt-out: NANN_INDEX_PROBE=0 -- the planner then falls back to its degree-based guess.  The probe allocates,
+  // launches on the NULL stream and copies back with blocking copies: it SYNCHRONISES the device (include/nann_hip.h says so).
+  static const bool enabled = [] { const char* e = std::getenv("NANN_INDEX_PROBE"); return !(e && e[0] == '0'); }();
+  if (!enabled) return;
+  const std::string saved_error = nann::g_err;  // a probe that fails must not leave ITS message behind a successful create
+  struct RestoreError { const std::string& s; ~RestoreError() { nann::g_err = s; } } restore{saved_error};
   const int d = ix->desc.d;
   const int64_t E = ix->desc.n_enter, N = ix->desc.n_items;
   if (E < 8 || N < 4096) return;  // (toy indices: the degree-based guess)
@@ -2501,7 +2393,9 @@ static void probe_index(nann_index* ix) {
   }
   if (buf) (void)hipFree(buf);
   nann_scorer_destroy(sc);
-  (void)hipGetLastError();
+  // only the probe's own non-sticky error (a failed hipMalloc, say) is cleared; a sticky device error stays set and the
+  // caller's next HIP call reports it
+  if (!ok) (void)hipGetLastError();
   if (!ok) return;
   double sum = 0.0, mx = 0.0;
   int n_valid = 0;
@@ -2533,13 +2427,8 @@ int nann_search_ex(const nann_index* ix, const nann_scorer* scorer, const float*
                    const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
                    int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                    int32_t* counters, int64_t* phase_ticks, nann_stream_t stream) {
-  if (!ix || !scorer || !level_topn || !out_item_ids || !status)
-    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search: null argument");
-  if (n_queries <= 0) return NANN_OK;
-  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
-    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
-  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn, nullptr, workspace, workspace_bytes,
-                     out_item_ids, out_scores, out_index, status, counters, phase_ticks, nullptr, nullptr, as_stream(stream));
+  return nann_search_opt(ix, scorer, q, n_queries, level_topn, nullptr, workspace, workspace_bytes, out_item_ids, out_scores,
+                         out_index, status, counters, phase_ticks, nullptr, nullptr, stream);  // deprecated: thin wrapper
 }
 
 int nann_search_opt(const nann_index* ix, const nann_scorer* scorer, const float* q, int64_t n_queries,
@@ -2569,13 +2458,8 @@ int nann_search_v(const nann_index* ix, const nann_scorer* scorer, const float* 
                   const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
                   int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
                   int32_t* status, int32_t* counters, nann_stream_t stream) {
-  if (!ix || !scorer || !level_topn_max || !out_item_ids || !status)
-    return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_v: null argument");
-  if (n_queries <= 0) return NANN_OK;
-  if (scorer->desc.d != ix->desc.d || scorer->desc.emb_dtype != ix->desc.emb_dtype)
-    return fail(NANN_ERR_BAD_ARGUMENT, "scorer and index disagree on d / dtype");
-  return search_impl(ix, scorer, nullptr, q, nullptr, nullptr, n_queries, level_topn_max, level_topn, workspace,
-                     workspace_bytes, out_item_ids, out_scores, out_index, status, counters, nullptr, nullptr, nullptr, as_stream(stream));
+  return nann_search_opt(ix, scorer, q, n_queries, level_topn_max, level_topn, workspace, workspace_bytes, out_item_ids,
+                         out_scores, out_index, status, counters, nullptr, nullptr, nullptr, stream);  // deprecated: thin wrapper
 }
 
 // ---- lifecycle of the pre-projected tables (ProjCache) -------------------------------------------------------
@@ -2678,16 +2562,16 @@ int nann_search_model(const nann_index* ix, const nann_model* m, const void* com
                       const int32_t level_topn[6], void* workspace, int64_t workspace_bytes,
                       int64_t* out_item_ids, float* out_scores, int32_t* out_index, int32_t* status,
                       int32_t* counters, nann_stream_t stream) {
-  return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn, nullptr, workspace, workspace_bytes, out_item_ids,
-                           out_scores, out_index, status, counters, nullptr, nullptr, stream);
+  return nann_search_model_opt(ix, m, comm_seq_f16, n_queries, level_topn, nullptr, workspace, workspace_bytes, out_item_ids,
+                               out_scores, out_index, status, counters, nullptr, nullptr, stream);  // deprecated: thin wrapper
 }
 
 int nann_search_model_v(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,
                         const int32_t level_topn_max[6], const int32_t* level_topn, void* workspace,
                         int64_t workspace_bytes, int64_t* out_item_ids, float* out_scores, int32_t* out_index,
                         int32_t* status, int32_t* counters, nann_stream_t stream) {
-  return search_model_impl(ix, m, comm_seq_f16, n_queries, level_topn_max, level_topn, workspace, workspace_bytes,
-                           out_item_ids, out_scores, out_index, status, counters, nullptr, nullptr, stream);
+  return nann_search_model_opt(ix, m, comm_seq_f16, n_queries, level_topn_max, level_topn, workspace, workspace_bytes,
+                               out_item_ids, out_scores, out_index, status, counters, nullptr, nullptr, stream);  // deprecated: thin wrapper
 }
 
 int nann_search_model_opt(const nann_index* ix, const nann_model* m, const void* comm_seq_f16, int64_t n_queries,

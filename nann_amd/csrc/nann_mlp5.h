@@ -141,12 +141,14 @@ __device__ __forceinline__ uint32_t lds_offset_of(const void* p) {  // a generic
 // pointer of the block behind it (this lane's row + 4 g floats; `row` again when there is none), and, when that block
 // belongs to another query, change = true and u_next = this lane's 16 bytes of that query's u x 2^7 (written to L.u_wr
 // behind the last read of the current u).  store(k, score): every lane, the block's score of its row (lanes g and g ^ 1
-// hold the same value).  VAR: timing builds (nann_mlp6.h NANN_PHASE_VAR).  KW3B >= 0: the packed output layer (below).
+// hold the same value).  VAR: timing builds (nann_mlp6.h NANN_PHASE_VAR; 16 = the PReLU decomposition priced in round 6).  KW3B >= 0: the packed output layer (below).
 struct SplitPipeLds {  // opaque LDS byte addresses (an `asm volatile("" : "+v"(x))` behind each, see wg_score_mlp_res)
   uint32_t w_lo, w_hi;  // W2 fragments below / above 64 KB, + lane * 16
   uint32_t v_at;        // Mlp2Vectors, + g * 16
   uint32_t u_at;        // the current query's u x 2^7 [256], + g * 16 (the fused kernel: = v_at)
   uint32_t u_wr;        // where this lane writes its 16 bytes of the next query's u (fused kernel: unused)
+  const float* seed_base = nullptr;  // VAR & 16 only (round 6 pricing build): a table whose rows stand in for the second
+  uint32_t seed_rows = 0;            // pre-projected table of the PReLU decomposition, [seed_rows, 256] f32
 };
 template <int VAR, int KW3B, class Advance, class Store>
 __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, const float* row, int n_blocks,
@@ -184,6 +186,12 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
     // packed f32 forms by hand (left to itself hipcc scalarises about half of them; the vector pipe's issue slots
     // are what bounds this loop): x + u, min(., 0) per half (there is no packed f32 min), (alpha - 1) min + (x + u)
     const f32x2 xs = xp + up;
+    if constexpr ((VAR & 16) != 0) {
+      // pricing build of VERDICT r5 item 2: prelu(x) = a x + (1 - a) max(x, 0), the linear part precomputed per item (a second
+      // table, gathered below) and per query, so the activation beside the MFMAs is ONE v_max per element and no beta read
+      (void)bp;
+      return __builtin_elementwise_max(xs, f32x2{0.0f, 0.0f});
+    }
     const f32x2 m = __builtin_elementwise_min(xs, f32x2{0.0f, 0.0f});
     return __builtin_elementwise_fma(m, bp, xs);
   };
@@ -218,6 +226,16 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
         const f32x4v v = vec4(kB2 + 32 * mt + 8 * rr);
         acc[mt][4 * rr] = v.x; acc[mt][4 * rr + 1] = v.y; acc[mt][4 * rr + 2] = v.z; acc[mt][4 * rr + 3] = v.w;
       }
+    f32x4v seed[(VAR & 16) ? 16 : 1];
+    if constexpr ((VAR & 16) != 0) {
+      // the item's linear part (a (.) P_i) W2: 128 f32 = 512 more bytes per scored row, issued at the top of the block, added to
+      // the accumulators behind its last MFMA (the products are linear in it).  Stand-in rows: another row of the table per row.
+      const uint32_t rid = (uint32_t)((row - L.seed_base) >> 8);
+      const uint32_t rid2 = (uint32_t)(((unsigned long long)rid * 2654435761ull + 12345ull) % L.seed_rows);
+      const float* srow = L.seed_base + (size_t)rid2 * 256 + ((row - L.seed_base) & 255);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) seed[i] = *reinterpret_cast<const f32x4v*>(srow + 8 * i);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < H1T; ++t) {
@@ -244,7 +262,7 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
           if (!(VAR & 2)) Wf[2 * mt] = fragt(nt, nq * 2 * H2T + 2 * mt);
           const int rr = 2 * nq + (mt & 1);  // u / beta of the next step's conversion (this step's were read above)
           if (!(VAR & 4)) {
-            if (mt < 2) cu[mt & 1] = uvec4(32 * ct + 8 * rr); else cb[mt & 1] = vec4(kBeta1 + 32 * ct + 8 * rr);
+            if (mt < 2) cu[mt & 1] = uvec4(32 * ct + 8 * rr); else if (!(VAR & 16)) cb[mt & 1] = vec4(kBeta1 + 32 * ct + 8 * rr);
             convert_b(hv[mt], Bh[nbuf][q][mt], Bl[nbuf][q][mt]);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -258,6 +276,15 @@ __device__ __forceinline__ void wave_mlp_split_pipeline(const SplitPipeLds& L, c
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+    }
+    if constexpr ((VAR & 16) != 0) {
+#pragma unroll
+      for (int mt = 0; mt < H2T; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const f32x4v v = seed[4 * mt + rr];
+          acc[mt][4 * rr] += v.x; acc[mt][4 * rr + 1] += v.y; acc[mt][4 * rr + 2] += v.z; acc[mt][4 * rr + 3] += v.w;
+        }
     }
     // PReLU of layer 2 and the bias-free output layer
     float part;

@@ -52,7 +52,8 @@ struct PhaseScoreArgs {
 };
 
 // timing builds (tools/build_res_variant.py -DNANN_PHASE_VAR=bits): the split-f16 scoring launch WITHOUT 1 = its gathers,
-// 2 = its W2 fragment reads, 4 = the PReLU / split arithmetic, 8 = the MFMAs -- run as a second, dry launch behind the real
+// 2 = its W2 fragment reads, 4 = the PReLU / split arithmetic, 8 = the MFMAs; 16 = WITH the PReLU decomposition's cost (one v_max per
+// element, 512 more gathered bytes per row: nann_mlp5.h) -- run as a second, dry launch behind the real
 // one (NANN_PHASE_SHADOW=1), so that both see the same lists
 #ifndef NANN_PHASE_VAR
 #define NANN_PHASE_VAR 0
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_phase_score(PhaseScoreArgs a) {
     SplitPipeLds L;
     L.w_lo = w_lo; L.w_hi = w_hi; L.v_at = v_at; L.u_at = u_at;
     L.u_wr = lds_offset_of(u_w) + (uint32_t)lane * 16u;
+    L.seed_base = a.proj; L.seed_rows = a.n_items;  // (read by the VAR & 16 pricing build only)
     wave_mlp_split_pipeline<VAR, NANN_PHASE_PACKED_EPI ? kW3b : -1>(
         L, row_ptr(cur, b_lo), b_hi - b_lo,
         [&](int k, const float* row, const float*& next, bool& change, float4& u_next) {  // the block behind block b_lo + k

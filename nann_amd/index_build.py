@@ -22,18 +22,23 @@ _SRC = os.path.join(_HERE, "csrc", "host", "hnsw_build.cpp")
 _SRCS = [_SRC, os.path.join(_HERE, "csrc", "host", "nann_graphdef_c.cpp"),
          os.path.join(_HERE, "csrc", "host", "nann_projcache_c.cpp")]
 _DEPS = _SRCS + [os.path.join(_HERE, "csrc", "host", "nann_graphdef.h"), os.path.join(_HERE, "csrc", "host", "nann_graphdef_text.h"),
-                 os.path.join(_HERE, "csrc", "host", "nann_blaze_options.h"), os.path.join(_HERE, "csrc", "host", "nann_projcache.h")]
+                 os.path.join(_HERE, "csrc", "host", "nann_blaze_options.h"), os.path.join(_HERE, "csrc", "host", "nann_npy.h"), os.path.join(_HERE, "csrc", "host", "nann_projcache.h")]
 _LIB_PATH = os.path.join(_HERE, "_build", "libnann_host.so")
 _LIB = None
 
 
-def build_host_lib(force=False):
-    """g++ -O3 the host-side builder into nann_amd/_build/libnann_host.so."""
-    if force or not os.path.exists(_LIB_PATH) or max(os.path.getmtime(p) for p in _DEPS) > os.path.getmtime(_LIB_PATH):
-        os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
-        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-mavx2", "-mfma", "-Wno-invalid-offsetof",
-                               "-o", _LIB_PATH] + _SRCS)
-    return _LIB_PATH
+def build_host_lib(force=False, sanitize=False):
+    """g++ -O3 the host-side builder into nann_amd/_build/libnann_host.so.  sanitize: the same sources under AddressSanitizer +
+    UBSan into libnann_host_asan.so -- what the parser fuzzers of the CPU suite load (tests/fuzz/; the process needs
+    LD_PRELOAD=libasan.so)."""
+    path = _LIB_PATH.replace(".so", "_asan.so") if sanitize else _LIB_PATH
+    if force or not os.path.exists(path) or max(os.path.getmtime(p) for p in _DEPS) > os.path.getmtime(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        flags = (["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+                 if sanitize else ["-O3"])
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-pthread", "-mavx2", "-mfma", "-Wno-invalid-offsetof",
+                                                 "-o", path] + _SRCS)
+    return path
 
 
 def _lib():

@@ -145,14 +145,15 @@ def search_options(traversal=None, slot_reserve=None, preprojection=None, mlp_fo
 
 
 class SearchResult:
-    __slots__ = ("item_ids", "scores", "index", "status", "counters", "phase_ticks", "plan", "_ws")
+    __slots__ = ("item_ids", "scores", "index", "status", "counters", "phase_ticks", "plan", "_ws", "slot_reserve")
 
-    def __init__(self, item_ids, scores, index, status, counters, phase_ticks=None, plan=None, ws=None):
+    def __init__(self, item_ids, scores, index, status, counters, phase_ticks=None, plan=None, ws=None, slot_reserve=None):
         self.item_ids, self.scores, self.index, self.status, self.counters = (
             item_ids, scores, index, status, counters)
         self.phase_ticks = phase_ticks
         self.plan = plan  # dict: what the planner chose (nann_search_plan)
         self._ws = ws
+        self.slot_reserve = slot_reserve  # nann_search_options.slot_reserve of the call (None: no options were passed)
 
     def reruns(self):
         """queries of this call that the hash-set kernel handed back to the bitmap kernel (synchronises the stream;
@@ -209,7 +210,8 @@ def search(index, scorer, q, level_topn, want_counters=True, want_phase_ticks=Fa
                                      C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
                                      _ptr(status), _ptr(counters), _ptr(ticks),
                                      C.byref(options) if options is not None else None, C.byref(plan), _stream()), "search")
-    return SearchResult(out_ids, out_scores, out_index, status, counters, ticks, _plan_dict(plan), ws)
+    return SearchResult(out_ids, out_scores, out_index, status, counters, ticks, _plan_dict(plan), ws,
+                        slot_reserve=int(options.slot_reserve) if options is not None else None)
 
 
 def search_model(index, model, comm_seq, level_topn, want_counters=True, options=None):
@@ -235,7 +237,8 @@ def search_model(index, model, comm_seq, level_topn, want_counters=True, options
                                            C.c_int64(ws.numel()), _ptr(out_ids), _ptr(out_scores), _ptr(out_index),
                                            _ptr(status), _ptr(counters),
                                            C.byref(options) if options is not None else None, C.byref(plan), _stream()), "search")
-    return SearchResult(out_ids, out_scores, out_index, status, counters, None, _plan_dict(plan), ws)
+    return SearchResult(out_ids, out_scores, out_index, status, counters, None, _plan_dict(plan), ws,
+                        slot_reserve=int(options.slot_reserve) if options is not None else None)
 
 
 def prepare(index, scorer):

@@ -147,6 +147,14 @@ class Comm:
         _check(lib().nann_comm_set_timing(self.handle, C.c_int32(1 if enabled else 0), C.c_int32(loopback_repeat),
                                           C.c_int32(loopback_wait_us)), "comm timing")
 
+    def wait(self, timeout_ms=-1):
+        """bounded wait for the last exchange enqueued on this communicator (nann_comm_wait): raises NannError and ABORTS the
+        communicator when RCCL reports an asynchronous error or the deadline passes -- a dead rank does not hang the node"""
+        _check(lib().nann_comm_wait(self.handle, C.c_int32(int(timeout_ms))), "comm wait")
+
+    def abort(self):
+        _check(lib().nann_comm_abort(self.handle), "comm abort")
+
     def last_breakdown(self):
         """{pack, all_gather, merge} ms of the last exchange (waits for it)"""
         ms = (C.c_float * 3)()
@@ -172,6 +180,7 @@ class ShardedSearch:
         self.comm = comm if comm is not None else (Comm(world, rank, group) if transport == "rccl" else None)
         self._ws = None
         self._comm_stream = None
+        self._warned_reserve = False
 
     def search_options(self, overlap=True, reserve=None):
         """nann_search_options for the searches whose exchanges this object overlaps (pass to retrieval.search).  The
@@ -180,10 +189,19 @@ class ShardedSearch:
         cost the search ~3 %, an exchange that only starts when the grid drains costs the whole overlap).  Per call
         since round 5 (the process-wide setter was never restored and taxed unrelated searches)."""
         from . import retrieval
-        real = self.transport == "rccl" and self.world > 1 and not getattr(self.comm, "is_loopback", False)
+        real = self._real_rccl()
         if reserve is None:
             reserve = self.RESERVED_SLOTS if (overlap and real) else 0
         return retrieval.search_options(slot_reserve=reserve)
+
+    def search(self, index, scorer, q, level_topn, overlap=True, **kw):
+        """retrieval.search with this object's options applied (the slot reserve an overlapped exchange needs): the search
+        whose result goes to merge(overlap=...)."""
+        from . import retrieval
+        return retrieval.search(index, scorer, q, level_topn, options=self.search_options(overlap=overlap), **kw)
+
+    def _real_rccl(self):
+        return self.transport == "rccl" and self.world > 1 and not getattr(self.comm, "is_loopback", False)
 
     def _exchange(self, result):
         """pack + ncclAllGather + merge on the CURRENT stream (nann_sharded_topk)"""
@@ -216,6 +234,14 @@ class ShardedSearch:
         if self.transport == "rccl":
             if not overlap:
                 return self._exchange(result)
+            if self._real_rccl() and not (getattr(result, "slot_reserve", None) or 0) > 0 and not self._warned_reserve:
+                # without reserved workgroup slots RCCL's kernels only start when the persistent traversal grid of
+                # the NEXT search drains -- the overlap is lost silently
+                import warnings
+                warnings.warn("ShardedSearch.merge(overlap=True): the search that produced this result ran without a slot reserve "
+                              "(pass sharded.search_options() to retrieval.search, or call sharded.search()); the exchange will "
+                              "not overlap the next search", RuntimeWarning, stacklevel=2)
+                self._warned_reserve = True
             dev = result.scores.device
             cur = torch.cuda.current_stream(dev)
             if self._comm_stream is None:
@@ -248,7 +274,10 @@ class ShardedSearch:
         s, i = merge_device(gs, gi, self.k)
         return i, s
 
-    def wait(self):
-        """make the caller's current stream wait for every overlapped exchange issued so far"""
+    def wait(self, timeout_ms=None):
+        """make the caller's current stream wait for every overlapped exchange issued so far.  timeout_ms (rccl transport): first
+        a BOUNDED host wait for the last exchange (Comm.wait: raises and aborts the communicator instead of hanging on a dead rank)"""
+        if timeout_ms is not None and self.transport == "rccl" and self.comm is not None:
+            self.comm.wait(timeout_ms)
         if self._comm_stream is not None:
             torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_the_abi():
 
 def test_abi_version_and_error_string():
     L = _lib.lib()
-    assert L.nann_abi_version() == 5
+    assert L.nann_abi_version() == 6
     assert isinstance(_lib.last_error(), str)
     assert L.nann_device_count() >= 0
 
@@ -79,3 +79,24 @@ def test_cpp_serving_host_builds_against_the_header_alone():
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "/nonexistent", "/nonexistent", "64"], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_deprecated_search_entry_points_only_forward():
+    """ABI v6: ONE search operation = nann_search_opt / nann_search_model_opt.  The five spellings of rounds 1-5 stay exported
+    for hosts built against v5, each as a single `return` of the canonical call; the hosts of this repo call the pair only."""
+    src = open(os.path.join(ROOT, "nann_amd", "csrc", "nann_hip.hip")).read()
+    hdr = open(os.path.join(ROOT, "include", "nann_hip.h")).read()
+    for name, target in (("nann_search", "nann_search_opt"), ("nann_search_v", "nann_search_opt"), ("nann_search_ex", "nann_search_opt"),
+                         ("nann_search_model", "nann_search_model_opt"), ("nann_search_model_v", "nann_search_model_opt")):
+        m = re.search(r"\nint %s\(([^)]*)\)\s*\{(.*?)\n\}\n" % name, src, flags=re.S)
+        assert m, name
+        body = re.sub(r"//[^\n]*", "", m.group(2)).strip()
+        assert re.fullmatch(r"return %s\((.|\n)*\);" % target, body), (name, body)
+        assert body.count(";") == 1, (name, body)
+        assert re.search(r"/\* deprecated: thin wrapper of %s \*/\s*int %s\(" % (target, name), hdr), name
+    deprecated = r"\bnann_search(_v|_ex)?\(|\bnann_search_model(_v)?\("
+    for rel in ("nann_amd/csrc/host/nann_serve.cpp", "nann_amd/tf_ops/nann_tf_ops.cc", "nann_amd/retrieval.py", "nann_amd/serving.py",
+                "nann_amd/shard.py", "nann_amd/evaluate.py"):
+        text = re.sub(r"//[^\n]*|#[^\n]*", "", open(os.path.join(ROOT, rel)).read())
+        text = re.sub(r'""".*?"""', "", text, flags=re.S)
+        assert not re.search(deprecated, text), rel

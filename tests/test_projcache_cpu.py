@@ -58,3 +58,13 @@ def test_a_slow_build_does_not_stall_the_other_tables():
     assert bad == 0 and builds1 == 1, list(out)
     assert hits_during >= 100, list(out)          # (under the old lock: 0 -- the first hit would return after the build)
     assert worst_us < 100_000, list(out)          # no hit waited for the 300 ms build
+
+
+def test_a_call_without_preprojection_never_gets_a_cached_table():
+    """nann_search_options.preprojection = 0 means "this call runs without tables" whatever earlier calls left
+    cached for the pair (acquire() used to look for a hit before it looked at `enabled`)."""
+    L = C.CDLL(index_build.build_host_lib())
+    out = (C.c_int64 * 3)()
+    assert L.nann_projcache_disabled_call(out) == 0
+    builds, got, bad = list(out)
+    assert builds == 1 and got == 0 and bad == 0, list(out)

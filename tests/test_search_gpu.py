@@ -923,7 +923,11 @@ def test_search_without_preprojection_matches(oracle):
     r1 = retrieval.search(dix, sc, cuda(q), topn)
     torch.cuda.synchronize()
     assert r1.plan["table"] and retrieval.table_bytes(dix, sc)[1] > 0
-    for r in (r0, r1):
+    # and in the REVERSE order -- with the pair's table cached by r1, a preprojection=0 call still runs without it
+    r2 = retrieval.search(dix, sc, cuda(q), topn, options=retrieval.search_options(preprojection=False))
+    torch.cuda.synchronize()
+    assert not r2.plan["table"] and retrieval.table_bytes(dix, sc)[1] > 0  # (the cached table stays for the calls that want it)
+    for r in (r0, r1, r2):
         _assert_same((r.status.cpu().numpy(), r.item_ids.cpu().numpy(), r.scores.cpu().numpy(),
                       r.index.cpu().numpy(), r.counters.cpu().numpy()), exp)
 

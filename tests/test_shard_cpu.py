@@ -138,3 +138,42 @@ def test_merge_host_order():
     i = np.array([[[10, 11, 12], [20, 21, 22]]], np.int64)
     ms, mi = shard.merge_host(s, i, 4)
     assert mi.tolist() == [[10, 20, 21, 11]] and ms.tolist() == [[5, 5, 4, 3]]
+
+
+def _worker_dead_peer(rank, world, port, tmp):
+    """rank 1 dies before the exchange; rank 0's merge must FAIL within the group's timeout instead of hanging"""
+    import datetime
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from nann_amd import retrieval, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=6))
+    dist.barrier()
+    if rank == 1:
+        os._exit(0)  # no goodbye: the process is gone
+    nq, k = 8, 20
+    local = retrieval.SearchResult(torch.zeros((nq, k), dtype=torch.int64), torch.zeros((nq, k)), None,
+                                   torch.zeros(nq, dtype=torch.int32), None)
+    time.sleep(0.5)
+    t0 = time.perf_counter()
+    verdict = "hung"
+    try:
+        shard.ShardedSearch([4] * 5 + [k], world, rank, merge="host", transport="records").merge(local)
+        verdict = "returned"
+    except Exception as e:  # gloo: connection closed by peer / timed out
+        verdict = "raised %.1f %s" % (time.perf_counter() - t0, type(e).__name__)
+    open(os.path.join(tmp, "dead_peer"), "w").write(verdict)
+    os._exit(0)  # (destroy_process_group would wait for the dead peer)
+
+
+def test_a_dead_rank_fails_the_exchange_instead_of_hanging(tmp_path):
+    """Host logic of VERDICT r5 missing 4 on the CPU transports: with a bounded process-group timeout a rank that died makes the
+    exchange RAISE on the survivors (the device path's counterpart is nann_comm_wait: tests/test_ops_gpu.py)."""
+    port = _free_port()
+    mp.spawn(_worker_dead_peer, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    verdict = open(tmp_path / "dead_peer").read()
+    assert verdict.startswith("raised"), verdict
+    assert float(verdict.split()[1]) < 30.0, verdict

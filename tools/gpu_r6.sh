@@ -34,6 +34,30 @@ d = json.loads(open('$OUT/bench_default_$TAG.json').read().strip().splitlines()[
 print('value', d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'roofline', json.dumps(d['roofline'])[:600])
 PY
       ;;
+    replicas_dry)  # bench.py --gpus 2 --replicas with both ranks on the one GPU (gloo carries the barriers): the code path, not a rate
+      NANN_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --replicas --dist-backend gloo --items 200000 --batch 1024 --steps 3 --warmup 1 --index-cache /tmp/idx --no-secondary --no-cpu-baseline > $OUT/bench_replicas_dry_$TAG.json 2> $OUT/bench_replicas_dry_$TAG.err
+      python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench_replicas_dry_$TAG.json').read().strip().splitlines()[-1])
+    print('replicas dry: value', d['value'], d['unit'], 'n_gpus', d['n_gpus'], 'parallelism', d['config']['parallelism'][:60], 'parity', d.get('parity'))
+except Exception as e:
+    print('replicas dry parse failed', e); print(open('$OUT/bench_replicas_dry_$TAG.err').read()[-1500:])
+PY
+      ;;
+    mlp_batches)  # configs[2] split-f16 at batch 1024 / 2048 / 4096, fused kernel and pipeline of phases (steady state)
+      for B in ${MLP_BATCHES:-1024 2048 4096}; do for M in fused phased; do
+        if [ $(left) -lt 60 ]; then echo "SKIP $B $M"; continue; fi
+        NANN_MLP_FORM=$M timeout 200 $BENCH --scorer mlp --batch $B --steps $(( 150 * 1024 / B )) --warmup $(( 100 * 1024 / B )) --no-secondary --no-cpu-baseline > $OUT/mlp_b${B}_${M}_$TAG.json 2> $OUT/mlp_b${B}_${M}_$TAG.err
+        python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/mlp_b${B}_${M}_$TAG.json').read().strip().splitlines()[-1])
+    print('MLP batch %5d %-6s qps %9.0f ms/step %7.4f frac_mfma %s frac_hbm %s' % ($B, '$M', d['value'], d['ms_per_step'], d['roofline'].get('frac_mfma', d['roofline'].get('frac')), d['roofline'].get('frac_hbm')))
+except Exception as e:
+    print('parse failed $B $M', e)
+PY
+      done; done ;;
     *) bash $R/tools/gpu_r5.sh $TAG $(left) $STEP ;;
   esac
 done
