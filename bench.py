@@ -957,6 +957,14 @@ def main():
         except Exception as e:
             sec["hbm_stress_config5_shape"] = {"error": repr(e)}
         result["secondary"] = sec
+        # the headline's table lives in the Infinity Cache; the line that IS bound by HBM's stream rate is named
+        stress_line = sec.get("hbm_stress_config5_shape") or {}
+        if isinstance(result.get("roofline"), dict) and isinstance(stress_line.get("roofline"), dict):
+            sr = stress_line["roofline"]
+            result["roofline"]["hbm_bound_evidence"] = {
+                "line": "secondary.hbm_stress_config5_shape", "workload": stress_line.get("workload"),
+                "table_MiB": sr.get("table_MiB"), "achieved_GBs": sr.get("achieved"), "frac_of_8TBs": sr.get("frac"),
+                "frac_of_achievable_hbm": sr.get("frac_of_achievable_hbm"), "counter_traffic_GBs": sr.get("counter_traffic_GBs")}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

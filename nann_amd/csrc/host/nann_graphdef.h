@@ -41,7 +41,15 @@ struct Tensor {
   std::vector<float> f;    // float-like payloads (f32 / f64 / f16 / bf16), converted to f32
   std::vector<int64_t> i;  // integer payloads (int32 / int64 / bool): shapes, permutations
   std::vector<std::string> s;  // string_val (DT_STRING)
-  int64_t count() const { int64_t c = 1; for (int64_t v : shape) c *= v; return c; }
+  // product of the dims; -1 when a dim is negative or the product leaves int64 (found by the wire fuzzer, round 6)
+  int64_t count() const {
+    int64_t c = 1;
+    for (int64_t v : shape) {
+      if (v < 0 || (v != 0 && c > INT64_MAX / v)) return -1;
+      c *= v;
+    }
+    return c;
+  }
 };
 
 // AttrValue (attr_value.proto), every member of its oneof: what the pinning tests compare between the binary and the
@@ -184,6 +192,9 @@ inline bool parse_tensor(Cursor c, Tensor* t) {
   for (int64_t v : t->shape) if (v < 0) return false;
   const int64_t n = t->count();
   if (n < 0 || n > (int64_t)1 << 31) return false;
+  // a *_val list is repeated up to the element count: a 20-byte message may not ask for gigabytes (tensor_content is bounded
+  // by the bytes that are there); the reference's model holds 24 576-element tensors at most
+  if (content.empty() && n > (int64_t)1 << 24) return false;
   auto fill = [&](auto& dst, const auto& src) {  // repeat the last value
     dst.resize((size_t)n);
     for (int64_t k = 0; k < n; ++k) dst[(size_t)k] = src.empty() ? 0 : src[(size_t)std::min<int64_t>(k, (int64_t)src.size() - 1)];

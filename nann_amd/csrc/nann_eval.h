@@ -15,6 +15,14 @@
 //     that word of `visited` (plain loads / stores to the slot: no atomic, no fence) and clears its word of `seen`;
 //   * the rows of a frontier are walked eight per wavefront and trip, their bounds and first 64 neighbours in flight
 //     together.
+// Round 6: with `seen` in LDS the two full scans of the bitmap per round (count, then emit: 2 x 31 trips of
+// every wavefront, each emit trip with a wavefront scan -- 64 % of the kernel by the phase-repeat builds) are gone.  A second-level
+// bitmap `dirty` (one LDS word per thread, overlaid on the phase scratch between a round's gather and its emit) records which
+// words of `seen` a round touched: the lane whose atomic OR finds a word still zero sets the word's bit.  Thread t owns words
+// [32 t, 32 t + 32) of both bitmaps, so its dirty word lists ITS touched words in ascending order and thread order is word order:
+// one pass reads `visited` for the touched words only (four loads in flight), turns seen[w] into the NEW bits and updates
+// visited; ONE workgroup scan of the per-thread counts gives every thread its place in the ascending output; a second pass over
+// the same few words writes the ids and clears `seen`.  Same sets in the same order: bit-identical to the oracle as before.
 // top_k_per_level / topk_eval up to kEvalMaxK = 2048 (the reference's are defaults, config.py:50-58).
 #pragma once
 #ifndef NANN_REPEAT_SCORE
@@ -22,6 +30,12 @@
 #endif
 #ifndef NANN_REPEAT_TOPK
 #define NANN_REPEAT_TOPK 0
+#endif
+#ifndef NANN_EVAL_TICKS
+#define NANN_EVAL_TICKS 0  // measurement builds: 100 MHz ticks per phase of a user, summed over the launch (EvalArgs.ticks; NANN_EVAL_TICKS=1 in the environment prints them)
+#endif
+#ifndef NANN_REPEAT_GATHER
+#define NANN_REPEAT_GATHER 0  // the walk of the frontier's rows into `seen` twice (idempotent: the bits are ORed)
 #endif
 #include "nann_search.h"
 
@@ -47,6 +61,8 @@ struct EvalArgs {
   unsigned long long slot_bytes;
   uint32_t bm_words;   // padded to a multiple of 4
   int cat_cap;         // entries of the result||next arrays
+  unsigned long long* ticks;  // measurement builds (NANN_EVAL_TICKS): 16 accumulators, else unused
+  int use_dirty;       // slot form: the second-level bitmap fits the phase scratch (eval_plan); the LDS form always has it
   int64_t* out_ids;    // [n_queries, topk_eval]
   float* out_scores;
   int32_t* out_index;
@@ -141,28 +157,74 @@ __device__ __forceinline__ void eval_score(const EvalArgs& a, int qi, const int3
 
 template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
 __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
-                                               unsigned char* scratch, float* qv, int* n_result) {
+                                               unsigned char* scratch, float* qv, int* n_result, bool clear_seen) {
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   int ctr_f = 0, ctr_s = 0;  // (uniform)
   int ctr_g = 0;             // this lane's share: row lengths it fetched (lanes 0-7 of every wavefront)
   constexpr int NW = NT / 64;
   EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
+#if NANN_EVAL_TICKS
+  long long tk_last = wall_clock64();
+  unsigned long long tk[10] = {};
+#define EVAL_TICK(i) do { __syncthreads(); const long long now_ = wall_clock64(); tk[i] += (unsigned long long)(now_ - tk_last); tk_last = now_; } while (0)
+#else
+#define EVAL_TICK(i) do { } while (0)
+#endif
   if constexpr (SC != kScorerAttn) {
     for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
   }
-  // the words of the bitmaps a thread owns: wavefront w, trip j, lane l -> word w C + 64 j + l (C a multiple of 64)
+  // ---- the second-level bitmap (round 6).  dirty word d, bit b <-> word 32 d + b of `seen` was touched this round (the lane
+  // whose atomic OR found the word still zero reports it).  Thread t owns dirty words [t D, (t + 1) D) and with them words
+  // [32 t D, 32 (t + 1) D) of `seen` and `visited`: its dirty words list ITS touched words in ascending order, and thread order is
+  // word order.  The dirty words live in the phase scratch behind the scan scratch: valid from a round's gather to its emit
+  // (scoring and top-k reuse the scratch; they are zeroed again behind them).  use_dirty: they fit (eval_plan; always in the
+  // LDS form) -- else the full scans of round 4, every bitmap word with one owner (wavefront w, trip j, lane l -> w C + 64 j + l).
+  const bool use_dirty = SEEN_LDS || a.use_dirty;
+  const uint32_t DW = (a.bm_words + 31u) >> 5;
+  const int D = (int)((DW + NT - 1) / NT);
+  uint32_t* dirty = reinterpret_cast<uint32_t*>(scratch + 256);
+  const uint32_t d0 = (uint32_t)tid * (uint32_t)D;
   const uint32_t C = (((a.bm_words + NW - 1) / NW) + 63u) & ~63u;
   const int J = (int)(C >> 6);
   const uint32_t w0 = (uint32_t)wave * C + (uint32_t)lane;
   auto seen_load = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? seen[w] : ld_word(&seen[w]); };
   auto seen_or = [&](uint32_t id) {
-    const uint32_t bit = 1u << (id & 31);
-    if constexpr (SEEN_LDS) atomicOr(&seen[id >> 5], bit);
-    else __hip_atomic_fetch_or(&seen[id >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t bit = 1u << (id & 31), w = id >> 5;
+    if constexpr (SEEN_LDS) {
+      if (atomicOr(&seen[w], bit) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
+    } else if (use_dirty) {
+      if (__hip_atomic_fetch_or(&seen[w], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
+    } else {
+      __hip_atomic_fetch_or(&seen[w], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   };
-  for (int j = 0; j < J; ++j) {  // (a user that failed may have left bits)
-    const uint32_t w = w0 + 64u * j;
-    if (w < a.bm_words) seen[w] = 0u;
+  auto zero_dirty = [&]() {
+    for (uint32_t d = (uint32_t)tid; d < DW; d += NT) dirty[d] = 0u;
+  };
+  // the touched words of this thread in ascending order, four at a time (so that their loads are in flight together):
+  // body(w[4], n) with n <= 4 valid word indices
+  auto for_dirty4 = [&](auto&& body) {
+    for (int dd = 0; dd < D; ++dd) {
+      const uint32_t d = d0 + (uint32_t)dd;
+      uint32_t dw = d < DW ? dirty[d] : 0u;
+      while (dw) {
+        uint32_t w[4];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (dw) { w[k] = d * 32u + (uint32_t)(__ffs(dw) - 1); dw &= dw - 1; n = k + 1; } else w[k] = 0u;
+        }
+        body(w, n);
+      }
+    }
+  };
+  if (clear_seen) {  // the slot's first user, or the one behind a user that failed with bits set: every other user leaves `seen` zero
+    if constexpr (SEEN_LDS) {
+      for (uint32_t w = (uint32_t)tid; w < a.bm_words; w += NT) seen[w] = 0u;
+    } else {
+      uint4* s4 = reinterpret_cast<uint4*>(seen);
+      for (uint32_t i = (uint32_t)tid; i < a.bm_words / 4u; i += NT) s4[i] = uint4{0u, 0u, 0u, 0u};
+    }
   }
   if (tid < 2) SS->flags[tid] = 0;
   __syncthreads();
@@ -174,12 +236,21 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   if (E <= 0) return NANN_ERR_EMPTY_SCORE_BATCH;
   eval_score<LPR, DT, SC, NT>(a, qi, a.enter, E, sv.cat_sc, scratch, qv, mlp_u);
   ctr_s += E;
+  EVAL_TICK(0);
   int n_res = min(a.top_k[2], E);
   int st = wg_topk<NT, kEvalMaxK>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr, scratch);
   if (st) return st;
+  EVAL_TICK(1);
 
   for (int level = 1; level >= 0; --level) {  // search_level (:299-337)
     if (tid < 2) SS->flags[tid] = 0;  // (the scratch was reused since)
+    if (use_dirty) {
+      zero_dirty();
+      // visited = {} for the level: plain 16-byte stores by everybody (bm_words is a multiple of 4); the owners' stores of the
+      // marks below are ordered behind them by the barrier
+      uint4* v4 = reinterpret_cast<uint4*>(sv.visited);
+      for (uint32_t i = (uint32_t)tid; i < a.bm_words / 4u; i += NT) v4[i] = uint4{0u, 0u, 0u, 0u};
+    }
     __syncthreads();
     // visited = idx_ep (:311): the marks go through `seen`; result -> front of the concat arrays; candidates = result
     for (int i = tid; i < n_res; i += NT) {
@@ -192,29 +263,43 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
     }
     __syncthreads();
     if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    for (int j = 0; j < J; ++j) {  // the owners: visited = marks, seen = 0
-      const uint32_t w = w0 + 64u * j;
-      if (w < a.bm_words) {
-        const uint32_t s = seen_load(w);
-        sv.visited[w] = s;
-        if (s) seen[w] = 0u;
+    if (use_dirty) {  // the owners of the marked words: visited = marks, seen = 0
+      for_dirty4([&](const uint32_t (&w)[4], int n) {
+        uint32_t sw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sw[k] = k < n ? seen_load(w[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < n) { sv.visited[w[k]] = sw[k]; seen[w[k]] = 0u; }
+      });
+      __syncthreads();  // (every owner has read its dirty words)
+      zero_dirty();
+    } else {
+      for (int j = 0; j < J; ++j) {  // the owners: visited = marks, seen = 0
+        const uint32_t w = w0 + 64u * j;
+        if (w < a.bm_words) {
+          const uint32_t s = seen_load(w);
+          sv.visited[w] = s;
+          if (s) seen[w] = 0u;
+        }
       }
     }
     __syncthreads();
+    EVAL_TICK(2);
     int n_cand = n_res;
     const int32_t* __restrict__ values = a.nbv[level];
     const int64_t* __restrict__ rs = a.nbrs[level];
     for (int it = 0; it < a.num_scoring[level]; ++it) {
       // ---- neighbours of the candidates -> bits of `seen`: eight rows per wavefront and trip
       ctr_f += n_cand;
-      {
+      for (int rep = 0; rep <= NANN_REPEAT_GATHER; ++rep) {
         int bad = 0;
         for (int base = wave * 8; base < n_cand; base += NW * 8) {
           long long s = 0, e = 0;
           if (lane < 8 && base + lane < n_cand) {
             const int32_t c = sv.cand[base + lane];
             s = rs[c]; e = rs[c + 1];
-            ctr_g += (int)(e - s);
+            if (rep == 0) ctr_g += (int)(e - s);
           }
           int32_t v[8];
           long long sr[8], er[8];
@@ -238,26 +323,64 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       }
       __syncthreads();
       if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-      // ---- new = seen & ~visited, counted per owner ...
-      // (round 5) With `seen` in LDS a thread owns at most kEvalOwned words: its words of `visited` are fetched HERE, all at
-      // once, and serve both passes below.  The passes used to read visited[w] inside `if (s)`, one dependent L2 round trip
-      // per trip of a wavefront and pass -- 2 x 31 of them per round, which was most of this kernel's time.
-      uint32_t visw[kEvalOwned];
-      if constexpr (SEEN_LDS) {
+      EVAL_TICK(3);
+      // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
+      int n_next = 0;
+      if (use_dirty) {
+        // pass 1, this thread's touched words only: count the new bits
+        uint32_t cnt = 0;
+        for_dirty4([&](const uint32_t (&w)[4], int n) {
+          uint32_t vis[4], sw[4];
 #pragma unroll
-        for (int j = 0; j < kEvalOwned; ++j) {
-          const uint32_t w = w0 + 64u * j;
-          visw[j] = (j < J && w < a.bm_words) ? sv.visited[w] : 0u;
-        }
-      }
-      uint32_t cnt = 0;
-      if constexpr (SEEN_LDS) {
+          for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[w[k]] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
 #pragma unroll
-        for (int j = 0; j < kEvalOwned; ++j) {
-          const uint32_t w = w0 + 64u * j;
-          if (j < J && w < a.bm_words) cnt += (uint32_t)__popc(seen[w] & ~visw[j]);
-        }
+          for (int k = 0; k < 4; ++k)
+            if (k < n) {
+              const uint32_t nw = sw[k] & ~vis[k];
+              if constexpr (SEEN_LDS) {  // LDS is coherent in program order: keep the NEW bits for pass 2, update visited now
+                seen[w[k]] = nw;
+                if (nw) sv.visited[w[k]] = vis[k] | nw;
+              }
+              cnt += (uint32_t)__popc(nw);
+            }
+        });
+        uint32_t total;
+        uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);  // thread order = word order = ascending ids
+        n_next = (int)total;
+        ctr_s += n_next;
+        if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
+        // pass 2: the ids; seen = 0 for the next round
+        int32_t* dst = sv.cat_ids + n_res;
+        for_dirty4([&](const uint32_t (&w)[4], int n) {
+          uint32_t nw[4];
+          if constexpr (SEEN_LDS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nw[k] = k < n ? seen[w[k]] : 0u;
+          } else {  // the slot form reads both words again (L2 hits) instead of a store -> load of the same word through L2
+            uint32_t vis[4], sw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[w[k]] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              nw[k] = sw[k] & ~vis[k];
+              if (k < n && nw[k]) sv.visited[w[k]] = vis[k] | nw[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < n) {
+              seen[w[k]] = 0u;
+              uint32_t x = nw[k];
+              while (x) {
+                dst[at++] = (int32_t)(w[k] * 32u + (uint32_t)(__ffs(x) - 1));
+                x &= x - 1;
+              }
+            }
+        });
+        __syncthreads();  // (every owner has read its dirty words)
+        zero_dirty();
       } else {
+        uint32_t cnt = 0;
         for (int j = 0; j < J; ++j) {
           const uint32_t w = w0 + 64u * j;
           if (w < a.bm_words) {
@@ -265,23 +388,31 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
             if (s) cnt += (uint32_t)__popc(s & ~sv.visited[w]);
           }
         }
-      }
-      const uint32_t wtot = wave_total(wave_scan_add(cnt));
-      if (lane == 0) SS->wave_tot[wave] = wtot;
-      __syncthreads();
-      uint32_t run = 0, total = 0;
-      for (int w = 0; w < NW; ++w) {
-        const uint32_t t = SS->wave_tot[w];
-        if (w < wave) run += t;
-        total += t;
-      }
-      const int n_next = (int)total;
-      ctr_s += n_next;
-      if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
-      // ---- ... and written out in word order = ascending ids (:316-319); visited |= new (:321), seen = 0
-      {
+        const uint32_t wtot = wave_total(wave_scan_add(cnt));
+        if (lane == 0) SS->wave_tot[wave] = wtot;
+        __syncthreads();
+        uint32_t run = 0, total = 0;
+        for (int w = 0; w < NW; ++w) {
+          const uint32_t t = SS->wave_tot[w];
+          if (w < wave) run += t;
+          total += t;
+        }
+        n_next = (int)total;
+        ctr_s += n_next;
+        if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
         int32_t* dst = sv.cat_ids + n_res;
-        auto emit_word = [&](uint32_t w, uint32_t nw) {
+        for (int j = 0; j < J; ++j) {  // word order = ascending ids; every bitmap word has ONE owner thread
+          const uint32_t w = w0 + 64u * j;
+          uint32_t nw = 0;
+          if (w < a.bm_words) {
+            const uint32_t s = seen_load(w);
+            if (s) {
+              const uint32_t vis = sv.visited[w];
+              nw = s & ~vis;
+              sv.visited[w] = vis | s;
+              seen[w] = 0u;
+            }
+          }
           const uint32_t c = (uint32_t)__popc(nw);
           const uint32_t inc = wave_scan_add(c);
           uint32_t at = run + inc - c;
@@ -291,41 +422,10 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
             dst[at++] = (int32_t)(w * 32u + (uint32_t)b);
           }
           run += wave_total(inc);
-        };
-        if constexpr (SEEN_LDS) {
-#pragma unroll
-          for (int j = 0; j < kEvalOwned; ++j) {
-            if (j >= J) break;  // (uniform)
-            const uint32_t w = w0 + 64u * j;
-            uint32_t nw = 0;
-            if (w < a.bm_words) {
-              const uint32_t s = seen[w];
-              if (s) {
-                nw = s & ~visw[j];
-                sv.visited[w] = visw[j] | s;
-                seen[w] = 0u;
-              }
-            }
-            emit_word(w, nw);
-          }
-        } else {
-          for (int j = 0; j < J; ++j) {
-            const uint32_t w = w0 + 64u * j;
-            uint32_t nw = 0;
-            if (w < a.bm_words) {
-              const uint32_t s = seen_load(w);
-              if (s) {
-                const uint32_t vis = sv.visited[w];
-                nw = s & ~vis;
-                sv.visited[w] = vis | s;
-                seen[w] = 0u;
-              }
-            }
-            emit_word(w, nw);
-          }
         }
       }
       __syncthreads();
+      EVAL_TICK(4);
       if (n_next == 0) {  // plain TF ops score an empty batch as an empty tensor: the result is cut to min(k, n), no candidate is left
         n_res = min(a.top_k[level], n_res);
         n_cand = 0;
@@ -335,6 +435,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
 #if NANN_REPEAT_SCORE  // measurement builds (tools/build_res_variant.py --unit nann_eval_inst.hip): a phase run twice costs what it costs once
       eval_score<LPR, DT, SC, NT>(a, qi, sv.cat_ids + n_res, n_next, sv.cat_sc + n_res, scratch, qv, mlp_u);
 #endif
+      EVAL_TICK(5);
       const int n_cat = n_res + n_next;
       const int k = min(a.top_k[level], n_cat);
 #if NANN_REPEAT_TOPK
@@ -345,29 +446,38 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       st = wg_topk<NT, kEvalMaxK>(sv.cat_ids, sv.cat_sc, nullptr, n_cat, k, nullptr, sv.res_ids, sv.res_sc, nullptr, nullptr,
                                   scratch);  // :326-328
       if (st) return st;
-      // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331)
+      EVAL_TICK(6);
+      // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331).  Round 6: every thread takes a
+      // CONTIGUOUS run of the new nodes, so one workgroup scan places them (it was one scan, two barriers, per 1024 nodes)
       const float worst = sv.res_sc[k - 1];
-      uint32_t n_new = 0;
-      for (int base = 0; base < n_next; base += NT) {
-        const int i = base + tid;
-        const bool keep = i < n_next && sv.cat_sc[n_res + i] >= worst;
-        uint32_t tot;
-        const uint32_t pos = n_new + wg_excl_scan<NT>(keep ? 1u : 0u, SS, &tot);
-        if (keep && pos < (uint32_t)kEvalMaxK) sv.cand[pos] = sv.cat_ids[n_res + i];
-        n_new += tot;
+      {
+        const int per = (n_next + NT - 1) / NT;
+        const int lo = min(tid * per, n_next), hi = min(lo + per, n_next);
+        uint32_t mine = 0;
+        for (int i = lo; i < hi; ++i) mine += sv.cat_sc[n_res + i] >= worst ? 1u : 0u;
+        uint32_t n_new;
+        uint32_t pos = wg_excl_scan<NT>(mine, SS, &n_new);
+        if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
+        for (int i = lo; i < hi; ++i)
+          if (sv.cat_sc[n_res + i] >= worst) sv.cand[pos++] = sv.cat_ids[n_res + i];
+        n_cand = (int)n_new;
       }
-      if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
-      __syncthreads();
-      n_cand = (int)n_new;
+      __syncthreads();  // (the copy below overwrites cat_ids[n_res ..] that the selection above reads)
       n_res = k;
       for (int i = tid; i < k; i += NT) {
         sv.cat_ids[i] = sv.res_ids[i];
         sv.cat_sc[i] = sv.res_sc[i];
       }
       if (tid < 2) SS->flags[tid] = 0;  // (the scratch was reused since)
+      if (use_dirty) zero_dirty();
       __syncthreads();
+      EVAL_TICK(7);
     }
   }
+#if NANN_EVAL_TICKS
+  if (tid == 0 && a.ticks)
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.ticks[i], tk[i]);
+#endif
   *n_result = n_res;
   if (a.counters) {  // (the kernel zeroed the user's three words before the call)
     if (tid == 0) { atomicAdd(&a.counters[(size_t)qi * 3 + 0], ctr_f); atomicAdd(&a.counters[(size_t)qi * 3 + 2], ctr_s); }
@@ -399,6 +509,7 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
   sv.cand = reinterpret_cast<int32_t*>(slot + off[6]);
   WsHeader* hdr = reinterpret_cast<WsHeader*>(a.ws);
   const int K = a.topk_eval;
+  bool clear_seen = true;  // (uniform)
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) misc[0] = (int)atomicAdd(&hdr->queue, 1u);
@@ -408,8 +519,11 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
     if (a.counters && threadIdx.x < 3) a.counters[(size_t)qi * 3 + threadIdx.x] = 0;
     int n_res = 0;
     int st;
-    if constexpr (SEEN_LDS) st = search_eval_one<LPR, DT, SC, NT, true>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res);
-    else st = search_eval_one<LPR, DT, SC, NT, false>(a, qi, sv, sv.seen, scratch, qv, &n_res);
+    // `seen` is all-zero behind a user that succeeded (the emit pass clears what the round touched); the slot's first user
+    // and the one behind a failure clear it whole.  (Without the dirty words the owners clear as they scan: same invariant.)
+    if constexpr (SEEN_LDS) st = search_eval_one<LPR, DT, SC, NT, true>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res, clear_seen);
+    else st = search_eval_one<LPR, DT, SC, NT, false>(a, qi, sv, sv.seen, scratch, qv, &n_res, clear_seen);
+    clear_seen = st != 0;
     __syncthreads();
     const int n = st ? 0 : min(K, n_res);  // results[:topk_eval] (:358), item ids (:360)
     for (int i = threadIdx.x; i < K; i += NT) {
@@ -444,6 +558,7 @@ inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
 // instantiations: nann_eval_inst.hip (L2, attention model), nann_mlp_inst.hip (MLP, f32 MFMA).  seen_lds: the L2
 // instances only (eval_l2_lds_bytes() = what the plan checks against the CU's LDS)
 size_t eval_l2_lds_base();
+size_t eval_dirty_room();  // bytes of the phase scratch the second-level bitmap may take (the smallest instance's)
 int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_attn(int d, int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d64(int dt, int slots, const EvalArgs& a, hipStream_t st);

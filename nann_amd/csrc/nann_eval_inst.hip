@@ -12,6 +12,8 @@ static int eval_l2(int dt, int slots, const EvalArgs& a, hipStream_t st) {
 }
 
 size_t eval_l2_lds_base() { return eval_lds_base<NANN_SCORER_L2, kNT>(); }
+// every instance has at least the top-k scratch of kEvalMaxK (eval_scratch_bytes is a max over it)
+size_t eval_dirty_room() { return (sizeof(TopkScratchT<kEvalMaxK>) + 255) & ~(size_t)255; }
 
 int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st) {
 #define NANN_EVAL_L2(LPR_) return seen_lds ? eval_l2<LPR_, true>(dt, slots, a, st) : eval_l2<LPR_, false>(dt, slots, a, st)

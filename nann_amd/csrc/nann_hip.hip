@@ -2656,6 +2656,9 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   a.topk_eval = topk_eval;
   a.ws = static_cast<unsigned char*>(workspace);
   a.bm_words = ix->bm_words;
+  // the second-level bitmap (nann_eval.h, round 6): one bit per word of `seen`, overlaid on the phase scratch behind the scan
+  // scratch -- it fits shards of up to ~7 M items; beyond, the slot form keeps round 4's full scans
+  a.use_dirty = 256 + (size_t)((ix->bm_words + 31u) >> 5) * 4 <= eval_dirty_room() ? 1 : 0;
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index; a.n_out = n_out; a.status = status;
   a.counters = counters;
   a.mlp = MlpParams{};
@@ -2663,6 +2666,22 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   a.kt = kt; a.upad = upad;
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
   const int dt = ix->desc.emb_dtype, d = ix->desc.d;
+  // measurement builds of nann_eval.h (-DNANN_EVAL_TICKS=1, tools/build_res_variant.py): per-phase ticks of the launch on stderr
+  static const bool want_ticks = [] { const char* e = std::getenv("NANN_EVAL_TICKS"); return e && e[0] == '1'; }();
+  a.ticks = nullptr;
+  if (want_ticks && !attn && scorer->desc.kind != NANN_SCORER_MLP) {
+    static unsigned long long* g_ticks = nullptr;
+    if (!g_ticks) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_ticks), 16 * 8));
+    HIP_TRY(hipMemsetAsync(g_ticks, 0, 16 * 8, st));
+    a.ticks = g_ticks;
+    rc = launch_eval_l2(d / 8, dt, seen_lds, slots, a, st);
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpyAsync(h, g_ticks, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::fprintf(stderr, "EVALTICKS users %lld (100 MHz ticks, sum over users) entry_score %llu entry_topk %llu level_start %llu gather %llu scan %llu score %llu topk %llu select %llu\n",
+                 (long long)n_queries, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    return rc;
+  }
   if (attn) {
     a.attn = attn->P;
     return launch_eval_attn(d, dt, slots, a, st);

@@ -309,6 +309,23 @@ def test_huge_const(tmp_path):
     assert e.value.status == 106
     with pytest.raises(ops.NotFoundError):  # :96-98
         ops.HugeConst(str(tmp_path / "missing.npy"), np.int64, (1,))
+    # round 6: npy format 2.0 (npy.h:541-571 accepts 1.0 and 2.0) and 3.0 load like 1.0; Fortran order is refused (:108-109)
+    for version in ((2, 0), (3, 0)):
+        pv = str(tmp_path / ("v%d.npy" % version[0]))
+        with open(pv, "wb") as f:
+            np.lib.format.write_array(f, a, version=version)
+        assert (ops.HugeConst(pv, np.float16, (300, 64)).tensor.cpu().numpy() == a).all()
+    pf = str(tmp_path / "fortran.npy")
+    with open(pf, "wb") as f:
+        np.lib.format.write_array(f, np.asfortranarray(a), version=(1, 0))
+    with pytest.raises(ops.UnimplementedError) as e:
+        ops.HugeConst(pf, np.float16, (300, 64))
+    assert e.value.status == 102 and "Fortran order NOT supported." in str(e.value)
+    trunc = str(tmp_path / "trunc.npy")
+    open(trunc, "wb").write(open(p, "rb").read()[:-100])
+    with pytest.raises(ops.NotFoundError) as e:  # the header promises more than the file holds: refused before any allocation
+        ops.HugeConst(trunc, np.float16, (300, 64))
+    assert "truncated npy payload" in str(e.value)
 
 
 # ---------------------------------------------------------------- shard merge

@@ -45,6 +45,19 @@ except Exception as e:
     print('replicas dry parse failed', e); print(open('$OUT/bench_replicas_dry_$TAG.err').read()[-1500:])
 PY
       ;;
+    eval_vars)  # phase-repeat builds of the evaluation traversal (a phase run twice costs what it costs once): shipped, then var_ev_*
+      for L in $R/nann_amd/_build/libnann_hip.so $R/nann_amd/_build/var_ev_*/libnann_hip.so; do
+        V=$(basename $(dirname $L)); [ "$V" = "_build" ] && V=shipped
+        NANN_HIP_LIB=$L timeout 300 python tools/eval_bench.py /tmp/idx 1024 2 > $OUT/eval_var_${V}_$TAG.json 2> $OUT/eval_var_${V}_$TAG.err
+        python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/eval_var_${V}_$TAG.json').read().strip().splitlines()[-1])
+    print('EVALVAR %-10s defaults %.3f ms  wide %.3f ms  (bit-identical %s/%s)' % ('$V', d['defaults_400_200_100']['ms_per_launch'], d['wide_2000_1000_500']['ms_per_launch'], d['defaults_400_200_100']['bit_identical'], d['wide_2000_1000_500']['bit_identical']))
+except Exception as e:
+    print('EVALVAR $V failed', e)
+PY
+      done ;;
     mlp_batches)  # configs[2] split-f16 at batch 1024 / 2048 / 4096, fused kernel and pipeline of phases (steady state)
       for B in ${MLP_BATCHES:-1024 2048 4096}; do for M in fused phased; do
         if [ $(left) -lt 60 ]; then echo "SKIP $B $M"; continue; fi
