@@ -61,6 +61,7 @@ struct EvalArgs {
   unsigned long long slot_bytes;
   uint32_t bm_words;   // padded to a multiple of 4
   int cat_cap;         // entries of the result||next arrays
+  uint32_t vis_words;  // words of a slot's `visited` region (the transposed layout rounds the owners' runs up)
   unsigned long long* ticks;  // measurement builds (NANN_EVAL_TICKS): 16 accumulators, else unused
   int use_dirty;       // slot form: the second-level bitmap fits the phase scratch (eval_plan); the LDS form always has it
   int64_t* out_ids;    // [n_queries, topk_eval]
@@ -86,10 +87,21 @@ struct EvalSlot {
   int32_t* cand;
 };
 
+// words of `visited` in its transposed layout: 32 words for every dirty word, the dirty words rounded up to a whole number per
+// thread of either workgroup size (512, 1024)
+__host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words) {
+  const uint32_t dw = (bm_words + 31u) >> 5;
+  return ((dw + 1023u) / 1024u) * 1024u * 32u;
+}
+// bytes of `seen` in LDS: skewed by one word per 32 (search_eval_one)
+__host__ __device__ inline size_t eval_seen_lds_bytes(uint32_t bm_words) {
+  return (((size_t)bm_words + (bm_words >> 5) + 1) * 4 + 255) & ~(size_t)255;
+}
+
 __host__ __device__ inline unsigned long long eval_slot_layout(uint32_t bm_words, int cat_cap, unsigned long long off[7]) {
   unsigned long long o = 0;
   auto put = [&](int i, unsigned long long bytes) { off[i] = o; o += (bytes + 255ull) & ~255ull; };
-  put(0, 4ull * bm_words);
+  put(0, 4ull * eval_vis_words(bm_words));
   put(1, 4ull * bm_words);
   put(2, 4ull * cat_cap);
   put(3, 4ull * cat_cap);
@@ -123,6 +135,7 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, EvalScanScratch* S,
   return base + inc - v;
 }
 
+constexpr int kEvalBatch = 8;   // words of `visited` an owner fetches together (a rolled loop of 32 / kEvalBatch trips: registers)
 constexpr int kEvalOwned = 32;  // words of a bitmap one thread owns when `seen` is in LDS (eval_plan: bm_words <= threads x this)
 
 __device__ __forceinline__ uint32_t ld_word(const uint32_t* p) {  // past the L1: the word is changed by atomics performed in L2
@@ -187,11 +200,20 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   const uint32_t C = (((a.bm_words + NW - 1) / NW) + 63u) & ~63u;
   const int J = (int)(C >> 6);
   const uint32_t w0 = (uint32_t)wave * C + (uint32_t)lane;
-  auto seen_load = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? seen[w] : ld_word(&seen[w]); };
+  // Physical layouts (round 6, second step).  `seen` in LDS is SKEWED by one word per 32 (word w at w + w / 32): the owners read
+  // words 32 t + j, lanes 32 words apart -- two LDS banks for the whole wavefront without the skew.  `visited` (the slot, only
+  // ever touched by its owners) is TRANSPOSED: word j of thread t's run r at (32 r + j) NT + t, so that a wavefront's loads of
+  // "my j-th word" are 256 contiguous bytes.
+  auto sp = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? w + (w >> 5) : w; };
+  auto vp = [&](uint32_t w) -> uint32_t {
+    const uint32_t d = w >> 5, t = d / (uint32_t)D, r = d - t * (uint32_t)D;
+    return (r * 32u + (w & 31u)) * (uint32_t)NT + t;
+  };
+  auto seen_load = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? seen[sp(w)] : ld_word(&seen[w]); };
   auto seen_or = [&](uint32_t id) {
     const uint32_t bit = 1u << (id & 31), w = id >> 5;
     if constexpr (SEEN_LDS) {
-      if (atomicOr(&seen[w], bit) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
+      if (atomicOr(&seen[sp(w)], bit) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
     } else if (use_dirty) {
       if (__hip_atomic_fetch_or(&seen[w], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
     } else {
@@ -220,7 +242,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   };
   if (clear_seen) {  // the slot's first user, or the one behind a user that failed with bits set: every other user leaves `seen` zero
     if constexpr (SEEN_LDS) {
-      for (uint32_t w = (uint32_t)tid; w < a.bm_words; w += NT) seen[w] = 0u;
+      for (uint32_t w = (uint32_t)tid; w < a.bm_words + (a.bm_words >> 5) + 1u; w += NT) seen[w] = 0u;
     } else {
       uint4* s4 = reinterpret_cast<uint4*>(seen);
       for (uint32_t i = (uint32_t)tid; i < a.bm_words / 4u; i += NT) s4[i] = uint4{0u, 0u, 0u, 0u};
@@ -249,7 +271,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       // visited = {} for the level: plain 16-byte stores by everybody (bm_words is a multiple of 4); the owners' stores of the
       // marks below are ordered behind them by the barrier
       uint4* v4 = reinterpret_cast<uint4*>(sv.visited);
-      for (uint32_t i = (uint32_t)tid; i < a.bm_words / 4u; i += NT) v4[i] = uint4{0u, 0u, 0u, 0u};
+      for (uint32_t i = (uint32_t)tid; i < a.vis_words / 4u; i += NT) v4[i] = uint4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
     // visited = idx_ep (:311): the marks go through `seen`; result -> front of the concat arrays; candidates = result
@@ -263,14 +285,24 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
     }
     __syncthreads();
     if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    if (use_dirty) {  // the owners of the marked words: visited = marks, seen = 0
+    if (SEEN_LDS && D == 1) {  // the owners of the marked words: visited = marks, seen = 0 (one dirty word per thread: its own)
+      const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
+      if (dw) {
+        for (uint32_t x = dw; x; x &= x - 1) {
+          const uint32_t j = (uint32_t)(__ffs(x) - 1), pw = sp((uint32_t)tid * 32u + j);
+          sv.visited[j * NT + (uint32_t)tid] = seen[pw];
+          seen[pw] = 0u;
+        }
+        dirty[tid] = 0u;
+      }
+    } else if (use_dirty) {
       for_dirty4([&](const uint32_t (&w)[4], int n) {
         uint32_t sw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) sw[k] = k < n ? seen_load(w[k]) : 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < n) { sv.visited[w[k]] = sw[k]; seen[w[k]] = 0u; }
+          if (k < n) { sv.visited[vp(w[k])] = sw[k]; seen[sp(w[k])] = 0u; }
       });
       __syncthreads();  // (every owner has read its dirty words)
       zero_dirty();
@@ -294,12 +326,18 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       ctr_f += n_cand;
       for (int rep = 0; rep <= NANN_REPEAT_GATHER; ++rep) {
         int bad = 0;
+        long long s_nx = 0, e_nx = 0;  // the bounds of the NEXT trip's rows are fetched under this trip's values and atomics
+        if (lane < 8 && wave * 8 + lane < n_cand) {
+          const int32_t c = sv.cand[wave * 8 + lane];
+          s_nx = rs[c]; e_nx = rs[c + 1];
+        }
         for (int base = wave * 8; base < n_cand; base += NW * 8) {
-          long long s = 0, e = 0;
-          if (lane < 8 && base + lane < n_cand) {
-            const int32_t c = sv.cand[base + lane];
-            s = rs[c]; e = rs[c + 1];
-            if (rep == 0) ctr_g += (int)(e - s);
+          const long long s = s_nx, e = e_nx;
+          if (rep == 0) ctr_g += (int)(e - s);
+          s_nx = 0; e_nx = 0;
+          if (lane < 8 && base + NW * 8 + lane < n_cand) {
+            const int32_t c = sv.cand[base + NW * 8 + lane];
+            s_nx = rs[c]; e_nx = rs[c + 1];
           }
           int32_t v[8];
           long long sr[8], er[8];
@@ -326,20 +364,68 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       EVAL_TICK(3);
       // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
       int n_next = 0;
-      if (use_dirty) {
+      if (SEEN_LDS && D == 1) {
+        // The LDS form: one dirty word per thread, its own.  Its touched words' `visited` in two batches of sixteen (coalesced)
+        // loads; the NEW bits go back into seen[w] (LDS, conflict-free thanks to the skew) for the emit behind the one scan.
+        const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
+        if (dw) dirty[tid] = 0u;  // (nobody else touches it before the next round's gather, barriers away)
+        // ALL 32 of the thread's words of `visited`, touched or not, in ONE batch: under the load of 255 other CUs' scoring a
+        // dependent trip to the slot costs microseconds (a slot's visited words do not stay in the XCD's L2: 32 slots x 128 KB
+        // are the whole of it), and batches of 4 / 8 / 16 touched words were 5 / 4 / 2 such trips.  Buffer loads: one VGPR of
+        // offset for all of them, the word's stride in an SGPR (32 flat addresses cost 64 registers and spilled).
+        uint32_t cnt = 0;
+        {
+          const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(sv.visited, 0, (int)(a.vis_words * 4u), 0x00020000);
+          uint32_t vis[32];
+#pragma unroll
+          for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
+          if (dw) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+              if ((dw >> j) & 1u) {
+                const uint32_t pw = sp((uint32_t)tid * 32u + (uint32_t)j);
+                const uint32_t nw = seen[pw] & ~vis[j];
+                seen[pw] = nw;
+                if (nw) __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
+                cnt += (uint32_t)__popc(nw);
+              }
+          }
+        }
+        EVAL_TICK(8);
+        uint32_t total;
+        uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);  // thread order = word order = ascending ids
+        n_next = (int)total;
+        ctr_s += n_next;
+        if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
+        EVAL_TICK(9);
+        if (cnt) {
+          int32_t* dst = sv.cat_ids + n_res;
+          uint32_t dw2 = dw;
+          while (dw2) {
+            const uint32_t w = (uint32_t)tid * 32u + (uint32_t)(__ffs(dw2) - 1);
+            dw2 &= dw2 - 1;
+            uint32_t x = seen[sp(w)];
+            if (x) seen[sp(w)] = 0u;
+            while (x) {
+              dst[at++] = (int32_t)(w * 32u + (uint32_t)(__ffs(x) - 1));
+              x &= x - 1;
+            }
+          }
+        }
+      } else if (use_dirty) {
         // pass 1, this thread's touched words only: count the new bits
         uint32_t cnt = 0;
         for_dirty4([&](const uint32_t (&w)[4], int n) {
           uint32_t vis[4], sw[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[w[k]] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
+          for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[vp(w[k])] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (k < n) {
               const uint32_t nw = sw[k] & ~vis[k];
               if constexpr (SEEN_LDS) {  // LDS is coherent in program order: keep the NEW bits for pass 2, update visited now
-                seen[w[k]] = nw;
-                if (nw) sv.visited[w[k]] = vis[k] | nw;
+                seen[sp(w[k])] = nw;
+                if (nw) sv.visited[vp(w[k])] = vis[k] | nw;
               }
               cnt += (uint32_t)__popc(nw);
             }
@@ -355,21 +441,21 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
           uint32_t nw[4];
           if constexpr (SEEN_LDS) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nw[k] = k < n ? seen[w[k]] : 0u;
+            for (int k = 0; k < 4; ++k) nw[k] = k < n ? seen[sp(w[k])] : 0u;
           } else {  // the slot form reads both words again (L2 hits) instead of a store -> load of the same word through L2
             uint32_t vis[4], sw[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[w[k]] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
+            for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[vp(w[k])] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               nw[k] = sw[k] & ~vis[k];
-              if (k < n && nw[k]) sv.visited[w[k]] = vis[k] | nw[k];
+              if (k < n && nw[k]) sv.visited[vp(w[k])] = vis[k] | nw[k];
             }
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (k < n) {
-              seen[w[k]] = 0u;
+              seen[sp(w[k])] = 0u;
               uint32_t x = nw[k];
               while (x) {
                 dst[at++] = (int32_t)(w[k] * 32u + (uint32_t)(__ffs(x) - 1));
@@ -476,7 +562,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   }
 #if NANN_EVAL_TICKS
   if (tid == 0 && a.ticks)
-    for (int i = 0; i < 8; ++i) atomicAdd(&a.ticks[i], tk[i]);
+    for (int i = 0; i < 10; ++i) atomicAdd(&a.ticks[i], tk[i]);
 #endif
   *n_result = n_res;
   if (a.counters) {  // (the kernel zeroed the user's three words before the call)
@@ -491,7 +577,7 @@ template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
 __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kScratchBytes = eval_scratch_bytes<SC, NT>();
-  const size_t bm_bytes = SEEN_LDS ? (((size_t)a.bm_words * 4 + 255) & ~(size_t)255) : 0;
+  const size_t bm_bytes = SEEN_LDS ? eval_seen_lds_bytes(a.bm_words) : 0;
   unsigned char* scratch = smem + bm_bytes;
   float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);
   int* misc = reinterpret_cast<int*>(qv + kMaxD);
@@ -546,7 +632,7 @@ constexpr size_t eval_lds_base() { return (size_t)eval_scratch_bytes<SC, NT>() +
 template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
 inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
   auto kern = k_search_eval<LPR, DT, SC, NT, SEEN_LDS>;
-  const size_t lds_bytes = eval_lds_base<SC, NT>() + (SEEN_LDS ? (((size_t)a.bm_words * 4 + 255) & ~(size_t)255) : 0);
+  const size_t lds_bytes = eval_lds_base<SC, NT>() + (SEEN_LDS ? eval_seen_lds_bytes(a.bm_words) : 0);
   if (lds_bytes > 48 * 1024)
     NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -2614,7 +2614,7 @@ static int eval_plan(const nann_index* ix, int64_t n_queries, bool l2, int* cat_
   *cat_cap = (int)(kEvalMaxK + nxt);
   unsigned long long off[7];
   *slot_bytes = eval_slot_layout(ix->bm_words, *cat_cap, off);
-  const size_t lds = eval_l2_lds_base() + (((size_t)ix->bm_words * 4 + 255) & ~(size_t)255);
+  const size_t lds = eval_l2_lds_base() + eval_seen_lds_bytes(ix->bm_words);
   static const bool force_hbm = [] { const char* e = std::getenv("NANN_EVAL_SEEN"); return e && std::string(e) == "hbm"; }();
   // (a thread of the LDS form owns at most kEvalOwned words of the bitmaps and keeps its words of `visited` in registers
   //  for a round's two scans: 16 wavefronts x 64 lanes x 32 words = 2^20 items)
@@ -2659,6 +2659,7 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   // the second-level bitmap (nann_eval.h, round 6): one bit per word of `seen`, overlaid on the phase scratch behind the scan
   // scratch -- it fits shards of up to ~7 M items; beyond, the slot form keeps round 4's full scans
   a.use_dirty = 256 + (size_t)((ix->bm_words + 31u) >> 5) * 4 <= eval_dirty_room() ? 1 : 0;
+  a.vis_words = eval_vis_words(ix->bm_words);
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index; a.n_out = n_out; a.status = status;
   a.counters = counters;
   a.mlp = MlpParams{};
@@ -2678,8 +2679,8 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
     unsigned long long h[16];
     HIP_TRY(hipMemcpyAsync(h, g_ticks, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    std::fprintf(stderr, "EVALTICKS users %lld (100 MHz ticks, sum over users) entry_score %llu entry_topk %llu level_start %llu gather %llu scan %llu score %llu topk %llu select %llu\n",
-                 (long long)n_queries, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    std::fprintf(stderr, "EVALTICKS users %lld (100 MHz ticks, sum over users) entry_score %llu entry_topk %llu level_start %llu gather %llu scan %llu score %llu topk %llu select %llu | scan: pass1 %llu wgscan %llu (emit = scan)\n",
+                 (long long)n_queries, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
     return rc;
   }
   if (attn) {
