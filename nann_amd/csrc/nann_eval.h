@@ -62,6 +62,7 @@ struct EvalArgs {
   uint32_t bm_words;   // padded to a multiple of 4
   int cat_cap;         // entries of the result||next arrays
   uint32_t vis_words;  // words of a slot's `visited` region (the transposed layout rounds the owners' runs up)
+  uint32_t lds_words;  // LDS form: words of the region that holds `seen` and, from a round's emit to its end, the staged scores / results
   unsigned long long* ticks;  // measurement builds (NANN_EVAL_TICKS): 16 accumulators, else unused
   int use_dirty;       // slot form: the second-level bitmap fits the phase scratch (eval_plan); the LDS form always has it
   int64_t* out_ids;    // [n_queries, topk_eval]
@@ -93,9 +94,12 @@ __host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words) {
   const uint32_t dw = (bm_words + 31u) >> 5;
   return ((dw + 1023u) / 1024u) * 1024u * 32u;
 }
-// bytes of `seen` in LDS: skewed by one word per 32 (search_eval_one)
+// bytes of the LDS region of `seen`: the bitmap skewed by one word per 32 (search_eval_lds), and at least the staging area of a
+// small round (the kept results + 12 K scores) -- the region is `seen` from a round's gather to its emit and staging behind it
+constexpr int kEvalStageMinWords = 2 * 2048 + 12288;
 __host__ __device__ inline size_t eval_seen_lds_bytes(uint32_t bm_words) {
-  return (((size_t)bm_words + (bm_words >> 5) + 1) * 4 + 255) & ~(size_t)255;
+  const size_t skewed = (size_t)bm_words + (bm_words >> 5) + 1;
+  return ((skewed > (size_t)kEvalStageMinWords ? skewed : (size_t)kEvalStageMinWords) * 4 + 255) & ~(size_t)255;
 }
 
 __host__ __device__ inline unsigned long long eval_slot_layout(uint32_t bm_words, int cat_cap, unsigned long long off[7]) {
@@ -135,7 +139,6 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, EvalScanScratch* S,
   return base + inc - v;
 }
 
-constexpr int kEvalBatch = 8;   // words of `visited` an owner fetches together (a rolled loop of 32 / kEvalBatch trips: registers)
 constexpr int kEvalOwned = 32;  // words of a bitmap one thread owns when `seen` is in LDS (eval_plan: bm_words <= threads x this)
 
 __device__ __forceinline__ uint32_t ld_word(const uint32_t* p) {  // past the L1: the word is changed by atomics performed in L2
@@ -168,21 +171,26 @@ __device__ __forceinline__ void eval_score(const EvalArgs& a, int qi, const int3
   __syncthreads();
 }
 
-template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
-__device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
-                                               unsigned char* scratch, float* qv, int* n_result, bool clear_seen) {
+#if NANN_EVAL_TICKS
+#define EVAL_TICK_DECL long long tk_last = wall_clock64(); unsigned long long tk[10] = {}
+#define EVAL_TICK(i) do { __syncthreads(); const long long now_ = wall_clock64(); tk[i] += (unsigned long long)(now_ - tk_last); tk_last = now_; } while (0)
+#define EVAL_TICK_FLUSH do { if (local_tid() == 0 && a.ticks) for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&a.ticks[i_], tk[i_]); } while (0)
+#else
+#define EVAL_TICK_DECL do { } while (0)
+#define EVAL_TICK(i) do { } while (0)
+#define EVAL_TICK_FLUSH do { } while (0)
+#endif
+
+// ---- the slot form: `seen` in the slot (atomics performed in L2); MLP / attention scorers, shards whose bitmap does not fit LDS
+template <int LPR, int DT, int SC, int NT>
+__device__ __forceinline__ int search_eval_slot(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
+                                                unsigned char* scratch, float* qv, int* n_result, bool clear_seen) {
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   int ctr_f = 0, ctr_s = 0;  // (uniform)
   int ctr_g = 0;             // this lane's share: row lengths it fetched (lanes 0-7 of every wavefront)
   constexpr int NW = NT / 64;
   EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
-#if NANN_EVAL_TICKS
-  long long tk_last = wall_clock64();
-  unsigned long long tk[10] = {};
-#define EVAL_TICK(i) do { __syncthreads(); const long long now_ = wall_clock64(); tk[i] += (unsigned long long)(now_ - tk_last); tk_last = now_; } while (0)
-#else
-#define EVAL_TICK(i) do { } while (0)
-#endif
+  EVAL_TICK_DECL;
   if constexpr (SC != kScorerAttn) {
     for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
   }
@@ -190,9 +198,9 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   // whose atomic OR found the word still zero reports it).  Thread t owns dirty words [t D, (t + 1) D) and with them words
   // [32 t D, 32 (t + 1) D) of `seen` and `visited`: its dirty words list ITS touched words in ascending order, and thread order is
   // word order.  The dirty words live in the phase scratch behind the scan scratch: valid from a round's gather to its emit
-  // (scoring and top-k reuse the scratch; they are zeroed again behind them).  use_dirty: they fit (eval_plan; always in the
-  // LDS form) -- else the full scans of round 4, every bitmap word with one owner (wavefront w, trip j, lane l -> w C + 64 j + l).
-  const bool use_dirty = SEEN_LDS || a.use_dirty;
+  // (scoring and top-k reuse the scratch; they are zeroed again behind them).  use_dirty: they fit (eval_plan) -- else the full
+  // scans of round 4, every bitmap word with one owner (wavefront w, trip j, lane l -> w C + 64 j + l).
+  const bool use_dirty = a.use_dirty;
   const uint32_t DW = (a.bm_words + 31u) >> 5;
   const int D = (int)((DW + NT - 1) / NT);
   uint32_t* dirty = reinterpret_cast<uint32_t*>(scratch + 256);
@@ -200,21 +208,16 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
   const uint32_t C = (((a.bm_words + NW - 1) / NW) + 63u) & ~63u;
   const int J = (int)(C >> 6);
   const uint32_t w0 = (uint32_t)wave * C + (uint32_t)lane;
-  // Physical layouts (round 6, second step).  `seen` in LDS is SKEWED by one word per 32 (word w at w + w / 32): the owners read
-  // words 32 t + j, lanes 32 words apart -- two LDS banks for the whole wavefront without the skew.  `visited` (the slot, only
-  // ever touched by its owners) is TRANSPOSED: word j of thread t's run r at (32 r + j) NT + t, so that a wavefront's loads of
-  // "my j-th word" are 256 contiguous bytes.
-  auto sp = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? w + (w >> 5) : w; };
+  // `visited` (the slot, only ever touched by its owners) is TRANSPOSED when the dirty words are in use: word j of thread t's
+  // run r at (32 r + j) NT + t, so that a wavefront's loads of "my j-th word" are 256 contiguous bytes
   auto vp = [&](uint32_t w) -> uint32_t {
     const uint32_t d = w >> 5, t = d / (uint32_t)D, r = d - t * (uint32_t)D;
     return (r * 32u + (w & 31u)) * (uint32_t)NT + t;
   };
-  auto seen_load = [&](uint32_t w) -> uint32_t { return SEEN_LDS ? seen[sp(w)] : ld_word(&seen[w]); };
+  auto seen_load = [&](uint32_t w) -> uint32_t { return ld_word(&seen[w]); };
   auto seen_or = [&](uint32_t id) {
     const uint32_t bit = 1u << (id & 31), w = id >> 5;
-    if constexpr (SEEN_LDS) {
-      if (atomicOr(&seen[sp(w)], bit) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
-    } else if (use_dirty) {
+    if (use_dirty) {
       if (__hip_atomic_fetch_or(&seen[w], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
     } else {
       __hip_atomic_fetch_or(&seen[w], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -241,12 +244,8 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
     }
   };
   if (clear_seen) {  // the slot's first user, or the one behind a user that failed with bits set: every other user leaves `seen` zero
-    if constexpr (SEEN_LDS) {
-      for (uint32_t w = (uint32_t)tid; w < a.bm_words + (a.bm_words >> 5) + 1u; w += NT) seen[w] = 0u;
-    } else {
-      uint4* s4 = reinterpret_cast<uint4*>(seen);
-      for (uint32_t i = (uint32_t)tid; i < a.bm_words / 4u; i += NT) s4[i] = uint4{0u, 0u, 0u, 0u};
-    }
+    uint4* s4 = reinterpret_cast<uint4*>(seen);
+    for (uint32_t i = (uint32_t)tid; i < a.bm_words / 4u; i += NT) s4[i] = uint4{0u, 0u, 0u, 0u};
   }
   if (tid < 2) SS->flags[tid] = 0;
   __syncthreads();
@@ -285,24 +284,14 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
     }
     __syncthreads();
     if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    if (SEEN_LDS && D == 1) {  // the owners of the marked words: visited = marks, seen = 0 (one dirty word per thread: its own)
-      const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
-      if (dw) {
-        for (uint32_t x = dw; x; x &= x - 1) {
-          const uint32_t j = (uint32_t)(__ffs(x) - 1), pw = sp((uint32_t)tid * 32u + j);
-          sv.visited[j * NT + (uint32_t)tid] = seen[pw];
-          seen[pw] = 0u;
-        }
-        dirty[tid] = 0u;
-      }
-    } else if (use_dirty) {
+    if (use_dirty) {  // the owners of the marked words: visited = marks, seen = 0
       for_dirty4([&](const uint32_t (&w)[4], int n) {
         uint32_t sw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) sw[k] = k < n ? seen_load(w[k]) : 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < n) { sv.visited[vp(w[k])] = sw[k]; seen[sp(w[k])] = 0u; }
+          if (k < n) { sv.visited[vp(w[k])] = sw[k]; seen[w[k]] = 0u; }
       });
       __syncthreads();  // (every owner has read its dirty words)
       zero_dirty();
@@ -364,55 +353,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       EVAL_TICK(3);
       // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
       int n_next = 0;
-      if (SEEN_LDS && D == 1) {
-        // The LDS form: one dirty word per thread, its own.  Its touched words' `visited` in two batches of sixteen (coalesced)
-        // loads; the NEW bits go back into seen[w] (LDS, conflict-free thanks to the skew) for the emit behind the one scan.
-        const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
-        if (dw) dirty[tid] = 0u;  // (nobody else touches it before the next round's gather, barriers away)
-        // ALL 32 of the thread's words of `visited`, touched or not, in ONE batch: under the load of 255 other CUs' scoring a
-        // dependent trip to the slot costs microseconds (a slot's visited words do not stay in the XCD's L2: 32 slots x 128 KB
-        // are the whole of it), and batches of 4 / 8 / 16 touched words were 5 / 4 / 2 such trips.  Buffer loads: one VGPR of
-        // offset for all of them, the word's stride in an SGPR (32 flat addresses cost 64 registers and spilled).
-        uint32_t cnt = 0;
-        {
-          const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(sv.visited, 0, (int)(a.vis_words * 4u), 0x00020000);
-          uint32_t vis[32];
-#pragma unroll
-          for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
-          if (dw) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j)
-              if ((dw >> j) & 1u) {
-                const uint32_t pw = sp((uint32_t)tid * 32u + (uint32_t)j);
-                const uint32_t nw = seen[pw] & ~vis[j];
-                seen[pw] = nw;
-                if (nw) __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
-                cnt += (uint32_t)__popc(nw);
-              }
-          }
-        }
-        EVAL_TICK(8);
-        uint32_t total;
-        uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);  // thread order = word order = ascending ids
-        n_next = (int)total;
-        ctr_s += n_next;
-        if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
-        EVAL_TICK(9);
-        if (cnt) {
-          int32_t* dst = sv.cat_ids + n_res;
-          uint32_t dw2 = dw;
-          while (dw2) {
-            const uint32_t w = (uint32_t)tid * 32u + (uint32_t)(__ffs(dw2) - 1);
-            dw2 &= dw2 - 1;
-            uint32_t x = seen[sp(w)];
-            if (x) seen[sp(w)] = 0u;
-            while (x) {
-              dst[at++] = (int32_t)(w * 32u + (uint32_t)(__ffs(x) - 1));
-              x &= x - 1;
-            }
-          }
-        }
-      } else if (use_dirty) {
+      if (use_dirty) {
         // pass 1, this thread's touched words only: count the new bits
         uint32_t cnt = 0;
         for_dirty4([&](const uint32_t (&w)[4], int n) {
@@ -421,14 +362,7 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
           for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[vp(w[k])] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (k < n) {
-              const uint32_t nw = sw[k] & ~vis[k];
-              if constexpr (SEEN_LDS) {  // LDS is coherent in program order: keep the NEW bits for pass 2, update visited now
-                seen[sp(w[k])] = nw;
-                if (nw) sv.visited[vp(w[k])] = vis[k] | nw;
-              }
-              cnt += (uint32_t)__popc(nw);
-            }
+            if (k < n) cnt += (uint32_t)__popc(sw[k] & ~vis[k]);
         });
         uint32_t total;
         uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);  // thread order = word order = ascending ids
@@ -438,24 +372,19 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
         // pass 2: the ids; seen = 0 for the next round
         int32_t* dst = sv.cat_ids + n_res;
         for_dirty4([&](const uint32_t (&w)[4], int n) {
-          uint32_t nw[4];
-          if constexpr (SEEN_LDS) {
+          // both words again (L2 hits) instead of a store -> load of the same word through L2
+          uint32_t nw[4], vis[4], sw[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nw[k] = k < n ? seen[sp(w[k])] : 0u;
-          } else {  // the slot form reads both words again (L2 hits) instead of a store -> load of the same word through L2
-            uint32_t vis[4], sw[4];
+          for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[vp(w[k])] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { vis[k] = k < n ? sv.visited[vp(w[k])] : 0u; sw[k] = k < n ? seen_load(w[k]) : 0u; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              nw[k] = sw[k] & ~vis[k];
-              if (k < n && nw[k]) sv.visited[vp(w[k])] = vis[k] | nw[k];
-            }
+          for (int k = 0; k < 4; ++k) {
+            nw[k] = sw[k] & ~vis[k];
+            if (k < n && nw[k]) sv.visited[vp(w[k])] = vis[k] | nw[k];
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if (k < n) {
-              seen[sp(w[k])] = 0u;
+              seen[w[k]] = 0u;
               uint32_t x = nw[k];
               while (x) {
                 dst[at++] = (int32_t)(w[k] * 32u + (uint32_t)(__ffs(x) - 1));
@@ -560,10 +489,306 @@ __device__ __forceinline__ int search_eval_one(const EvalArgs& a, int qi, const 
       EVAL_TICK(7);
     }
   }
-#if NANN_EVAL_TICKS
-  if (tid == 0 && a.ticks)
-    for (int i = 0; i < 10; ++i) atomicAdd(&a.ticks[i], tk[i]);
-#endif
+  EVAL_TICK_FLUSH;
+  *n_result = n_res;
+  if (a.counters) {  // (the kernel zeroed the user's three words before the call)
+    if (tid == 0) { atomicAdd(&a.counters[(size_t)qi * 3 + 0], ctr_f); atomicAdd(&a.counters[(size_t)qi * 3 + 2], ctr_s); }
+    if (ctr_g) atomicAdd(&a.counters[(size_t)qi * 3 + 1], ctr_g);
+  }
+  return NANN_OK;
+}
+
+// A barrier that orders LDS only: it does not wait for this thread's global stores (a round's copies to the slot are read by
+// nobody before the next full barrier, which a __syncthreads() -- a workgroup-scope fence -- would make every wavefront sit out)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ long long readlane64(long long v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v & 0xffffffffull), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), l);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- the LDS form (L2 scorer, shards of up to 2^20 items): `seen` in LDS, one dirty word per thread (its own 32 words of both
+// bitmaps).  Round 6, third step: with one 1 024-thread workgroup per CU nothing hides a dependent trip to the slot (1-3 us under
+// the other CUs' scoring), and a round took ~20 of them -- the frontier, its row bounds and rows one after the other, `visited`,
+// the new ids out and in again, their scores out and in again for top-k, its results out and in again for the threshold, the
+// frontier out, the results to the front of the concat arrays.  `seen` is ALL ZERO outside gather -> emit, so its LDS doubles as a
+// STAGING AREA from a round's emit to its end: the round's scores (result || new, n_cat <= lds_words - 4096: 28 K for 2^20 items,
+// else they stay in the slot) and top-k's output live there, the frontier lives in the phase scratch; the extents used are zeroed
+// again at the round's end.  Only ids cross to the slot (emit -> score / top-k gather / threshold: prefetched, off the critical
+// path), the results' copy to the front of the concat arrays is fire-and-forget behind an LDS-only barrier, and the walk of a
+// frontier fetches ALL its row bounds, then 32 rows per wavefront in flight together.  Same sets, same orders, same arithmetic:
+// bit-identical to the oracle as before.
+template <int LPR, int DT, int NT>
+__device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
+                                               unsigned char* scratch, float* qv, int* n_result, bool clear_seen) {
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  int ctr_f = 0, ctr_s = 0;  // (uniform)
+  int ctr_g = 0;             // this lane's share: row lengths it fetched (lanes 0-7 of every wavefront)
+  constexpr int NW = NT / 64;
+  constexpr int NF = kEvalMaxK / NT;  // kept results per thread
+  static_assert(kEvalMaxK % NT == 0 && NF >= 1, "a thread carries kEvalMaxK / NT scores of the kept results");
+  // phase scratch: [scan scratch 256 | dirty: NT words | frontier: kEvalMaxK ids | ...] (top-k's scratch overlays all of it:
+  // the dirty words are zeroed and the frontier is written behind it)
+  EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
+  uint32_t* dirty = reinterpret_cast<uint32_t*>(scratch + 256);
+  int32_t* cand = reinterpret_cast<int32_t*>(scratch + 256 + NT * 4);
+  static_assert(256 + NT * 4 + kEvalMaxK * 4 <= kPhaseScratch, "phase scratch too small for the frontier");
+  // staging area (the region of `seen`): [kept ids: kEvalMaxK | kept scores: kEvalMaxK | scores of result || new: CAP]
+  int32_t* st_res_ids = reinterpret_cast<int32_t*>(seen);
+  float* st_res_sc = reinterpret_cast<float*>(seen + kEvalMaxK);
+  float* st_cat_sc = reinterpret_cast<float*>(seen + 2 * kEvalMaxK);
+  const int CAP = (int)a.lds_words - 2 * kEvalMaxK;
+  EVAL_TICK_DECL;
+  for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
+  const uint32_t DW = (a.bm_words + 31u) >> 5;  // <= NT (eval_plan): thread t owns dirty word t = words [32 t, 32 t + 32) of both bitmaps
+  // `seen` is SKEWED by one word per 32 (word w at w + w / 32): the owners read words 32 t + j, lanes 32 words apart -- two LDS
+  // banks for the whole wavefront without the skew.  `visited` (the slot, only ever touched by its owners) is TRANSPOSED: word j
+  // of thread t at j NT + t, so that a wavefront's loads of "my j-th word" are 256 contiguous bytes.
+  auto sp = [](uint32_t w) -> uint32_t { return w + (w >> 5); };
+  auto seen_or = [&](uint32_t id) {
+    const uint32_t bit = 1u << (id & 31), w = id >> 5;
+    if (atomicOr(&seen[sp(w)], bit) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
+  };
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(sv.visited, 0, (int)(a.vis_words * 4u), 0x00020000);
+  if (clear_seen) {  // the slot's first user, or the one behind a user that failed with the region in use: every other user leaves it zero
+    for (uint32_t w = (uint32_t)tid; w < a.lds_words; w += NT) seen[w] = 0u;
+  }
+  dirty[tid] = 0u;
+  if (tid < 2) SS->flags[tid] = 0;
+  __syncthreads();
+
+  // the kept results leave the staging area: ids and scores to the front of the slot's concat arrays (fire and forget: the next
+  // reader is a full barrier away), the ids to the frontier when the results ARE the next frontier (level start, :308); then the
+  // extents of the region that the round used are zeroed -- `seen` again
+  auto publish = [&](int k, int n_staged, bool to_cand) {
+    for (int i = tid; i < k; i += NT) {
+      const int32_t id = st_res_ids[i];
+      sv.cat_ids[i] = id;
+      sv.cat_sc[i] = st_res_sc[i];
+      if (to_cand) cand[i] = id;
+    }
+    lds_barrier();
+    for (int i = tid; i < k; i += NT) { seen[i] = 0u; seen[kEvalMaxK + i] = 0u; }
+    for (int i = tid; i < n_staged; i += NT) seen[2 * kEvalMaxK + i] = 0u;
+    dirty[tid] = 0u;  // (top-k's scratch lay over them)
+    if (tid < 2) SS->flags[tid] = 0;
+    lds_barrier();
+  };
+
+  // start level: score every enter point, keep min(k, n) (:349-353)
+  const int E = a.n_enter;
+  if (E <= 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+  const bool near = (unsigned long long)a.n_items * (unsigned)(a.d * 2) <= 0xffffffffull && a.n_items <= (1u << 24);
+  wg_score_l2_part<LPR, DT, NW>(a.emb, a.d, a.enter, 0, E, qv, sv.cat_sc, wave, near);
+  __syncthreads();
+  ctr_s += E;
+  EVAL_TICK(0);
+  int n_res = min(a.top_k[2], E);
+  int st = wg_topk<NT, kEvalMaxK>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
+  if (st) return st;
+  EVAL_TICK(1);
+  publish(n_res, 0, true);
+  bool cand_is_result = true;  // (uniform) the frontier array holds the kept ids
+
+  for (int level = 1; level >= 0; --level) {  // search_level (:299-337)
+    if (!cand_is_result) {  // (a level that ended on an empty round, or ran no round: its result, cut, from the slot)
+      __syncthreads();
+      for (int i = tid; i < n_res; i += NT) cand[i] = sv.cat_ids[i];
+      __syncthreads();
+    }
+    // visited = idx_ep (:311): the marks go through `seen`; candidates = result
+    for (int i = tid; i < n_res; i += NT) {
+      const int32_t id = cand[i];
+      if ((uint32_t)id >= a.n_items) { SS->flags[1] = 1; continue; }
+      seen_or((uint32_t)id);
+    }
+    __syncthreads();
+    if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+    {  // the owners: visited = marks -- ALL 32 words of every thread, which is also the level's visited = {} --, seen = 0
+      const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        uint32_t m = 0u;
+        if ((dw >> j) & 1u) {
+          const uint32_t pw = sp((uint32_t)tid * 32u + (uint32_t)j);
+          m = seen[pw];
+          seen[pw] = 0u;
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(m, vrs, tid * 4, j * NT * 4, 0);
+      }
+      if (dw) dirty[tid] = 0u;
+    }
+    lds_barrier();  // (a thread's words of `visited` are its own: nobody else waits for the stores)
+    EVAL_TICK(2);
+    int n_cand = n_res;
+    const int32_t* __restrict__ values = a.nbv[level];
+    const int64_t* __restrict__ rs = a.nbrs[level];
+    for (int it = 0; it < a.num_scoring[level]; ++it) {
+      // ---- neighbours of the candidates -> bits of `seen`.  Wavefront w walks rows [8 (w + NW t), + 8) for t = 0, 1, ...; four
+      // trips at a time: their bounds (lanes 0-7, one load each way per trip) in flight together, then their 32 rows
+      ctr_f += n_cand;
+      for (int rep = 0; rep <= NANN_REPEAT_GATHER; ++rep) {
+        int bad = 0;
+        for (int t0 = 0; t0 * NW * 8 < n_cand; t0 += 4) {
+          long long s4[4];
+          int len4[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = (t0 + t) * NW * 8 + wave * 8 + lane;
+            long long s = 0, e = 0;
+            if (lane < 8 && r < n_cand) {
+              const int32_t c = cand[r];
+              s = rs[c]; e = rs[c + 1];
+            }
+            s4[t] = s; len4[t] = (int)(e - s);
+          }
+          if (rep == 0) ctr_g += len4[0] + len4[1] + len4[2] + len4[3];
+          int32_t v[4][8];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const long long sr = readlane64(s4[t], r);
+              const int len = __builtin_amdgcn_readlane(len4[t], r);
+              v[t][r] = lane < len ? values[sr + lane] : 0;
+            }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int len = __builtin_amdgcn_readlane(len4[t], r);
+              if (lane < len) {
+                if ((uint32_t)v[t][r] < a.n_items) seen_or((uint32_t)v[t][r]); else bad = 1;
+              }
+              if (len > 64) {  // (rows of more than 64 neighbours)
+                const long long sr = readlane64(s4[t], r);
+                for (int j = 64 + lane; j < len; j += 64) {
+                  const int32_t x = values[sr + j];
+                  if ((uint32_t)x < a.n_items) seen_or((uint32_t)x); else bad = 1;
+                }
+              }
+            }
+        }
+        if (bad) SS->flags[1] = 1;
+      }
+      __syncthreads();
+      if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+      EVAL_TICK(3);
+      // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
+      // ALL 32 of the thread's words of `visited`, touched or not, in ONE batch (batches of 4 / 8 / 16 touched words were 5 / 4 / 2
+      // dependent trips) -- and with them this thread's scores of the kept results (the front of the concat arrays), which go to
+      // the staging area behind the emit.  Buffer loads: one VGPR of offset for all of them, the word's stride in an SGPR.
+      const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
+      if (dw) dirty[tid] = 0u;  // (nobody else touches it before the next round's gather, barriers away)
+      float fs[NF];
+      uint32_t cnt = 0;
+      {
+        uint32_t vis[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) fs[j] = sv.cat_sc[min(tid + j * NT, n_res - 1)];
+        if (dw) {
+#pragma unroll
+          for (int j = 0; j < 32; ++j)
+            if ((dw >> j) & 1u) {
+              const uint32_t pw = sp((uint32_t)tid * 32u + (uint32_t)j);
+              const uint32_t nw = seen[pw] & ~vis[j];
+              seen[pw] = nw;  // the NEW bits, for the emit behind the scan
+              if (nw) __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
+              cnt += (uint32_t)__popc(nw);
+            }
+        }
+      }
+      EVAL_TICK(8);
+      uint32_t total;
+      uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);  // thread order = word order = ascending ids
+      const int n_next = (int)total;
+      ctr_s += n_next;
+      if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
+      EVAL_TICK(9);
+      if (cnt) {
+        int32_t* dst = sv.cat_ids + n_res;
+        uint32_t dw2 = dw;
+        while (dw2) {
+          const uint32_t w = (uint32_t)tid * 32u + (uint32_t)(__ffs(dw2) - 1);
+          dw2 &= dw2 - 1;
+          uint32_t x = seen[sp(w)];
+          if (x) seen[sp(w)] = 0u;
+          while (x) {
+            dst[at++] = (int32_t)(w * 32u + (uint32_t)(__ffs(x) - 1));
+            x &= x - 1;
+          }
+        }
+      }
+      __syncthreads();  // the new ids are in the slot, `seen` is zero: the region is the staging area from here
+      EVAL_TICK(4);
+      if (n_next == 0) {  // plain TF ops score an empty batch as an empty tensor: the result is cut to min(k, n), no candidate is left
+        n_res = min(a.top_k[level], n_res);
+        n_cand = 0;
+        cand_is_result = false;
+        continue;
+      }
+      const int n_cat = n_res + n_next;
+      const int k = min(a.top_k[level], n_cat);
+      const bool last = it + 1 == a.num_scoring[level];  // the level's last round: its frontier is never walked
+      auto rest = [&](auto fits_c) -> int {
+        constexpr bool FITS = decltype(fits_c)::value;
+        float* cat_sc;
+        if constexpr (FITS) cat_sc = st_cat_sc; else cat_sc = sv.cat_sc;
+        if constexpr (FITS) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j)
+            if (tid + j * NT < n_res) st_cat_sc[tid + j * NT] = fs[j];
+        }
+        for (int rep = 0; rep <= NANN_REPEAT_SCORE; ++rep) {  // :323
+          wg_score_l2_part<LPR, DT, NW>(a.emb, a.d, sv.cat_ids + n_res, 0, n_next, qv, cat_sc + n_res, wave, near);
+          __syncthreads();
+        }
+        EVAL_TICK(5);
+        int rc = 0;
+        for (int rep = 0; rep <= NANN_REPEAT_TOPK; ++rep) {  // :326-328
+          rc = wg_topk<NT, kEvalMaxK>(sv.cat_ids, cat_sc, nullptr, n_cat, k, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
+          if (rc) return rc;
+        }
+        EVAL_TICK(6);
+        if (!last) {
+          // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331): every thread takes a
+          // CONTIGUOUS run of the new nodes, one workgroup scan places them; a run's ids are fetched four at a time, wanted or not
+          const float worst = st_res_sc[k - 1];
+          const int per = (n_next + NT - 1) / NT;
+          const int lo = min(tid * per, n_next), hi = min(lo + per, n_next);
+          uint32_t mine = 0;
+          for (int i = lo; i < hi; ++i) mine += cat_sc[n_res + i] >= worst ? 1u : 0u;
+          uint32_t n_new;
+          uint32_t pos = wg_excl_scan<NT>(mine, SS, &n_new);
+          if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
+          if (mine) {
+            for (int i0 = lo; i0 < hi; i0 += 4) {
+              int32_t idv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) idv[u] = sv.cat_ids[n_res + min(i0 + u, hi - 1)];
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (i0 + u < hi && cat_sc[n_res + i0 + u] >= worst) cand[pos++] = idv[u];
+            }
+          }
+          n_cand = (int)n_new;
+          __syncthreads();  // (the copy below overwrites cat_ids[n_res ..] that the selection above reads)
+        } else {
+          n_cand = k;
+        }
+        publish(k, FITS ? n_cat : 0, last);
+        return 0;
+      };
+      st = n_cat <= CAP ? rest(std::true_type{}) : rest(std::false_type{});
+      if (st) return st;
+      n_res = k;
+      cand_is_result = last;
+      EVAL_TICK(7);
+    }
+  }
+  EVAL_TICK_FLUSH;
   *n_result = n_res;
   if (a.counters) {  // (the kernel zeroed the user's three words before the call)
     if (tid == 0) { atomicAdd(&a.counters[(size_t)qi * 3 + 0], ctr_f); atomicAdd(&a.counters[(size_t)qi * 3 + 2], ctr_s); }
@@ -607,15 +832,22 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
     int st;
     // `seen` is all-zero behind a user that succeeded (the emit pass clears what the round touched); the slot's first user
     // and the one behind a failure clear it whole.  (Without the dirty words the owners clear as they scan: same invariant.)
-    if constexpr (SEEN_LDS) st = search_eval_one<LPR, DT, SC, NT, true>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res, clear_seen);
-    else st = search_eval_one<LPR, DT, SC, NT, false>(a, qi, sv, sv.seen, scratch, qv, &n_res, clear_seen);
+    if constexpr (SEEN_LDS) {
+      static_assert(SC == NANN_SCORER_L2, "the LDS form is the L2 scorer's");
+      st = search_eval_lds<LPR, DT, NT>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res, clear_seen);
+    } else {
+      st = search_eval_slot<LPR, DT, SC, NT>(a, qi, sv, sv.seen, scratch, qv, &n_res, clear_seen);
+    }
     clear_seen = st != 0;
     __syncthreads();
+    // the kept results: the LDS form leaves them at the front of the concat arrays (its result arrays are in LDS)
+    const int32_t* res_ids = SEEN_LDS ? sv.cat_ids : sv.res_ids;
+    const float* res_sc = SEEN_LDS ? sv.cat_sc : sv.res_sc;
     const int n = st ? 0 : min(K, n_res);  // results[:topk_eval] (:358), item ids (:360)
     for (int i = threadIdx.x; i < K; i += NT) {
-      const int32_t r = i < n ? sv.res_ids[i] : 0;
+      const int32_t r = i < n ? res_ids[i] : 0;
       a.out_ids[(size_t)qi * K + i] = i < n ? a.item_ids[r] : 0;
-      if (a.out_scores) a.out_scores[(size_t)qi * K + i] = i < n ? sv.res_sc[i] : 0.0f;
+      if (a.out_scores) a.out_scores[(size_t)qi * K + i] = i < n ? res_sc[i] : 0.0f;
       if (a.out_index) a.out_index[(size_t)qi * K + i] = r;
     }
     if (threadIdx.x == 0) {

@@ -2660,6 +2660,7 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   // scratch -- it fits shards of up to ~7 M items; beyond, the slot form keeps round 4's full scans
   a.use_dirty = 256 + (size_t)((ix->bm_words + 31u) >> 5) * 4 <= eval_dirty_room() ? 1 : 0;
   a.vis_words = eval_vis_words(ix->bm_words);
+  a.lds_words = (uint32_t)(eval_seen_lds_bytes(ix->bm_words) / 4);
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index; a.n_out = n_out; a.status = status;
   a.counters = counters;
   a.mlp = MlpParams{};
