@@ -112,10 +112,14 @@ def unit_command(obj, parts, odir, extra_flags=(), save_temps=True):
            ["-Rpass-analysis=kernel-resource-usage", "-c", unit, "-o", os.path.join(odir, obj)]
 
 
-def _build_into(OUT_DIR, LIB, extra_flags, verbose):
+def _build_into(OUT_DIR, LIB, extra_flags, verbose, only=None):
+    """only: names of the objects to recompile (kernel iteration: `python -m nann_amd.build --only nann_eval.o`); the others are
+    linked as they lie -- the caller vouches that their sources did not change."""
     os.makedirs(OUT_DIR, exist_ok=True)
     procs = []
     for obj, parts in UNITS:
+        if only is not None and obj not in only:
+            continue
         # one directory per object: --save-temps keeps the device assembly for the audit below
         odir = os.path.join(OUT_DIR, obj[:-2] + ".d")
         os.makedirs(odir, exist_ok=True)
@@ -152,4 +156,9 @@ def _build_into(OUT_DIR, LIB, extra_flags, verbose):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--only" in sys.argv:
+        names = sys.argv[sys.argv.index("--only") + 1].split(",")
+        assert all(any(n == o for o, _ in UNITS) for n in names), names
+        print(_build_into(OUT_DIR, LIB, (), True, only=names))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -98,7 +98,7 @@ __host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words) {
 // small round (the kept results + 12 K scores) -- the region is `seen` from a round's gather to its emit and staging behind it
 constexpr int kEvalStageMinWords = 2 * 2048 + 12288;
 __host__ __device__ inline size_t eval_seen_lds_bytes(uint32_t bm_words) {
-  const size_t skewed = (size_t)bm_words + (bm_words >> 5) + 1;
+  const size_t skewed = (size_t)((bm_words + 31u) >> 5) * 33u;  // (every owner's run of 32 words whole)
   return ((skewed > (size_t)kEvalStageMinWords ? skewed : (size_t)kEvalStageMinWords) * 4 + 255) & ~(size_t)255;
 }
 
@@ -122,19 +122,23 @@ struct EvalScanScratch {
 };
 
 // exclusive prefix of v over the workgroup (thread order); *total = the sum.  Two barriers.
-template <int NT>
+// A barrier that orders LDS only: it does not wait for this thread's global stores (a round's copies to the slot are read by
+// nobody before the next full barrier, which a __syncthreads() -- a workgroup-scope fence -- would make every wavefront sit out)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT, bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, EvalScanScratch* S, uint32_t* total) {
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
   const uint32_t inc = wave_scan_add(v);
   if (lane == 63) S->wave_tot[wave] = inc;
-  __syncthreads();
+  if constexpr (LDS_ONLY) lds_barrier(); else __syncthreads();
   uint32_t base = 0, tot = 0;
   for (int w = 0; w < NT / 64; ++w) {
     const uint32_t t = S->wave_tot[w];
     if (w < wave) base += t;
     tot += t;
   }
-  __syncthreads();
+  if constexpr (LDS_ONLY) lds_barrier(); else __syncthreads();
   *total = tot;
   return base + inc - v;
 }
@@ -498,9 +502,6 @@ __device__ __forceinline__ int search_eval_slot(const EvalArgs& a, int qi, const
   return NANN_OK;
 }
 
-// A barrier that orders LDS only: it does not wait for this thread's global stores (a round's copies to the slot are read by
-// nobody before the next full barrier, which a __syncthreads() -- a workgroup-scope fence -- would make every wavefront sit out)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ long long readlane64(long long v, int l) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v & 0xffffffffull), l);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), l);
@@ -527,40 +528,48 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
   constexpr int NW = NT / 64;
   constexpr int NF = kEvalMaxK / NT;  // kept results per thread
   static_assert(kEvalMaxK % NT == 0 && NF >= 1, "a thread carries kEvalMaxK / NT scores of the kept results");
-  // phase scratch: [scan scratch 256 | dirty: NT words | frontier: kEvalMaxK ids | ...] (top-k's scratch overlays all of it:
-  // the dirty words are zeroed and the frontier is written behind it)
+  // phase scratch: [scan scratch 256 | frontier: kEvalMaxK ids | ...] (top-k's scratch overlays all of it: the frontier is
+  // written behind it)
   EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
-  uint32_t* dirty = reinterpret_cast<uint32_t*>(scratch + 256);
-  int32_t* cand = reinterpret_cast<int32_t*>(scratch + 256 + NT * 4);
-  static_assert(256 + NT * 4 + kEvalMaxK * 4 <= kPhaseScratch, "phase scratch too small for the frontier");
+  int32_t* cand = reinterpret_cast<int32_t*>(scratch + 256);
+  static_assert(256 + kEvalMaxK * 4 <= kPhaseScratch, "phase scratch too small for the frontier");
   // staging area (the region of `seen`): [kept ids: kEvalMaxK | kept scores: kEvalMaxK | scores of result || new: CAP]
   int32_t* st_res_ids = reinterpret_cast<int32_t*>(seen);
   float* st_res_sc = reinterpret_cast<float*>(seen + kEvalMaxK);
   float* st_cat_sc = reinterpret_cast<float*>(seen + 2 * kEvalMaxK);
-  const int CAP = (int)a.lds_words - 2 * kEvalMaxK;
+  const int CAP = (int)a.lds_words - 2 * kEvalMaxK;  // scores only: result || new up to here
+  const int CAP2 = CAP / 2;                          // scores and ids: [scores: CAP2 | ids: CAP2]
+  int32_t* st_cat_ids = reinterpret_cast<int32_t*>(seen + 2 * kEvalMaxK + CAP2);
+  // the ascending list of new ids is written while `seen` is still being read: into the phase scratch (the frontier is dead
+  // by then), and moved to the staging area behind the barrier
+  int32_t* emit_lds = cand;
+  constexpr int kEmitCap = (kPhaseScratch - 256) / 4;
   EVAL_TICK_DECL;
   for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
-  const uint32_t DW = (a.bm_words + 31u) >> 5;  // <= NT (eval_plan): thread t owns dirty word t = words [32 t, 32 t + 32) of both bitmaps
-  // `seen` is SKEWED by one word per 32 (word w at w + w / 32): the owners read words 32 t + j, lanes 32 words apart -- two LDS
-  // banks for the whole wavefront without the skew.  `visited` (the slot, only ever touched by its owners) is TRANSPOSED: word j
-  // of thread t at j NT + t, so that a wavefront's loads of "my j-th word" are 256 contiguous bytes.
-  auto sp = [](uint32_t w) -> uint32_t { return w + (w >> 5); };
+  // Thread t owns words [32 t, 32 t + 32) of both bitmaps (t < DW <= NT, eval_plan), so thread order is word order.  `seen` is
+  // SKEWED by one word per 32 (word w at w + w / 32 = 33 t + j): the owners read their j-th words together, lanes 33 words apart
+  // -- conflict-free; without the skew, two LDS banks for the whole wavefront.  `visited` (the slot, only ever touched by its
+  // owners) is TRANSPOSED: word j of thread t at j NT + t, so that a wavefront's loads of "my j-th word" are 256 contiguous
+  // bytes.  An owner reads ALL 32 of its words of `seen`, eight at a time in flight (a word's read behind the test of a
+  // second-level "touched" bit was one LDS round trip per word, 32 in a row; and the bit cost the walk a second atomic per word).
+  const uint32_t DW = (a.bm_words + 31u) >> 5;
+  const bool owner = (uint32_t)tid < DW;
+  const uint32_t own = (uint32_t)tid * 33u;
   auto seen_or = [&](uint32_t id) {
-    const uint32_t bit = 1u << (id & 31), w = id >> 5;
-    if (atomicOr(&seen[sp(w)], bit) == 0u) atomicOr(&dirty[w >> 5], 1u << (w & 31));
+    const uint32_t w = id >> 5;
+    atomicOr(&seen[w + (w >> 5)], 1u << (id & 31));
   };
   const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(sv.visited, 0, (int)(a.vis_words * 4u), 0x00020000);
   if (clear_seen) {  // the slot's first user, or the one behind a user that failed with the region in use: every other user leaves it zero
     for (uint32_t w = (uint32_t)tid; w < a.lds_words; w += NT) seen[w] = 0u;
   }
-  dirty[tid] = 0u;
   if (tid < 2) SS->flags[tid] = 0;
   __syncthreads();
 
   // the kept results leave the staging area: ids and scores to the front of the slot's concat arrays (fire and forget: the next
   // reader is a full barrier away), the ids to the frontier when the results ARE the next frontier (level start, :308); then the
   // extents of the region that the round used are zeroed -- `seen` again
-  auto publish = [&](int k, int n_staged, bool to_cand) {
+  auto publish = [&](int k, int n_staged, int n_staged_ids, bool to_cand) {
     for (int i = tid; i < k; i += NT) {
       const int32_t id = st_res_ids[i];
       sv.cat_ids[i] = id;
@@ -570,7 +579,7 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
     lds_barrier();
     for (int i = tid; i < k; i += NT) { seen[i] = 0u; seen[kEvalMaxK + i] = 0u; }
     for (int i = tid; i < n_staged; i += NT) seen[2 * kEvalMaxK + i] = 0u;
-    dirty[tid] = 0u;  // (top-k's scratch lay over them)
+    for (int i = tid; i < n_staged_ids; i += NT) seen[2 * kEvalMaxK + CAP2 + i] = 0u;
     if (tid < 2) SS->flags[tid] = 0;
     lds_barrier();
   };
@@ -587,7 +596,7 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
   int st = wg_topk<NT, kEvalMaxK>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
   if (st) return st;
   EVAL_TICK(1);
-  publish(n_res, 0, true);
+  publish(n_res, 0, 0, true);
   bool cand_is_result = true;  // (uniform) the frontier array holds the kept ids
 
   for (int level = 1; level >= 0; --level) {  // search_level (:299-337)
@@ -602,21 +611,20 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
       if ((uint32_t)id >= a.n_items) { SS->flags[1] = 1; continue; }
       seen_or((uint32_t)id);
     }
-    __syncthreads();
+    lds_barrier();
     if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    {  // the owners: visited = marks -- ALL 32 words of every thread, which is also the level's visited = {} --, seen = 0
-      const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
+    if (owner) {  // visited = marks -- ALL 32 words of every owner, which is also the level's visited = {} --, seen = 0
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        uint32_t m = 0u;
-        if ((dw >> j) & 1u) {
-          const uint32_t pw = sp((uint32_t)tid * 32u + (uint32_t)j);
-          m = seen[pw];
-          seen[pw] = 0u;
+      for (int b = 0; b < 4; ++b) {
+        uint32_t sw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sw[i] = seen[own + 8 * b + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (sw[i]) seen[own + 8 * b + i] = 0u;
+          __builtin_amdgcn_raw_buffer_store_b32(sw[i], vrs, tid * 4, (8 * b + i) * NT * 4, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b32(m, vrs, tid * 4, j * NT * 4, 0);
       }
-      if (dw) dirty[tid] = 0u;
     }
     lds_barrier();  // (a thread's words of `visited` are its own: nobody else waits for the stores)
     EVAL_TICK(2);
@@ -671,84 +679,119 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
         }
         if (bad) SS->flags[1] = 1;
       }
-      __syncthreads();
+      lds_barrier();  // (the walk loads; what is still on its way to the slot -- the last round's results, an owner's words of
+                      //  `visited` -- is read back by the thread that stored it)
       if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
       EVAL_TICK(3);
       // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
-      // ALL 32 of the thread's words of `visited`, touched or not, in ONE batch (batches of 4 / 8 / 16 touched words were 5 / 4 / 2
-      // dependent trips) -- and with them this thread's scores of the kept results (the front of the concat arrays), which go to
-      // the staging area behind the emit.  Buffer loads: one VGPR of offset for all of them, the word's stride in an SGPR.
-      const uint32_t dw = (uint32_t)tid < DW ? dirty[tid] : 0u;
-      if (dw) dirty[tid] = 0u;  // (nobody else touches it before the next round's gather, barriers away)
+      // ALL 32 of the thread's words of `visited` in ONE batch (touched words only, 4 / 8 / 16 at a time, were 5 / 4 / 2 dependent
+      // trips) -- and with them this thread's ids and scores of the kept results (the front of the concat arrays), which go to the
+      // staging area behind the emit.  Buffer loads: one VGPR of offset for all of them, the word's stride in an SGPR.
+      uint32_t vis[32];
+      int32_t fi[NF];
       float fs[NF];
-      uint32_t cnt = 0;
-      {
-        uint32_t vis[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
+      for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) fs[j] = sv.cat_sc[min(tid + j * NT, n_res - 1)];
-        if (dw) {
+      for (int j = 0; j < NF; ++j) {
+        fi[j] = sv.cat_ids[min(tid + j * NT, n_res - 1)];
+        fs[j] = sv.cat_sc[min(tid + j * NT, n_res - 1)];
+      }
+      uint32_t cnt = 0, nd = 0;  // new bits of this thread's words; which of its words have any
+      if (owner) {
 #pragma unroll
-          for (int j = 0; j < 32; ++j)
-            if ((dw >> j) & 1u) {
-              const uint32_t pw = sp((uint32_t)tid * 32u + (uint32_t)j);
-              const uint32_t nw = seen[pw] & ~vis[j];
-              seen[pw] = nw;  // the NEW bits, for the emit behind the scan
-              if (nw) __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
+        for (int b = 0; b < 4; ++b) {
+          uint32_t sw[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sw[i] = seen[own + 8 * b + i];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int j = 8 * b + i;
+            const uint32_t nw = sw[i] & ~vis[j];
+            if (sw[i] != nw) seen[own + j] = nw;  // the NEW bits stay, for the emit behind the scan
+            if (nw) {
+              __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
+              nd |= 1u << j;
               cnt += (uint32_t)__popc(nw);
             }
+          }
         }
       }
       EVAL_TICK(8);
       uint32_t total;
-      uint32_t at = wg_excl_scan<NT>(cnt, SS, &total);  // thread order = word order = ascending ids
+      uint32_t at = wg_excl_scan<NT, true>(cnt, SS, &total);  // thread order = word order = ascending ids
       const int n_next = (int)total;
       ctr_s += n_next;
       if (n_res + n_next > a.cat_cap) return NANN_ERR_CAPACITY;
       EVAL_TICK(9);
-      if (cnt) {
-        int32_t* dst = sv.cat_ids + n_res;
-        uint32_t dw2 = dw;
-        while (dw2) {
-          const uint32_t w = (uint32_t)tid * 32u + (uint32_t)(__ffs(dw2) - 1);
-          dw2 &= dw2 - 1;
-          uint32_t x = seen[sp(w)];
-          if (x) seen[sp(w)] = 0u;
-          while (x) {
-            dst[at++] = (int32_t)(w * 32u + (uint32_t)(__ffs(x) - 1));
-            x &= x - 1;
-          }
-        }
-      }
-      __syncthreads();  // the new ids are in the slot, `seen` is zero: the region is the staging area from here
-      EVAL_TICK(4);
       if (n_next == 0) {  // plain TF ops score an empty batch as an empty tensor: the result is cut to min(k, n), no candidate is left
+        __syncthreads();  // (`seen` is zero again: the owners wrote their words' new bits, none)
         n_res = min(a.top_k[level], n_res);
         n_cand = 0;
         cand_is_result = false;
         continue;
       }
       const int n_cat = n_res + n_next;
-      const int k = min(a.top_k[level], n_cat);
-      const bool last = it + 1 == a.num_scoring[level];  // the level's last round: its frontier is never walked
-      auto rest = [&](auto fits_c) -> int {
-        constexpr bool FITS = decltype(fits_c)::value;
-        float* cat_sc;
-        if constexpr (FITS) cat_sc = st_cat_sc; else cat_sc = sv.cat_sc;
-        if constexpr (FITS) {
+      // where the round's ids and scores live: 2 = both in the staging area, 1 = the scores, 0 = neither (the slot, as the slot form)
+      const int mode = (n_next <= kEmitCap && n_cat <= CAP2) ? 2 : n_cat <= CAP ? 1 : 0;
+      auto emit = [&](int32_t* dst) {  // this thread's words with new bits, four reads in flight; seen = 0 behind them
+        uint32_t m = nd;
+        while (m) {
+          uint32_t j[4], x[4];
+          int n = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (m) { j[u] = (uint32_t)(__ffs(m) - 1); m &= m - 1; n = u + 1; } else j[u] = j[0];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = seen[own + j[u]];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < n) {
+              seen[own + j[u]] = 0u;
+              const uint32_t w = (uint32_t)tid * 32u + j[u];
+              uint32_t y = x[u];
+              while (y) {
+                dst[at++] = (int32_t)(w * 32u + (uint32_t)(__ffs(y) - 1));
+                y &= y - 1;
+              }
+            }
+        }
+      };
+      if (mode == 2) {
+        if (cnt) emit(emit_lds);
+        lds_barrier();  // `seen` is zero: the region is the staging area from here
+        for (int i = tid; i < n_next; i += NT) st_cat_ids[n_res + i] = emit_lds[i];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          if (tid + j * NT < n_res) { st_cat_ids[tid + j * NT] = fi[j]; st_cat_sc[tid + j * NT] = fs[j]; }
+        lds_barrier();
+      } else {
+        if (cnt) emit(sv.cat_ids + n_res);
+        __syncthreads();  // the new ids are in the slot, `seen` is zero: the region is the staging area from here
+        if (mode == 1) {
 #pragma unroll
           for (int j = 0; j < NF; ++j)
             if (tid + j * NT < n_res) st_cat_sc[tid + j * NT] = fs[j];
         }
+      }
+      EVAL_TICK(4);
+      const int k = min(a.top_k[level], n_cat);
+      const bool last = it + 1 == a.num_scoring[level];  // the level's last round: its frontier is never walked
+      auto rest = [&](auto mode_c) -> int {
+        constexpr int MODE = decltype(mode_c)::value;
+        const int32_t* cat_ids;
+        float* cat_sc;
+        if constexpr (MODE == 2) cat_ids = st_cat_ids; else cat_ids = sv.cat_ids;
+        if constexpr (MODE >= 1) cat_sc = st_cat_sc; else cat_sc = sv.cat_sc;
         for (int rep = 0; rep <= NANN_REPEAT_SCORE; ++rep) {  // :323
-          wg_score_l2_part<LPR, DT, NW>(a.emb, a.d, sv.cat_ids + n_res, 0, n_next, qv, cat_sc + n_res, wave, near);
+          wg_score_l2_part<LPR, DT, NW>(a.emb, a.d, cat_ids + n_res, 0, n_next, qv, cat_sc + n_res, wave, near);
           __syncthreads();
         }
         EVAL_TICK(5);
         int rc = 0;
         for (int rep = 0; rep <= NANN_REPEAT_TOPK; ++rep) {  // :326-328
-          rc = wg_topk<NT, kEvalMaxK>(sv.cat_ids, cat_sc, nullptr, n_cat, k, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
+          rc = wg_topk<NT, kEvalMaxK>(cat_ids, cat_sc, nullptr, n_cat, k, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
           if (rc) return rc;
         }
         EVAL_TICK(6);
@@ -761,13 +804,13 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
           uint32_t mine = 0;
           for (int i = lo; i < hi; ++i) mine += cat_sc[n_res + i] >= worst ? 1u : 0u;
           uint32_t n_new;
-          uint32_t pos = wg_excl_scan<NT>(mine, SS, &n_new);
+          uint32_t pos = wg_excl_scan<NT, true>(mine, SS, &n_new);
           if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
           if (mine) {
             for (int i0 = lo; i0 < hi; i0 += 4) {
               int32_t idv[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) idv[u] = sv.cat_ids[n_res + min(i0 + u, hi - 1)];
+              for (int u = 0; u < 4; ++u) idv[u] = cat_ids[n_res + min(i0 + u, hi - 1)];
 #pragma unroll
               for (int u = 0; u < 4; ++u)
                 if (i0 + u < hi && cat_sc[n_res + i0 + u] >= worst) cand[pos++] = idv[u];
@@ -778,10 +821,10 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
         } else {
           n_cand = k;
         }
-        publish(k, FITS ? n_cat : 0, last);
+        publish(k, MODE >= 1 ? n_cat : 0, MODE == 2 ? n_cat : 0, last);
         return 0;
       };
-      st = n_cat <= CAP ? rest(std::true_type{}) : rest(std::false_type{});
+      st = mode == 2 ? rest(std::integral_constant<int, 2>{}) : mode == 1 ? rest(std::integral_constant<int, 1>{}) : rest(std::integral_constant<int, 0>{});
       if (st) return st;
       n_res = k;
       cand_is_result = last;

@@ -19,7 +19,8 @@ def main():
     source = "nann_mlp_res_inst.hip"
     if flags and flags[0] == "--unit":
         source, flags = flags[1], flags[2:]
-    B.build()  # the shipped objects must exist
+    if not os.environ.get("NANN_VARIANT_NO_BASE_BUILD"):
+        B.build()  # the shipped objects must exist (NANN_VARIANT_NO_BASE_BUILD=1: link against them as they lie)
     out = os.path.join(B.OUT_DIR, "var_" + name)
     os.makedirs(out, exist_ok=True)
     unit = next(u for u in B.UNITS if any(src == source for src, _ in u[1]))  # the object the kernels live in
