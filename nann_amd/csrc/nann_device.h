@@ -1274,6 +1274,11 @@ struct TopkScratchT {
   uint32_t misc[4];               // [0] nsel, [2] unordered append cursor
   uint32_t orv, andv;
   uint32_t wcnt[kNW];
+  // large k (the evaluation traversal, KCAP > kMaxK = 1024): the selected pairs are GROUPED by the leading radix digit of their keys --
+  // above[b] = keys of the row with a larger digit = the rank at which bin b starts, cursor[b] = selected pairs in bin b -- so that
+  // a pair is ranked against its own bin only (step 4)
+  uint32_t above[KCAP > 1024 ? 256 : 1];
+  uint32_t cursor[KCAP > 1024 ? 256 : 1];
 };
 typedef TopkScratchT<kMaxK> TopkScratch;
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
@@ -1284,7 +1289,8 @@ static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too sma
 
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
 // SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
-template <int NS, bool SCL, int NT, int KCAP = kMaxK>
+// BIN: rank the selected pairs bin by bin (TopkScratchT::above / cursor; KCAP > kMaxK only -- the evaluation traversal's LDS form)
+template <int NS, bool SCL, int NT, int KCAP = kMaxK, bool BIN = false>
 __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
                                             const float* lds_scores, int n, int k, int32_t* out_pos,
                                             int32_t* out_ids, float* out_scores, const int64_t* id_map,
@@ -1308,6 +1314,12 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   }
   uint32_t* hist = reinterpret_cast<uint32_t*>(S->sel);  // [4][256]; sel is not in use before step 3
   for (int i = tid; i < 4 * 256; i += NT) hist[i] = 0;
+  constexpr bool BINNED = BIN;  // (the serving kernels keep the all-pairs ranking: their k is 200)
+  static_assert(!BIN || KCAP > 1024, "the bin tables exist for KCAP > kMaxK");
+  const uint32_t bin_max = (uint32_t)max(64, k >> 3);  // a fuller bin (keys crowded into one leading digit): the all-pairs ranking instead
+  if constexpr (BINNED) {
+    for (int i = tid; i < 256; i += NT) S->cursor[i] = 0;
+  }
   if (tid < 4) S->misc[tid] = 0;
   if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
   __syncthreads();
@@ -1347,8 +1359,15 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   //          (LDS histogram -> 256-bin suffix scan).  A pass ends the search early when the
   //          bin holding the k-th key is needed in full.  T is relative to kbase until the end.
   uint32_t T = 0, c_ge = (uint32_t)n, c_gt = 0;
+  int shift0 = 0;        // the leading digit of a key: ((key - kbase) >> shift0) & mask0 (pass 0 of the search)
+  uint32_t mask0 = 0u;
   if (diff != 0u) {
     const int hb = 31 - __clz((int)diff);  // highest differing bit
+    {
+      const int nb0 = hb + 1 < 8 ? hb + 1 : 8;
+      shift0 = hb + 1 - nb0;
+      mask0 = (1u << nb0) - 1u;
+    }
     T = 0u;
     int top = hb + 1;          // undecided low bits
     uint32_t kk = (uint32_t)k;  // still to find among keys that match T above `top`
@@ -1373,6 +1392,9 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       const uint32_t ab2 = ab3 + hv.w;  // > 4l+2
       const uint32_t ab1 = ab2 + hv.z;  // > 4l+1
       const uint32_t ab0 = ab1 + hv.y;  // > 4l
+      if constexpr (BINNED) {
+        if (pass == 0 && wave == 0) { S->above[4 * lane] = ab0; S->above[4 * lane + 1] = ab1; S->above[4 * lane + 2] = ab2; S->above[4 * lane + 3] = ab3; }
+      }
       int hit = -1;
       if (ab3 < kk && kk <= ab3 + hv.w) hit = 3;
       else if (ab2 < kk && kk <= ab2 + hv.z) hit = 2;
@@ -1402,7 +1424,40 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   pt.sub(PH_TK_SEARCH, tsub);
   const bool partial_eq = c_ge > (uint32_t)k;
   // ---- 3. collect -----------------------------------------------------------
-  if (!partial_eq) {
+  const bool use_bins = BINNED && diff != 0u;  // (uniform)
+  // a selected pair goes to the next free place of its bin: every key of a higher bin is selected too, so bin b's pairs are
+  // the ranks [above[b], above[b] + cursor[b])
+  auto place = [&](uint32_t kj, int i) {
+    const uint32_t bin = ((kj - kbase) >> shift0) & mask0;
+    const uint32_t p = atomicAdd(&S->cursor[bin], 1u);
+    if (p >= bin_max) S->misc[3] = 1u;
+    S->sel[S->above[bin] + p] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
+  };
+  if (use_bins) {
+    NANN_FOR_KEYS({
+      if (valid && (partial_eq ? kj > T : kj >= T)) place(kj, i);
+    })
+    if (partial_eq) {  // keys == T: the first (k - c_gt) in position order (as below), placed in T's bin
+      const uint32_t r = (uint32_t)k - c_gt;
+      uint32_t eq_base = 0;
+      NANN_FOR_KEYS({
+        const bool e = valid && kj == T;
+        const uint64_t m = __ballot(e);
+        if (lane == 0) S->wcnt[wave] = (uint32_t)popc64(m);
+        __syncthreads();
+        uint32_t wb = 0, tot = 0;
+        for (int w = 0; w < NT / 64; ++w) {
+          const uint32_t t = S->wcnt[w];
+          if (w < wave) wb += t;
+          tot += t;
+        }
+        const uint32_t rank = eq_base + wb + (uint32_t)popc64(m & lt);
+        if (e && rank < r) place(kj, i);
+        eq_base += tot;
+        __syncthreads();
+      })
+    }
+  } else if (!partial_eq) {
     NANN_FOR_KEYS({
       const bool s = valid && kj >= T;
       const uint64_t m = __ballot(s);
@@ -1458,7 +1513,8 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   // the id of "my" element (e = tid) is fetched now so that its latency hides under the ranking
   int32_t my_id = 0;
   if (tid < k && ids) my_id = ids[(int)(~(uint32_t)(S->sel[tid] & 0xffffffffull))];
-  if (split) {
+  const bool binned = use_bins && S->misc[3] == 0u;  // (uniform: read behind the barrier)
+  if (split && !binned) {
     const int segs = NT / K2;
     const int e = tid & (K2 - 1), seg = tid / K2;
     const int len = (k + segs - 1) / segs;
@@ -1482,7 +1538,20 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   for (int e = tid; e < k; e += NT) {
     const unsigned long long mine = S->sel[e];
     int rank = 0;
-    if (split) {
+    if (binned) {  // against the pairs of its own bin
+      const uint32_t bin = (((uint32_t)(mine >> 32) - kbase) >> shift0) & mask0;
+      const int lo = (int)S->above[bin], hi = lo + (int)S->cursor[bin];
+      rank = lo;
+      int o = lo;
+      for (; o + 4 <= hi; o += 4) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = S->sel[o + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rank += (v[u] > mine) ? 1 : 0;
+      }
+      for (; o < hi; ++o) rank += (S->sel[o] > mine) ? 1 : 0;
+    } else if (split) {
       for (int sg = 0; sg < NT / K2; ++sg) rank += S->prank[sg * K2 + e];
     } else {
       int o = 0;
@@ -1538,6 +1607,19 @@ __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, 
   if (n <= kTopkEPT * NT) NANN_TOPK_CASE(kTopkEPT, false);
   NANN_TOPK_CASE(0, false);
 #undef NANN_TOPK_CASE
+}
+
+// The same with three register-slot cases instead of ten and the bin-grouped ranking: the evaluation traversal's LDS form (its n
+// is in the thousands, its k in the hundreds; every case is a copy of the whole selection in every instance of the kernel)
+template <int NT, int KCAP>
+__device__ __forceinline__ int wg_topk_binned(const int32_t* ids, const float* scores, int n, int k, int32_t* out_ids,
+                                              float* out_scores, unsigned char* scratch) {
+  if (k < 0 || k > KCAP) return 7;  // NANN_ERR_BAD_ARGUMENT
+  if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
+  if (k == 0) return 0;
+  if (n <= 4 * NT) return wg_topk_impl<4, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer());
+  if (n <= 8 * NT) return wg_topk_impl<8, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer());
+  return wg_topk_impl<0, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer());
 }
 
 }  // namespace nann

@@ -593,7 +593,7 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
   ctr_s += E;
   EVAL_TICK(0);
   int n_res = min(a.top_k[2], E);
-  int st = wg_topk<NT, kEvalMaxK>(a.enter, sv.cat_sc, nullptr, E, n_res, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
+  int st = wg_topk_binned<NT, kEvalMaxK>(a.enter, sv.cat_sc, E, n_res, st_res_ids, st_res_sc, scratch);
   if (st) return st;
   EVAL_TICK(1);
   publish(n_res, 0, 0, true);
@@ -791,7 +791,7 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
         EVAL_TICK(5);
         int rc = 0;
         for (int rep = 0; rep <= NANN_REPEAT_TOPK; ++rep) {  // :326-328
-          rc = wg_topk<NT, kEvalMaxK>(cat_ids, cat_sc, nullptr, n_cat, k, nullptr, st_res_ids, st_res_sc, nullptr, nullptr, scratch);
+          rc = wg_topk_binned<NT, kEvalMaxK>(cat_ids, cat_sc, n_cat, k, st_res_ids, st_res_sc, scratch);
           if (rc) return rc;
         }
         EVAL_TICK(6);
@@ -916,11 +916,12 @@ inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
   return NANN_OK;
 }
 
-// instantiations: nann_eval_inst.hip (L2, attention model), nann_mlp_inst.hip (MLP, f32 MFMA).  seen_lds: the L2
+// instantiations: nann_eval_inst.hip (L2 slot form, attention model), nann_eval_lds_inst.hip (L2, LDS form), nann_mlp_inst.hip (MLP, f32 MFMA).  seen_lds: the L2
 // instances only (eval_l2_lds_bytes() = what the plan checks against the CU's LDS)
 size_t eval_l2_lds_base();
 size_t eval_dirty_room();  // bytes of the phase scratch the second-level bitmap may take (the smallest instance's)
 int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st);
+int launch_eval_l2_lds(int lpr, int dt, int slots, const EvalArgs& a, hipStream_t st);  // nann_eval_lds_inst.hip
 int launch_eval_attn(int d, int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d64(int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d128(int dt, int slots, const EvalArgs& a, hipStream_t st);
