@@ -532,7 +532,10 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
   // written behind it)
   EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
   int32_t* cand = reinterpret_cast<int32_t*>(scratch + 256);
-  static_assert(256 + kEvalMaxK * 4 <= kPhaseScratch, "phase scratch too small for the frontier");
+  // the frontier's row bounds for the walk: start (48 bits) | length (16 bits; eval_plan: the LDS form takes indices whose rows
+  // are shorter than 2^16)
+  unsigned long long* bnd = reinterpret_cast<unsigned long long*>(scratch + 256 + kEvalMaxK * 4);
+  static_assert(256 + kEvalMaxK * 12 <= kPhaseScratch, "phase scratch too small for the frontier and its row bounds");
   // staging area (the region of `seen`): [kept ids: kEvalMaxK | kept scores: kEvalMaxK | scores of result || new: CAP]
   int32_t* st_res_ids = reinterpret_cast<int32_t*>(seen);
   float* st_res_sc = reinterpret_cast<float*>(seen + kEvalMaxK);
@@ -574,7 +577,7 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
       const int32_t id = st_res_ids[i];
       sv.cat_ids[i] = id;
       sv.cat_sc[i] = st_res_sc[i];
-      if (to_cand) cand[i] = id;
+      if (to_cand) { cand[i] = id; sv.res_ids[i] = id; }  // (the next level's frontier and its marks, below)
     }
     lds_barrier();
     for (int i = tid; i < k; i += NT) { seen[i] = 0u; seen[kEvalMaxK + i] = 0u; }
@@ -602,39 +605,52 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
   for (int level = 1; level >= 0; --level) {  // search_level (:299-337)
     if (!cand_is_result) {  // (a level that ended on an empty round, or ran no round: its result, cut, from the slot)
       __syncthreads();
-      for (int i = tid; i < n_res; i += NT) cand[i] = sv.cat_ids[i];
+      for (int i = tid; i < n_res; i += NT) {
+        const int32_t id = sv.cat_ids[i];
+        cand[i] = id;
+        sv.res_ids[i] = id;
+      }
       __syncthreads();
     }
-    // visited = idx_ep (:311): the marks go through `seen`; candidates = result
-    for (int i = tid; i < n_res; i += NT) {
-      const int32_t id = cand[i];
-      if ((uint32_t)id >= a.n_items) { SS->flags[1] = 1; continue; }
-      seen_or((uint32_t)id);
-    }
-    lds_barrier();
-    if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
-    if (owner) {  // visited = marks -- ALL 32 words of every owner, which is also the level's visited = {} --, seen = 0
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        uint32_t sw[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sw[i] = seen[own + 8 * b + i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (sw[i]) seen[own + 8 * b + i] = 0u;
-          __builtin_amdgcn_raw_buffer_store_b32(sw[i], vrs, tid * 4, (8 * b + i) * NT * 4, 0);
-        }
-      }
-    }
-    lds_barrier();  // (a thread's words of `visited` are its own: nobody else waits for the stores)
+    // visited = idx_ep (:311), candidates = result.  The level's marks -- its starting result, <= top_k ids -- are NOT put into
+    // `visited`: they stay a list (the slot's result array; a thread reads back the entries it wrote) and are taken out of
+    // `seen` behind every walk, one atomic each.  So a level starts without a pass over the bitmaps, and its first round needs
+    // no word of `visited`: it WRITES all of them (visited = new), which is also the level's visited = {}.
+    const int n_marks = n_res;
     EVAL_TICK(2);
     int n_cand = n_res;
     const int32_t* __restrict__ values = a.nbv[level];
     const int64_t* __restrict__ rs = a.nbrs[level];
     for (int it = 0; it < a.num_scoring[level]; ++it) {
-      // ---- neighbours of the candidates -> bits of `seen`.  Wavefront w walks rows [8 (w + NW t), + 8) for t = 0, 1, ...; four
-      // trips at a time: their bounds (lanes 0-7, one load each way per trip) in flight together, then their 32 rows
+      // ---- neighbours of the candidates -> bits of `seen`.  Every thread fetches the bounds of its rows of the frontier (one
+      // trip for all of them) into LDS; then wavefront w walks rows [8 (w + NW t), + 8) for t = 0, 1, ..., four trips at a time:
+      // 32 rows per wavefront in flight together.  The level's marks ride along, for the removal behind the walk.
       ctr_f += n_cand;
+      const bool first = it == 0;
+      int32_t mk[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) mk[j] = sv.res_ids[min(tid + j * NT, n_marks - 1)];
+      {
+        long long s[NF], e[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = tid + j * NT;
+          s[j] = 0; e[j] = 0;
+          if (r < n_cand) {
+            const int32_t c = cand[r];
+            s[j] = rs[c]; e[j] = rs[c + 1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = tid + j * NT;
+          if (r < n_cand) {
+            bnd[r] = (unsigned long long)s[j] | ((unsigned long long)(e[j] - s[j]) << 48);
+            ctr_g += (int)(e[j] - s[j]);
+          }
+        }
+      }
+      lds_barrier();
       for (int rep = 0; rep <= NANN_REPEAT_GATHER; ++rep) {
         int bad = 0;
         for (int t0 = 0; t0 * NW * 8 < n_cand; t0 += 4) {
@@ -643,14 +659,10 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int r = (t0 + t) * NW * 8 + wave * 8 + lane;
-            long long s = 0, e = 0;
-            if (lane < 8 && r < n_cand) {
-              const int32_t c = cand[r];
-              s = rs[c]; e = rs[c + 1];
-            }
-            s4[t] = s; len4[t] = (int)(e - s);
+            unsigned long long b = 0ull;
+            if (lane < 8 && r < n_cand) b = bnd[r];
+            s4[t] = (long long)(b & 0xffffffffffffull); len4[t] = (int)(b >> 48);
           }
-          if (rep == 0) ctr_g += len4[0] + len4[1] + len4[2] + len4[3];
           int32_t v[4][8];
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -681,42 +693,62 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
       }
       lds_barrier();  // (the walk loads; what is still on its way to the slot -- the last round's results, an owner's words of
                       //  `visited` -- is read back by the thread that stored it)
+#pragma unroll
+      for (int j = 0; j < NF; ++j)  // seen \= marks
+        if (tid + j * NT < n_marks) {
+          const uint32_t id = (uint32_t)mk[j];
+          if (id >= a.n_items) SS->flags[1] = 1;
+          else atomicAnd(&seen[(id >> 5) + (id >> 10)], ~(1u << (id & 31)));
+        }
+      lds_barrier();
       if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
       EVAL_TICK(3);
       // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
       // ALL 32 of the thread's words of `visited` in ONE batch (touched words only, 4 / 8 / 16 at a time, were 5 / 4 / 2 dependent
-      // trips) -- and with them this thread's ids and scores of the kept results (the front of the concat arrays), which go to the
-      // staging area behind the emit.  Buffer loads: one VGPR of offset for all of them, the word's stride in an SGPR.
-      uint32_t vis[32];
+      // trips; the level's first round has none to fetch) -- and with them this thread's ids and scores of the kept results (the
+      // front of the concat arrays), which go to the staging area behind the emit.  Buffer loads: one VGPR of offset for all of
+      // them, the word's stride in an SGPR.
       int32_t fi[NF];
       float fs[NF];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        fi[j] = sv.cat_ids[min(tid + j * NT, n_res - 1)];
-        fs[j] = sv.cat_sc[min(tid + j * NT, n_res - 1)];
-      }
       uint32_t cnt = 0, nd = 0;  // new bits of this thread's words; which of its words have any
-      if (owner) {
+      auto owners = [&](auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        uint32_t vis[32];
+        if constexpr (!FIRST) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          uint32_t sw[8];
+          for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, j * NT * 4, 0);
+        }
 #pragma unroll
-          for (int i = 0; i < 8; ++i) sw[i] = seen[own + 8 * b + i];
+        for (int j = 0; j < NF; ++j) {
+          fi[j] = sv.cat_ids[min(tid + j * NT, n_res - 1)];
+          fs[j] = sv.cat_sc[min(tid + j * NT, n_res - 1)];
+        }
+        if (owner) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int j = 8 * b + i;
-            const uint32_t nw = sw[i] & ~vis[j];
-            if (sw[i] != nw) seen[own + j] = nw;  // the NEW bits stay, for the emit behind the scan
-            if (nw) {
-              __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
-              nd |= 1u << j;
-              cnt += (uint32_t)__popc(nw);
+          for (int b = 0; b < 4; ++b) {
+            uint32_t sw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sw[i] = seen[own + 8 * b + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int j = 8 * b + i;
+              if constexpr (FIRST) {  // visited = new: every word written
+                __builtin_amdgcn_raw_buffer_store_b32(sw[i], vrs, tid * 4, j * NT * 4, 0);
+                if (sw[i]) { nd |= 1u << j; cnt += (uint32_t)__popc(sw[i]); }
+              } else {
+                const uint32_t nw = sw[i] & ~vis[j];
+                if (sw[i] != nw) seen[own + j] = nw;  // the NEW bits stay, for the emit behind the scan
+                if (nw) {
+                  __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, j * NT * 4, 0);
+                  nd |= 1u << j;
+                  cnt += (uint32_t)__popc(nw);
+                }
+              }
             }
           }
         }
-      }
+      };
+      if (first) owners(std::true_type{}); else owners(std::false_type{});
       EVAL_TICK(8);
       uint32_t total;
       uint32_t at = wg_excl_scan<NT, true>(cnt, SS, &total);  // thread order = word order = ascending ids
@@ -797,7 +829,7 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
         EVAL_TICK(6);
         if (!last) {
           // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331): every thread takes a
-          // CONTIGUOUS run of the new nodes, one workgroup scan places them; a run's ids are fetched four at a time, wanted or not
+          // CONTIGUOUS run of the new nodes, one workgroup scan places them
           const float worst = st_res_sc[k - 1];
           const int per = (n_next + NT - 1) / NT;
           const int lo = min(tid * per, n_next), hi = min(lo + per, n_next);
@@ -806,16 +838,10 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
           uint32_t n_new;
           uint32_t pos = wg_excl_scan<NT, true>(mine, SS, &n_new);
           if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
-          if (mine) {
-            for (int i0 = lo; i0 < hi; i0 += 4) {
-              int32_t idv[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) idv[u] = cat_ids[n_res + min(i0 + u, hi - 1)];
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (i0 + u < hi && cat_sc[n_res + i0 + u] >= worst) cand[pos++] = idv[u];
-            }
-          }
+          for (int i = lo; i < hi; ++i)  // the POSITIONS of the frontier's rows first ...
+            if (cat_sc[n_res + i] >= worst) cand[pos++] = i;
+          lds_barrier();
+          for (int p = tid; p < (int)n_new; p += NT) cand[p] = cat_ids[n_res + cand[p]];  // ... then their ids, one trip for all
           n_cand = (int)n_new;
           __syncthreads();  // (the copy below overwrites cat_ids[n_res ..] that the selection above reads)
         } else {
