@@ -1294,7 +1294,11 @@ template <int NS, bool SCL, int NT, int KCAP = kMaxK, bool BIN = false>
 __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
                                             const float* lds_scores, int n, int k, int32_t* out_pos,
                                             int32_t* out_ids, float* out_scores, const int64_t* id_map,
-                                            int64_t* out_mapped, unsigned char* scratch, SubTimer pt) {
+                                            int64_t* out_mapped, unsigned char* scratch, SubTimer pt,
+                                            int n_all = 0x7fffffff, uint32_t floor_key = 0u) {
+  // (BIN only) positions >= n_all take part only with a key above floor_key: a row that is a sorted list of >= k kept results
+  // followed by candidates needs only the candidates that beat the worst kept result -- TopKV2 breaks ties towards the lower
+  // position, so a candidate at or below it can displace nothing; same output, a fraction of the histogram traffic
   TopkScratchT<KCAP>* S = reinterpret_cast<TopkScratchT<KCAP>*>(scratch);
   long long tsub = pt.now();
   const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
@@ -1316,7 +1320,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   for (int i = tid; i < 4 * 256; i += NT) hist[i] = 0;
   constexpr bool BINNED = BIN;  // (the serving kernels keep the all-pairs ranking: their k is 200)
   static_assert(!BIN || KCAP > 1024, "the bin tables exist for KCAP > kMaxK");
-  const uint32_t bin_max = (uint32_t)max(64, k >> 3);  // a fuller bin (keys crowded into one leading digit): the all-pairs ranking instead
+  const uint32_t bin_max = (uint32_t)max(64, k >> 1);  // a fuller bin (half the keys crowded into one leading digit): the all-pairs ranking instead
   if constexpr (BINNED) {
     for (int i = tid; i < 256; i += NT) S->cursor[i] = 0;
   }
@@ -1329,15 +1333,15 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   if constexpr (REG) {                                                        \
     _Pragma("unroll") for (int j = 0; j < NS; ++j) {                          \
       const int i = j * NT + tid;                                             \
-      const bool valid = i < n;                                               \
       const uint32_t kj = key[j];                                             \
+      const bool valid = i < n && (!BIN || i < n_all || kj > floor_key);      \
       __VA_ARGS__                                                             \
     }                                                                         \
   } else {                                                                    \
     for (int i0 = 0; i0 < n; i0 += NT) {                                      \
       const int i = i0 + tid;                                                 \
-      const bool valid = i < n;                                               \
-      const uint32_t kj = valid ? score_key(scores[i]) : 0u;                  \
+      const uint32_t kj = i < n ? score_key(scores[i]) : 0u;                  \
+      const bool valid = i < n && (!BIN || i < n_all || kj > floor_key);      \
       __VA_ARGS__                                                             \
     }                                                                         \
   }
@@ -1346,11 +1350,15 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   //          over the bins (the raw keys of scores within a few binades share all but 2-3 values of
   //          their top 8 undecided bits, and same-bin LDS atomics serialise)
   {
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    NANN_FOR_KEYS({ if (valid) { lo = min(lo, kj); hi = max(hi, kj); } })
+    uint32_t lo = 0xffffffffu, hi = 0u, nv = 0u;
+    NANN_FOR_KEYS({ if (valid) { lo = min(lo, kj); hi = max(hi, kj); ++nv; } })
     lo = wave_min(lo);
     hi = wave_max(hi);
     if (lane == 0) { atomicMin(&S->andv, lo); atomicMax(&S->orv, hi); }
+    if constexpr (BIN) {  // the keys that take part (misc[1])
+      const uint32_t wv = wave_total(wave_scan_add(nv));
+      if (lane == 0) atomicAdd(&S->misc[1], wv);
+    }
   }
   __syncthreads();
   const uint32_t kbase = S->andv;          // smallest key
@@ -1358,7 +1366,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   // ---- 2b. k-th largest key: radix select over the undecided bits, 8 bits per pass
   //          (LDS histogram -> 256-bin suffix scan).  A pass ends the search early when the
   //          bin holding the k-th key is needed in full.  T is relative to kbase until the end.
-  uint32_t T = 0, c_ge = (uint32_t)n, c_gt = 0;
+  uint32_t T = 0, c_ge = BIN ? S->misc[1] : (uint32_t)n, c_gt = 0;
   int shift0 = 0;        // the leading digit of a key: ((key - kbase) >> shift0) & mask0 (pass 0 of the search)
   uint32_t mask0 = 0u;
   if (diff != 0u) {
@@ -1611,15 +1619,17 @@ __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, 
 
 // The same with three register-slot cases instead of ten and the bin-grouped ranking: the evaluation traversal's LDS form (its n
 // is in the thousands, its k in the hundreds; every case is a copy of the whole selection in every instance of the kernel)
+// n_all / floor_key: wg_topk_impl (the caller vouches that at least k keys take part).
 template <int NT, int KCAP>
 __device__ __forceinline__ int wg_topk_binned(const int32_t* ids, const float* scores, int n, int k, int32_t* out_ids,
-                                              float* out_scores, unsigned char* scratch) {
+                                              float* out_scores, unsigned char* scratch, int n_all = 0x7fffffff,
+                                              uint32_t floor_key = 0u) {
   if (k < 0 || k > KCAP) return 7;  // NANN_ERR_BAD_ARGUMENT
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;
-  if (n <= 4 * NT) return wg_topk_impl<4, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer());
-  if (n <= 8 * NT) return wg_topk_impl<8, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer());
-  return wg_topk_impl<0, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer());
+  if (n <= 4 * NT) return wg_topk_impl<4, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer(), n_all, floor_key);
+  if (n <= 8 * NT) return wg_topk_impl<8, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer(), n_all, floor_key);
+  return wg_topk_impl<0, false, NT, KCAP, true>(ids, scores, nullptr, n, k, nullptr, out_ids, out_scores, nullptr, nullptr, scratch, no_timer(), n_all, floor_key);
 }
 
 }  // namespace nann

@@ -822,8 +822,11 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
         }
         EVAL_TICK(5);
         int rc = 0;
+        // (the kept results are sorted and, once there are k of them, only candidates that beat the worst one can enter)
+        const bool full = n_res >= k;
+        const uint32_t floor_key = full ? score_key(cat_sc[n_res - 1]) : 0u;
         for (int rep = 0; rep <= NANN_REPEAT_TOPK; ++rep) {  // :326-328
-          rc = wg_topk_binned<NT, kEvalMaxK>(cat_ids, cat_sc, n_cat, k, st_res_ids, st_res_sc, scratch);
+          rc = wg_topk_binned<NT, kEvalMaxK>(cat_ids, cat_sc, n_cat, k, st_res_ids, st_res_sc, scratch, full ? n_res : 0x7fffffff, floor_key);
           if (rc) return rc;
         }
         EVAL_TICK(6);
@@ -834,12 +837,26 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
           const int per = (n_next + NT - 1) / NT;
           const int lo = min(tid * per, n_next), hi = min(lo + per, n_next);
           uint32_t mine = 0;
-          for (int i = lo; i < hi; ++i) mine += cat_sc[n_res + i] >= worst ? 1u : 0u;
+          for (int i0 = lo; i0 < hi; i0 += 8) {  // (eight scores in flight: they may be in the slot)
+            float sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sc[u] = cat_sc[n_res + min(i0 + u, hi - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine += (i0 + u < hi && sc[u] >= worst) ? 1u : 0u;
+          }
           uint32_t n_new;
           uint32_t pos = wg_excl_scan<NT, true>(mine, SS, &n_new);
           if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
-          for (int i = lo; i < hi; ++i)  // the POSITIONS of the frontier's rows first ...
-            if (cat_sc[n_res + i] >= worst) cand[pos++] = i;
+          if (mine) {
+            for (int i0 = lo; i0 < hi; i0 += 8) {  // the POSITIONS of the frontier's rows first ...
+              float sc[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) sc[u] = cat_sc[n_res + min(i0 + u, hi - 1)];
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (i0 + u < hi && sc[u] >= worst) cand[pos++] = i0 + u;
+            }
+          }
           lds_barrier();
           for (int p = tid; p < (int)n_new; p += NT) cand[p] = cat_ids[n_res + cand[p]];  // ... then their ids, one trip for all
           n_cand = (int)n_new;
