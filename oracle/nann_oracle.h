@@ -269,7 +269,29 @@ int oracle_merge_topk(const float* scores, const int64_t* ids, int n_shards,
  * Inference-mode batch norm is folded to y = x * bn_scale + bn_shift
  * (scale = gamma / sqrt(moving_var + 1e-3), shift = beta - moving_mean * scale).
  * No attention mask: zero-padded sequence positions take part in the softmax, as in
- * nonlinear_attention().  All dense layers: acc = bias; acc = fmaf(x[k], W[k][j], acc), k ascending. */
+ * nonlinear_attention().  All dense layers: acc = bias; acc = fmaf(x[k], W[k][j], acc), k ascending.
+ *
+ * The conventions this restatement ASSUMES and nothing the reference holds pins (no TensorFlow-written frozen graph of
+ * Model.forward, no checkpoint under NANN_impls): the day such a file appears, the diff against it is this table.
+ *   convention                     assumed here                                          where the reference states it
+ *   -----------------------------  ----------------------------------------------------  -------------------------------------
+ *   batch-norm epsilon             1e-3 (tf.layers.batch_normalization's default)        model_util.py:53 passes none
+ *   batch-norm at inference        moving_mean / moving_variance, folded into scale /    model_util.py:53 (training=training);
+ *                                  shift per channel: y = x * scale + shift              convert_meta.py:361-398 freezes them
+ *   batch-norm position            dense -> bn -> prelu, bias inside the dense layer     model_util.py:42-67
+ *   prelu                          max(x, 0) + alpha * min(x, 0), alpha per channel,     model_util.py:9-11
+ *                                  initial value as trained (no constraint on its sign)
+ *   Tensordot / dense layout       weights [in, out] row-major, y_j = sum_k x_k W[k][j]  model_util.py:44-49,81-85 (tf.layers.dense
+ *                                  (kernel of tf.layers.dense; no transpose)             = Tensordot on the last axis in the graph)
+ *   attention scale                1 / sqrt(4E) on the logits, softmax over all L        model_util.py:87-93
+ *                                  positions, padded ones included (no mask)
+ *   attention pooling              weights applied to the RAW sequence u_l, not to k_l   model_util.py:95
+ *   concat order of the DNN input  [attended user vector ; item row]                     model.py:213
+ *   output layer                   no bias, no activation: the logit                     model.py:218-219
+ *   item row dtype                 the index's storage type widened to f32 exactly       build_hnsw_index.py:41-66 (f32 on disk)
+ *   accumulation order             k ascending, one fmaf per term (XLA's CPU dot may     blaze_xla_predictor.cc:360-459 leaves it
+ *                                  tile differently: tolerance 1e-5, north_star)         to the compiled graph
+ */
 typedef struct {
   int d, E, L, emb_dtype;
   const float *wq1, *bq1, *aq; /* [d,2E] [2E] [2E] */
