@@ -1270,16 +1270,18 @@ __device__ __forceinline__ void wg_score_l2(const void* __restrict__ table, int 
 template <int KCAP>  // largest k (kMaxK for the serving kernels; the evaluation traversal keeps more per level)
 struct TopkScratchT {
   unsigned long long sel[KCAP < 512 ? 512 : KCAP];  // first: 16-byte aligned (the four 256-bin radix histograms alias it)
-  unsigned short prank[kNT];      // partial ranks of the rank sort: [segment][element]
-  uint32_t misc[4];               // [0] nsel, [2] unordered append cursor
+  union {
+    unsigned short prank[kNT];    // partial ranks of the all-pairs rank sort: [segment][element]
+    // the bin-grouped ranking (BIN, round 6): the selected pairs are GROUPED by the leading radix digit of their keys --
+    // above[b] = keys of the row with a larger digit = the rank at which bin b starts, cursor[b] = selected pairs in bin b -- so
+    // that a pair is ranked against its own bin only (step 4).  Dead before the all-pairs ranking (its fallback) starts.
+    struct { uint32_t above[256]; uint32_t cursor[256]; } bins;
+  };
+  uint32_t misc[4];               // [0] nsel, [1] keys that take part (BIN), [2] unordered append cursor, [3] a bin overflowed (BIN)
   uint32_t orv, andv;
   uint32_t wcnt[kNW];
-  // large k (the evaluation traversal, KCAP > kMaxK = 1024): the selected pairs are GROUPED by the leading radix digit of their keys --
-  // above[b] = keys of the row with a larger digit = the rank at which bin b starts, cursor[b] = selected pairs in bin b -- so that
-  // a pair is ranked against its own bin only (step 4)
-  uint32_t above[KCAP > 1024 ? 256 : 1];
-  uint32_t cursor[KCAP > 1024 ? 256 : 1];
 };
+static_assert(kNT * sizeof(unsigned short) == 512 * sizeof(uint32_t), "the bin tables overlay the partial ranks");
 typedef TopkScratchT<kMaxK> TopkScratch;
 // candidate scores of the current round, kept in LDS behind the top-k scratch so that
 // the selection does not wait on L2 (positions < kLdsScores only)
@@ -1289,7 +1291,7 @@ static_assert(sizeof(ExpandWalkScratch) <= kPhaseScratch, "phase scratch too sma
 
 // NS = register slots per thread (n <= NS * kNT); NS == 0 re-reads keys from memory.
 // SCL = the first n scores are also in LDS (lds_scores); requires NS > 0.
-// BIN: rank the selected pairs bin by bin (TopkScratchT::above / cursor; KCAP > kMaxK only -- the evaluation traversal's LDS form)
+// BIN: rank the selected pairs bin by bin (TopkScratchT::bins)
 template <int NS, bool SCL, int NT, int KCAP = kMaxK, bool BIN = false>
 __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* scores,
                                             const float* lds_scores, int n, int k, int32_t* out_pos,
@@ -1319,10 +1321,9 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   uint32_t* hist = reinterpret_cast<uint32_t*>(S->sel);  // [4][256]; sel is not in use before step 3
   for (int i = tid; i < 4 * 256; i += NT) hist[i] = 0;
   constexpr bool BINNED = BIN;  // (the serving kernels keep the all-pairs ranking: their k is 200)
-  static_assert(!BIN || KCAP > 1024, "the bin tables exist for KCAP > kMaxK");
   const uint32_t bin_max = (uint32_t)max(64, k >> 1);  // a fuller bin (half the keys crowded into one leading digit): the all-pairs ranking instead
   if constexpr (BINNED) {
-    for (int i = tid; i < 256; i += NT) S->cursor[i] = 0;
+    for (int i = tid; i < 256; i += NT) S->bins.cursor[i] = 0;
   }
   if (tid < 4) S->misc[tid] = 0;
   if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
@@ -1401,7 +1402,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
       const uint32_t ab1 = ab2 + hv.z;  // > 4l+1
       const uint32_t ab0 = ab1 + hv.y;  // > 4l
       if constexpr (BINNED) {
-        if (pass == 0 && wave == 0) { S->above[4 * lane] = ab0; S->above[4 * lane + 1] = ab1; S->above[4 * lane + 2] = ab2; S->above[4 * lane + 3] = ab3; }
+        if (pass == 0 && wave == 0) { S->bins.above[4 * lane] = ab0; S->bins.above[4 * lane + 1] = ab1; S->bins.above[4 * lane + 2] = ab2; S->bins.above[4 * lane + 3] = ab3; }
       }
       int hit = -1;
       if (ab3 < kk && kk <= ab3 + hv.w) hit = 3;
@@ -1437,9 +1438,9 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
   // the ranks [above[b], above[b] + cursor[b])
   auto place = [&](uint32_t kj, int i) {
     const uint32_t bin = ((kj - kbase) >> shift0) & mask0;
-    const uint32_t p = atomicAdd(&S->cursor[bin], 1u);
+    const uint32_t p = atomicAdd(&S->bins.cursor[bin], 1u);
     if (p >= bin_max) S->misc[3] = 1u;
-    S->sel[S->above[bin] + p] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
+    S->sel[S->bins.above[bin] + p] = ((unsigned long long)kj << 32) | (uint32_t)(~(uint32_t)i);
   };
   if (use_bins) {
     NANN_FOR_KEYS({
@@ -1548,7 +1549,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     int rank = 0;
     if (binned) {  // against the pairs of its own bin
       const uint32_t bin = (((uint32_t)(mine >> 32) - kbase) >> shift0) & mask0;
-      const int lo = (int)S->above[bin], hi = lo + (int)S->cursor[bin];
+      const int lo = (int)S->bins.above[bin], hi = lo + (int)S->bins.cursor[bin];
       rank = lo;
       int o = lo;
       for (; o + 4 <= hi; o += 4) {
@@ -1591,7 +1592,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
 }
 
 // lds_scores != nullptr: the first n scores are mirrored in LDS (n <= kLdsScores)
-template <int NT = kNT, int KCAP = kMaxK>
+template <int NT = kNT, int KCAP = kMaxK, bool BIN = false>
 __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, const float* lds_scores,
                                        int n, int k, int32_t* out_pos, int32_t* out_ids,
                                        float* out_scores, const int64_t* id_map, int64_t* out_mapped,
@@ -1600,7 +1601,7 @@ __device__ __forceinline__ int wg_topk(const int32_t* ids, const float* scores, 
   if (n < k) return 4;               // NANN_ERR_TOPK_K_GT_N, topk_op.cc:67-71
   if (k == 0) return 0;
 #define NANN_TOPK_CASE(NS_, SCL_)                                                                   \
-  return wg_topk_impl<NS_, SCL_, NT, KCAP>(ids, scores, lds_scores, n, k, out_pos, out_ids, out_scores, \
+  return wg_topk_impl<NS_, SCL_, NT, KCAP, BIN>(ids, scores, lds_scores, n, k, out_pos, out_ids, out_scores, \
                                            id_map, out_mapped, scratch, pt)
   if (lds_scores != nullptr && n <= kLdsScores) {
     if (n <= 1 * NT) NANN_TOPK_CASE(1, true);

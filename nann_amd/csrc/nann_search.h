@@ -275,6 +275,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     }
   }
 
+  // top-k ranks its selected pairs bin by bin (nann_device.h, round 6) in the L2 traversals: ~11 of a lone query's 144 us were the
+  // all-pairs ranking (the register-starved MLP / attention kernels keep it: their selection is a percent of their time)
+#ifndef NANN_TOPK_BINS
+#define NANN_TOPK_BINS 1
+#endif
+  constexpr bool kTopkBins = NANN_TOPK_BINS && SC == NANN_SCORER_L2;
   // The schedule of build_opt_graph.py:109-149 as six stages with ONE call site per
   // building block: stage 0 = entry layer (:111-112), 1 = level 1 (:114-127),
   // 2..4 = the three level-0 rounds (:129-141), 5 = final top-k (:143-149).
@@ -555,12 +561,12 @@ __device__ __forceinline__ int search_one(const SearchArgs& a, int qi, const Slo
     mark(PH_OTHER);
 #if NANN_REPEAT_TOPK
     for (int rep = 0; rep < NANN_REPEAT_TOPK; ++rep) {
-      (void)wg_topk<NT>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
+      (void)wg_topk<NT, kMaxK, kTopkBins>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
                         nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch, pt);
       __syncthreads();
     }
 #endif
-    const int st = wg_topk<NT>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
+    const int st = wg_topk<NT, kMaxK, kTopkBins>(tk_ids, tk_sc, (r < NANN_NUM_ROUNDS) ? lds_scores : nullptr, tk_n, tk_k,
                                nullptr, tk_out_ids, tk_out_sc, tk_map, tk_out_map, scratch, pt);
     mark(PH_TOPK);
     if (st) return st;
