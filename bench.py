@@ -700,7 +700,8 @@ def eval_graph_rate(handles, dim, n_enter, n_users=1024):
             out.update(res)
         else:
             out[name] = res
-    out["kernel"] = "k_search_eval: seen bitmap in LDS, owner-thread scan against visited (nann_eval.h); parity: tests/test_search_gpu.py, tools/eval_bench.py"
+    out["kernel"] = ("k_search_eval, LDS form (search_eval_lds, nann_eval.h): seen bitmap in LDS doubling as the round's staging area, owner-thread scan "
+                     "against visited, marks as a list, bin-ranked top-k; parity: tests/test_search_gpu.py, tools/eval_bench.py")
     return out
 
 
