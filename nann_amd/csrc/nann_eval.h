@@ -469,7 +469,7 @@ __device__ __forceinline__ int search_eval_slot(const EvalArgs& a, int qi, const
       // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331).  Round 6: every thread takes a
       // CONTIGUOUS run of the new nodes, so one workgroup scan places them (it was one scan, two barriers, per 1024 nodes)
       const float worst = sv.res_sc[k - 1];
-      {
+      if (it + 1 < a.num_scoring[level]) {  // (a level's last round: its frontier is never walked -- and cannot overflow)
         const int per = (n_next + NT - 1) / NT;
         const int lo = min(tid * per, n_next), hi = min(lo + per, n_next);
         uint32_t mine = 0;

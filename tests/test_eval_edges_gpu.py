@@ -1,0 +1,102 @@
+"""-m gpu: edge cases of the evaluation traversal's LDS form (search_eval_lds, nann_eval.h; round 6) against
+oracle_search_eval, bit for bit: score ties in bulk (duplicated item rows: TopKV2's tie-break by position decides what is kept,
+what beats the worst kept result and which bin a pair is ranked in), every row equal (the radix search has nothing to split),
+bf16 / f32 rows and wider rows, a shard at the LDS form's limit of 2^20 items and one item beyond it (the slot form), and the
+three placements of a round's lists (ids and scores staged / scores staged / neither) in one run."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import bits, cuda, queries_for, require_gpu, synth_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    require_gpu()
+
+
+def _check(oracle, oix, dix, osc, sc, qs, cfg, want_ok=1):
+    from nann_amd import retrieval
+    r = retrieval.search_eval(dix, sc, cuda(qs), *cfg)
+    torch.cuda.synchronize()
+    st, n_out = r.status.cpu().numpy(), r.n_out.cpu().numpy()
+    ids, scs, idx = r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy()
+    n_ok = 0
+    for b, q in enumerate(qs):
+        rc, eids, esc, eidx = oracle.search_eval(oix, osc, q, *cfg)
+        assert st[b] == rc, (cfg, b, st[b], rc)
+        if rc:
+            assert n_out[b] == 0 and not ids[b].any()
+            continue
+        n = len(eids)
+        assert n_out[b] == n, (cfg, b, n_out[b], n)
+        assert (idx[b, :n] == eidx).all(), (cfg, b, np.nonzero(idx[b, :n] != eidx)[0][:8])
+        assert (ids[b, :n] == eids).all()
+        assert (bits(scs[b, :n]) == bits(esc)).all()
+        assert not ids[b, n:].any() and not scs[b, n:].any()
+        n_ok += 1
+    assert n_ok >= want_ok
+    return r
+
+
+CFGS = [((3, 1, 1), (400, 200, 100), 200), ((3, 2, 1), (1024, 700, 300), 1024), ((3, 1, 1), (2000, 1000, 500), 1500),
+        ((2, 2, 1), (60, 40, 16), 30)]
+
+
+@pytest.mark.parametrize("distinct", [256, 1])
+def test_eval_score_ties_in_bulk(oracle, distinct):
+    """Item rows drawn from `distinct` vectors: groups of ~80 items (or all 20 000) score the same bits for every user."""
+    from nann_amd import ops, retrieval
+    g, _, _ = synth_index(20000, 64, 32)
+    embs = g["item_embs"][np.arange(20000) % distinct].copy()
+    oix = oracle.Index(embs, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    dix = retrieval.Index(cuda(embs), g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    sc, osc = ops.Scorer("l2", 64), oracle.Scorer("l2", 64, oracle.EMB_F16)
+    qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 12, seed=11)])
+    # (every row equal: every new node ties at a round's threshold and joins the next frontier, which holds 2 048 -- the
+    #  library's documented limit, NANN_ERR_CAPACITY beyond it --, so only narrow levels and single rounds stay below it)
+    cfgs = CFGS if distinct > 1 else [((2, 2, 1), (60, 40, 16), 30), ((1, 1, 1), (400, 200, 100), 200), ((1, 1, 1), (2000, 1000, 500), 1500)]
+    for cfg in cfgs:
+        _check(oracle, oix, dix, osc, sc, qs, cfg, want_ok=12)
+
+
+@pytest.mark.parametrize("d,dtype", [(128, "bf16"), (256, "f32"), (256, "f16"), (512, "bf16"), (64, "f32")])
+def test_eval_row_dtypes_and_dims(oracle, d, dtype):
+    from nann_amd import ops, retrieval
+    g, _, _ = synth_index(20000, d, 32)
+    x = g["item_embs"].astype(np.float32)
+    if dtype == "bf16":
+        dev = cuda(x).to(torch.bfloat16)
+        host, code, tdt = dev.view(torch.int16).cpu().numpy().view(np.uint16), oracle.EMB_BF16, torch.bfloat16
+    elif dtype == "f32":
+        host, dev, code, tdt = x, cuda(x), oracle.EMB_F32, torch.float32
+    else:
+        host, dev, code, tdt = g["item_embs"], cuda(g["item_embs"]), oracle.EMB_F16, torch.float16
+    oix = oracle.Index(host, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    dix = retrieval.Index(dev, g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+    sc, osc = ops.Scorer("l2", d, tdt), oracle.Scorer("l2", d, code)
+    qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 8, seed=12)])
+    for cfg in CFGS[:3]:
+        _check(oracle, oix, dix, osc, sc, qs, cfg, want_ok=8)
+
+
+@pytest.mark.parametrize("n_items", [(1 << 20), (1 << 20) + 1])
+def test_eval_at_the_lds_forms_limit(oracle, n_items):
+    """2^20 items: every thread of the workgroup owns 32 words of the bitmaps (the LDS form's limit); one item more: the slot
+    form.  Same results from both, equal to the oracle's."""
+    from nann_amd import index_build, ops, retrieval, synth
+    d = 64
+    embs, assign = synth.make_corpus(n_items, d, n_clusters=256, noise=1.0, seed=77)
+    ids = synth.make_item_ids(n_items, seed=78)
+    g = index_build.build_hnsw_gpu(cuda(embs), num_neighbors=16, ef_construction=32, seed=5)
+    nbv = [np.asarray(g["nb_values"][l]).astype(np.int32) for l in (0, 1)]
+    nbr = [np.asarray(g["nb_row_splits"][l]).astype(np.int64) for l in (0, 1)]
+    ep = np.asarray(g["enter_points"]).astype(np.int32)
+    oix = oracle.Index(embs, ids, nbv, nbr, ep)
+    dix = retrieval.Index(cuda(embs), ids, nbv, nbr, ep)
+    sc, osc = ops.Scorer("l2", d), oracle.Scorer("l2", d, oracle.EMB_F16)
+    qs = np.stack([oracle.user_seq_mean(s) for s in synth.make_queries(embs, assign, 6, seed=13)])
+    for cfg in CFGS[:1] + CFGS[2:3]:
+        _check(oracle, oix, dix, osc, sc, qs, cfg, want_ok=6)
