@@ -696,6 +696,11 @@ def eval_graph_rate(handles, dim, n_enter, n_users=1024):
                "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1),
                "rows_scored_per_user": round(float(S.mean()), 1), "gathered_per_user": round(float(G.mean()), 1),
                "roofline": hbm_roofline(bytes_launch, ms, "k_search_eval")}
+        pmc = load_pmc_traffic("eval_graph_f3_" + name)  # (the committed rocprofv3 passes of tools/eval_bench.py: the same two launches)
+        if pmc is not None:
+            res["roofline"]["traffic"] = pmc["bytes_per_launch"]
+            res["roofline"]["traffic_source"] = pmc["source"]
+            res["roofline"]["counter_traffic_GBs"] = round(pmc["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
         if name == "defaults":
             out.update(res)
         else:

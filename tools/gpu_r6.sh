@@ -58,6 +58,21 @@ except Exception as e:
     print('EVALVAR $V failed', e)
 PY
       done ;;
+    eval_pmc)  # fabric-side bytes of the evaluation traversal (FETCH_SIZE, WRITE_SIZE: one pass each, counters only) -> eval_pmc_$TAG.txt
+      ( cd /tmp; python $R/tools/eval_bench.py /tmp/idx 1024 0 > /dev/null 2>&1
+        for C in FETCH_SIZE WRITE_SIZE; do
+          rm -rf /tmp/prof/pe_$C
+          timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/prof/pe_$C -o pmc -- python $R/tools/eval_bench.py /tmp/idx 1024 0 > /dev/null 2>&1
+          python - <<PY
+import csv, glob
+vals = []
+for f in glob.glob("/tmp/prof/pe_$C/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_search_eval" in r.get("Kernel_Name", ""):
+            vals.append(float(r["Counter_Value"]))
+print("$C", "k_search_eval dispatches", len(vals), "values", [round(v, 1) for v in vals])
+PY
+        done ) | tee $OUT/eval_pmc_$TAG.txt ;;
     mlp_batches)  # configs[2] split-f16 at batch 1024 / 2048 / 4096, fused kernel and pipeline of phases (steady state)
       for B in ${MLP_BATCHES:-1024 2048 4096}; do for M in fused phased; do
         if [ $(left) -lt 60 ]; then echo "SKIP $B $M"; continue; fi
