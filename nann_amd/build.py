@@ -22,8 +22,9 @@ UNITS = [("nann_core.o", [("nann_hip.hip", {}), ("nann_comm.hip", {}), ("nann_hn
          ("nann_attn.o", [("nann_attn_inst.hip", {})]),
          ("nann_attn_split.o", [("nann_attn_split_inst.hip", {})]),
          ("nann_eval.o", [("nann_eval_inst.hip", {})]),
-         ("nann_eval_lds.o", [("nann_eval_lds_inst.hip", {})])]
-DEPS = ["nann_hip.hip", "nann_mlp_inst.hip", "nann_mlp_res_inst.hip", "nann_mlp5.h", "nann_mlp6.h", "nann_l2_inst.hip", "nann_attn_inst.hip", "nann_attn_split_inst.hip", "nann_attn_split.h", "nann_attn_proj.h", "nann_eval_inst.hip", "nann_eval_lds_inst.hip", "nann_eval.h", "nann_comm.hip", "nann_hnsw_build.hip", "nann_device.h", "nann_mlp.h", "nann_mlp2.h", "nann_mlp3.h",
+         ("nann_eval_lds.o", [("nann_eval_lds_inst.hip", {})]),
+         ("nann_eval_win.o", [("nann_eval_win_inst.hip", {})])]
+DEPS = ["nann_hip.hip", "nann_mlp_inst.hip", "nann_mlp_res_inst.hip", "nann_mlp5.h", "nann_mlp6.h", "nann_l2_inst.hip", "nann_attn_inst.hip", "nann_attn_split_inst.hip", "nann_attn_split.h", "nann_attn_proj.h", "nann_eval_inst.hip", "nann_eval_lds_inst.hip", "nann_eval_win_inst.hip", "nann_eval.h", "nann_comm.hip", "nann_hnsw_build.hip", "nann_device.h", "nann_mlp.h", "nann_mlp2.h", "nann_mlp3.h",
         "nann_attn.h", "nann_attn_kernels.h", "nann_search.h", os.path.join("host", "nann_graphdef.h"), os.path.join("host", "nann_graphdef_text.h"), os.path.join("host", "nann_blaze_options.h"), os.path.join("host", "nann_npy.h"), os.path.join("host", "nann_projcache.h"),
         os.path.join("..", "..", "include", "nann_hip.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-fast-math", "-ffp-contract=off"]

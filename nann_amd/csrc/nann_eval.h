@@ -88,17 +88,30 @@ struct EvalSlot {
   int32_t* cand;
 };
 
-// words of `visited` in its transposed layout: 32 words for every dirty word, the dirty words rounded up to a whole number per
-// thread of either workgroup size (512, 1024)
-__host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words) {
-  const uint32_t dw = (bm_words + 31u) >> 5;
-  return ((dw + 1023u) / 1024u) * 1024u * 32u;
+// The LDS form sweeps the id space in WINDOWS of kEvalWinOwners x 32 words of the bitmaps (round 6: shards beyond 2^20 items):
+// thread t of the workgroup owns words [32 t, 32 t + 32) of the window, the window's `seen` bits live in LDS, and a round walks
+// its frontier once per window.  One window (the 1M-item shards of configs[1-4]): every owner of the index in one sweep.
+constexpr uint32_t kEvalWinOwners = 992;  // (992 x 33 words of skewed bitmap + the phase scratch + q: 157 KB of the CU's 160)
+constexpr uint32_t kEvalMaxWindows = 8;   // shards of up to 8.1 M items; beyond: the slot form
+__host__ __device__ inline uint32_t eval_owners(uint32_t bm_words) { return (bm_words + 31u) >> 5; }  // threads' worth of words
+__host__ __device__ inline uint32_t eval_win_owners(uint32_t bm_words) {
+  const uint32_t dw = eval_owners(bm_words);
+  return dw < kEvalWinOwners ? dw : kEvalWinOwners;
 }
-// bytes of the LDS region of `seen`: the bitmap skewed by one word per 32 (search_eval_lds), and at least the staging area of a
-// small round (the kept results + 12 K scores) -- the region is `seen` from a round's gather to its emit and staging behind it
+__host__ __device__ inline uint32_t eval_windows(uint32_t bm_words) {
+  const uint32_t dw = eval_owners(bm_words), ow = eval_win_owners(bm_words);
+  return ow ? (dw + ow - 1u) / ow : 1u;
+}
+// words of `visited` in its transposed layout: per window 32 words for each of the workgroup's 1 024 threads (word j of thread t
+// of window w at (32 w + j) 1024 + t); the slot form's runs (thread t: dirty words [t D, (t + 1) D)) fit the same space
+__host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words) {
+  return eval_windows(bm_words) * 1024u * 32u;
+}
+// bytes of the LDS region of `seen`: a window's bitmap skewed by one word per 32 (search_eval_lds), and at least the staging area
+// of a small round (the kept results + 12 K scores) -- the region is `seen` from a round's gather to its emit and staging behind it
 constexpr int kEvalStageMinWords = 2 * 2048 + 12288;
 __host__ __device__ inline size_t eval_seen_lds_bytes(uint32_t bm_words) {
-  const size_t skewed = (size_t)((bm_words + 31u) >> 5) * 33u;  // (every owner's run of 32 words whole)
+  const size_t skewed = (size_t)eval_win_owners(bm_words) * 33u;  // (every owner's run of 32 words whole)
   return ((skewed > (size_t)kEvalStageMinWords ? skewed : (size_t)kEvalStageMinWords) * 4 + 255) & ~(size_t)255;
 }
 
@@ -143,7 +156,6 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, EvalScanScratch* S,
   return base + inc - v;
 }
 
-constexpr int kEvalOwned = 32;  // words of a bitmap one thread owns when `seen` is in LDS (eval_plan: bm_words <= threads x this)
 
 __device__ __forceinline__ uint32_t ld_word(const uint32_t* p) {  // past the L1: the word is changed by atomics performed in L2
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -883,8 +895,401 @@ __device__ __forceinline__ int search_eval_lds(const EvalArgs& a, int qi, const 
   return NANN_OK;
 }
 
-// LDS: [seen bitmap (SEEN_LDS) | scratch | q | misc]
-template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
+// ---- the LDS form sweeping the id space in WINDOWS (shards of ~1 M to ~8 M items; round 6).  The one-window function above with
+// the walk -> marks -> owners' pass -> scan -> emit of a round once per window of kEvalWinOwners x 32 bitmap words: the window's
+// `seen` bits in LDS, its words of `visited` in the slot, the frontier's bounds (LDS) fetched once and its rows walked once per
+// window (L2 hits), the new ids to the slot window after window -- ascending across windows as inside one.  A function of its
+// own: as a flag of the one-window function the sweep's loop cost that kernel 15 registers, 60 B of spills and 3 %.
+template <int LPR, int DT, int NT>
+__device__ __forceinline__ int search_eval_win(const EvalArgs& a, int qi, const EvalSlot& sv, uint32_t* seen,
+                                               unsigned char* scratch, float* qv, int* n_result, bool clear_seen) {
+  const int tid = local_tid(), lane = tid & 63, wave = tid >> 6;
+  int ctr_f = 0, ctr_s = 0;  // (uniform)
+  int ctr_g = 0;             // this lane's share: row lengths it fetched (lanes 0-7 of every wavefront)
+  constexpr int NW = NT / 64;
+  constexpr int NF = kEvalMaxK / NT;  // kept results per thread
+  static_assert(kEvalMaxK % NT == 0 && NF >= 1, "a thread carries kEvalMaxK / NT scores of the kept results");
+  // phase scratch: [scan scratch 256 | frontier: kEvalMaxK ids | ...] (top-k's scratch overlays all of it: the frontier is
+  // written behind it)
+  EvalScanScratch* SS = reinterpret_cast<EvalScanScratch*>(scratch);
+  int32_t* cand = reinterpret_cast<int32_t*>(scratch + 256);
+  // the frontier's row bounds for the walk: start (48 bits) | length (16 bits; eval_plan: the LDS form takes indices whose rows
+  // are shorter than 2^16)
+  unsigned long long* bnd = reinterpret_cast<unsigned long long*>(scratch + 256 + kEvalMaxK * 4);
+  static_assert(256 + kEvalMaxK * 12 <= kPhaseScratch, "phase scratch too small for the frontier and its row bounds");
+  // staging area (the region of `seen`): [kept ids: kEvalMaxK | kept scores: kEvalMaxK | scores of result || new: CAP]
+  int32_t* st_res_ids = reinterpret_cast<int32_t*>(seen);
+  float* st_res_sc = reinterpret_cast<float*>(seen + kEvalMaxK);
+  float* st_cat_sc = reinterpret_cast<float*>(seen + 2 * kEvalMaxK);
+  const int CAP = (int)a.lds_words - 2 * kEvalMaxK;  // scores only: result || new up to here
+  const int CAP2 = CAP / 2;                          // scores and ids: [scores: CAP2 | ids: CAP2]
+  int32_t* st_cat_ids = reinterpret_cast<int32_t*>(seen + 2 * kEvalMaxK + CAP2);
+  // the ascending list of new ids is written while `seen` is still being read: into the phase scratch (the frontier is dead
+  // by then), and moved to the staging area behind the barrier
+  int32_t* emit_lds = cand;
+  constexpr int kEmitCap = (kPhaseScratch - 256) / 4;
+  EVAL_TICK_DECL;
+  for (int k = tid; k < a.d; k += NT) qv[k] = a.q[(size_t)qi * a.d + k];
+  // Thread t owns words [32 t, 32 t + 32) of both bitmaps' current window (t < OW <= NT), so thread order is word order.  `seen` is
+  // SKEWED by one word per 32 (word w at w + w / 32 = 33 t + j): the owners read their j-th words together, lanes 33 words apart
+  // -- conflict-free; without the skew, two LDS banks for the whole wavefront.  `visited` (the slot, only ever touched by its
+  // owners) is TRANSPOSED: word j of thread t at j NT + t, so that a wavefront's loads of "my j-th word" are 256 contiguous
+  // bytes.  An owner reads ALL 32 of its words of `seen`, eight at a time in flight (a word's read behind the test of a
+  // second-level "touched" bit was one LDS round trip per word, 32 in a row; and the bit cost the walk a second atomic per word).
+  const uint32_t DW = (a.bm_words + 31u) >> 5;   // owners' worth of bitmap words in the whole index
+  const uint32_t OW = eval_win_owners(a.bm_words);  // ... in a window (kEvalWinOwners, or all of them)
+  constexpr bool MULTI = true;
+  const int W = (int)eval_windows(a.bm_words);  // windows of a round
+  const uint32_t own = (uint32_t)tid * 33u;
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(sv.visited, 0, (int)(a.vis_words * 4u), 0x00020000);
+  if (clear_seen) {  // the slot's first user, or the one behind a user that failed with the region in use: every other user leaves it zero
+    for (uint32_t w = (uint32_t)tid; w < a.lds_words; w += NT) seen[w] = 0u;
+  }
+  if (tid < 2) SS->flags[tid] = 0;
+  __syncthreads();
+
+  // the kept results leave the staging area: ids and scores to the front of the slot's concat arrays (fire and forget: the next
+  // reader is a full barrier away), the ids to the frontier when the results ARE the next frontier (level start, :308); then the
+  // extents of the region that the round used are zeroed -- `seen` again
+  auto publish = [&](int k, int n_staged, int n_staged_ids, bool to_cand) {
+    for (int i = tid; i < k; i += NT) {
+      const int32_t id = st_res_ids[i];
+      sv.cat_ids[i] = id;
+      sv.cat_sc[i] = st_res_sc[i];
+      if (to_cand) { cand[i] = id; sv.res_ids[i] = id; }  // (the next level's frontier and its marks, below)
+    }
+    lds_barrier();
+    for (int i = tid; i < k; i += NT) { seen[i] = 0u; seen[kEvalMaxK + i] = 0u; }
+    for (int i = tid; i < n_staged; i += NT) seen[2 * kEvalMaxK + i] = 0u;
+    for (int i = tid; i < n_staged_ids; i += NT) seen[2 * kEvalMaxK + CAP2 + i] = 0u;
+    if (tid < 2) SS->flags[tid] = 0;
+    lds_barrier();
+  };
+
+  // start level: score every enter point, keep min(k, n) (:349-353)
+  const int E = a.n_enter;
+  if (E <= 0) return NANN_ERR_EMPTY_SCORE_BATCH;
+  const bool near = (unsigned long long)a.n_items * (unsigned)(a.d * 2) <= 0xffffffffull && a.n_items <= (1u << 24);
+  wg_score_l2_part<LPR, DT, NW>(a.emb, a.d, a.enter, 0, E, qv, sv.cat_sc, wave, near);
+  __syncthreads();
+  ctr_s += E;
+  EVAL_TICK(0);
+  int n_res = min(a.top_k[2], E);
+  int st = wg_topk_binned<NT, kEvalMaxK>(a.enter, sv.cat_sc, E, n_res, st_res_ids, st_res_sc, scratch);
+  if (st) return st;
+  EVAL_TICK(1);
+  publish(n_res, 0, 0, true);
+  bool cand_is_result = true;  // (uniform) the frontier array holds the kept ids
+
+  for (int level = 1; level >= 0; --level) {  // search_level (:299-337)
+    if (!cand_is_result) {  // (a level that ended on an empty round, or ran no round: its result, cut, from the slot)
+      __syncthreads();
+      for (int i = tid; i < n_res; i += NT) {
+        const int32_t id = sv.cat_ids[i];
+        cand[i] = id;
+        sv.res_ids[i] = id;
+      }
+      __syncthreads();
+    }
+    // visited = idx_ep (:311), candidates = result.  The level's marks -- its starting result, <= top_k ids -- are NOT put into
+    // `visited`: they stay a list (the slot's result array; a thread reads back the entries it wrote) and are taken out of
+    // `seen` behind every walk, one atomic each.  So a level starts without a pass over the bitmaps, and its first round needs
+    // no word of `visited`: it WRITES all of them (visited = new), which is also the level's visited = {}.
+    const int n_marks = n_res;
+    EVAL_TICK(2);
+    int n_cand = n_res;
+    const int32_t* __restrict__ values = a.nbv[level];
+    const int64_t* __restrict__ rs = a.nbrs[level];
+    for (int it = 0; it < a.num_scoring[level]; ++it) {
+      // ---- neighbours of the candidates -> bits of `seen`.  Every thread fetches the bounds of its rows of the frontier (one
+      // trip for all of them) into LDS; then wavefront w walks rows [8 (w + NW t), + 8) for t = 0, 1, ..., four trips at a time:
+      // 32 rows per wavefront in flight together.  The level's marks ride along, for the removal behind the walk.
+      ctr_f += n_cand;
+      const bool first = it == 0;
+      int32_t mk[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) mk[j] = sv.res_ids[min(tid + j * NT, n_marks - 1)];
+      {
+        long long s[NF], e[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = tid + j * NT;
+          s[j] = 0; e[j] = 0;
+          if (r < n_cand) {
+            const int32_t c = cand[r];
+            s[j] = rs[c]; e[j] = rs[c + 1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int r = tid + j * NT;
+          if (r < n_cand) {
+            bnd[r] = (unsigned long long)s[j] | ((unsigned long long)(e[j] - s[j]) << 48);
+            ctr_g += (int)(e[j] - s[j]);
+          }
+        }
+      }
+      lds_barrier();
+      int32_t fi[NF];
+      float fs[NF];
+      int n_next = 0, mode = 0;
+      // one sweep of the id space per window: walk, take the marks out, the owners' pass, the scan, the emit
+      for (int w = 0; w < W; ++w) {
+        const uint32_t w_lo = (uint32_t)w * OW * 32u;            // first bitmap word of the window
+        const uint32_t w_n = min(OW, DW - (uint32_t)w * OW) * 32u;  // its words
+        const bool owner = (uint32_t)tid * 32u < w_n;
+        auto seen_or = [&](uint32_t id) {
+          const uint32_t lw = (id >> 5) - w_lo;  // (one window: every id is inside)
+          if (!MULTI || lw < w_n) atomicOr(&seen[lw + (lw >> 5)], 1u << (id & 31));
+        };
+        for (int rep = 0; rep <= NANN_REPEAT_GATHER; ++rep) {
+          int bad = 0;
+          for (int t0 = 0; t0 * NW * 8 < n_cand; t0 += 4) {
+            long long s4[4];
+            int len4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int r = (t0 + t) * NW * 8 + wave * 8 + lane;
+              unsigned long long b = 0ull;
+              if (lane < 8 && r < n_cand) b = bnd[r];
+              s4[t] = (long long)(b & 0xffffffffffffull); len4[t] = (int)(b >> 48);
+            }
+            int32_t v[4][8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const long long sr = readlane64(s4[t], r);
+                const int len = __builtin_amdgcn_readlane(len4[t], r);
+                v[t][r] = lane < len ? values[sr + lane] : 0;
+              }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const int len = __builtin_amdgcn_readlane(len4[t], r);
+                if (lane < len) {
+                  if ((uint32_t)v[t][r] < a.n_items) seen_or((uint32_t)v[t][r]); else bad = 1;
+                }
+                if (len > 64) {  // (rows of more than 64 neighbours)
+                  const long long sr = readlane64(s4[t], r);
+                  for (int j = 64 + lane; j < len; j += 64) {
+                    const int32_t x = values[sr + j];
+                    if ((uint32_t)x < a.n_items) seen_or((uint32_t)x); else bad = 1;
+                  }
+                }
+              }
+          }
+          if (bad) SS->flags[1] = 1;
+        }
+        lds_barrier();  // (the walk loads; what is still on its way to the slot -- the last round's results, an owner's words
+                        //  of `visited` -- is read back by the thread that stored it)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)  // seen \= marks
+          if (tid + j * NT < n_marks) {
+            const uint32_t id = (uint32_t)mk[j];
+            const uint32_t lw = (id >> 5) - w_lo;
+            if (id >= a.n_items) SS->flags[1] = 1;
+            else if (!MULTI || lw < w_n) atomicAnd(&seen[lw + (lw >> 5)], ~(1u << (id & 31)));
+          }
+        lds_barrier();
+        if (SS->flags[1]) return NANN_ERR_INDEX_OUT_OF_RANGE;
+        EVAL_TICK(3);
+        // ---- new = seen & ~visited, in ascending id order (:316-319); visited |= new (:321), seen = 0
+        // ALL 32 of the thread's words of the window's `visited` in ONE batch (touched words only, 4 / 8 / 16 at a time, were
+        // 5 / 4 / 2 dependent trips; the level's first round has none to fetch) -- and with them this thread's ids and scores of
+        // the kept results (the front of the concat arrays), which go to the staging area behind the emit.  Buffer loads: one
+        // VGPR of offset for all of them, the word's stride in an SGPR.
+        uint32_t cnt = 0, nd = 0;  // new bits of this thread's words; which of its words have any
+        const int vbase = w * 32 * NT * 4;  // the window's words of `visited` (bytes)
+        auto owners = [&](auto first_c) {
+          constexpr bool FIRST = decltype(first_c)::value;
+          uint32_t vis[32];
+          if constexpr (!FIRST) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) vis[j] = __builtin_amdgcn_raw_buffer_load_b32(vrs, tid * 4, vbase + j * NT * 4, 0);
+          }
+          if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+              fi[j] = sv.cat_ids[min(tid + j * NT, n_res - 1)];
+              fs[j] = sv.cat_sc[min(tid + j * NT, n_res - 1)];
+            }
+          }
+          if (owner) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              uint32_t sw[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) sw[i] = seen[own + 8 * b + i];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int j = 8 * b + i;
+                if constexpr (FIRST) {  // visited = new: every word written
+                  __builtin_amdgcn_raw_buffer_store_b32(sw[i], vrs, tid * 4, vbase + j * NT * 4, 0);
+                  if (sw[i]) { nd |= 1u << j; cnt += (uint32_t)__popc(sw[i]); }
+                } else {
+                  const uint32_t nw = sw[i] & ~vis[j];
+                  if (sw[i] != nw) seen[own + j] = nw;  // the NEW bits stay, for the emit behind the scan
+                  if (nw) {
+                    __builtin_amdgcn_raw_buffer_store_b32(vis[j] | nw, vrs, tid * 4, vbase + j * NT * 4, 0);
+                    nd |= 1u << j;
+                    cnt += (uint32_t)__popc(nw);
+                  }
+                }
+              }
+            }
+          }
+        };
+        if (first) owners(std::true_type{}); else owners(std::false_type{});
+        EVAL_TICK(8);
+        uint32_t total;
+        uint32_t at = wg_excl_scan<NT, true>(cnt, SS, &total);  // thread order = word order = ascending ids
+        ctr_s += (int)total;
+        if (n_res + n_next + (int)total > a.cat_cap) return NANN_ERR_CAPACITY;
+        EVAL_TICK(9);
+        auto emit = [&](int32_t* dst) {  // this thread's words with new bits, four reads in flight; seen = 0 behind them
+          uint32_t m = nd;
+          while (m) {
+            uint32_t j[4], x[4];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (m) { j[u] = (uint32_t)(__ffs(m) - 1); m &= m - 1; n = u + 1; } else j[u] = j[0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = seen[own + j[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (u < n) {
+                seen[own + j[u]] = 0u;
+                const uint32_t wd = w_lo + (uint32_t)tid * 32u + j[u];
+                uint32_t y = x[u];
+                while (y) {
+                  dst[at++] = (int32_t)(wd * 32u + (uint32_t)(__ffs(y) - 1));
+                  y &= y - 1;
+                }
+              }
+          }
+        };
+        if constexpr (MULTI) {  // several windows: the ids to the slot, window after window (the region is `seen` again for the next one)
+          if (cnt) emit(sv.cat_ids + n_res + n_next);
+          n_next += (int)total;
+          lds_barrier();
+          continue;
+        }
+        n_next = (int)total;
+        if (n_next == 0) break;
+        // where the round's ids and scores live: 2 = both in the staging area, 1 = the scores, 0 = neither (the slot, as the slot form)
+        mode = (n_next <= kEmitCap && n_res + n_next <= CAP2) ? 2 : n_res + n_next <= CAP ? 1 : 0;
+        if (mode == 2) {
+          if (cnt) emit(emit_lds);
+          lds_barrier();  // `seen` is zero: the region is the staging area from here
+          for (int i = tid; i < n_next; i += NT) st_cat_ids[n_res + i] = emit_lds[i];
+#pragma unroll
+          for (int j = 0; j < NF; ++j)
+            if (tid + j * NT < n_res) { st_cat_ids[tid + j * NT] = fi[j]; st_cat_sc[tid + j * NT] = fs[j]; }
+          lds_barrier();
+        } else {
+          if (cnt) emit(sv.cat_ids + n_res);
+        }
+      }
+      if (n_next == 0) {  // plain TF ops score an empty batch as an empty tensor: the result is cut to min(k, n), no candidate is left
+        __syncthreads();  // (`seen` is zero again: the owners wrote their words' new bits, none)
+        n_res = min(a.top_k[level], n_res);
+        n_cand = 0;
+        cand_is_result = false;
+        continue;
+      }
+      const int n_cat = n_res + n_next;
+      if constexpr (MULTI) mode = n_cat <= CAP ? 1 : 0;
+      if (mode != 2) {
+        __syncthreads();  // the new ids are in the slot, `seen` is zero: the region is the staging area from here
+        if (mode == 1) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j)
+            if (tid + j * NT < n_res) st_cat_sc[tid + j * NT] = fs[j];
+        }
+      }
+      EVAL_TICK(4);
+      const int k = min(a.top_k[level], n_cat);
+      const bool last = it + 1 == a.num_scoring[level];  // the level's last round: its frontier is never walked
+      auto rest = [&](auto mode_c) -> int {
+        constexpr int MODE = decltype(mode_c)::value;
+        const int32_t* cat_ids;
+        float* cat_sc;
+        if constexpr (MODE == 2) cat_ids = st_cat_ids; else cat_ids = sv.cat_ids;
+        if constexpr (MODE >= 1) cat_sc = st_cat_sc; else cat_sc = sv.cat_sc;
+        for (int rep = 0; rep <= NANN_REPEAT_SCORE; ++rep) {  // :323
+          wg_score_l2_part<LPR, DT, NW>(a.emb, a.d, cat_ids + n_res, 0, n_next, qv, cat_sc + n_res, wave, near);
+          __syncthreads();
+        }
+        EVAL_TICK(5);
+        int rc = 0;
+        // (the kept results are sorted and, once there are k of them, only candidates that beat the worst one can enter)
+        const bool full = n_res >= k;
+        const uint32_t floor_key = full ? score_key(cat_sc[n_res - 1]) : 0u;
+        for (int rep = 0; rep <= NANN_REPEAT_TOPK; ++rep) {  // :326-328
+          rc = wg_topk_binned<NT, kEvalMaxK>(cat_ids, cat_sc, n_cat, k, st_res_ids, st_res_sc, scratch, full ? n_res : 0x7fffffff, floor_key);
+          if (rc) return rc;
+        }
+        EVAL_TICK(6);
+        if (!last) {
+          // next frontier: new nodes scoring at least the worst kept result, in id order (:330-331): every thread takes a
+          // CONTIGUOUS run of the new nodes, one workgroup scan places them
+          const float worst = st_res_sc[k - 1];
+          const int per = (n_next + NT - 1) / NT;
+          const int lo = min(tid * per, n_next), hi = min(lo + per, n_next);
+          uint32_t mine = 0;
+          for (int i0 = lo; i0 < hi; i0 += 8) {  // (eight scores in flight: they may be in the slot)
+            float sc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sc[u] = cat_sc[n_res + min(i0 + u, hi - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine += (i0 + u < hi && sc[u] >= worst) ? 1u : 0u;
+          }
+          uint32_t n_new;
+          uint32_t pos = wg_excl_scan<NT, true>(mine, SS, &n_new);
+          if (n_new > (uint32_t)kEvalMaxK) return NANN_ERR_CAPACITY;  // more ties at the threshold than a frontier holds
+          if (mine) {
+            for (int i0 = lo; i0 < hi; i0 += 8) {  // the POSITIONS of the frontier's rows first ...
+              float sc[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) sc[u] = cat_sc[n_res + min(i0 + u, hi - 1)];
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (i0 + u < hi && sc[u] >= worst) cand[pos++] = i0 + u;
+            }
+          }
+          lds_barrier();
+          for (int p = tid; p < (int)n_new; p += NT) cand[p] = cat_ids[n_res + cand[p]];  // ... then their ids, one trip for all
+          n_cand = (int)n_new;
+          __syncthreads();  // (the copy below overwrites cat_ids[n_res ..] that the selection above reads)
+        } else {
+          n_cand = k;
+        }
+        publish(k, MODE >= 1 ? n_cat : 0, MODE == 2 ? n_cat : 0, last);
+        return 0;
+      };
+      st = mode == 2 ? rest(std::integral_constant<int, 2>{}) : mode == 1 ? rest(std::integral_constant<int, 1>{}) : rest(std::integral_constant<int, 0>{});
+      if (st) return st;
+      n_res = k;
+      cand_is_result = last;
+      EVAL_TICK(7);
+    }
+  }
+  EVAL_TICK_FLUSH;
+  *n_result = n_res;
+  if (a.counters) {  // (the kernel zeroed the user's three words before the call)
+    if (tid == 0) { atomicAdd(&a.counters[(size_t)qi * 3 + 0], ctr_f); atomicAdd(&a.counters[(size_t)qi * 3 + 2], ctr_s); }
+    if (ctr_g) atomicAdd(&a.counters[(size_t)qi * 3 + 1], ctr_g);
+  }
+  return NANN_OK;
+}
+
+// LDS: [seen bitmap (SEEN_LDS) | scratch | q | misc].  SEEN_LDS: 0 = the slot form, 1 = the LDS form, one window (shards of up to
+// ~1 M items), 2 = the LDS form sweeping the id space in windows
+template <int LPR, int DT, int SC, int NT, int SEEN_LDS>
 __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kScratchBytes = eval_scratch_bytes<SC, NT>();
@@ -920,7 +1325,8 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
     // and the one behind a failure clear it whole.  (Without the dirty words the owners clear as they scan: same invariant.)
     if constexpr (SEEN_LDS) {
       static_assert(SC == NANN_SCORER_L2, "the LDS form is the L2 scorer's");
-      st = search_eval_lds<LPR, DT, NT>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res, clear_seen);
+      if constexpr (SEEN_LDS == 2) st = search_eval_win<LPR, DT, NT>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res, clear_seen);
+      else st = search_eval_lds<LPR, DT, NT>(a, qi, sv, reinterpret_cast<uint32_t*>(smem), scratch, qv, &n_res, clear_seen);
     } else {
       st = search_eval_slot<LPR, DT, SC, NT>(a, qi, sv, sv.seen, scratch, qv, &n_res, clear_seen);
     }
@@ -947,7 +1353,7 @@ __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
 template <int SC, int NT>
 constexpr size_t eval_lds_base() { return (size_t)eval_scratch_bytes<SC, NT>() + kMaxD * 4 + 256; }
 
-template <int LPR, int DT, int SC, int NT, bool SEEN_LDS>
+template <int LPR, int DT, int SC, int NT, int SEEN_LDS>
 inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
   auto kern = k_search_eval<LPR, DT, SC, NT, SEEN_LDS>;
   const size_t lds_bytes = eval_lds_base<SC, NT>() + (SEEN_LDS ? eval_seen_lds_bytes(a.bm_words) : 0);
@@ -964,7 +1370,8 @@ inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
 size_t eval_l2_lds_base();
 size_t eval_dirty_room();  // bytes of the phase scratch the second-level bitmap may take (the smallest instance's)
 int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st);
-int launch_eval_l2_lds(int lpr, int dt, int slots, const EvalArgs& a, hipStream_t st);  // nann_eval_lds_inst.hip
+int launch_eval_l2_lds(int lpr, int dt, int slots, const EvalArgs& a, hipStream_t st);  // nann_eval_lds_inst.hip (one window)
+int launch_eval_l2_win(int lpr, int dt, int slots, const EvalArgs& a, hipStream_t st);  // nann_eval_win_inst.hip (several)
 int launch_eval_attn(int d, int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d64(int dt, int slots, const EvalArgs& a, hipStream_t st);
 int launch_eval_mlp_d128(int dt, int slots, const EvalArgs& a, hipStream_t st);

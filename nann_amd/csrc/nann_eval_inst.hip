@@ -10,9 +10,9 @@ namespace nann {
 
 template <int LPR>
 static int eval_l2_slot(int dt, int slots, const EvalArgs& a, hipStream_t st) {
-  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_L2, kNT, false>(slots, a, st);
-  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_L2, kNT, false>(slots, a, st);
-  return launch_eval_as<LPR, DT_F32, NANN_SCORER_L2, kNT, false>(slots, a, st);
+  if (dt == NANN_F16) return launch_eval_as<LPR, DT_F16, NANN_SCORER_L2, kNT, 0>(slots, a, st);
+  if (dt == NANN_BF16) return launch_eval_as<LPR, DT_BF16, NANN_SCORER_L2, kNT, 0>(slots, a, st);
+  return launch_eval_as<LPR, DT_F32, NANN_SCORER_L2, kNT, 0>(slots, a, st);
 }
 
 size_t eval_l2_lds_base() { return eval_lds_base<NANN_SCORER_L2, kNT>(); }
@@ -20,10 +20,10 @@ size_t eval_l2_lds_base() { return eval_lds_base<NANN_SCORER_L2, kNT>(); }
 size_t eval_dirty_room() { return (sizeof(TopkScratchT<kEvalMaxK>) + 255) & ~(size_t)255; }
 
 int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st) {
-  if (seen_lds) return launch_eval_l2_lds(lpr, dt, slots, a, st);
+  if (seen_lds) return eval_windows(a.bm_words) > 1 ? launch_eval_l2_win(lpr, dt, slots, a, st) : launch_eval_l2_lds(lpr, dt, slots, a, st);
 #if NANN_EVAL_DEV
   if (lpr != 16 || dt != NANN_F16) return fail(NANN_ERR_UNSUPPORTED, "NANN_EVAL_DEV build: 128-d f16 only");
-  return launch_eval_as<16, DT_F16, NANN_SCORER_L2, kNT, false>(slots, a, st);
+  return launch_eval_as<16, DT_F16, NANN_SCORER_L2, kNT, 0>(slots, a, st);
 #else
   switch (lpr) {
     case 8: return eval_l2_slot<8>(dt, slots, a, st);
@@ -38,10 +38,10 @@ int launch_eval_attn(int d, int dt, int slots, const EvalArgs& a, hipStream_t st
 #if NANN_EVAL_DEV
   return fail(NANN_ERR_UNSUPPORTED, "NANN_EVAL_DEV build: no attention instances");
 #else
-  if (d == 64 && dt == NANN_F16) return launch_eval_as<8, DT_F16, kScorerAttn, kAttnNT, false>(slots, a, st);
-  if (d == 64 && dt == NANN_BF16) return launch_eval_as<8, DT_BF16, kScorerAttn, kAttnNT, false>(slots, a, st);
-  if (d == 128 && dt == NANN_F16) return launch_eval_as<16, DT_F16, kScorerAttn, kAttnNT, false>(slots, a, st);
-  if (d == 128 && dt == NANN_BF16) return launch_eval_as<16, DT_BF16, kScorerAttn, kAttnNT, false>(slots, a, st);
+  if (d == 64 && dt == NANN_F16) return launch_eval_as<8, DT_F16, kScorerAttn, kAttnNT, 0>(slots, a, st);
+  if (d == 64 && dt == NANN_BF16) return launch_eval_as<8, DT_BF16, kScorerAttn, kAttnNT, 0>(slots, a, st);
+  if (d == 128 && dt == NANN_F16) return launch_eval_as<16, DT_F16, kScorerAttn, kAttnNT, 0>(slots, a, st);
+  if (d == 128 && dt == NANN_BF16) return launch_eval_as<16, DT_BF16, kScorerAttn, kAttnNT, 0>(slots, a, st);
   return fail(NANN_ERR_UNSUPPORTED, "attention scorer: d in {64, 128}, rows f16 or bf16");
 #endif
 }

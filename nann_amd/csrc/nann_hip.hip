@@ -2616,9 +2616,9 @@ static int eval_plan(const nann_index* ix, int64_t n_queries, bool l2, int* cat_
   *slot_bytes = eval_slot_layout(ix->bm_words, *cat_cap, off);
   const size_t lds = eval_l2_lds_base() + eval_seen_lds_bytes(ix->bm_words);
   static const bool force_hbm = [] { const char* e = std::getenv("NANN_EVAL_SEEN"); return e && std::string(e) == "hbm"; }();
-  // (a thread of the LDS form owns at most kEvalOwned words of the bitmaps and keeps its words of `visited` in registers
-  //  for a round's two scans: 16 wavefronts x 64 lanes x 32 words = 2^20 items)
-  *seen_lds = l2 && lds <= di.lds_max && !force_hbm && ix->bm_words <= (uint32_t)(kNT * kEvalOwned) && deg < 65536;  // (a row's length rides in 16 bits of its packed bounds)
+  // (a thread of the LDS form owns 32 words of the bitmaps' current window; a round sweeps the id space window by window:
+  //  nann_eval.h, kEvalWinOwners / kEvalMaxWindows)
+  *seen_lds = l2 && lds <= di.lds_max && !force_hbm && eval_windows(ix->bm_words) <= kEvalMaxWindows && deg < 65536;  // (a row's length rides in 16 bits of its packed bounds)
   // workgroups per CU: two (2048 threads) unless the LDS bitmap leaves room for one
   const int per_cu = (*seen_lds && 2 * lds > di.lds_max) ? 1 : 2;
   *slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));

@@ -1,7 +1,7 @@
 """-m gpu: edge cases of the evaluation traversal's LDS form (search_eval_lds, nann_eval.h; round 6) against
 oracle_search_eval, bit for bit: score ties in bulk (duplicated item rows: TopKV2's tie-break by position decides what is kept,
 what beats the worst kept result and which bin a pair is ranked in), every row equal (the radix search has nothing to split),
-bf16 / f32 rows and wider rows, a shard at the LDS form's limit of 2^20 items and one item beyond it (the slot form), and the
+bf16 / f32 rows and wider rows, a shard of 2^20 items and one item more (the LDS form sweeping the id space in two windows), and the
 three placements of a round's lists (ids and scores staged / scores staged / neither) in one run."""
 import numpy as np
 import pytest
@@ -84,8 +84,8 @@ def test_eval_row_dtypes_and_dims(oracle, d, dtype):
 
 @pytest.mark.parametrize("n_items", [(1 << 20), (1 << 20) + 1])
 def test_eval_at_the_lds_forms_limit(oracle, n_items):
-    """2^20 items: every thread of the workgroup owns 32 words of the bitmaps (the LDS form's limit); one item more: the slot
-    form.  Same results from both, equal to the oracle's."""
+    """2^20 items and one more: beyond one window of 992 x 32 bitmap words, so a round sweeps the id space in two windows
+    (search_eval_win), the second one a few words wide.  Equal to the oracle's results."""
     from nann_amd import index_build, ops, retrieval, synth
     d = 64
     embs, assign = synth.make_corpus(n_items, d, n_clusters=256, noise=1.0, seed=77)

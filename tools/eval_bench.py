@@ -22,18 +22,24 @@ def main():
     cache = sys.argv[1] if len(sys.argv) > 1 else None
     users = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     n_check = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    # [items dim dtype ef]: another shard shape, e.g. `4000000 256 bf16 256` = configs[4]'s shard (the LDS form in windows)
+    items = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000
+    dim = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+    dtype = sys.argv[6] if len(sys.argv) > 6 else "f16"
+    ef = int(sys.argv[7]) if len(sys.argv) > 7 else 128
     dev = torch.device("cuda")
-    g = bench.make_index(1_000_000, 128, 128, "hnsw", 1.0, "f16", 0, dev, bench.usable_cores(), cache_dir=cache)
+    g = bench.make_index(items, dim, ef, "hnsw", 1.0, dtype, 0, dev, bench.usable_cores(), cache_dir=cache)
     index = retrieval.Index.from_dict(g, device=dev)
-    scorer = ops.Scorer("l2", 128, torch.float16)
-    seqs = bench.make_query_batches(128, users, 1, 1.0, dev, n_clusters=bench.n_clusters_for(1_000_000, 128))[0]
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype]
+    scorer = ops.Scorer("l2", dim, tdt)
+    seqs = bench.make_query_batches(dim, users, 1, 1.0, dev, n_clusters=bench.n_clusters_for(items, ef))[0]
     q = ops.user_seq_mean(seqs)
     torch.cuda.synchronize()
     from oracle import oracle as O
     oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
-    osc = O.Scorer("l2", 128, O.EMB_F16)
+    osc = O.Scorer("l2", dim, {"f16": O.EMB_F16, "bf16": O.EMB_BF16, "f32": O.EMB_F32}[dtype])
     qh = q.cpu().numpy()
-    out = {"workload": "1M x 128-d f16 index (configs[1]), L2 scorer, %d users per launch" % users,
+    out = {"workload": "%d x %d-d %s index, L2 scorer, %d users per launch" % (items, dim, dtype, users),
            "seen": os.environ.get("NANN_EVAL_SEEN", "lds")}
     for name, cfg in (("defaults_400_200_100", ((3, 1, 1), (400, 200, 100), 200)),
                       ("wide_2000_1000_500", ((3, 1, 1), (2000, 1000, 500), 1000))):
