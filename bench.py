@@ -667,7 +667,7 @@ def batch_sweep(handles, topn, sizes, dim, n_enter):
     return sweep
 
 
-def eval_graph_rate(handles, dim, n_enter, n_users=1024):
+def eval_graph_rate(handles, dim, n_enter, n_users=1024, pmc_prefix="eval_graph_f3_"):
     """f3: users/s of the evaluation graph's traversal in one kernel (nann_search_eval): the reference's defaults
     (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned) and a wide setting above the serving kernels' 1024.
     roofline: SURVEY.md 8(d)'s byte formula over the kernel's OWN counters (nann_search_eval_ex: rows walked F, neighbours
@@ -696,7 +696,7 @@ def eval_graph_rate(handles, dim, n_enter, n_users=1024):
                "failed": int((r.status != 0).sum()), "mean_rows": round(float(r.n_out.float().mean()), 1),
                "rows_scored_per_user": round(float(S.mean()), 1), "gathered_per_user": round(float(G.mean()), 1),
                "roofline": hbm_roofline(bytes_launch, ms, "k_search_eval")}
-        pmc = load_pmc_traffic("eval_graph_f3_" + name)  # (the committed rocprofv3 passes of tools/eval_bench.py: the same two launches)
+        pmc = load_pmc_traffic(pmc_prefix + name) if pmc_prefix else None  # (the committed rocprofv3 passes of tools/eval_bench.py: the same two launches)
         if pmc is not None:
             res["roofline"]["traffic"] = pmc["bytes_per_launch"]
             res["roofline"]["traffic_source"] = pmc["source"]
@@ -951,6 +951,12 @@ def main():
             stress = run_workload(f"{args.stress_items}x256bf16_ef256", args, dev, rank, world, cfg,
                                   want_cpu=not args.no_cpu_baseline, want_parity=True, want_recall=False)
             sec["hbm_stress_config5_shape"] = strip(stress)
+            try:  # f3 on the same shard: the LDS form sweeping the id space in windows (round 6; this shard: 4 of them)
+                ev = eval_graph_rate(stress["_handles"], 256, stress["n_enter"], pmc_prefix=None)
+                ev["kernel"] = "k_search_eval, LDS form in windows (search_eval_win, nann_eval.h): shards beyond ~1 M items; parity: tests/test_eval_edges_gpu.py, tools/eval_bench.py"
+                sec["eval_graph_f3_config5_shape"] = ev
+            except Exception as e:
+                sec["eval_graph_f3_config5_shape"] = {"error": repr(e)}
             try:  # the same rows and beam under the MLP scorer: wide beams take the bitmap plan + pre-projected scorer
                 cfg = dict(cfg, scorer="mlp", mlp_precision="split", batch=1024, steps=20, warmup=40,
                            parity_queries=32, _index=stress["_index"])
