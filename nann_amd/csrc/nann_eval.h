@@ -63,6 +63,8 @@ struct EvalArgs {
   int cat_cap;         // entries of the result||next arrays
   uint32_t vis_words;  // words of a slot's `visited` region (the transposed layout rounds the owners' runs up)
   uint32_t lds_words;  // LDS form: words of the region that holds `seen` and, from a round's emit to its end, the staged scores / results
+  uint32_t win_owners; // LDS form: owners (threads' worth of 32 bitmap words) of a window; n_windows of them cover the index
+  int n_windows;
   unsigned long long* ticks;  // measurement builds (NANN_EVAL_TICKS): 16 accumulators, else unused
   int use_dirty;       // slot form: the second-level bitmap fits the phase scratch (eval_plan); the LDS form always has it
   int64_t* out_ids;    // [n_queries, topk_eval]
@@ -94,31 +96,34 @@ struct EvalSlot {
 constexpr uint32_t kEvalWinOwners = 992;  // (992 x 33 words of skewed bitmap + the phase scratch + q: 157 KB of the CU's 160)
 constexpr uint32_t kEvalMaxWindows = 8;   // shards of up to 8.1 M items; beyond: the slot form
 __host__ __device__ inline uint32_t eval_owners(uint32_t bm_words) { return (bm_words + 31u) >> 5; }  // threads' worth of words
-__host__ __device__ inline uint32_t eval_win_owners(uint32_t bm_words) {
+__host__ __device__ inline uint32_t eval_win_owners(uint32_t bm_words, uint32_t owners_max = kEvalWinOwners) {
   const uint32_t dw = eval_owners(bm_words);
-  return dw < kEvalWinOwners ? dw : kEvalWinOwners;
+  return dw < owners_max ? dw : owners_max;
 }
-__host__ __device__ inline uint32_t eval_windows(uint32_t bm_words) {
-  const uint32_t dw = eval_owners(bm_words), ow = eval_win_owners(bm_words);
+__host__ __device__ inline uint32_t eval_windows(uint32_t bm_words, uint32_t owners_max = kEvalWinOwners) {
+  const uint32_t dw = eval_owners(bm_words), ow = eval_win_owners(bm_words, owners_max);
   return ow ? (dw + ow - 1u) / ow : 1u;
 }
-// words of `visited` in its transposed layout: per window 32 words for each of the workgroup's 1 024 threads (word j of thread t
-// of window w at (32 w + j) 1024 + t); the slot form's runs (thread t: dirty words [t D, (t + 1) D)) fit the same space
-__host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words) {
-  return eval_windows(bm_words) * 1024u * 32u;
+// words of `visited` in its transposed layout: per window 32 words for each of the workgroup's (at most) 1 024 threads (word j of
+// thread t of window w at (32 w + j) NT + t); the slot form's runs (thread t: dirty words [t D, (t + 1) D)) fit the same space
+__host__ __device__ inline uint32_t eval_vis_words(uint32_t bm_words, uint32_t owners_max = kEvalWinOwners) {
+  return eval_windows(bm_words, owners_max) * 1024u * 32u;
 }
 // bytes of the LDS region of `seen`: a window's bitmap skewed by one word per 32 (search_eval_lds), and at least the staging area
 // of a small round (the kept results + 12 K scores) -- the region is `seen` from a round's gather to its emit and staging behind it
 constexpr int kEvalStageMinWords = 2 * 2048 + 12288;
-__host__ __device__ inline size_t eval_seen_lds_bytes(uint32_t bm_words) {
-  const size_t skewed = (size_t)eval_win_owners(bm_words) * 33u;  // (every owner's run of 32 words whole)
-  return ((skewed > (size_t)kEvalStageMinWords ? skewed : (size_t)kEvalStageMinWords) * 4 + 255) & ~(size_t)255;
+__host__ __device__ inline size_t eval_seen_lds_bytes(uint32_t bm_words, uint32_t owners_max = kEvalWinOwners,
+                                                      size_t stage_min_words = kEvalStageMinWords) {
+  const size_t skewed = (size_t)eval_win_owners(bm_words, owners_max) * 33u;  // (every owner's run of 32 words whole)
+  return ((skewed > stage_min_words ? skewed : stage_min_words) * 4 + 255) & ~(size_t)255;
 }
+// (owners_max / stage_min_words: tools/rejected/nann_eval_pair_variant.patch -- two 512-thread workgroups per CU with windows of 352
+//  owners measured 10-12 % slower than one 1 024-thread workgroup, profiles/r6j_eval_pair_variant_ab.jsonl)
 
-__host__ __device__ inline unsigned long long eval_slot_layout(uint32_t bm_words, int cat_cap, unsigned long long off[7]) {
+__host__ __device__ inline unsigned long long eval_slot_layout(uint32_t bm_words, uint32_t vis_words, int cat_cap, unsigned long long off[7]) {
   unsigned long long o = 0;
   auto put = [&](int i, unsigned long long bytes) { off[i] = o; o += (bytes + 255ull) & ~255ull; };
-  put(0, 4ull * eval_vis_words(bm_words));
+  put(0, 4ull * vis_words);
   put(1, 4ull * bm_words);
   put(2, 4ull * cat_cap);
   put(3, 4ull * cat_cap);
@@ -937,9 +942,9 @@ __device__ __forceinline__ int search_eval_win(const EvalArgs& a, int qi, const 
   // bytes.  An owner reads ALL 32 of its words of `seen`, eight at a time in flight (a word's read behind the test of a
   // second-level "touched" bit was one LDS round trip per word, 32 in a row; and the bit cost the walk a second atomic per word).
   const uint32_t DW = (a.bm_words + 31u) >> 5;   // owners' worth of bitmap words in the whole index
-  const uint32_t OW = eval_win_owners(a.bm_words);  // ... in a window (kEvalWinOwners, or all of them)
+  const uint32_t OW = a.win_owners;  // ... in a window (kEvalWinOwners, or all of them)
   constexpr bool MULTI = true;
-  const int W = (int)eval_windows(a.bm_words);  // windows of a round
+  const int W = a.n_windows;  // windows of a round
   const uint32_t own = (uint32_t)tid * 33u;
   const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(sv.visited, 0, (int)(a.vis_words * 4u), 0x00020000);
   if (clear_seen) {  // the slot's first user, or the one behind a user that failed with the region in use: every other user leaves it zero
@@ -1293,13 +1298,13 @@ template <int LPR, int DT, int SC, int NT, int SEEN_LDS>
 __global__ __launch_bounds__(NT) void k_search_eval(EvalArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kScratchBytes = eval_scratch_bytes<SC, NT>();
-  const size_t bm_bytes = SEEN_LDS ? eval_seen_lds_bytes(a.bm_words) : 0;
+  const size_t bm_bytes = SEEN_LDS ? (((size_t)a.lds_words * 4 + 255) & ~(size_t)255) : 0;
   unsigned char* scratch = smem + bm_bytes;
   float* qv = reinterpret_cast<float*>(scratch + kScratchBytes);
   int* misc = reinterpret_cast<int*>(qv + kMaxD);
 
   unsigned long long off[7];
-  eval_slot_layout(a.bm_words, a.cat_cap, off);
+  eval_slot_layout(a.bm_words, a.vis_words, a.cat_cap, off);
   unsigned char* slot = a.ws + 256 + (unsigned long long)blockIdx.x * a.slot_bytes;
   EvalSlot sv;
   sv.visited = reinterpret_cast<uint32_t*>(slot + off[0]);
@@ -1356,7 +1361,7 @@ constexpr size_t eval_lds_base() { return (size_t)eval_scratch_bytes<SC, NT>() +
 template <int LPR, int DT, int SC, int NT, int SEEN_LDS>
 inline int launch_eval_as(int slots, const EvalArgs& a, hipStream_t st) {
   auto kern = k_search_eval<LPR, DT, SC, NT, SEEN_LDS>;
-  const size_t lds_bytes = eval_lds_base<SC, NT>() + (SEEN_LDS ? eval_seen_lds_bytes(a.bm_words) : 0);
+  const size_t lds_bytes = eval_lds_base<SC, NT>() + (SEEN_LDS ? (((size_t)a.lds_words * 4 + 255) & ~(size_t)255) : 0);
   if (lds_bytes > 48 * 1024)
     NANN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

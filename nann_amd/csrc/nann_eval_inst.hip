@@ -20,7 +20,7 @@ size_t eval_l2_lds_base() { return eval_lds_base<NANN_SCORER_L2, kNT>(); }
 size_t eval_dirty_room() { return (sizeof(TopkScratchT<kEvalMaxK>) + 255) & ~(size_t)255; }
 
 int launch_eval_l2(int lpr, int dt, int seen_lds, int slots, const EvalArgs& a, hipStream_t st) {
-  if (seen_lds) return eval_windows(a.bm_words) > 1 ? launch_eval_l2_win(lpr, dt, slots, a, st) : launch_eval_l2_lds(lpr, dt, slots, a, st);
+  if (seen_lds) return a.n_windows > 1 ? launch_eval_l2_win(lpr, dt, slots, a, st) : launch_eval_l2_lds(lpr, dt, slots, a, st);
 #if NANN_EVAL_DEV
   if (lpr != 16 || dt != NANN_F16) return fail(NANN_ERR_UNSUPPORTED, "NANN_EVAL_DEV build: 128-d f16 only");
   return launch_eval_as<16, DT_F16, NANN_SCORER_L2, kNT, 0>(slots, a, st);

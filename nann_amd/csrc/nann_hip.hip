@@ -2601,9 +2601,15 @@ int nann_model_table_bytes(const nann_model* m, const nann_index* ix, int64_t* t
 // ---- the evaluation graph's traversal (nann_eval.h) ----------------------------------------
 }  // extern "C"
 
-// l2: the L2 scorer's instances may keep `seen` in LDS (nann_eval.h) -- when the index's bitmap fits beside their scratch
-static int eval_plan(const nann_index* ix, int64_t n_queries, bool l2, int* cat_cap, unsigned long long* slot_bytes, int* slots,
-                     int* seen_lds) {
+// l2: the L2 scorer's instances may keep `seen` in LDS (nann_eval.h) -- a window of the index's bitmap beside their scratch.
+// seen_lds: 0 = the slot form, 1 = the LDS form, 2 = the LDS form with more than one window.  l2 == false also sizes the
+// workspace: the most slots any plan of this index takes.
+struct EvalPlan {
+  int cat_cap = 0, slots = 0, seen_lds = 0, n_windows = 1;
+  unsigned long long slot_bytes = 0;
+  uint32_t vis_words = 0, lds_words = 0, win_owners = 0;
+};
+static int eval_plan(const nann_index* ix, int64_t n_queries, bool l2, EvalPlan* p) {
   DeviceInfo di;
   const int rc = device_info(&di);
   if (rc) return rc;
@@ -2611,17 +2617,22 @@ static int eval_plan(const nann_index* ix, int64_t n_queries, bool l2, int* cat_
   const int64_t deg = std::max<int64_t>(std::max(ix->max_deg[0], ix->max_deg[1]), 1);
   const int64_t nxt = std::max<int64_t>(std::min<int64_t>(ix->desc.n_items, (int64_t)kEvalMaxK * deg), ix->desc.n_enter);
   if (kEvalMaxK + nxt > 0x3fffffffll) return fail(NANN_ERR_UNSUPPORTED, "candidate bound too large");
-  *cat_cap = (int)(kEvalMaxK + nxt);
-  unsigned long long off[7];
-  *slot_bytes = eval_slot_layout(ix->bm_words, *cat_cap, off);
+  p->cat_cap = (int)(kEvalMaxK + nxt);
   const size_t lds = eval_l2_lds_base() + eval_seen_lds_bytes(ix->bm_words);
   static const bool force_hbm = [] { const char* e = std::getenv("NANN_EVAL_SEEN"); return e && std::string(e) == "hbm"; }();
   // (a thread of the LDS form owns 32 words of the bitmaps' current window; a round sweeps the id space window by window:
   //  nann_eval.h, kEvalWinOwners / kEvalMaxWindows)
-  *seen_lds = l2 && lds <= di.lds_max && !force_hbm && eval_windows(ix->bm_words) <= kEvalMaxWindows && deg < 65536;  // (a row's length rides in 16 bits of its packed bounds)
-  // workgroups per CU: two (2048 threads) unless the LDS bitmap leaves room for one
-  const int per_cu = (*seen_lds && 2 * lds > di.lds_max) ? 1 : 2;
-  *slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
+  const bool lds_ok = lds <= di.lds_max && !force_hbm && eval_windows(ix->bm_words) <= kEvalMaxWindows && deg < 65536;  // (a row's length rides in 16 bits of its packed bounds)
+  p->win_owners = eval_win_owners(ix->bm_words);
+  p->n_windows = (int)eval_windows(ix->bm_words);
+  p->seen_lds = (l2 && lds_ok) ? (p->n_windows > 1 ? 2 : 1) : 0;
+  p->lds_words = (uint32_t)(eval_seen_lds_bytes(ix->bm_words) / 4);
+  p->vis_words = eval_vis_words(ix->bm_words);
+  unsigned long long off[7];
+  p->slot_bytes = eval_slot_layout(ix->bm_words, p->vis_words, p->cat_cap, off);
+  // workgroups per CU: two (the slot form: 2048 threads) unless the LDS bitmap leaves room for one
+  const int per_cu = p->seen_lds ? 1 : 2;
+  p->slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_queries, (int64_t)di.cus * per_cu));
   return NANN_OK;
 }
 
@@ -2637,10 +2648,14 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
       return fail(NANN_ERR_UNSUPPORTED, "top_k_per_level entries must be in [1, 2048]");
   if (topk_eval < 1 || topk_eval > kEvalMaxK) return fail(NANN_ERR_UNSUPPORTED, "topk_eval must be in [1, 2048]");
   EvalArgs a;
-  int slots = 0, seen_lds = 0;
   const bool l2 = !attn && scorer->desc.kind != NANN_SCORER_MLP;
-  int rc = eval_plan(ix, n_queries, l2, &a.cat_cap, &a.slot_bytes, &slots, &seen_lds);
+  EvalPlan pl, sizing;
+  int rc = eval_plan(ix, n_queries, l2, &pl);
+  if (!rc) rc = eval_plan(ix, n_queries, false, &sizing);  // (the workspace the caller sized: nann_search_eval_workspace_bytes)
   if (rc) return rc;
+  const int slots = pl.slots, seen_lds = pl.seen_lds;
+  a.cat_cap = pl.cat_cap;
+  a.slot_bytes = sizing.slot_bytes;  // every plan lays its slots out at the sizing stride (its own arrays sit at the front)
   if (!workspace || workspace_bytes < (int64_t)(256 + a.slot_bytes * (unsigned long long)slots))
     return fail(NANN_ERR_CAPACITY, "workspace smaller than nann_search_eval_workspace_bytes()");
   a.emb = ix->desc.item_embs;
@@ -2659,8 +2674,10 @@ static int eval_impl(const nann_index* ix, const nann_scorer* scorer, const nann
   // the second-level bitmap (nann_eval.h, round 6): one bit per word of `seen`, overlaid on the phase scratch behind the scan
   // scratch -- it fits shards of up to ~7 M items; beyond, the slot form keeps round 4's full scans
   a.use_dirty = 256 + (size_t)((ix->bm_words + 31u) >> 5) * 4 <= eval_dirty_room() ? 1 : 0;
-  a.vis_words = eval_vis_words(ix->bm_words);
-  a.lds_words = (uint32_t)(eval_seen_lds_bytes(ix->bm_words) / 4);
+  a.vis_words = pl.vis_words;
+  a.lds_words = pl.lds_words;
+  a.win_owners = pl.win_owners;
+  a.n_windows = pl.n_windows;
   a.out_ids = out_item_ids; a.out_scores = out_scores; a.out_index = out_index; a.n_out = n_out; a.status = status;
   a.counters = counters;
   a.mlp = MlpParams{};
@@ -2702,11 +2719,10 @@ extern "C" {
 
 int nann_search_eval_workspace_bytes(const nann_index* ix, const nann_model* m, int64_t n_queries, int64_t* nbytes) {
   if (!ix || !nbytes) return fail(NANN_ERR_BAD_ARGUMENT, "nann_search_eval_workspace_bytes: null argument");
-  int cat_cap = 0, slots = 0, seen_lds = 0;
-  unsigned long long slot_bytes = 0;
-  const int rc = eval_plan(ix, n_queries, false, &cat_cap, &slot_bytes, &slots, &seen_lds);  // (the most slots any scorer's plan takes)
+  EvalPlan sizing;
+  const int rc = eval_plan(ix, n_queries, false, &sizing);  // (the most slots, the widest `visited` any scorer's plan takes)
   if (rc) return rc;
-  *nbytes = (int64_t)(256 + slot_bytes * (unsigned long long)slots + 256 + (m ? model_query_bytes(m, n_queries) : 0));
+  *nbytes = (int64_t)(256 + sizing.slot_bytes * (unsigned long long)sizing.slots + 256 + (m ? model_query_bytes(m, n_queries) : 0));
   return NANN_OK;
 }
 
