@@ -11,6 +11,8 @@ million-item corpora take the most memory and time of the suite.
   configs[4]  one shard shape beyond the LDS bitmap: 1.2M x 256-d bf16, ef=256 -- L2 (planner: 32K-slot
               hash set), the bitmap request that the planner must turn into the HBM bitmap, and the MLP
               traversal (planner: HBM bitmap)
+  f3          the evaluation traversal at configs[1]'s shape (LDS form, one window) and at the 1.2M x 256-d bf16 shard shape
+              (LDS form in two windows): oracle-exact on a sample + properties on 1 024 users
 """
 import os
 import sys
@@ -340,3 +342,31 @@ def test_config4_full_shard_4m_256d_bf16_ef256_mlp(oracle):
     _properties(r, g, topn, len(g["enter_points"]))
     _assert_equals_oracle(r, exp, sel)
     del _IDX[(4_000_000, 256, 256, "bf16", 0)]  # 4 GB of host + device arrays: not kept for the session
+
+
+@pytest.mark.parametrize("items,dim,ef,dtype", [(1_000_000, 128, 128, "f16"), (1_200_000, 256, 256, "bf16")])
+def test_eval_graph_at_baseline_shapes(oracle, items, dim, ef, dtype):
+    """f3 at configs[1]'s shape (the LDS form, one window) and at the 1.2M x 256-d bf16 shard shape (the LDS form sweeping the id
+    space in two windows): a sample of users bit-identical to oracle_search_eval, and over 1 024 users the properties a
+    correct run has at any size -- every user answered, rows sorted by score with distinct item ids, results independent of
+    the batch they ran in."""
+    from nann_amd import ops, retrieval
+    g, oix, dix = _index(items, dim, ef, dtype)
+    tdt, code = (torch.float16, oracle.EMB_F16) if dtype == "f16" else (torch.bfloat16, oracle.EMB_BF16)
+    sc, osc = ops.Scorer("l2", dim, tdt), oracle.Scorer("l2", dim, code)
+    q = _queries(dim, 1024, seed=99, items=items, ef=ef)
+    cfg = ((3, 1, 1), (400, 200, 100), 200)
+    r = retrieval.search_eval(dix, sc, q, *cfg)
+    torch.cuda.synchronize()
+    st, n_out = r.status.cpu().numpy(), r.n_out.cpu().numpy()
+    ids, scs, idx = r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy()
+    assert (st == 0).all() and (n_out == 200).all()
+    assert (np.diff(scs, axis=1) <= 0).all()
+    assert all(len(set(row.tolist())) == 200 for row in ids[::16])
+    qh = q.cpu().numpy()
+    for b in range(0, 1024, 128):
+        rc, eids, esc, eidx = oracle.search_eval(oix, osc, qh[b], *cfg)
+        assert rc == 0 and (idx[b] == eidx).all() and (ids[b] == eids).all() and (bits(scs[b]) == bits(esc)).all()
+    r2 = retrieval.search_eval(dix, sc, q[512:576], *cfg)
+    torch.cuda.synchronize()
+    assert (r2.index.cpu().numpy() == idx[512:576]).all() and (bits(r2.scores.cpu().numpy()) == bits(scs[512:576])).all()
