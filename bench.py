@@ -952,7 +952,7 @@ def main():
                                   want_cpu=not args.no_cpu_baseline, want_parity=True, want_recall=False)
             sec["hbm_stress_config5_shape"] = strip(stress)
             try:  # f3 on the same shard: the LDS form sweeping the id space in windows (round 6; this shard: 4 of them)
-                ev = eval_graph_rate(stress["_handles"], 256, stress["n_enter"], pmc_prefix=None)
+                ev = eval_graph_rate(stress["_handles"], 256, stress["n_enter"], pmc_prefix=f"eval_graph_f3_{args.stress_items}x256bf16_")
                 ev["kernel"] = "k_search_eval, LDS form in windows (search_eval_win, nann_eval.h): shards beyond ~1 M items; parity: tests/test_eval_edges_gpu.py, tools/eval_bench.py"
                 sec["eval_graph_f3_config5_shape"] = ev
             except Exception as e:

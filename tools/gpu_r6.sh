@@ -59,10 +59,11 @@ except Exception as e:
 PY
       done ;;
     eval_pmc)  # fabric-side bytes of the evaluation traversal (FETCH_SIZE, WRITE_SIZE: one pass each, counters only) -> eval_pmc_$TAG.txt
-      ( cd /tmp; python $R/tools/eval_bench.py /tmp/idx 1024 0 > /dev/null 2>&1
+      # EVAL_SHAPE="4000000 256 bf16 256": another shard shape (tools/eval_bench.py's trailing arguments)
+      ( cd /tmp; python $R/tools/eval_bench.py /tmp/idx 1024 0 ${EVAL_SHAPE:-} > /dev/null 2>&1
         for C in FETCH_SIZE WRITE_SIZE; do
           rm -rf /tmp/prof/pe_$C
-          timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/prof/pe_$C -o pmc -- python $R/tools/eval_bench.py /tmp/idx 1024 0 > /dev/null 2>&1
+          timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/prof/pe_$C -o pmc -- python $R/tools/eval_bench.py /tmp/idx 1024 0 ${EVAL_SHAPE:-} > /dev/null 2>&1
           python - <<PY
 import csv, glob
 vals = []
