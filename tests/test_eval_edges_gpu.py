@@ -100,3 +100,38 @@ def test_eval_at_the_lds_forms_limit(oracle, n_items):
     qs = np.stack([oracle.user_seq_mean(s) for s in synth.make_queries(embs, assign, 6, seed=13)])
     for cfg in CFGS[:1] + CFGS[2:3]:
         _check(oracle, oix, dix, osc, sc, qs, cfg, want_ok=6)
+
+
+def test_eval_random_shapes(oracle):
+    """Forty random settings of Model.retrieval -- rounds per level 0..4, top_k_per_level 1..2048, topk_eval 1..2048 -- on graphs of
+    300, 6 000 and 60 000 items: small frontiers that run dry, levels without a round, k above what a level can hold, lists that
+    cross the three placements of a round's ids and scores.  Every user equal to the oracle (status included)."""
+    from nann_amd import ops
+    rng = np.random.default_rng(20261001)
+    sc, osc = ops.Scorer("l2", 64), oracle.Scorer("l2", 64, oracle.EMB_F16)
+    shapes = [(300, 8), (6000, 32), (60000, 32)]
+    n_ok = 0
+    for trial in range(40):
+        n, ef = shapes[trial % 3]
+        g, oix, dix = synth_index(n, 64, ef)
+        qs = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, 4, seed=100 + trial)])
+        kmax = 2048 if trial % 4 else 64
+        top_k = tuple(int(x) for x in rng.integers(1, kmax + 1, size=3))
+        cfg = ((int(rng.integers(0, 5)), int(rng.integers(0, 4)), 1), top_k, int(rng.integers(1, kmax + 1)))
+        from nann_amd import retrieval
+        r = retrieval.search_eval(dix, sc, cuda(qs), *cfg)
+        torch.cuda.synchronize()
+        st, n_out = r.status.cpu().numpy(), r.n_out.cpu().numpy()
+        ids, scs, idx = r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy()
+        for b, q in enumerate(qs):
+            rc, eids, esc, eidx = oracle.search_eval(oix, osc, q, *cfg)
+            if st[b] == 103 and rc == 0:
+                continue  # NANN_ERR_CAPACITY: more than 2 048 new nodes tie at a threshold (the library's documented limit)
+            assert st[b] == rc, (cfg, n, b, st[b], rc)
+            if rc:
+                continue
+            k = len(eids)
+            assert n_out[b] == k, (cfg, n, b, n_out[b], k)
+            assert (idx[b, :k] == eidx).all() and (ids[b, :k] == eids).all() and (bits(scs[b, :k]) == bits(esc)).all(), (cfg, n, b)
+            n_ok += 1
+    assert n_ok >= 120
