@@ -6,23 +6,18 @@
 //     (tf.unique + tf.sets.difference, :316-319);
 //   * top_k keeps min(k, n) (:268) and an exhausted frontier is not an error (plain TF scoring);
 //   * the next frontier = the new nodes scoring at least the worst kept result (:330-331).
-// Ascending sets want a bitmap, not a list.  Round 4's form (round 2-3: both bitmaps in HBM behind device-scope atomics
-// and fences, 5 ms per user):
-//   * `seen` takes one bit per neighbour of the frontier, visited or not -- atomics only, in LDS when the index's bitmap
-//     fits beside the phase scratch (1 M items: 125 KB), else in the slot (performed in L2);
-//   * a word-order scan of `seen` against `visited` IS the ascending, duplicate-free list of new nodes -- no sort; every
-//     bitmap word has ONE owner thread (wavefront w, trip j, lane l -> word w C + 64 j + l), which alone reads and writes
-//     that word of `visited` (plain loads / stores to the slot: no atomic, no fence) and clears its word of `seen`;
-//   * the rows of a frontier are walked eight per wavefront and trip, their bounds and first 64 neighbours in flight
-//     together.
-// Round 6: with `seen` in LDS the two full scans of the bitmap per round (count, then emit: 2 x 31 trips of
-// every wavefront, each emit trip with a wavefront scan -- 64 % of the kernel by the phase-repeat builds) are gone.  A second-level
-// bitmap `dirty` (one LDS word per thread, overlaid on the phase scratch between a round's gather and its emit) records which
-// words of `seen` a round touched: the lane whose atomic OR finds a word still zero sets the word's bit.  Thread t owns words
-// [32 t, 32 t + 32) of both bitmaps, so its dirty word lists ITS touched words in ascending order and thread order is word order:
-// one pass reads `visited` for the touched words only (four loads in flight), turns seen[w] into the NEW bits and updates
-// visited; ONE workgroup scan of the per-thread counts gives every thread its place in the ascending output; a second pass over
-// the same few words writes the ids and clears `seen`.  Same sets in the same order: bit-identical to the oracle as before.
+// Ascending sets want a bitmap, not a list: `seen` takes one bit per neighbour of the frontier, visited or not (atomics only), and a
+// word-order scan of `seen` against `visited` IS the ascending, duplicate-free list of new nodes -- no sort; every bitmap word has
+// ONE owner thread, which alone reads and writes that word of `visited` (plain loads / stores to the slot: no atomic, no fence)
+// and clears its word of `seen`.  Three forms of that (history and measurements: DESIGN.md 4.4):
+//   * search_eval_lds  -- L2 scorer, shards of up to ~1 M items (round 4; rebuilt in round 6): `seen` in LDS, thread t owning
+//     words [32 t, 32 t + 32) of both bitmaps; `seen` is all zero outside gather -> emit, so its LDS is the round's staging area for
+//     ids, scores and top-k's output; the frontier and its row bounds in the phase scratch; a level's marks a list; LDS-only
+//     barriers behind fire-and-forget copies to the slot; top-k ranked bin by bin over the candidates that can still enter;
+//   * search_eval_win  -- the same sweeping the id space in windows of 992 x 32 bitmap words: shards of up to ~8 M items;
+//   * search_eval_slot -- `seen` in the slot (atomics performed in L2), a second-level bitmap of touched words in LDS: the MLP and
+//     attention scorers (whose weights own the LDS) and larger shards.
+// All three produce the same sets in the same orders with the same arithmetic: bit-identical to oracle_search_eval.
 // top_k_per_level / topk_eval up to kEvalMaxK = 2048 (the reference's are defaults, config.py:50-58).
 #pragma once
 #ifndef NANN_REPEAT_SCORE
