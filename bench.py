@@ -667,7 +667,7 @@ def batch_sweep(handles, topn, sizes, dim, n_enter):
     return sweep
 
 
-def eval_graph_rate(handles, dim, n_enter, n_users=1024, pmc_prefix="eval_graph_f3_"):
+def eval_graph_rate(handles, dim, n_enter, n_users=1024, pmc_prefix="eval_graph_f3_", g=None, dtype="f16", n_check=4):
     """f3: users/s of the evaluation graph's traversal in one kernel (nann_search_eval): the reference's defaults
     (config.py:50-58: 3/1/1 rounds, top 400/200/100, 200 returned) and a wide setting above the serving kernels' 1024.
     roofline: SURVEY.md 8(d)'s byte formula over the kernel's OWN counters (nann_search_eval_ex: rows walked F, neighbours
@@ -701,6 +701,19 @@ def eval_graph_rate(handles, dim, n_enter, n_users=1024, pmc_prefix="eval_graph_
             res["roofline"]["traffic"] = pmc["bytes_per_launch"]
             res["roofline"]["traffic_source"] = pmc["source"]
             res["roofline"]["counter_traffic_GBs"] = round(pmc["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+        if g is not None and n_check > 0:  # checker leg, outside the timed region: a few users against oracle_search_eval, bit for bit
+            from oracle import oracle as O
+            oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
+            osc = O.Scorer("l2", dim, {"f16": O.EMB_F16, "bf16": O.EMB_BF16, "f32": O.EMB_F32}[dtype])
+            qh, st, n_out = q.cpu().numpy(), r.status.cpu().numpy(), r.n_out.cpu().numpy()
+            ids, scs, idx = r.item_ids.cpu().numpy(), r.scores.cpu().numpy(), r.index.cpu().numpy()
+            same = 0
+            for b in range(0, n_users, max(1, n_users // n_check))[:n_check]:
+                rc, eids, esc, eidx = O.search_eval(oix, osc, qh[b], *cfg)
+                k = len(eids) if rc == 0 else 0
+                same += bool(st[b] == rc and n_out[b] == k and (idx[b, :k] == eidx[:k]).all() and (ids[b, :k] == eids[:k]).all()
+                             and (scs[b, :k].view(np.uint32) == np.asarray(esc[:k], np.float32).view(np.uint32)).all())
+            res["parity"] = {"users_checked": n_check, "bit_identical_to_oracle_search_eval": same}
         if name == "defaults":
             out.update(res)
         else:
@@ -905,7 +918,7 @@ def main():
         except Exception as e:  # a failing extra must not take the headline line with it
             sec["batch_sweep"] = {"error": repr(e)}
         try:
-            sec["eval_graph_f3"] = eval_graph_rate(prim["_handles"], args.dim, prim["n_enter"])
+            sec["eval_graph_f3"] = eval_graph_rate(prim["_handles"], args.dim, prim["n_enter"], g=prim["_index"], dtype=args.dtype)
         except Exception as e:
             sec["eval_graph_f3"] = {"error": repr(e)}
         for prec in ("split", "exact"):
@@ -952,7 +965,8 @@ def main():
                                   want_cpu=not args.no_cpu_baseline, want_parity=True, want_recall=False)
             sec["hbm_stress_config5_shape"] = strip(stress)
             try:  # f3 on the same shard: the LDS form sweeping the id space in windows (round 6; this shard: 4 of them)
-                ev = eval_graph_rate(stress["_handles"], 256, stress["n_enter"], pmc_prefix=f"eval_graph_f3_{args.stress_items}x256bf16_")
+                ev = eval_graph_rate(stress["_handles"], 256, stress["n_enter"], pmc_prefix=f"eval_graph_f3_{args.stress_items}x256bf16_",
+                                     g=stress["_index"], dtype="bf16", n_check=2)
                 ev["kernel"] = "k_search_eval, LDS form in windows (search_eval_win, nann_eval.h): shards beyond ~1 M items; parity: tests/test_eval_edges_gpu.py, tools/eval_bench.py"
                 sec["eval_graph_f3_config5_shape"] = ev
             except Exception as e:
