@@ -10,12 +10,13 @@ LIB = os.path.join(OUT_DIR, "libnann_hip.so")
 # translation units: (object name, [(source, {macro: value} defined around its #include), ...]) -- compiled in parallel, then
 # linked.  A unit of several sources is compiled through a generated wrapper (_build/<obj>.d/unit.hip) that includes them
 # one after the other.  Round 5: 13 units -> 9: the three small host-facing files share one object, the
-# bf16 and f32 L2 instances another, the resident-layer-2 MLP kernels ride with the d = 64 MLP instances; the longest unit
-# (nann_eval: ~140 s) still bounds the wall time of a full build, ~160 s on 8 cores.
+# resident-layer-2 MLP kernels ride with the d = 64 MLP instances.  Round 6: 12 units -- the evaluation traversal's LDS forms are
+# units of their own, and the bf16 and f32 L2 instances are two again (their shared unit had become the longest: it alone bounded
+# a build from scratch at ~6 min on 8 cores).
 UNITS = [("nann_core.o", [("nann_hip.hip", {}), ("nann_comm.hip", {}), ("nann_hnsw_build.hip", {})]),
          ("nann_l2_f16.o", [("nann_l2_inst.hip", {"NANN_L2_DT": "0", "NANN_L2_NAME": "f16"})]),
-         ("nann_l2_bf16_f32.o", [("nann_l2_inst.hip", {"NANN_L2_DT": "1", "NANN_L2_NAME": "bf16"}),
-                                 ("nann_l2_inst.hip", {"NANN_L2_DT": "2", "NANN_L2_NAME": "f32"})]),
+         ("nann_l2_bf16.o", [("nann_l2_inst.hip", {"NANN_L2_DT": "1", "NANN_L2_NAME": "bf16"})]),
+         ("nann_l2_f32.o", [("nann_l2_inst.hip", {"NANN_L2_DT": "2", "NANN_L2_NAME": "f32"})]),
          ("nann_mlp_d64_res.o", [("nann_mlp_inst.hip", {"NANN_MLP_D": "64"}), ("nann_mlp_res_inst.hip", {})]),
          ("nann_mlp_d128.o", [("nann_mlp_inst.hip", {"NANN_MLP_D": "128"})]),
          ("nann_mlp_d256.o", [("nann_mlp_inst.hip", {"NANN_MLP_D": "256"})]),
