@@ -701,6 +701,10 @@ def eval_graph_rate(handles, dim, n_enter, n_users=1024, pmc_prefix="eval_graph_
             res["roofline"]["traffic"] = pmc["bytes_per_launch"]
             res["roofline"]["traffic_source"] = pmc["source"]
             res["roofline"]["counter_traffic_GBs"] = round(pmc["bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+        res["roofline"]["achievable_hbm_GBs"] = HBM_ACHIEVABLE_GBS
+        res["roofline"]["binds"] = ("one 1 024-thread workgroup per CU (the bitmap window owns the LDS): scoring at what a lone workgroup draws with 32 registers of "
+                                    "rows in flight (~46 GB/s per CU), the other phases -- walk, owners' pass, scan / emit, top-k -- chains of dependent "
+                                    "trips and barriers with nothing to overlap them (DESIGN.md 4.4)")
         if g is not None and n_check > 0:  # checker leg, outside the timed region: a few users against oracle_search_eval, bit for bit
             from oracle import oracle as O
             oix = O.Index(g["item_embs"], g["item_ids"], g["nb_values"], g["nb_row_splits"], g["enter_points"])
