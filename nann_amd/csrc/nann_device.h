@@ -1277,8 +1277,8 @@ struct TopkScratchT {
     // that a pair is ranked against its own bin only (step 4).  Dead before the all-pairs ranking (its fallback) starts.
     struct { uint32_t above[256]; uint32_t cursor[256]; } bins;
   };
-  uint32_t misc[4];               // [0] nsel, [1] keys that take part (BIN), [2] unordered append cursor, [3] a bin overflowed (BIN)
-  uint32_t orv, andv;
+  uint32_t misc[4];               // [0] nsel, [2] unordered append cursor, [3] a bin overflowed (BIN)
+  uint32_t wlo[kNW], whi[kNW];    // per-wavefront min / max key (step 2a)
   uint32_t wcnt[kNW];
 };
 static_assert(kNT * sizeof(unsigned short) == 512 * sizeof(uint32_t), "the bin tables overlay the partial ranks");
@@ -1318,18 +1318,6 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
 #pragma unroll
     for (int j = 0; j < NS; ++j) key[j] = (j * NT + tid < n) ? score_key(raw[j]) : 0u;
   }
-  uint32_t* hist = reinterpret_cast<uint32_t*>(S->sel);  // [4][256]; sel is not in use before step 3
-  for (int i = tid; i < 4 * 256; i += NT) hist[i] = 0;
-  constexpr bool BINNED = BIN;  // (the serving kernels keep the all-pairs ranking: their k is 200)
-  const uint32_t bin_max = (uint32_t)max(64, k >> 1);  // a fuller bin (half the keys crowded into one leading digit): the all-pairs ranking instead
-  if constexpr (BINNED) {
-    for (int i = tid; i < 256; i += NT) S->bins.cursor[i] = 0;
-  }
-  if (tid < 4) S->misc[tid] = 0;
-  if (tid == 0) { S->orv = 0u; S->andv = 0xffffffffu; }
-  __syncthreads();
-  pt.sub(PH_TK_LOAD, tsub);
-
 #define NANN_FOR_KEYS(...)                                                    \
   if constexpr (REG) {                                                        \
     _Pragma("unroll") for (int j = 0; j < NS; ++j) {                          \
@@ -1349,25 +1337,39 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
 
   // ---- 2a. range of the keys: the search runs on key - min(key), whose leading digit is spread
   //          over the bins (the raw keys of scores within a few binades share all but 2-3 values of
-  //          their top 8 undecided bits, and same-bin LDS atomics serialise)
+  //          their top 8 undecided bits, and same-bin LDS atomics serialise).  Round 6: per-wavefront
+  //          results, reduced by everybody behind the ONE barrier that also covers the zeroing below
+  //          (it was three LDS atomics per wavefront and a barrier of its own).
   {
     uint32_t lo = 0xffffffffu, hi = 0u, nv = 0u;
     NANN_FOR_KEYS({ if (valid) { lo = min(lo, kj); hi = max(hi, kj); ++nv; } })
     lo = wave_min(lo);
     hi = wave_max(hi);
-    if (lane == 0) { atomicMin(&S->andv, lo); atomicMax(&S->orv, hi); }
-    if constexpr (BIN) {  // the keys that take part (misc[1])
-      const uint32_t wv = wave_total(wave_scan_add(nv));
-      if (lane == 0) atomicAdd(&S->misc[1], wv);
-    }
+    const uint32_t wv = BIN ? wave_total(wave_scan_add(nv)) : 0u;  // the keys that take part
+    if (lane == 0) { S->wlo[wave] = lo; S->whi[wave] = hi; S->wcnt[wave] = wv; }
   }
+  uint32_t* hist = reinterpret_cast<uint32_t*>(S->sel);  // [4][256]; sel is not in use before step 3
+  for (int i = tid; i < 4 * 256; i += NT) hist[i] = 0;
+  constexpr bool BINNED = BIN;  // (the serving kernels keep the all-pairs ranking: their k is 200)
+  const uint32_t bin_max = (uint32_t)max(64, k >> 1);  // a fuller bin (half the keys crowded into one leading digit): the all-pairs ranking instead
+  if constexpr (BINNED) {
+    for (int i = tid; i < 256; i += NT) S->bins.cursor[i] = 0;
+  }
+  if (tid < 4) S->misc[tid] = 0;
   __syncthreads();
-  const uint32_t kbase = S->andv;          // smallest key
-  const uint32_t diff = S->orv - kbase;    // largest key - smallest key
+  pt.sub(PH_TK_LOAD, tsub);
+  uint32_t kbase = 0xffffffffu, kmax = 0u, nvalid = 0u;
+  for (int w = 0; w < NT / 64; ++w) {
+    kbase = min(kbase, S->wlo[w]);  // smallest key
+    kmax = max(kmax, S->whi[w]);
+    nvalid += S->wcnt[w];
+  }
+  const uint32_t diff = kmax - kbase;  // largest key - smallest key
+  // (wcnt is reused by the collect of keys equal to the threshold: every thread has read it before the barriers in between)
   // ---- 2b. k-th largest key: radix select over the undecided bits, 8 bits per pass
   //          (LDS histogram -> 256-bin suffix scan).  A pass ends the search early when the
   //          bin holding the k-th key is needed in full.  T is relative to kbase until the end.
-  uint32_t T = 0, c_ge = BIN ? S->misc[1] : (uint32_t)n, c_gt = 0;
+  uint32_t T = 0, c_ge = BIN ? nvalid : (uint32_t)n, c_gt = 0;
   int shift0 = 0;        // the leading digit of a key: ((key - kbase) >> shift0) & mask0 (pass 0 of the search)
   uint32_t mask0 = 0u;
   if (diff != 0u) {
@@ -1425,7 +1427,7 @@ __device__ __forceinline__ int wg_topk_impl(const int32_t* ids, const float* sco
     }
     T += kbase;
   } else {
-    T = S->andv;  // all keys equal
+    T = kbase;  // all keys equal
   }
   // c_ge = #keys >= T >= k; c_gt = #keys > T (when the search ran to the last bit).  If
   // c_ge > k, T is the exact k-th key and only some of the keys equal to T are admitted.
