@@ -1022,3 +1022,24 @@ def test_mlp_traversal_scores_against_float64_numpy(oracle, precision, form):
         assert (np.diff(got[b]) <= 0).all()  # sorted descending
     # exact f32: fmaf chains of 256 + 256 + 128 terms; split-f16: north_star's 1e-5
     assert worst <= (3e-6 if precision == "exact" else 1e-5), worst
+
+
+@pytest.mark.parametrize("mode", ["auto", "lds_bitmap"])
+def test_search_random_level_topn(oracle, mode):
+    """Thirty random level_topn vectors (beams of 1..600 per stage, top-k 1..400) on graphs of 20 000 and 60 000 items, batches of
+    3 and 300 queries (one and two workgroups per CU): every selection size the bin-grouped ranking of top-k sees, requests the
+    reference fails included -- status, ids, scores and counters equal to the oracle's."""
+    rng = np.random.default_rng(61)
+    sc = oracle.Scorer("l2", 64, oracle.EMB_F16)
+    n_valid = 0
+    for trial in range(30):
+        g, oix, dix = synth_index(20000 if trial % 2 else 60000, 64, 32)
+        E = len(g["enter_points"])
+        nq = 3 if trial % 3 == 0 else 300
+        q = np.stack([oracle.user_seq_mean(s) for s in queries_for(g, nq, seed=200 + trial)])
+        t = [int(rng.integers(1, min(E, 600) + 1))] + [int(x) for x in rng.integers(1, 601, size=4)]
+        t.append(int(rng.integers(1, min(400, t[1] + t[2] + t[3] + t[4]) + 1)))
+        exp = oracle.search_batch(oix, sc, q, t, n_threads=8)
+        _assert_same(_run(dix, q, t, mode), exp)
+        n_valid += int((exp[0] == 0).sum())
+    assert n_valid > 1000
